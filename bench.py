@@ -1,0 +1,277 @@
+#!/usr/bin/env python
+"""
+bench.py - throughput of the SISR/APF hot path on MI355X, BASELINE.json's metric:
+
+    particle-steps/s = batch x particles x T / wall-time   (+ achieved HBM GB/s of the dominant kernel)
+
+A "step" (``--steps K``) is one full ``batch_filter`` pass of the fused HIP loop over T synthetic observations with all
+inputs already resident in HBM.  Workloads (``--workload``):
+
+    apf_lgo_1m   (default) BASELINE.json configs[1]: sine diffusion, APF + LinearGaussianObservations,
+                 1 048 576 particles, T = 250, systematic resampling
+    sv_batch     configs[2]: Verhulst SV, APF + Bootstrap, 64 series x 65 536 particles
+    lorenz_mn    configs[3]: Lorenz-63, SISR + Bootstrap, 4 194 304 particles, multinomial resampling
+    smc2_shard   configs[4]: one theta-shard of SMC^2 (1 024 / n_gpus filters x 8 192 particles, T = 500)
+
+Multi-GPU (``torchrun --nproc-per-node N bench.py --gpus N``): one process per GPU; the path does not shard a single
+filter (that would need a cross-GPU scan), so every rank runs its own independent filters (weak scaling) and the
+only exchange is the RCCL all-gather of the per-filter log-likelihoods - the step SMC^2 / parallel PMMH chains need.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. ``roofline`` and ``cpu_baseline``.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (filter, proposal, resampler, N, B_total, D, T)
+    "apf_lgo_1m": dict(filter="apf", proposal="lgo", resampler="systematic", N=1 << 20, B=1, D=1, T=250),
+    "sv_batch": dict(filter="apf", proposal="bootstrap", resampler="systematic", N=65536, B=64, D=1, T=1000),
+    "lorenz_mn": dict(filter="sisr", proposal="bootstrap", resampler="multinomial", N=1 << 22, B=1, D=3, T=2000),
+    "smc2_shard": dict(filter="apf", proposal="bootstrap", resampler="systematic", N=8192, B=1024, D=1, T=500),
+}
+
+
+def build_problem(name, dtype, device, world, rank, t_override=None):
+    from pyfilter_amd import resampling, timeseries as ts
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    w = dict(WORKLOADS[name])
+    if t_override:
+        w["T"] = t_override
+    t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
+    gen = torch.Generator().manual_seed(123 + rank)
+    b = w["B"]
+    if name == "apf_lgo_1m":
+        hidden = models.SineDiffusion(t(0.0), t(1.0), dt=0.1)
+        ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.1)))
+        x, ys = torch.randn((), generator=gen).item(), []
+        for _ in range(w["T"]):
+            x = x + math.sin(x) * 0.1 + math.sqrt(0.1) * torch.randn((), generator=gen).item()
+            ys.append(x + 0.1 * torch.randn((), generator=gen).item())
+        y = torch.tensor(ys, dtype=dtype)
+    elif name == "sv_batch":
+        kappa = 0.05 + 0.01 * torch.rand(b, generator=gen)
+        gamma = 1.0 + 0.2 * torch.rand(b, generator=gen)
+        sigma = 0.10 + 0.05 * torch.rand(b, generator=gen)
+        mu = 0.05 * torch.randn(b, generator=gen)
+        hidden = models.Verhulst(kappa.to(dtype).to(device), gamma.to(dtype).to(device), sigma.to(dtype).to(device),
+                                 dt=0.2, initial=(t(1.0), t(0.1)))
+        ssm = models.StochasticVolatilityModel(hidden, mu.to(dtype).to(device))
+        v, ys = torch.ones(b), []
+        for _ in range(w["T"]):
+            v = (v + kappa * (gamma - v) * v * 0.2 + sigma * v * math.sqrt(0.2) * torch.randn(b, generator=gen)).clamp_min(1e-3)
+            ys.append(mu + v * torch.randn(b, generator=gen))
+        y = torch.stack(ys).to(dtype)
+    elif name == "lorenz_mn":
+        hidden = models.Lorenz63(t(10.0), t(28.0), t(8.0 / 3.0), t(1.0), dt=0.01)
+        a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]])
+        ssm = ts.LinearStateSpaceModel(hidden, (a, t([0.0]), t([math.sqrt(0.1)])), torch.Size([2]))
+        x = torch.tensor([-5.91652, -5.52332, 24.5723], dtype=torch.float64)
+        ys = []
+        for _ in range(w["T"]):
+            f = torch.stack((-10.0 * (x[0] - x[1]), 28.0 * x[0] - x[1] - x[0] * x[2], x[0] * x[1] - 8.0 / 3.0 * x[2]))
+            x = x + f * 0.01 + 0.1 * torch.randn(3, generator=gen, dtype=torch.float64)
+            ys.append(0.8 * x[[0, 2]] + math.sqrt(0.1) * torch.randn(2, generator=gen, dtype=torch.float64))
+        y = torch.stack(ys).to(dtype)
+    elif name == "smc2_shard":
+        b = w["B"] = max(1, w["B"] // world)  # theta-particles block-sharded across the ranks
+        kappa = 0.01 + 0.05 * torch.rand(b, generator=gen)
+        gamma = 0.2 * torch.randn(b, generator=gen)
+        sigma = 0.03 + 0.04 * torch.rand(b, generator=gen)
+        hidden = models.OrnsteinUhlenbeck(kappa.to(dtype).to(device), gamma.to(dtype).to(device),
+                                          sigma.to(dtype).to(device), dt=1.0)
+        ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.05)))
+        g2 = torch.Generator().manual_seed(123)  # the data are shared by all shards
+        x, ys = 0.0, []
+        for _ in range(w["T"]):
+            x = x * math.exp(-0.025) + 0.05 * math.sqrt((1 - math.exp(-0.05)) / 0.05) * torch.randn((), generator=g2).item()
+            ys.append(x + 0.05 * torch.randn((), generator=g2).item())
+        y = torch.tensor(ys, dtype=dtype)
+    else:
+        raise KeyError(name)
+
+    cls = {"sisr": SISR, "apf": APF}[w["filter"]]
+    prop = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[w["proposal"]]()
+    rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[w["resampler"]]
+    filt = cls(ssm, w["N"], proposal=prop, resampling=rs, seed=2024 + rank)
+    if w["B"] > 1 or name in ("sv_batch", "smc2_shard"):
+        filt.set_batch_shape(torch.Size([w["B"]]))
+    return filt, y.to(device), w
+
+
+def alg_bytes_per_particle(w, kernel, e=4):
+    """Algorithmic HBM bytes per particle per launch (with int32 ancestors: 4 B instead of 8):
+    reduce 4+4D | scan 8 (+4D for the APF's in-register pre-weight) | step 4 (cdf) + 4D (x[anc]) + 4D (x') + 4 (logw') + 4 (anc)."""
+    d = w["D"]  # e = bytes per state / weight element (4 for fp32)
+    if kernel == "reduce":
+        return e * (1 + d)
+    if kernel == "scan":
+        return e * 2 + (e * d if w["filter"] == "apf" else 0)
+    return e * (2 + 2 * d) + 4
+
+
+def cpu_baseline(name, w, seconds_budget=15.0):
+    """The oracle (torch-CPU restatement of the reference's aten-op sequence) timed on this box's host cores on a
+    bounded sample of the same workload: same N, B, model, filter; as many time steps as fit the budget."""
+    from oracle import cpu_ref, models as M
+
+    if name not in ("apf_lgo_1m",):
+        return None
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    spec = M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
+    n = w["N"]
+    g = torch.Generator().manual_seed(1)
+    y = torch.randn(4096, generator=g)
+    x0 = torch.randn(n, 1)
+
+    def run(steps):
+        t0 = time.perf_counter()
+        cpu_ref.batch_filter(spec, w["filter"], w["proposal"], y[:steps], x0, None, None)
+        return time.perf_counter() - t0
+
+    run(2)  # warm-up
+    per_step = run(3) / 3
+    steps = int(max(5, min(400, seconds_budget / per_step)))
+    dt = run(steps)
+    return {
+        "value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+        "sample": f"{name}: N={n}, B=1, {steps} time steps ({dt:.1f} s), fp32, torch {torch.__version__} CPU, "
+                  f"{cores} threads; oracle/cpu_ref.py (same aten-op sequence as the reference)",
+        "ms_per_filter_step": 1e3 * dt / steps,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="apf_lgo_1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--T", type=int, default=None, help="override the number of observations")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+    dtype = {"f32": torch.float32, "f64": torch.float64}[args.dtype]
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+
+    filt, y, w = build_problem(args.workload, dtype, device, world, rank, args.T)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def one_pass():
+        res = filt.batch_filter(y, bar=False)
+        ll = res.loglikelihood.reshape(-1)
+        if world > 1:  # the path's only exchange: every rank learns every filter's log-likelihood
+            out = torch.empty(world * ll.numel(), dtype=ll.dtype, device=device)
+            dist.all_gather_into_tensor(out, ll.contiguous())
+            return res, out
+        return res, ll
+
+    for _ in range(args.warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, ll_all = one_pass()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    units_per_pass = w["N"] * w["B"] * w["T"] * world
+    value = units_per_pass * args.steps / elapsed
+
+    # ---- per-kernel durations (HIP events on the launch stream) in a separate instrumented pass ------------------
+    filt._time_kernels = True
+    filt.batch_filter(y, bar=False)
+    torch.cuda.synchronize()
+    filt._time_kernels = False
+    kms = filt.kernel_ms
+    names = ("reduce", "scan", "step")
+    dom = max(range(3), key=lambda i: kms[i])
+    esz = 8 if dtype == torch.float64 else 4
+    launch_bytes = {k: alg_bytes_per_particle(w, k, esz) * w["N"] * w["B"] for k in names}
+    achieved = launch_bytes[names[dom]] / (kms[dom] * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": f"k_fused_{'reduce scan step'.split()[dom]}", "achieved": achieved,
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "bytes_per_launch": launch_bytes[names[dom]],
+        "kernel_us": {n_: 1e3 * kms[i] for i, n_ in enumerate(names)},
+        "all_kernels_GBs": {n_: launch_bytes[n_] / (kms[i] * 1e-3) / 1e9 for i, n_ in enumerate(names)},
+        "step_alg_bytes_per_particle": sum(alg_bytes_per_particle(w, k, esz) for k in names),
+        "whole_step_GBs": sum(alg_bytes_per_particle(w, k, esz) for k in names) * value / world / 1e9,
+    }
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(args.workload, w)
+        out = {
+            "metric": "particle-steps/sec (batch x particles x T), 1M-particle APF",
+            "value": value,
+            "unit": "particle-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {w['filter'].upper()} + {w['proposal']} proposal, {w['resampler']} "
+                            f"resampling, N={w['N']} particles x B={w['B']} filters per GPU, T={w['T']}, state dim {w['D']}",
+                "ms_per_filter_step": 1e3 * elapsed / args.steps / w["T"],
+                "parallelism": "independent filters per GPU + all-gather of log-likelihoods" if world > 1 else "single GPU",
+                "loglikelihood_sample": float(ll_all.reshape(-1)[0]),
+            },
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/*
+ * pf_amd.h - C ABI of libpfamd.so: the MI355X (gfx950) particle-filter inner loop that replaces, behind pyfilter's
+ * own Python API, the per-time-step propagate -> log-weight -> normalise -> resample -> gather cycle of
+ * pyfilter.filters.particle.{SISR, APF} (reference tree: /root/reference/pyfilter, v0.29.0).
+ *
+ * The reference has no FFI of its own (it is pure Python on torch), so each entry point below
+ * names the reference *function* it replaces.  INTEGRATION.md shows the ctypes stub a pyfilter maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (PF_OK) or a negative PF_E* code / positive hipError_t; nothing throws or aborts;
+ *   - all pointers are BORROWED raw device pointers (torch.Tensor.data_ptr()); the caller owns and keeps them alive;
+ *   - the library allocates nothing: scratch is a caller-provided workspace sized by pf_workspace_bytes();
+ *   - every launch goes to the caller's hipStream_t (passed as void*) and is asynchronous; no host sync inside;
+ *   - no global mutable state: re-entrant per (device, stream);
+ *   - dtype: PF_F32 or PF_F64 - the arithmetic type of state and weights (reference default fp32, constants.py:6);
+ *   - layout ("column" = one filter of the reference's batch dim):
+ *         weights / log-weights / cdf / ancestors : (B, N)    contiguous, particle index fastest
+ *         state                                   : (D, B, N) contiguous SoA (D = 1 for a scalar state)
+ *     i.e. the reference's (N, [B], [D]) tensors (filters/particle/base.py:51-62) are *views* of these buffers
+ *     (torch: buf.permute(2, 1, 0)).  Ancestors are int32 here, int64 in the reference.
+ */
+#ifndef PF_AMD_H
+#define PF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_OK 0
+#define PF_EINVAL (-1)     /* bad argument (shape, dtype, null pointer) */
+#define PF_EWORKSPACE (-2) /* workspace too small */
+#define PF_EUNSUPPORTED (-3)
+
+#define PF_F32 0
+#define PF_F64 1
+
+/* hidden-process kinds: x' = loc(x) + scale(x) * eps, eps ~ N(0, inc_scale)    */
+#define PF_HID_LINEAR 0      /* loc = alpha + beta x,                       scale = sigma     hp = (alpha, beta, sigma) */
+#define PF_HID_SINE_EM 1     /* loc = x + sin(x - gamma) dt,                scale = sigma     hp = (gamma, sigma)        */
+#define PF_HID_VERHULST_EM 2 /* loc = x + kappa (gamma - x) x dt,           scale = sigma x   hp = (kappa, gamma, sigma) */
+#define PF_HID_LORENZ63_EM 3 /* Lorenz-63 drift, Euler-Maruyama (D = 3),    scale = sigma     hp = (s, r, b, sigma)      */
+#define PF_HID_OU 4          /* exact OU step                                                 hp = (kappa, gamma, sigma) */
+/* observation kinds */
+#define PF_OBS_LINEAR 0 /* y ~ N(b + A x, s)   (LinearStateSpaceModel; proposals/linear.py:48) */
+#define PF_OBS_SV 1     /* y ~ N(mu, scale = x)                                                 */
+/* proposals (pyfilter/filters/particle/proposals) */
+#define PF_PROP_BOOTSTRAP 0
+#define PF_PROP_LGO 1 /* LinearGaussianObservations */
+/* filters */
+#define PF_FILTER_SISR 0
+#define PF_FILTER_APF 1
+/* resamplers (pyfilter/resampling.py) */
+#define PF_RESAMPLE_SYSTEMATIC 0
+#define PF_RESAMPLE_MULTINOMIAL 1
+
+/* Closed description of a state-space model (the "kernel_id" view of a stochproc StateSpaceModel). */
+typedef struct pf_model {
+    int32_t hid_kind;
+    int32_t obs_kind;
+    int32_t dim;     /* D >= 1 (a scalar state is D = 1) */
+    int32_t obs_dim; /* O >= 1 (a scalar observation is O = 1); O = 1 required when D = 1 */
+    double dt;
+    double inc_scale; /* 1 for the discrete kinds, sqrt(dt) for Euler-Maruyama */
+    /* (B, NP) parameter rows, dtype = the call's dtype, NP = 4*D + O*D + 2*O, one row per column:
+     *   [ hp0[D] hp1[D] hp2[D] hp3[D] | A[O x D] row-major | b[O] | s[O] ]   (PF_OBS_SV: b[0] = mu) */
+    const void* params;
+} pf_model;
+
+const char* pf_version(void);
+const char* pf_error_string(int code);
+
+/* Scratch bytes any call below needs for an (N, B, D) problem. */
+int pf_workspace_bytes(int64_t N, int64_t B, int64_t D, size_t* bytes);
+
+/* ------------------------------------------------------------------------------------------------------------ *
+ * L1 primitives
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* pyfilter.utils.normalize (utils.py:49-64) + get_ess (utils.py:8-20).
+ * logw (B,N) is sanitised IN PLACE exactly as the reference does (NaN,+inf -> -inf; -inf -> lowest finite);
+ * W (B,N) <- softmax over the particle axis (may be NULL); lse (B) <- log sum exp (may be NULL);
+ * ess (B) <- 1 / sum W^2 (may be NULL). */
+int pf_normalize(void* logw, void* W, void* lse, void* ess, int64_t N, int64_t B, int dtype, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* pyfilter.resampling.systematic (resampling.py:24-52), normalized=True path:
+ * cdf = cumsum(W) with an fp64 carry rounded per element to dtype, cdf[N-1] = 1, idx = searchsorted_left(cdf, (i+u)/N).
+ * W (B,N) normalised weights; u: (B) uniforms, one per column - or, with u_per_element != 0, (B,N) one per grid
+ * position, the arrangement of the reference's own known-answer test (tests/test_resampling.py:39-47);
+ * colmask (B) uint8 or NULL: only columns with colmask != 0 are
+ * resampled, the others' idx are left untouched (SISR's masked resampling, sisr.py:29-31);
+ * cdf (B,N) scratch/out; idx (B,N) int32 out. */
+int pf_systematic(const void* W, const void* u, int u_per_element, const uint8_t* colmask, void* cdf, int32_t* idx,
+                  int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* systematic with normalized=False (resampling.py:8-21 then :24-52): logw is sanitised in place, the softmax is
+ * never materialised (cdf is built from exp(logw - tile max) with an fp64 carry). */
+int pf_systematic_logw(void* logw, const void* u, int u_per_element, const uint8_t* colmask, void* cdf, int32_t* idx,
+                       int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* pyfilter.resampling.multinomial (resampling.py:55-65): N iid inverse-CDF draws per column.
+ * v (B,N) uniforms or NULL (then Philox(seed, step)); output order is iid (unsorted) like torch.multinomial. */
+int pf_multinomial(const void* W, const void* v, uint64_t seed, uint32_t step, const uint8_t* colmask, void* cdf,
+                   int32_t* idx, int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* pyfilter.filters.utils.batched_gather (filters/utils.py:4-21) along the particle axis, for all D components;
+ * columns with colmask == 0 are copied through unchanged (SISR's masked_scatter, sisr.py:37-44). */
+int pf_gather(const void* x, const int32_t* idx, const uint8_t* colmask, void* out, int64_t N, int64_t B,
+              int64_t D, int dtype, void* stream);
+
+/* pyfilter.filters.particle.utils.log_likelihood (particle/utils.py:7-22): max v + log sum W exp(v - max);
+ * W == NULL means 1/N.  v (B,N) is NOT sanitised (a NaN poisons the column, as in the reference). out (B). */
+int pf_loglik(const void* v, const void* W, void* out, int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes,
+              void* stream);
+
+/* get_filter_mean_and_variance (particle/utils.py:26-65), covariance=False: mean (B,D), var (B,D). */
+int pf_moments(const void* x, const void* W, void* mean, void* var, int64_t N, int64_t B, int64_t D, int dtype,
+               void* ws, size_t ws_bytes, void* stream);
+
+/* Proposal.pre_weight (proposals/base.py:69-85 | linear.py:57-86) for a built-in model: out (B,N).
+ * y: (By, O) with By in {1, B}. */
+int pf_pre_weight(const pf_model* model, int proposal, const void* x, const void* y, int64_t y_rows, void* out,
+                  int64_t N, int64_t B, int dtype, void* stream);
+
+/* Proposal.sample_and_weight (bootstrap.py:10-14 | linear.py:38-55) for a built-in model:
+ * x_out (D,B,N) new particles, w_out (B,N) importance log-weights (NOT sanitised).
+ * z (D,B,N) standard normals, or NULL -> Philox(seed, step). weigh = 0: propagate only (w_out may be NULL)
+ * (ParticleFilterPrediction.create_state_from_prediction, particle/state.py:38-42). */
+int pf_sample_and_weight(const pf_model* model, int proposal, int weigh, const void* x, const void* y,
+                         int64_t y_rows, const void* z, uint64_t seed, uint32_t step, void* x_out, void* w_out,
+                         int64_t N, int64_t B, int dtype, void* stream);
+
+/* hidden.initial_sample: x (D,B,N) <- m0[d] + s0[d] * z, z from `z` or Philox(seed). m0, s0: (D) host doubles. */
+int pf_initial_sample(const double* m0, const double* s0, const void* z, uint64_t seed, void* x, int64_t N,
+                      int64_t B, int64_t D, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------ *
+ * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and
+ * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; three kernels per step.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct pf_filter_args {
+    pf_model model;
+    int32_t filter;    /* PF_FILTER_* */
+    int32_t proposal;  /* PF_PROP_* */
+    int32_t resampler; /* PF_RESAMPLE_* */
+    int32_t dtype;
+    int64_t N, B;
+    double ess_threshold; /* relative: resample when ess < ess_threshold * N (particle/base.py:42) */
+    uint64_t seed;
+    /* state, double buffered: slot (step & 1) is read, the other written */
+    void* x[2];     /* (D,B,N) */
+    void* logw[2];  /* (B,N)   */
+    int32_t* anc;   /* (B,N) ancestors of the latest step (SISR keeps them when no resampling happened) */
+    void* cdf;      /* (B,N) scratch */
+    /* observations */
+    const void* y;            /* (T, y_rows, O) */
+    int64_t y_rows;           /* 1 or B */
+    const uint8_t* observed;  /* (T) 0 = all-NaN observation or unobserved sub-step: propagate only, ll = 0 */
+    /* optional tapes (parity mode); NULL -> Philox */
+    const void* z_tape; /* (T, D, B, N) */
+    const void* u_tape; /* (T, B) */
+    /* results */
+    void* means;     /* (T+1, B, D) filter_means incl. the initial state (filters/result.py:119-131) */
+    void* vars;      /* (T+1, B, D) */
+    void* ll_steps;  /* (T, B) per-step log-likelihood increments */
+    void* ll_total;  /* (B) running sum, updated in place */
+    int32_t* step_counter; /* device int32: index of the next step; kernels read their step from here */
+    void* ws;
+    size_t ws_bytes;
+} pf_filter_args;
+
+/* Runs steps [*step_counter, *step_counter + n_steps) (the host passes t0 = the counter's current value).
+ * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps). */
+int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
+
+/* Measurement variant of pf_filter_run: brackets every kernel launch with HIP events on `stream`, synchronises the
+ * stream and returns the average duration in ms of the three step kernels in kernel_ms[0..2] =
+ * {reduce, scan, resample+propagate+weight}.  Same results as pf_filter_run; not for throughput numbers. */
+int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
+                        float* kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PF_AMD_H */

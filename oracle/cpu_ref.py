@@ -279,6 +279,8 @@ def batch_filter(
         y: ``(T,[O])`` or - for B independent scalar series - ``(T,B)``.
         x0: ``(N,[B],[D])`` initial particles.
         z_tape: ``(T,N,[B],[D])`` standard normals;  u_tape: ``(T,B)`` uniforms (``B=1`` when unbatched) or None.
+            Either may be None: the draws then come from torch's global CPU generator, as in the reference (this is
+            the mode ``bench.py`` times as the CPU baseline).
 
     Returns dict with ``filter_means (T+1,[B],max(D,1))``, ``filter_variance``, ``loglikelihood ([B])``, final
     ``x, w, prev_inds`` and - with ``record_steps`` - per-step ``x, w, ll, idx``.
@@ -299,8 +301,9 @@ def batch_filter(
 
     for t in range(y.shape[0]):
         y_t = y[t]
-        z = z_tape[t]
+        # no tape: draw like the reference does (torch's global CPU generator), u first then z (Appendix A)
         u = None if u_tape is None else u_tape[t]
+        z = z_tape[t] if z_tape is not None else torch.randn(x.shape, dtype=x.dtype)
         if bool(y_t.isnan().all()):
             if filt == "sisr":  # predict still runs (and may resample) before the propagate-only move
                 x, w, _, idx, _ = sisr_predict(spec, x, w, prev, u, thr, resampler)

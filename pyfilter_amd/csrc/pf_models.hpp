@@ -1,0 +1,319 @@
+// pf_models.hpp - per-particle model arithmetic for the built-in model kinds (device side).
+//
+// These are the closed forms of SURVEY.md §8(a) row M / a12-a15.  In the reference they are chains of aten ops
+// issued by user lambdas + stochproc + torch.distributions:
+//   mean_scale / propagate        -> stochproc AffineProcess (call sites proposals/linear.py:41, bootstrap.py:11)
+//   obs log-density               -> LinearStateSpaceModel.build_density(x).log_prob(y)   (bootstrap.py:12-14)
+//   default APF pre-weight        -> proposals/base.py:69-85 + pre_weight_funcs.py:9-11
+//   LinearGaussianObservations    -> proposals/linear.py:38-86 + proposals/utils.py:219-267
+// Everything is evaluated in registers; parameters are uniform per column (one filter = one parameter row).
+#pragma once
+#include "pf_device.hpp"
+
+#define PF_MAXD 3
+#define PF_MAXO 3
+
+#include "../../include/pf_amd.h"  // PF_HID_*, PF_OBS_*, PF_PROP_*, PF_FILTER_* kind codes
+
+namespace pf {
+
+#define PF_LOG_SQRT_2PI 0.91893853320467274178
+
+template <int D> struct ObsDim {
+    static constexpr int MAXO = (D == 1) ? 1 : PF_MAXO;
+};
+
+// Per-column parameter row, layout (in units of T):
+//   [ hp0[D] hp1[D] hp2[D] hp3[D] | A[O*D] (row-major O x D) | ob[O] | os[O] ]       NP = 4*D + O*D + 2*O
+template <typename T, int D> struct ColParams {
+    static constexpr int MAXO = ObsDim<D>::MAXO;
+    T hp[4][D];
+    T A[MAXO][D];
+    T ob[MAXO];
+    T os[MAXO];
+    T y[MAXO];
+    int O;
+
+    __device__ __forceinline__ void load(const T* __restrict__ row, int O_, const T* __restrict__ yrow) {
+        O = O_;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int d = 0; d < D; ++d) hp[k][d] = row[k * D + d];
+        const T* a = row + 4 * D;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            const bool on = o < O_;
+#pragma unroll
+            for (int d = 0; d < D; ++d) A[o][d] = on ? a[o * D + d] : T(0);
+            ob[o] = on ? a[O_ * D + o] : T(0);
+            os[o] = on ? a[O_ * D + O_ + o] : T(1);
+            y[o] = (on && yrow) ? yrow[o] : T(0);
+        }
+    }
+};
+
+struct ModelDesc {
+    int hid_kind;
+    int obs_kind;
+    int obs_dim;  // O >= 1
+    double dt;
+    double inc_scale;  // scale of the increment distribution: 1 or sqrt(dt)
+};
+
+// hidden.mean_scale(x) -> (loc, scale)
+template <typename T, int D>
+__device__ __forceinline__ void mean_scale(const ModelDesc& md, const ColParams<T, D>& cp, const T (&x)[D],
+                                           T (&loc)[D], T (&scale)[D]) {
+    const T dt = (T)md.dt;
+    switch (md.hid_kind) {
+        case PF_HID_LINEAR:
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                loc[d] = cp.hp[0][d] + cp.hp[1][d] * x[d];
+                scale[d] = cp.hp[2][d];
+            }
+            break;
+        case PF_HID_SINE_EM:
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                loc[d] = x[d] + pf_sin(x[d] - cp.hp[0][d]) * dt;
+                scale[d] = cp.hp[1][d];
+            }
+            break;
+        case PF_HID_VERHULST_EM:
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                loc[d] = x[d] + cp.hp[0][d] * (cp.hp[1][d] - x[d]) * x[d] * dt;
+                scale[d] = cp.hp[2][d] * x[d];
+            }
+            break;
+        case PF_HID_LORENZ63_EM:
+            if constexpr (D == 3) {
+                const T s = cp.hp[0][0], r = cp.hp[1][0], b = cp.hp[2][0];
+                const T f0 = -s * (x[0] - x[1]);
+                const T f1 = r * x[0] - x[1] - x[0] * x[2];
+                const T f2 = x[0] * x[1] - b * x[2];
+                loc[0] = x[0] + f0 * dt;
+                loc[1] = x[1] + f1 * dt;
+                loc[2] = x[2] + f2 * dt;
+#pragma unroll
+                for (int d = 0; d < D; ++d) scale[d] = cp.hp[3][d];
+            }
+            break;
+        case PF_HID_OU:
+        default:
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const T kappa = cp.hp[0][d], gamma = cp.hp[1][d], sigma = cp.hp[2][d];
+                const T e = pf_exp(-kappa * dt);
+                loc[d] = gamma + (x[d] - gamma) * e;
+                scale[d] = sigma * pf_sqrt((T(1) - pf_exp(T(-2) * kappa * dt)) / (T(2) * kappa));
+            }
+            break;
+    }
+}
+
+template <typename T> __device__ __forceinline__ T normal_logpdf(T y, T loc, T scale) {
+    const T r = y - loc;
+    return -(r * r) / (T(2) * scale * scale) - pf_log(scale) - T(PF_LOG_SQRT_2PI);
+}
+
+// model.build_density(x).log_prob(y)
+template <typename T, int D>
+__device__ __forceinline__ T obs_logpdf(const ModelDesc& md, const ColParams<T, D>& cp, const T (&x)[D]) {
+    if (md.obs_kind == PF_OBS_SV) return normal_logpdf(cp.y[0], cp.ob[0], x[0]);
+    T lp = T(0);
+#pragma unroll
+    for (int o = 0; o < ColParams<T, D>::MAXO; ++o) {
+        if (o < cp.O) {
+            T loc = cp.ob[o];
+#pragma unroll
+            for (int d = 0; d < D; ++d) loc += cp.A[o][d] * x[d];
+            lp += normal_logpdf(cp.y[o], loc, cp.os[o]);
+        }
+    }
+    return lp;
+}
+
+// log density of x_new under the transition started at (loc, scale): Normal(0, inc).log_prob(eps) - log|scale|
+template <typename T, int D>
+__device__ __forceinline__ T transition_logpdf(const ModelDesc& md, const T (&xn)[D], const T (&loc)[D],
+                                               const T (&scale)[D]) {
+    const T inc = (T)md.inc_scale;
+    const T c = pf_log(inc) + T(PF_LOG_SQRT_2PI);
+    T lp = T(0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const T eps = (xn[d] - loc[d]) / scale[d];
+        lp += -(eps * eps) / (T(2) * inc * inc) - c - pf_log(pf_abs(scale[d]));
+    }
+    return lp;
+}
+
+// lower Cholesky factor of a K x K SPD matrix (K <= 3), fully unrolled
+template <typename T, int K> __device__ __forceinline__ void chol_lower(const T (&a)[K][K], T (&l)[K][K]) {
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) l[i][j] = T(0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        T s = a[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= l[j][k] * l[j][k];
+        const T ljj = pf_sqrt(s);
+        l[j][j] = ljj;
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            T t = a[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= l[i][k] * l[j][k];
+            l[i][j] = t / ljj;
+        }
+    }
+}
+
+// inverse of an SPD K x K matrix through its Cholesky factor
+template <typename T, int K> __device__ __forceinline__ void spd_inverse(const T (&a)[K][K], T (&inv)[K][K]) {
+    T l[K][K];
+    chol_lower<T, K>(a, l);
+    T li[K][K];  // L^{-1}, lower
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) li[i][j] = T(0);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        li[j][j] = T(1) / l[j][j];
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            T t = T(0);
+#pragma unroll
+            for (int k = j; k < i; ++k) t -= l[i][k] * li[k][j];
+            li[i][j] = t / l[i][i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            T t = T(0);
+#pragma unroll
+            for (int k = 0; k < K; ++k) t += li[k][i] * li[k][j];  // (L^-T L^-1)_{ij}
+            inv[i][j] = t;
+        }
+}
+
+// APF first-stage weight  (proposal.pre_weight(y, x))
+template <typename T, int D>
+__device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
+                                        const T (&x)[D]) {
+    T loc[D], scale[D];
+    mean_scale<T, D>(md, cp, x, loc, scale);
+    if (proposal == PF_PROP_BOOTSTRAP) return obs_logpdf<T, D>(md, cp, loc);
+
+    // LinearGaussianObservations.pre_weight: N(y; b + A x_{t-1}, diag(s^2) + A diag(g^2) A^T)  (linear.py:57-86)
+    constexpr int MO = ColParams<T, D>::MAXO;
+    T cov[MO][MO], r[MO];
+#pragma unroll
+    for (int o = 0; o < MO; ++o) {
+        const bool on = o < cp.O;
+        T lo = cp.ob[o];
+#pragma unroll
+        for (int d = 0; d < D; ++d) lo += cp.A[o][d] * x[d];
+        r[o] = on ? (cp.y[o] - lo) : T(0);
+#pragma unroll
+        for (int p = 0; p < MO; ++p) {
+            T c = (o == p) ? (on ? cp.os[o] * cp.os[o] : T(1)) : T(0);
+#pragma unroll
+            for (int d = 0; d < D; ++d) c += cp.A[o][d] * scale[d] * scale[d] * cp.A[p][d];
+            cov[o][p] = c;
+        }
+    }
+    if constexpr (MO == 1) {
+        return normal_logpdf(r[0], T(0), pf_sqrt(cov[0][0]));
+    } else {
+        T l[MO][MO];
+        chol_lower<T, MO>(cov, l);
+        // solve L v = r
+        T v[MO], quad = T(0), logdet = T(0);
+#pragma unroll
+        for (int i = 0; i < MO; ++i) {
+            T t = r[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) t -= l[i][k] * v[k];
+            v[i] = t / l[i][i];
+            quad += v[i] * v[i];
+            logdet += pf_log(l[i][i]);
+        }
+        return -T(0.5) * quad - logdet - T(cp.O) * T(PF_LOG_SQRT_2PI);
+    }
+}
+
+// proposal.sample_and_weight(y, prediction): new state and importance weight given the draws z
+template <typename T, int D>
+__device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
+                                               const T (&x)[D], const T (&z)[D], T (&xn)[D]) {
+    T loc[D], scale[D];
+    mean_scale<T, D>(md, cp, x, loc, scale);
+    if (proposal == PF_PROP_BOOTSTRAP) {
+        const T inc = (T)md.inc_scale;
+#pragma unroll
+        for (int d = 0; d < D; ++d) xn[d] = loc[d] + scale[d] * (z[d] * inc);
+        return obs_logpdf<T, D>(md, cp, xn);
+    }
+
+    // optimal proposal for linear-Gaussian observations (find_optimal_density, proposals/utils.py:219-267):
+    //   precision = diag(g^-2) + A^T diag(s^-2) A ; cov = precision^-1 ; mean = cov (g^-2 m + A^T s^-2 (y - b))
+    constexpr int MO = ColParams<T, D>::MAXO;
+    T hvi[D], prec[D][D], rhs[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        hvi[d] = T(1) / (scale[d] * scale[d]);
+        rhs[d] = hvi[d] * loc[d];
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) prec[i][j] = (i == j) ? hvi[i] : T(0);
+#pragma unroll
+    for (int o = 0; o < MO; ++o) {
+        if (o < cp.O) {
+            const T ovi = T(1) / (cp.os[o] * cp.os[o]);
+            const T ry = ovi * (cp.y[o] - cp.ob[o]);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                rhs[i] += cp.A[o][i] * ry;
+#pragma unroll
+                for (int j = 0; j < D; ++j) prec[i][j] += cp.A[o][i] * ovi * cp.A[o][j];
+            }
+        }
+    }
+    T cov[D][D], km[D], l[D][D];
+    if constexpr (D == 1) {
+        cov[0][0] = T(1) / prec[0][0];
+    } else {
+        spd_inverse<T, D>(prec, cov);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T t = T(0);
+#pragma unroll
+        for (int j = 0; j < D; ++j) t += cov[i][j] * rhs[j];
+        km[i] = t;
+    }
+    chol_lower<T, D>(cov, l);
+    T logq = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T t = km[i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) t += l[i][j] * z[j];
+        xn[i] = t;
+        logq += -T(0.5) * z[i] * z[i] - pf_log(l[i][i]) - T(PF_LOG_SQRT_2PI);
+    }
+    return obs_logpdf<T, D>(md, cp, xn) + transition_logpdf<T, D>(md, xn, loc, scale) - logq;
+}
+
+}  // namespace pf

@@ -1,0 +1,331 @@
+"""
+``ParticleFilter`` (``pyfilter/filters/particle/base.py:14-103,159-174``) with the MI355X fast path:
+
+``batch_filter`` runs the whole time loop inside ``libpfamd.so`` (``pf_filter_run``: three fused HIP kernels per step,
+no host synchronisation, ESS mask / NaN flags decided on the device) whenever the model is a built-in kind, the
+proposal is ``Bootstrap`` / ``LinearGaussianObservations`` and the resampler is this package's ``systematic`` /
+``multinomial``.  Anything else (user callables, custom resamplers, ``record_states=True``) takes the step-by-step
+route through ``predict`` / ``correct`` - which still calls the HIP primitives for normalise / scan / search / gather /
+moments and evaluates only the user's model callables with PyTorch-ROCm ops.
+"""
+import ctypes as C
+from typing import Callable, Optional, Union
+
+import torch
+
+from ... import _lib as L
+from ... import ops
+from ...resampling import multinomial, systematic
+from ...timeseries import StateSpaceModel, TimeseriesState
+from ...timeseries.models import pack_params
+from ..base import BaseFilter
+from ..result import FilterResult
+from .proposals import Bootstrap, LinearGaussianObservations, Proposal
+from .proposals.base import KernelContext
+from .state import ParticleFilterCorrection, ParticleFilterPrediction
+
+_DEFAULT_SEED = 2024
+
+
+class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPrediction]):
+    _FILTER_KIND = None  # PF_FILTER_*
+
+    def __init__(
+        self,
+        model,
+        particles: int,
+        resampling: Callable[[torch.Tensor], torch.Tensor] = systematic,
+        proposal: Union[str, Proposal] = None,
+        ess_threshold=0.9,
+        seed: Optional[int] = None,
+        **kwargs,
+    ):
+        """
+        Args:
+            model: a ``StateSpaceModel`` or a builder ``context -> StateSpaceModel`` (see ``BaseFilter``).
+            particles: number of particles N.
+            resampling: ``systematic`` (default) or ``multinomial`` from :mod:`pyfilter_amd.resampling`, or any
+                callable ``(w, normalized=False) -> LongTensor`` (then the step-by-step route is used).
+            proposal: defaults to :class:`Bootstrap`.
+            ess_threshold: relative ESS below which SISR resamples (``particle/base.py:42``).
+            seed: seed of the in-kernel Philox generator (extension; the reference draws from torch's global RNG).
+        """
+        super().__init__(model, **kwargs)
+        self._base_particles = torch.Size([particles])
+        self._resample_threshold = ess_threshold * particles
+        self._resampler = resampling
+        self._proposal: Proposal = proposal if proposal is not None else Bootstrap()
+        self._seed = _DEFAULT_SEED if seed is None else int(seed)
+        self._ctx: Optional[KernelContext] = None
+        self._z_tape = None
+        self._u_tape = None
+        self._z0 = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    @property
+    def particles(self) -> torch.Size:
+        """``Size([N, *batch_shape])`` (particles first: ``particle/base.py:51-62``)."""
+        return torch.Size([*self._base_particles, *self.batch_shape])
+
+    @property
+    def proposal(self) -> Proposal:
+        return self._proposal
+
+    def increase_particles(self, factor: int):
+        self._base_particles = torch.Size([int(factor * self._base_particles[0])])
+        self._resample_threshold *= factor
+
+    def initialize_model(self, context):
+        super().initialize_model(context)
+        self._proposal.set_model(self._model)
+
+    def set_tape(self, z: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, z0: Optional[torch.Tensor] = None):
+        """Parity mode: inject the random draws instead of generating them with Philox.
+
+        Args:
+            z: standard normals per step in the reference's layout ``(T, N, [B], [D])``.
+            u: resampling uniforms ``(T, B)`` (``(T, 1)`` / ``(T,)`` when unbatched).
+            z0: standard normals ``(N, [B], [D])`` of the initial sample.
+        """
+        self._z_tape, self._u_tape, self._z0 = z, u, z0
+        self._ctx = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    @property
+    def _batched(self) -> bool:
+        return len(self.batch_shape) > 0
+
+    @property
+    def _has_event(self) -> bool:
+        return self._model.hidden.n_dim > 0
+
+    def _device_dtype(self):
+        hidden = self._model.hidden
+        dtype = next((p.dtype for p in hidden.parameters if p.is_floating_point()), torch.get_default_dtype())
+        return hidden.device, dtype
+
+    def _kernel_kind(self):
+        return getattr(self._model, "kernel_kind", None)
+
+    def _build_context(self, device, dtype) -> Optional[KernelContext]:
+        kind = self._kernel_kind()
+        if kind is None or device.type != "cuda":
+            return None
+        n = self._base_particles[0]
+        b = self.batch_shape[0] if self._batched else 1
+        params = pack_params(self._model, b, dtype, device)
+        ctx = KernelContext(kind, params, self._seed, self._batched, self._has_event)
+        if self._z_tape is not None:
+            z = self._z_tape.to(device=device, dtype=dtype)
+            t = z.shape[0]
+            z = z.reshape(t, n, b, kind.dim) if True else z
+            ctx.z_tape = z.permute(0, 3, 2, 1).contiguous()  # (T, D, B, N)
+        if self._u_tape is not None:
+            ctx.u_tape = self._u_tape.to(device=device, dtype=dtype).reshape(self._u_tape.shape[0], b).contiguous()
+        return ctx
+
+    def initialize(self) -> ParticleFilterCorrection:
+        assert self._model is not None, "Model has not been initialized!"
+        self._proposal.set_model(self.ssm)
+        device, dtype = self._device_dtype()
+        self._ctx = self._build_context(device, dtype)
+        self._proposal._set_context(self._ctx)
+
+        n = self._base_particles[0]
+        b = self.batch_shape[0] if self._batched else 1
+        hidden = self._model.hidden
+        if self._ctx is not None and hasattr(hidden, "init_mean"):
+            d = self._ctx.kind.dim
+            z0 = None
+            if self._z0 is not None:
+                z0 = ops.to_soa(self._z0.to(device=device, dtype=dtype), self._batched, self._has_event)
+            m0 = hidden.init_mean.reshape(-1).expand(d) if hidden.init_mean.numel() in (1, d) else None
+            s0 = hidden.init_scale.reshape(-1).expand(d) if hidden.init_scale.numel() in (1, d) else None
+            if m0 is not None and s0 is not None:
+                soa = ops.initial_sample_soa(m0.tolist(), s0.tolist(), n, b, d, dtype, device, self._seed, z0)
+                x = TimeseriesState(0, ops.from_soa(soa, self._batched, self._has_event), hidden.event_shape)
+            else:
+                x = hidden.initial_sample(self.particles)
+        else:
+            x = hidden.initial_sample(self.particles)
+            if x.value.device != device:
+                x = x.copy(values=x.value.to(device))
+
+        w_cols = torch.zeros((b, n), device=device, dtype=x.value.dtype)
+        weights = ops.from_cols(w_cols, self._batched)
+        prev_inds = torch.arange(n, device=device)
+        if self._batched:
+            prev_inds = prev_inds.unsqueeze(-1).expand(self.particles)
+        ll = torch.zeros(self.batch_shape, device=device, dtype=x.value.dtype)
+        return ParticleFilterCorrection(x, weights, ll, prev_inds)
+
+    def _propagate_only(self, prediction):
+        return prediction.create_state_from_prediction(self._model, propagate=self._proposal._propagate)
+
+    def copy(self):
+        """NB: like the reference (``particle/base.py:165``) the *absolute* threshold is handed to the copy's
+        ``ess_threshold`` - a copied SISR therefore effectively always resamples."""
+        res = type(self)(
+            model=self._model_builder,
+            particles=self._base_particles[0],
+            resampling=self._resampler,
+            proposal=self._proposal.copy(),
+            ess_threshold=self._resample_threshold,
+            seed=self._seed,
+            record_states=self.record_states,
+            record_moments=self.record_moments,
+            nan_strategy=self._nan_strategy,
+            record_intermediary_states=self._record_intermediary,
+        )
+        res.set_batch_shape(self.batch_shape)
+        return res
+
+    # ------------------------------------------------------------------------------------------------------------
+    # resampling helpers used by SISR / APF on the step-by-step route
+    # ------------------------------------------------------------------------------------------------------------
+    def _resampler_kind(self) -> Optional[int]:
+        if self._resampler is systematic:
+            return L.RESAMPLE_SYSTEMATIC
+        if self._resampler is multinomial:
+            return L.RESAMPLE_MULTINOMIAL
+        return None
+
+    def _uniforms(self, step: int, b: int, like: torch.Tensor) -> torch.Tensor:
+        if self._ctx is not None and self._ctx.u_tape is not None:
+            return self._ctx.u_tape[step]
+        return torch.empty(b, device=like.device, dtype=like.dtype).uniform_()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # the fused loop
+    # ------------------------------------------------------------------------------------------------------------
+    def _fused_capable(self, device) -> bool:
+        return (
+            device.type == "cuda"
+            and self._FILTER_KIND is not None
+            and self._kernel_kind() is not None
+            and type(self._proposal) in (Bootstrap, LinearGaussianObservations)
+            and not self._proposal._custom_pre_weight
+            and self._resampler_kind() is not None
+            and self.record_states is False
+            and not self._record_intermediary
+            and hasattr(self._model.hidden, "init_mean")
+        )
+
+    def batch_filter(self, y, bar=True, init_state=None) -> FilterResult:
+        assert self._model is not None, "Model has not been initialized!"
+        device, _ = self._device_dtype()
+        if not self._fused_capable(device) or not isinstance(y, torch.Tensor):
+            return super().batch_filter(y, bar=bar, init_state=init_state)
+        return self._batch_filter_fused(y, init_state)
+
+    def _batch_filter_fused(self, y: torch.Tensor, init_state=None) -> FilterResult:
+        state = init_state or self.initialize()
+        if self._ctx is None:  # init_state supplied before any initialize()
+            self._proposal.set_model(self.ssm)
+            self._ctx = self._build_context(*self._device_dtype())
+            self._proposal._set_context(self._ctx)
+        ctx = self._ctx
+        kind = ctx.kind
+        x0 = state.timeseries_state.value
+        device, dtype = x0.device, x0.dtype
+        n = self._base_particles[0]
+        b = self.batch_shape[0] if self._batched else 1
+        d, o = kind.dim, kind.obs_dim
+
+        result = self.initialize_with_result(state)
+        t_obs = y.shape[0]
+        if t_obs == 0:
+            return result
+
+        # ---- step schedule: observe_every_step > 1 inserts propagate-only sub-steps (filters/base.py:204-210) ----
+        oes = int(self._model.observe_every_step)
+        t_start = int(state.timeseries_state.time_index)
+        y_dev = y.to(device=device, dtype=dtype).reshape(t_obs, -1, o)
+        if y_dev.shape[1] not in (1, b):
+            raise L.PfAmdError(f"observations of shape {tuple(y.shape)} do not broadcast against batch {b}")
+        rows = y_dev.shape[1]
+        y_nan = y_dev.isnan().reshape(t_obs, -1).all(dim=1)
+        if oes == 1:
+            steps = t_obs
+            y_steps = y_dev
+            observed = (~y_nan).to(torch.uint8)
+            obs_rows = torch.arange(1, steps + 1, device=device)
+        else:
+            sched, t = [], t_start
+            for k in range(t_obs):
+                while t % oes != 0:
+                    sched.append(-1)
+                    t += 1
+                sched.append(k)
+                t += 1
+            steps = len(sched)
+            sched_t = torch.tensor(sched, device=device)
+            y_steps = torch.full((steps, rows, o), float("nan"), device=device, dtype=dtype)
+            is_obs = sched_t >= 0
+            y_steps[is_obs] = y_dev
+            observed = torch.zeros(steps, dtype=torch.uint8, device=device)
+            observed[is_obs] = (~y_nan).to(torch.uint8)
+            obs_rows = torch.nonzero(is_obs).reshape(-1) + 1
+        y_steps = y_steps.contiguous()
+
+        # ---- buffers --------------------------------------------------------------------------------------------
+        x_a = ops.to_soa(x0, self._batched, self._has_event).clone()
+        x_b = torch.empty_like(x_a)
+        lw_a = ops.to_cols(state.weights).clone()
+        lw_b = torch.empty_like(lw_a)
+        anc = ops.to_cols(state.previous_indices.to(torch.int32)).contiguous().clone()
+        cdf = torch.empty_like(lw_a)
+        means = torch.empty((steps + 1, b, d), device=device, dtype=dtype)
+        variances = torch.empty_like(means)
+        ll_steps = torch.zeros((steps, b), device=device, dtype=dtype)
+        ll_total = torch.zeros(b, device=device, dtype=dtype)
+        ctr = torch.zeros(4, device=device, dtype=torch.int32)
+        ws = L.new_workspace(n, b, device)
+
+        a = L.PfFilterArgs()
+        a.model = ops.make_model_struct(kind, ctx.params)
+        a.filter, a.proposal, a.resampler = self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL, self._resampler_kind()
+        a.dtype = L.dtype_code(dtype)
+        a.N, a.B = n, b
+        a.ess_threshold = float(self._resample_threshold) / float(n)
+        a.seed = self._seed
+        a.x[0], a.x[1] = x_a.data_ptr(), x_b.data_ptr()
+        a.logw[0], a.logw[1] = lw_a.data_ptr(), lw_b.data_ptr()
+        a.anc, a.cdf = anc.data_ptr(), cdf.data_ptr()
+        a.y, a.y_rows, a.observed = y_steps.data_ptr(), rows, observed.data_ptr()
+        z_tape = u_tape = None
+        if ctx.z_tape is not None:
+            z_tape = ctx.z_tape[t_start:t_start + steps].contiguous()
+            assert z_tape.shape[0] == steps, "z tape shorter than the number of steps"
+        if ctx.u_tape is not None:
+            u_tape = ctx.u_tape[t_start:t_start + steps].contiguous()
+        a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)
+        a.means, a.vars = means.data_ptr(), variances.data_ptr()
+        a.ll_steps, a.ll_total = ll_steps.data_ptr(), ll_total.data_ptr()
+        a.step_counter = ctr.data_ptr()
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+
+        # NB the kernels index tapes / observations by the *local* step 0..steps-1 and draw Philox numbers by it too
+        if getattr(self, "_time_kernels", False):
+            kms = (C.c_float * 3)()
+            L.check(L.load().pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")
+            self.kernel_ms = tuple(kms)
+        else:
+            L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
+        self._last_run = dict(x=(x_a, x_b), logw=(lw_a, lw_b), anc=anc, cdf=cdf, y=y_steps, observed=observed,
+                              z=z_tape, u=u_tape, ctr=ctr, ws=ws, ll_steps=ll_steps)  # keep device buffers alive
+
+        # ---- hand the results over in the reference's shapes -------------------------------------------------------
+        x_fin, lw_fin = (x_a, lw_a) if steps % 2 == 0 else (x_b, lw_b)
+        final_x = TimeseriesState(t_start + steps, ops.from_soa(x_fin, self._batched, self._has_event),
+                                  self._model.hidden.event_shape)
+        shape_md = (lambda t: t if self._batched else t[:, 0])
+        means_v, vars_v = shape_md(means), shape_md(variances)
+        ll_last = ll_steps[-1] if self._batched else ll_steps[-1, 0]
+        last = ParticleFilterCorrection(
+            final_x, ops.from_cols(lw_fin, self._batched), ll_last, ops.from_cols(anc, self._batched).long(),
+            _moments=(means_v[-1], vars_v[-1]),
+        )
+        sel = obs_rows
+        result._extend_fused(means_v[sel], vars_v[sel], ll_total if self._batched else ll_total[0], last)
+        return result

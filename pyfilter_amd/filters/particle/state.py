@@ -1,0 +1,117 @@
+"""State objects of the particle filters (``pyfilter/filters/particle/state.py:14-211``).
+
+Tensors are exposed in the reference's layout - particles on dim 0, optional batch on dim 1, optional state dim last -
+as *views* of the library's ``(B, N)`` / ``(D, B, N)`` buffers.  Ancestors are int64 at this API like the
+reference's (``searchsorted`` output), int32 inside the kernels.
+"""
+from collections import OrderedDict
+from typing import Any, Dict, Optional
+
+import torch
+from torch import Tensor
+
+from ...timeseries import StateSpaceModel, TimeseriesState
+from ...utils import normalize
+from ..state import Correction, Prediction
+from .utils import get_filter_mean_and_variance
+
+
+class ParticleFilterPrediction(Prediction):
+    def __init__(self, prev_x: TimeseriesState, weights: Tensor, normalized_weights: Tensor, indices: Tensor):
+        self.prev_x = prev_x
+        self.weights = weights
+        self.normalized_weights = normalized_weights
+        self.indices = indices
+
+    def get_timeseries_state(self) -> TimeseriesState:
+        return self.prev_x
+
+    def create_state_from_prediction(self, model: StateSpaceModel, propagate=None):
+        """Propagate-only move for an unobserved step / NaN observation: weights carried, ``ll = 0`` (:38-42)."""
+        x_new = propagate(self.prev_x) if propagate is not None else model.hidden.propagate(self.prev_x)
+        new_ll = torch.zeros(self.normalized_weights.shape[1:], device=self.weights.device, dtype=self.weights.dtype)
+        return ParticleFilterCorrection(x_new, self.weights, new_ll, self.indices)
+
+
+class ParticleFilterCorrection(Correction):
+    def __init__(self, x: TimeseriesState, w: Tensor, ll: Tensor, prev_indices: Tensor, _moments=None):
+        super().__init__()
+        self["_x"] = x
+        self["_w"] = w
+        self["_ll"] = ll
+        self["_prev_inds"] = prev_indices
+        if _moments is None:  # the fused path hands over the moments its kernels already reduced
+            _moments = get_filter_mean_and_variance(x, self.normalized_weights())
+        self["_mean"], self["_var"] = _moments
+
+    @property
+    def timeseries_state(self) -> TimeseriesState:
+        return self["_x"]
+
+    @property
+    def weights(self) -> Tensor:
+        return self["_w"]
+
+    @property
+    def previous_indices(self) -> Tensor:
+        return self["_prev_inds"]
+
+    def get_loglikelihood(self) -> Tensor:
+        return self["_ll"]
+
+    def get_mean(self) -> Tensor:
+        return self["_mean"]
+
+    def get_variance(self) -> Tensor:
+        return self["_var"]
+
+    def get_covariance(self) -> Tensor:
+        if len(self.timeseries_state.event_shape) == 0:
+            return self.get_variance()
+        w = self.normalized_weights()
+        x = self.timeseries_state.value
+        mean = (w.unsqueeze(-1) * x).sum(dim=0)
+        c = x - mean
+        return (w.view(w.shape + (1, 1)) * (c.unsqueeze(-1) @ c.unsqueeze(-2))).sum(dim=0)
+
+    def normalized_weights(self) -> Tensor:
+        """``normalize(self.weights)`` - sanitises the stored log-weights in place, as the reference does."""
+        return normalize(self.weights)
+
+    def get_timeseries_state(self) -> TimeseriesState:
+        return self.timeseries_state
+
+    def resample(self, indices: Tensor):
+        """Gather whole filters along the batch dim (``:150-158``)."""
+        ts = self.timeseries_state
+        self["_x"] = ts.copy(values=ts.value[:, indices])
+        self["_w"] = self.weights[:, indices]
+        self["_ll"][indices] = self["_ll"][indices]
+        self["_prev_inds"] = self["_prev_inds"][:, indices]
+        self["_mean"] = self["_mean"][indices]
+        self["_var"] = self["_var"][indices]
+
+    def exchange(self, other: "ParticleFilterCorrection", mask: Tensor):
+        self["_x"].value[:, mask] = other.timeseries_state.value[:, mask]
+        self["_w"][:, mask] = other.weights[:, mask]
+        self["_ll"][mask] = other.get_loglikelihood()[mask]
+        self["_prev_inds"][:, mask] = other.previous_indices[:, mask]
+        self["_mean"][mask] = other["_mean"][mask]
+        self["_var"][mask] = other["_var"][mask]
+
+    def state_dict(self) -> Dict[str, Any]:
+        result = OrderedDict((k, v) for k, v in self.items() if isinstance(v, torch.Tensor))
+        result["_x"] = {"time_index": self.timeseries_state.time_index, "value": self.timeseries_state.value}
+        return result
+
+    def load_state_dict(self, state_dict: Dict[str, Any]):
+        values = state_dict["_x"]["value"]
+        mine = self.timeseries_state
+        assert mine.value.shape == values.shape, f"shape mismatch: {mine.value.shape} != {values.shape}"
+        self["_x"] = mine.propagate_from(values=values, time_increment=-mine.time_index + state_dict["_x"]["time_index"])
+        for k in ("_w", "_ll", "_prev_inds", "_mean", "_var"):
+            self[k] = state_dict[k]
+
+    def __repr__(self):
+        ts = self.timeseries_state
+        return f"{self.__class__.__name__}(time_index: {ts.time_index}, event_shape: {ts.event_shape})"

@@ -1,0 +1,226 @@
+"""
+Thin python wrappers over the C ABI working on the library's *internal* layouts:
+
+* ``cols``: ``(B, N)`` contiguous - one row per filter of the batch dim ("column" in the kernels' vocabulary);
+* ``soa`` : ``(D, B, N)`` contiguous - the particle ensemble, one plane per state component.
+
+The reference-layout API (``(N, [B], [D])``, particles first: pyfilter/filters/particle/base.py:51-62) lives in
+``pyfilter_amd.utils`` / ``resampling`` / ``filters`` and hands *views* of these buffers to the user.
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# layout helpers (views where possible, copies only for foreign layouts)
+# ----------------------------------------------------------------------------------------------------------------
+def to_cols(w: torch.Tensor) -> torch.Tensor:
+    """``(N,)`` or ``(N, B)`` -> ``(B, N)`` contiguous (no copy if ``w`` already is a view of such a buffer)."""
+    if w.dim() == 1:
+        return w.contiguous().unsqueeze(0)
+    if w.dim() != 2:
+        raise L.PfAmdError("weights must be (N,) or (N, B): nested batches are not supported (filters/base.py:116-119)")
+    return w.t().contiguous()
+
+
+def from_cols(c: torch.Tensor, batched: bool) -> torch.Tensor:
+    """``(B, N)`` -> the reference's ``(N, B)`` view, or ``(N,)`` when unbatched."""
+    return c.t() if batched else c[0]
+
+
+def to_soa(x: torch.Tensor, batched: bool, has_event: bool) -> torch.Tensor:
+    """``(N, [B], [D])`` -> ``(D, B, N)`` contiguous."""
+    if not has_event:
+        x = x.unsqueeze(-1)
+    if not batched:
+        x = x.unsqueeze(1)
+    return x.permute(2, 1, 0).contiguous()
+
+
+def from_soa(s: torch.Tensor, batched: bool, has_event: bool) -> torch.Tensor:
+    """``(D, B, N)`` -> the reference's ``(N, [B], [D])`` view."""
+    v = s.permute(2, 1, 0)
+    if not batched:
+        v = v[:, 0]
+    if not has_event:
+        v = v[..., 0]
+    return v
+
+
+def _mask_ptr(colmask: Optional[torch.Tensor]):
+    if colmask is None:
+        return None
+    assert colmask.dtype in (torch.uint8, torch.bool) and colmask.is_contiguous()
+    return colmask.data_ptr()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------------------------------------
+def normalize_cols(logw: torch.Tensor, want_w=True, want_lse=False, want_ess=False):
+    """pf_normalize on a ``(B, N)`` buffer (sanitised in place).  Returns (W|None, lse|None, ess|None)."""
+    L.require_gpu(logw)
+    b, n = logw.shape
+    W = torch.empty_like(logw) if want_w else None
+    lse = torch.empty(b, dtype=logw.dtype, device=logw.device) if want_lse else None
+    ess = torch.empty(b, dtype=logw.dtype, device=logw.device) if want_ess else None
+    ws = L.workspace(n, b, logw.device)
+    L.check(
+        L.load().pf_normalize(L.ptr(logw), L.ptr(W), L.ptr(lse), L.ptr(ess), n, b, L.dtype_code(logw.dtype),
+                              ws.data_ptr(), ws.numel(), L.stream_ptr()),
+        "pf_normalize",
+    )
+    return W, lse, ess
+
+
+def systematic_cols(w: torch.Tensor, u: torch.Tensor, normalized: bool, colmask: Optional[torch.Tensor] = None,
+                    idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Systematic resampling of ``(B, N)`` weights (``normalized``) or log-weights; returns int32 ``(B, N)``."""
+    L.require_gpu(w, u)
+    b, n = w.shape
+    per_elem = 1 if (u.dim() == 2 and u.shape == (b, n) and n > 1) else 0
+    u = (u if per_elem else u.reshape(-1)).to(w.dtype).contiguous()
+    assert per_elem or u.numel() == b, f"u must hold one uniform per column: {u.numel()} != {b}"
+    if idx is None:
+        idx = torch.empty((b, n), dtype=torch.int32, device=w.device)
+        if colmask is not None:
+            idx.copy_(torch.arange(n, device=w.device, dtype=torch.int32).unsqueeze(0).expand(b, n))
+    cdf = torch.empty_like(w)
+    ws = L.workspace(n, b, w.device)
+    fn = L.load().pf_systematic if normalized else L.load().pf_systematic_logw
+    L.check(
+        fn(L.ptr(w), L.ptr(u), per_elem, _mask_ptr(colmask), L.ptr(cdf), L.ptr(idx), n, b, L.dtype_code(w.dtype),
+           ws.data_ptr(), ws.numel(), L.stream_ptr()),
+        "pf_systematic",
+    )
+    return idx
+
+
+def multinomial_cols(W: torch.Tensor, seed: int, step: int = 0, v: Optional[torch.Tensor] = None,
+                     colmask: Optional[torch.Tensor] = None, idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    L.require_gpu(W, v)
+    b, n = W.shape
+    if idx is None:
+        idx = torch.empty((b, n), dtype=torch.int32, device=W.device)
+        if colmask is not None:
+            idx.copy_(torch.arange(n, device=W.device, dtype=torch.int32).unsqueeze(0).expand(b, n))
+    cdf = torch.empty_like(W)
+    ws = L.workspace(n, b, W.device)
+    L.check(
+        L.load().pf_multinomial(L.ptr(W), L.ptr(v), seed, step, _mask_ptr(colmask), L.ptr(cdf), L.ptr(idx), n, b,
+                                L.dtype_code(W.dtype), ws.data_ptr(), ws.numel(), L.stream_ptr()),
+        "pf_multinomial",
+    )
+    return idx
+
+
+def gather_soa(x: torch.Tensor, idx: torch.Tensor, colmask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[d, b, i] = x[d, b, idx[b, i]]`` (columns with ``colmask == 0`` copied through)."""
+    L.require_gpu(x, idx)
+    d, b, n = x.shape
+    assert idx.dtype == torch.int32 and idx.shape == (b, n) and idx.is_contiguous()
+    out = torch.empty_like(x)
+    L.check(
+        L.load().pf_gather(L.ptr(x), L.ptr(idx), _mask_ptr(colmask), L.ptr(out), n, b, d, L.dtype_code(x.dtype),
+                           L.stream_ptr()),
+        "pf_gather",
+    )
+    return out
+
+
+def loglik_cols(v: torch.Tensor, W: Optional[torch.Tensor]) -> torch.Tensor:
+    L.require_gpu(v, W)
+    b, n = v.shape
+    out = torch.empty(b, dtype=v.dtype, device=v.device)
+    ws = L.workspace(n, b, v.device)
+    L.check(
+        L.load().pf_loglik(L.ptr(v), L.ptr(W), L.ptr(out), n, b, L.dtype_code(v.dtype), ws.data_ptr(), ws.numel(),
+                           L.stream_ptr()),
+        "pf_loglik",
+    )
+    return out
+
+
+def moments_soa(x: torch.Tensor, W: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Weighted mean / variance per column: returns ``(B, D)`` tensors."""
+    L.require_gpu(x, W)
+    d, b, n = x.shape
+    mean = torch.empty((b, d), dtype=x.dtype, device=x.device)
+    var = torch.empty((b, d), dtype=x.dtype, device=x.device)
+    ws = L.workspace(n, b, x.device)
+    L.check(
+        L.load().pf_moments(L.ptr(x), L.ptr(W), L.ptr(mean), L.ptr(var), n, b, d, L.dtype_code(x.dtype),
+                            ws.data_ptr(), ws.numel(), L.stream_ptr()),
+        "pf_moments",
+    )
+    return mean, var
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# built-in model kernels
+# ----------------------------------------------------------------------------------------------------------------
+def make_model_struct(kind, params: torch.Tensor) -> L.PfModel:
+    m = L.PfModel()
+    m.hid_kind, m.obs_kind, m.dim, m.obs_dim = kind.hid_kind, kind.obs_kind, kind.dim, kind.obs_dim
+    m.dt, m.inc_scale = float(kind.dt), float(kind.inc_scale)
+    m.params = params.data_ptr()
+    return m
+
+
+def _y_rows(y: torch.Tensor, b: int, obs_dim: int) -> Tuple[torch.Tensor, int]:
+    """Canonical ``(rows, O)`` device layout of one observation: rows = 1 (shared) or B (one series per filter)."""
+    yy = y.reshape(-1, obs_dim) if y.numel() != obs_dim else y.reshape(1, obs_dim)
+    if yy.shape[0] not in (1, b):
+        raise L.PfAmdError(f"observation of shape {tuple(y.shape)} does not broadcast against batch {b}")
+    return yy.contiguous(), yy.shape[0]
+
+
+def pre_weight_soa(kind, params, proposal: int, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    L.require_gpu(x, y, params)
+    d, b, n = x.shape
+    yy, rows = _y_rows(y.to(x.dtype), b, kind.obs_dim)
+    out = torch.empty((b, n), dtype=x.dtype, device=x.device)
+    m = make_model_struct(kind, params)
+    L.check(
+        L.load().pf_pre_weight(C.byref(m), proposal, L.ptr(x), L.ptr(yy), rows, L.ptr(out), n, b,
+                               L.dtype_code(x.dtype), L.stream_ptr()),
+        "pf_pre_weight",
+    )
+    return out
+
+
+def sample_and_weight_soa(kind, params, proposal: int, x: torch.Tensor, y: Optional[torch.Tensor],
+                          z: Optional[torch.Tensor], seed: int, step: int, weigh: bool = True):
+    L.require_gpu(x, y, z, params)
+    d, b, n = x.shape
+    x_out = torch.empty_like(x)
+    w_out = torch.empty((b, n), dtype=x.dtype, device=x.device) if weigh else None
+    yy, rows = (None, 1)
+    if weigh:
+        yy, rows = _y_rows(y.to(x.dtype), b, kind.obs_dim)
+    if z is not None:
+        assert z.shape == x.shape and z.is_contiguous() and z.dtype == x.dtype
+    m = make_model_struct(kind, params)
+    L.check(
+        L.load().pf_sample_and_weight(C.byref(m), proposal, 1 if weigh else 0, L.ptr(x), L.ptr(yy), rows, L.ptr(z),
+                                      seed, step, L.ptr(x_out), L.ptr(w_out), n, b, L.dtype_code(x.dtype),
+                                      L.stream_ptr()),
+        "pf_sample_and_weight",
+    )
+    return x_out, w_out
+
+
+def initial_sample_soa(m0, s0, n: int, b: int, d: int, dtype, device, seed: int, z: Optional[torch.Tensor] = None):
+    x = torch.empty((d, b, n), dtype=dtype, device=device)
+    L.require_gpu(x, z)
+    am = (C.c_double * d)(*[float(v) for v in m0])
+    asd = (C.c_double * d)(*[float(v) for v in s0])
+    L.check(
+        L.load().pf_initial_sample(am, asd, L.ptr(z), seed, L.ptr(x), n, b, d, L.dtype_code(dtype), L.stream_ptr()),
+        "pf_initial_sample",
+    )
+    return x

@@ -1,0 +1,229 @@
+"""
+Host-side mirror of the slice of ``stochproc.timeseries`` (v0.3.0, an external dependency of the reference:
+``/root/reference/pyproject.toml:34``) that pyfilter's SISR/APF hot path touches - SURVEY.md §8(a) row M:
+
+``TimeseriesState``, ``StructuralStochasticProcess``, ``AffineProcess``, ``AffineEulerMaruyama``, ``StateSpaceModel``,
+``LinearStateSpaceModel`` with the members ``mean_scale / build_density / propagate / initial_sample / n_dim /
+event_shape / parameters / observe_every_step``.
+
+Two ways to define a model:
+
+* **built-in kinds** (``pyfilter_amd.timeseries.models``): closed-form processes whose arithmetic lives in the HIP
+  kernels (``csrc/pf_models.hpp``) - these run the fused three-kernel step;
+* **user callables** (exactly the reference's way, README.md:44-67): ``mean_scale`` / observation builders are python
+  callables evaluated with PyTorch-ROCm ops on the device; normalise / scan / search / gather / moments still run in
+  the HIP kernels.
+"""
+from math import sqrt
+from typing import Callable, Optional, Sequence
+
+import torch
+from torch.distributions import AffineTransform, Distribution, Independent, Normal, TransformedDistribution
+
+from .. import _lib as L
+
+
+def _as_tensor(p, device=None, dtype=None) -> torch.Tensor:
+    if isinstance(p, torch.Tensor):
+        return p
+    return torch.as_tensor(p, dtype=dtype or torch.get_default_dtype(), device=device)
+
+
+class TimeseriesState(dict):
+    """State of a timeseries: time index + values (possibly a lazily evaluated sampler, as pyfilter passes
+    ``density.sample``: proposals/linear.py:53)."""
+
+    def __init__(self, time_index, values, event_shape: torch.Size):
+        super().__init__()
+        self.time_index = time_index if isinstance(time_index, torch.Tensor) else torch.tensor(time_index)
+        self._values = values
+        self.event_shape = torch.Size(event_shape)
+
+    @property
+    def value(self) -> torch.Tensor:
+        if callable(self._values):
+            self._values = self._values()
+        return self._values
+
+    @value.setter
+    def value(self, v):
+        self._values = v
+
+    @property
+    def batch_shape(self) -> torch.Size:
+        v = self.value
+        return v.shape[: v.dim() - len(self.event_shape)]
+
+    def copy(self, values) -> "TimeseriesState":
+        return TimeseriesState(self.time_index, values, self.event_shape)
+
+    def propagate_from(self, values, time_increment=1) -> "TimeseriesState":
+        return TimeseriesState(self.time_index + time_increment, values, self.event_shape)
+
+
+class KernelKind:
+    """The ``kernel_id`` of a built-in model: everything ``csrc/pf_models.hpp`` needs (see ``pf_model`` in
+    ``include/pf_amd.h``)."""
+
+    def __init__(self, hid_kind: int, dim: int, dt: float, inc_scale: float):
+        self.hid_kind = hid_kind
+        self.dim = max(dim, 1)
+        self.dt = dt
+        self.inc_scale = inc_scale
+        self.obs_kind = None
+        self.obs_dim = None
+
+
+class StructuralStochasticProcess:
+    def __init__(self, parameters: Sequence, initial_kernel: Callable[..., Distribution], initial_parameters=None):
+        self.parameters = tuple(_as_tensor(p) for p in parameters)
+        self._initial_kernel = initial_kernel
+        self._initial_parameters = None if initial_parameters is None else tuple(_as_tensor(p) for p in initial_parameters)
+        self._event_shape = None
+
+    @property
+    def device(self) -> torch.device:
+        for p in self.parameters:
+            if p.is_cuda:
+                return p.device
+        return torch.device("cpu")
+
+    @property
+    def initial_distribution(self) -> Distribution:
+        return self._initial_kernel(*(self._initial_parameters or self.parameters))
+
+    @property
+    def event_shape(self) -> torch.Size:
+        if self._event_shape is None:
+            self._event_shape = self.initial_distribution.event_shape
+        return self._event_shape
+
+    @property
+    def n_dim(self) -> int:
+        return len(self.event_shape)
+
+    def initial_sample(self, shape=torch.Size([])) -> TimeseriesState:
+        return TimeseriesState(0, self.initial_distribution.sample(torch.Size(shape)), self.event_shape)
+
+    def build_density(self, x: TimeseriesState) -> Distribution:
+        raise NotImplementedError()
+
+    def propagate(self, x: TimeseriesState, time_increment=1) -> TimeseriesState:
+        return x.propagate_from(values=self.build_density(x).sample, time_increment=time_increment)
+
+    def to(self, device):
+        self.parameters = tuple(p.to(device) for p in self.parameters)
+        if self._initial_parameters is not None:
+            self._initial_parameters = tuple(p.to(device) for p in self._initial_parameters)
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+
+class AffineProcess(StructuralStochasticProcess):
+    """``x' = loc(x) + scale(x) * eps`` with ``(loc, scale) = mean_scale(x, *parameters)`` and ``eps`` drawn from
+    ``increment_distribution``."""
+
+    kernel_kind: Optional[KernelKind] = None
+
+    def __init__(self, mean_scale, parameters, increment_distribution, initial_kernel, initial_parameters=None):
+        super().__init__(parameters, initial_kernel, initial_parameters)
+        self._mean_scale = mean_scale
+        self.increment_distribution = increment_distribution
+
+    def mean_scale(self, x: TimeseriesState, parameters=None):
+        loc, scale = self._mean_scale(x, *(parameters or self.parameters))
+        return torch.broadcast_tensors(loc, _as_tensor(scale, device=loc.device, dtype=loc.dtype))
+
+    def build_density(self, x: TimeseriesState) -> Distribution:
+        loc, scale = self.mean_scale(x)
+        return TransformedDistribution(
+            self.increment_distribution, AffineTransform(loc, scale, event_dim=self.n_dim), validate_args=False
+        )
+
+    def to(self, device):
+        super().to(device)
+        inc = self.increment_distribution
+        base = inc.base_dist if isinstance(inc, Independent) else inc
+        if isinstance(base, Normal):
+            nb = Normal(base.loc.to(device), base.scale.to(device), validate_args=False)
+            self.increment_distribution = Independent(nb, inc.reinterpreted_batch_ndims) if isinstance(inc, Independent) else nb
+        return self
+
+
+class AffineEulerMaruyama(AffineProcess):
+    """Euler-Maruyama discretisation ``loc = x + f(x) dt``, ``scale = g(x)`` (README.md:44-62)."""
+
+    def __init__(self, dynamics, parameters, increment_distribution, dt, initial_kernel, initial_parameters=None):
+        self.dt = dt
+
+        def _ms(x, *params):
+            f, g = dynamics(x, *params)
+            return x.value + f * dt, g
+
+        super().__init__(_ms, parameters, increment_distribution, initial_kernel, initial_parameters)
+
+
+class StateSpaceModel:
+    """Hidden process + observation density builder ``f(x, *parameters) -> Distribution``."""
+
+    def __init__(self, hidden: StructuralStochasticProcess, f, parameters, observe_every_step: int = 1):
+        self.hidden = hidden
+        self._f = f
+        self.parameters = tuple(_as_tensor(p) for p in parameters)
+        self.observe_every_step = observe_every_step
+        self._event_shape = None
+        self.kernel_kind: Optional[KernelKind] = None
+
+    def build_density(self, x: TimeseriesState) -> Distribution:
+        return self._f(x, *self.parameters)
+
+    @property
+    def event_shape(self) -> torch.Size:
+        if self._event_shape is None:
+            self._event_shape = self.build_density(self.hidden.initial_sample()).event_shape
+        return self._event_shape
+
+    @property
+    def n_dim(self) -> int:
+        return len(self.event_shape)
+
+    def to(self, device):
+        self.hidden.to(device)
+        self.parameters = tuple(p.to(device) for p in self.parameters)
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+
+class LinearStateSpaceModel(StateSpaceModel):
+    """``y = b + A x + s v``; parameters ``(a, s)`` or ``(a, b, s)`` (normalised to ``(a, b, s)`` as
+    proposals/linear.py:48 expects)."""
+
+    def __init__(self, hidden, parameters, event_shape: torch.Size = torch.Size([]), observe_every_step: int = 1):
+        parameters = tuple(_as_tensor(p) for p in parameters)
+        if len(parameters) == 2:
+            a, s = parameters
+            parameters = (a, torch.zeros_like(s), s)
+        obs_event = torch.Size(event_shape)
+        hidden_is_1d = hidden.n_dim == 0
+
+        def _f(x, a, b, s):
+            loc = b + a * x.value if hidden_is_1d else b + (a @ x.value.unsqueeze(-1)).squeeze(-1)
+            d = Normal(loc, s, validate_args=False)
+            return Independent(d, 1) if len(obs_event) == 1 else d
+
+        super().__init__(hidden, _f, parameters, observe_every_step)
+        self._event_shape = obs_event
+        hk = getattr(hidden, "kernel_kind", None)
+        if hk is not None:
+            o = obs_event.numel() if len(obs_event) else 1
+            if hk.dim <= L.MAX_D and o <= L.MAX_O and (hk.dim > 1 or o == 1):
+                kind = KernelKind(hk.hid_kind, hk.dim, hk.dt, hk.inc_scale)
+                kind.obs_kind, kind.obs_dim = L.OBS_LINEAR, o
+                self.kernel_kind = kind
+
+
+from . import models  # noqa: E402,F401

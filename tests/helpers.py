@@ -1,0 +1,63 @@
+"""Shared test helpers: golden-fixture loading and construction of ``pyfilter_amd`` filters from the case table."""
+import math
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DT = {"f64": torch.float64, "f32": torch.float32}
+
+
+def load_golden(name, dt):
+    with np.load(os.path.join(GOLDEN, f"{name}_{dt}.npz")) as f:
+        return {k: torch.from_numpy(f[k]) for k in f.files}
+
+
+def build_ssm_from_case(case, dtype, device):
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.timeseries import models
+
+    b = case["B"]
+    t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
+    m = case["model"]
+    if m == "lg1d":
+        hidden = models.AR(t(0.0), t(0.99), t(0.05), initial=(t(0.0), t(0.05)))
+        ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.15)))
+    elif m == "sine":
+        hidden = models.SineDiffusion(t(0.0), t(1.0), dt=0.1)
+        ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.1)))
+    elif m == "sv_batched":
+        kappa = t([0.05 + 0.01 * i for i in range(b)])
+        gamma = t([1.0 + 0.1 * i for i in range(b)])
+        sigma = t([0.10 + 0.02 * i for i in range(b)])
+        mu = t([0.0 + 0.05 * i for i in range(b)])
+        hidden = models.Verhulst(kappa, gamma, sigma, dt=0.2, initial=(t(1.0), t(0.1)))
+        ssm = models.StochasticVolatilityModel(hidden, mu)
+    elif m == "lorenz":
+        hidden = models.Lorenz63(t(10.0), t(28.0), t(8.0 / 3.0), t(1.0), dt=0.01,
+                                 initial_mean=t([-5.91652, -5.52332, 24.5723]), initial_scale=t([math.sqrt(10.0)] * 3))
+        a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]])
+        ssm = ts.LinearStateSpaceModel(hidden, (a, t([0.0]), t([math.sqrt(0.1)])), torch.Size([2]))
+    elif m == "ou_batched":
+        kappa = t([0.025 * (i + 1) for i in range(b)])
+        gamma = t([0.0 + 0.1 * i for i in range(b)])
+        sigma = t([0.05 + 0.01 * i for i in range(b)])
+        hidden = models.OrnsteinUhlenbeck(kappa, gamma, sigma, dt=1.0, initial=(t(0.0), t(0.1)))
+        ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.05)))
+    else:
+        raise KeyError(m)
+    return ssm.to(device)
+
+
+def build_filter_from_case(case, g, dtype, device, tape=True, **kwargs):
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+
+    ssm = build_ssm_from_case(case, dtype, device)
+    prop = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[case["proposal"]]()
+    cls = {"sisr": SISR, "apf": APF}[case["filter"]]
+    filt = cls(ssm, case["N"], proposal=prop, ess_threshold=case["ess_threshold"], **kwargs)
+    filt.set_batch_shape(torch.Size([case["B"]]))
+    if tape:
+        filt.set_tape(z=g["z_tape"].to(dtype), u=g["u_tape"].to(dtype), z0=g["z0"].to(dtype))
+    return filt

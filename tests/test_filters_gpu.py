@@ -1,0 +1,208 @@
+"""GPU parity tests of the SISR / APF filters (fused ``batch_filter`` and the step-by-step route) against golden
+vectors of the unmodified reference on identical draws (tape mode), through ``libpfamd.so``.
+
+Tolerances: float64 runs - filter_means / variances / log-likelihood within 1e-9 relative of the reference's float64
+path (the north-star bar is 1e-5) and **identical ancestors**; float32 runs - within 2e-4 (the reference's own fp32
+path is only that close to exact arithmetic: BASELINE.md §2)."""
+import math
+
+import pytest
+import torch
+
+from oracle import cpu_ref
+from oracle.cases import CASES, build_spec
+from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = [(c["name"], d) for c in CASES for d in c["dtypes"]]
+
+
+def _tols(dt):
+    return dict(rtol=1e-9, atol=1e-11) if dt == "f64" else dict(rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,dt", PARAMS)
+def test_fused_batch_filter_matches_reference(name, dt):
+    case = next(c for c in CASES if c["name"] == name)
+    g = load_golden(name, dt)
+    filt = build_filter_from_case(case, g, DT[dt], "cuda")
+    res = filt.batch_filter(g["y"].cuda(), bar=False)
+    tol = _tols(dt)
+    torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
+    torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=tol["rtol"] * 10, atol=tol["atol"])
+    torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], **tol)
+    last = res.latest_state
+    if dt == "f64":
+        assert torch.equal(last.previous_indices.cpu(), g["step_idx"][-1]), "final ancestors differ"
+        torch.testing.assert_close(last.timeseries_state.value.cpu(), g["step_x"][-1], **tol)
+        torch.testing.assert_close(last.weights.cpu(), g["step_w"][-1], equal_nan=True, **tol)
+        torch.testing.assert_close(last.get_loglikelihood().cpu(), g["step_ll"][-1], **tol)
+    assert res.filter_means.shape == g["filter_means"].shape
+
+
+@pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f64"])
+def test_step_by_step_route_matches_reference(name, dt):
+    """predict()/correct() through the stand-alone primitives: every step's state, ancestors and ll."""
+    case = next(c for c in CASES if c["name"] == name)
+    g = load_golden(name, dt)
+    filt = build_filter_from_case(case, g, DT[dt], "cuda")
+    state = filt.initialize()
+    result = filt.initialize_with_result(state)
+    tol = _tols(dt)
+    torch.testing.assert_close(state.timeseries_state.value.cpu(), g["x0"], **tol)
+    y = g["y"].cuda()
+    for t in range(y.shape[0]):
+        state = filt.filter(y[t], state, result=result)
+        assert torch.equal(state.previous_indices.cpu(), g["step_idx"][t]), f"ancestors differ at step {t}"
+        torch.testing.assert_close(state.timeseries_state.value.cpu(), g["step_x"][t], **tol)
+        torch.testing.assert_close(state.weights.cpu(), g["step_w"][t], equal_nan=True, **tol)
+        torch.testing.assert_close(state.get_loglikelihood().cpu(), g["step_ll"][t], **tol)
+    torch.testing.assert_close(result.filter_means.cpu(), g["filter_means"], **tol)
+    torch.testing.assert_close(result.loglikelihood.cpu(), g["loglikelihood"], **tol)
+
+
+@pytest.mark.parametrize("filt_name,prop", [("apf", "lgo"), ("sisr", "bootstrap"), ("apf", "bootstrap"), ("sisr", "lgo")])
+def test_unbatched_equals_batch_of_one(filt_name, prop):
+    """batch_shape = [] (1-D weights) gives the same numbers as batch_shape = [1]."""
+    case = dict(name="x", model="sine", filter=filt_name, proposal=prop, N=512, B=1, T=12, ess_threshold=0.6, seed=1)
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn(12, 512, 1, generator=gen, dtype=torch.float64)
+    u = torch.rand(12, 1, generator=gen, dtype=torch.float64)
+    z0 = torch.randn(512, 1, generator=gen, dtype=torch.float64)
+    y = torch.randn(12, generator=gen, dtype=torch.float64).cuda()
+    g = dict(z_tape=z, u_tape=u, z0=z0)
+    f1 = build_filter_from_case(case, g, torch.float64, "cuda")
+    r1 = f1.batch_filter(y, bar=False)
+    f0 = build_filter_from_case(case, dict(z_tape=z[:, :, 0], u_tape=u, z0=z0[:, 0]), torch.float64, "cuda")
+    f0.set_batch_shape(torch.Size([]))
+    r0 = f0.batch_filter(y, bar=False)
+    assert r0.filter_means.shape == (13, 1) and r1.filter_means.shape == (13, 1, 1)
+    torch.testing.assert_close(r0.filter_means, r1.filter_means[:, 0], rtol=0, atol=0)
+    torch.testing.assert_close(r0.loglikelihood, r1.loglikelihood[0], rtol=0, atol=0)
+    assert r0.latest_state.weights.shape == (512,)
+
+
+@pytest.mark.parametrize("filt_name,prop,resampler", [("sisr", "bootstrap", "systematic"), ("apf", "lgo", "systematic"),
+                                                      ("sisr", "bootstrap", "multinomial"), ("apf", "bootstrap", "multinomial")])
+def test_kalman_statistical_parity_philox(filt_name, prop, resampler):
+    """The reference's own acceptance test (tests/filters/test_particle.py:63-111): filter means and log-likelihood
+    within 10 % (median relative deviation) of the exact Kalman filter on the 1-D linear-Gaussian model, N=1500,
+    T=100 - here with in-kernel Philox draws, float32, 10 % missing observations."""
+    from pyfilter_amd import resampling, timeseries as ts
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    torch.manual_seed(123)
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device="cuda")  # noqa: E731
+    hidden = models.AR(t(0.0), t(0.99), t(0.05))
+    ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.15)))
+    x, ys = 0.0, []
+    g = torch.Generator().manual_seed(9)
+    x = 0.05 * torch.randn((), generator=g).item()
+    for _ in range(100):
+        x = 0.99 * x + 0.05 * torch.randn((), generator=g).item()
+        ys.append(x + 0.15 * torch.randn((), generator=g).item())
+    y = torch.tensor(ys, dtype=torch.float32)
+    y[torch.rand(100, generator=g) < 0.1] = float("nan")
+    km, kll = cpu_ref.kalman_filter_1d(y.double(), 0.0, 0.99, 0.05, 1.0, 0.0, 0.15, 0.0, 0.05 ** 2)
+
+    cls = {"sisr": SISR, "apf": APF}[filt_name]
+    p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
+    rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[resampler]
+    for batch in (torch.Size([]), torch.Size([3])):
+        filt = cls(ssm, 1500, proposal=p.copy(), resampling=rs, seed=77)
+        filt.set_batch_shape(batch)
+        res = filt.batch_filter(y.cuda(), bar=False)
+        means = res.filter_means[1:].cpu().double()
+        if batch:
+            means = means[:, 0]
+            ll = res.loglikelihood[0].item()
+        else:
+            ll = res.loglikelihood.item()
+        dev = ((means.squeeze(-1) - km) / km).abs().median().item()
+        assert dev < 0.1, dev
+        assert abs((ll - kll) / kll) < 0.1, (ll, kll)
+
+
+def test_generic_route_with_user_callables():
+    """A model defined the reference's way (python callables, README.md:44-67) runs on the GPU through the HIP
+    primitives and agrees statistically with the built-in kind of the same model."""
+    from math import sqrt
+
+    from torch.distributions import Normal
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    dev = "cuda"
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)  # noqa: E731
+    dt_ = 0.1
+
+    def f(x, gamma, sigma):
+        return torch.sin(x.value - gamma), sigma
+
+    def init(gamma, sigma):
+        return Normal(torch.zeros_like(gamma), torch.ones_like(gamma))
+
+    inc = Normal(t(0.0), t(sqrt(dt_)))
+    user = ts.AffineEulerMaruyama(f, (t(0.0), t(1.0)), inc, dt=dt_, initial_kernel=init)
+    ssm_user = ts.LinearStateSpaceModel(user, (t(1.0), t(0.1)))
+    ssm_builtin = ts.LinearStateSpaceModel(models.SineDiffusion(t(0.0), t(1.0), dt=dt_), (t(1.0), t(0.1)))
+
+    g = torch.Generator().manual_seed(4)
+    x, ys = torch.randn((), generator=g).item(), []
+    for _ in range(60):
+        x = x + math.sin(x) * dt_ + sqrt(dt_) * torch.randn((), generator=g).item()
+        ys.append(x + 0.1 * torch.randn((), generator=g).item())
+    y = torch.tensor(ys, dtype=torch.float32, device=dev)
+
+    torch.manual_seed(0)
+    for cls, prop in ((APF, proposals.LinearGaussianObservations), (SISR, proposals.Bootstrap)):
+        fu = cls(ssm_user, 4000, proposal=prop())
+        fu.set_batch_shape(torch.Size([2]))
+        ru = fu.batch_filter(y, bar=False)
+        fb = cls(ssm_builtin, 4000, proposal=prop())
+        fb.set_batch_shape(torch.Size([2]))
+        rb = fb.batch_filter(y, bar=False)
+        assert ru.filter_means.shape == rb.filter_means.shape == (61, 2, 1)
+        assert (ru.filter_means[1:] - rb.filter_means[1:]).abs().mean().item() < 0.05
+        assert (ru.loglikelihood - rb.loglikelihood).abs().max().item() < 3.0
+
+
+def test_observe_every_step_and_state_dict():
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=torch.float64, device="cuda")  # noqa: E731
+    hidden = models.SineDiffusion(t(0.0), t(1.0), dt=0.1)
+    ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.1)), observe_every_step=3)
+    y = torch.randn(8, dtype=torch.float64, device="cuda")
+    gen = torch.Generator().manual_seed(0)
+    steps = 7 * 3 + 1
+    z = torch.randn(steps, 256, 2, generator=gen, dtype=torch.float64)
+    u = torch.rand(steps, 2, generator=gen, dtype=torch.float64)
+    z0 = torch.randn(256, 2, generator=gen, dtype=torch.float64)
+
+    def run(fused):
+        filt = APF(ssm, 256, record_states=(False if fused else 1))
+        filt.set_batch_shape(torch.Size([2]))
+        filt.set_tape(z=z, u=u, z0=z0)
+        return filt, filt.batch_filter(y, bar=False)
+
+    ff, rf = run(True)
+    fg, rg = run(False)  # record_states=1 forces the step-by-step route
+    assert rf.filter_means.shape == (9, 2, 1)
+    torch.testing.assert_close(rf.filter_means, rg.filter_means, rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(rf.loglikelihood, rg.loglikelihood, rtol=1e-9, atol=1e-11)
+    assert int(rf.latest_state.timeseries_state.time_index) == steps == int(rg.latest_state.timeseries_state.time_index)
+
+    sd = rf.state_dict()
+    assert "tensor_deque_None__filter_means" in sd["tensor_tuples"] and "log_likelihood" in sd
+    assert set(sd["state"].keys()) >= {"_x", "_w", "_ll", "_prev_inds", "_mean", "_var"}
+    fresh = ff.initialize_with_result(ff.initialize())
+    fresh.load_state_dict(sd)
+    torch.testing.assert_close(fresh.filter_means, rf.filter_means)
+    torch.testing.assert_close(fresh.latest_state.timeseries_state.value, rf.latest_state.timeseries_state.value)
