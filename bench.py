@@ -113,11 +113,10 @@ def build_problem(name, dtype, device, world, rank, t_override=None):
 
 
 def alg_bytes_per_particle(w, kernel, e=4):
-    """Algorithmic HBM bytes per particle per launch (with int32 ancestors: 4 B instead of 8):
-    reduce 4+4D | scan 8 (+4D for the APF's in-register pre-weight) | step 4 (cdf) + 4D (x[anc]) + 4D (x') + 4 (logw') + 4 (anc)."""
+    """Algorithmic HBM bytes per particle per launch (with int32 ancestors: 4 B instead of 8; the
+    separate reduce pass of §8(d) no longer exists - the step kernel reduces the state it writes from registers):
+    scan 8 (+4D for the APF's in-register pre-weight) | step 4 (cdf) + 4D (x[anc]) + 4D (x') + 4 (logw') + 4 (anc)."""
     d = w["D"]  # e = bytes per state / weight element (4 for fp32)
-    if kernel == "reduce":
-        return e * (1 + d)
     if kernel == "scan":
         return e * 2 + (e * d if w["filter"] == "apf" else 0)
     return e * (2 + 2 * d) + 4
@@ -235,18 +234,18 @@ def main():
     filt.batch_filter(y, bar=False)
     torch.cuda.synchronize()
     filt._time_kernels = False
-    kms = filt.kernel_ms
-    names = ("reduce", "scan", "step")
-    dom = max(range(3), key=lambda i: kms[i])
+    kms = dict(zip(("scan", "step"), filt.kernel_ms[1:3]))  # two kernels per time step
+    names = ("scan", "step")
+    dom = max(names, key=lambda k: kms[k])
     esz = 8 if dtype == torch.float64 else 4
     launch_bytes = {k: alg_bytes_per_particle(w, k, esz) * w["N"] * w["B"] for k in names}
-    achieved = launch_bytes[names[dom]] / (kms[dom] * 1e-3) / 1e9
+    achieved = launch_bytes[dom] / (kms[dom] * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": f"k_fused_{'reduce scan step'.split()[dom]}", "achieved": achieved,
+        "bound": "hbm", "kernel": f"k_fused_{dom}", "achieved": achieved,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-        "bytes_per_launch": launch_bytes[names[dom]],
-        "kernel_us": {n_: 1e3 * kms[i] for i, n_ in enumerate(names)},
-        "all_kernels_GBs": {n_: launch_bytes[n_] / (kms[i] * 1e-3) / 1e9 for i, n_ in enumerate(names)},
+        "bytes_per_launch": launch_bytes[dom],
+        "kernel_us": {k: 1e3 * kms[k] for k in names},
+        "all_kernels_GBs": {k: launch_bytes[k] / (kms[k] * 1e-3) / 1e9 for k in names},
         "step_alg_bytes_per_particle": sum(alg_bytes_per_particle(w, k, esz) for k in names),
         "whole_step_GBs": sum(alg_bytes_per_particle(w, k, esz) for k in names) * value / world / 1e9,
     }

@@ -139,7 +139,7 @@ int pf_initial_sample(const double* m0, const double* s0, const void* z, uint64_
 
 /* ------------------------------------------------------------------------------------------------------------ *
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and
- * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; three kernels per step.
+ * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; two kernels per step.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct pf_filter_args {
     pf_model model;
@@ -158,7 +158,9 @@ typedef struct pf_filter_args {
     /* observations */
     const void* y;            /* (T, y_rows, O) */
     int64_t y_rows;           /* 1 or B */
-    const uint8_t* observed;  /* (T) 0 = all-NaN observation or unobserved sub-step: propagate only, ll = 0 */
+    const uint8_t* observed;  /* HOST array (T): 0 = all-NaN observation or unobserved sub-step: propagate only,
+                               * ll = 0.  The only host-resident argument: the launch loop reads it to set each
+                               * kernel's flags, so no kernel needs a dependent flag load before its first data load. */
     /* optional tapes (parity mode); NULL -> Philox */
     const void* z_tape; /* (T, D, B, N) */
     const void* u_tape; /* (T, B) */
@@ -167,18 +169,19 @@ typedef struct pf_filter_args {
     void* vars;      /* (T+1, B, D) */
     void* ll_steps;  /* (T, B) per-step log-likelihood increments */
     void* ll_total;  /* (B) running sum, updated in place */
-    int32_t* step_counter; /* device int32: index of the next step; kernels read their step from here */
+    int32_t* step_counter; /* reserved (unused) */
     void* ws;
     size_t ws_bytes;
 } pf_filter_args;
 
-/* Runs steps [*step_counter, *step_counter + n_steps) (the host passes t0 = the counter's current value).
+/* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; two kernel launches per
+ * step (scan, then resample+propagate+weight+reduce) plus one reduce launch for the incoming state.
  * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps). */
 int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
 
 /* Measurement variant of pf_filter_run: brackets every kernel launch with HIP events on `stream`, synchronises the
- * stream and returns the average duration in ms of the three step kernels in kernel_ms[0..2] =
- * {reduce, scan, resample+propagate+weight}.  Same results as pf_filter_run; not for throughput numbers. */
+ * stream and returns the average duration in ms of the step kernels in kernel_ms[0..2] =
+ * {0 (reserved), scan, resample+propagate+weight+reduce}.  Same results as pf_filter_run; not for throughput numbers. */
 int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                         float* kernel_ms);
 

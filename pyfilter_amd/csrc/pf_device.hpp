@@ -40,8 +40,28 @@ __device__ __forceinline__ float pf_log(float x) { return logf(x); }
 __device__ __forceinline__ double pf_log(double x) { return log(x); }
 __device__ __forceinline__ float pf_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double pf_sqrt(double x) { return sqrt(x); }
-__device__ __forceinline__ float pf_sin(float x) { return sinf(x); }
+// float sine: Cody-Waite reduction by pi (three-constant split, exact products for |k| < 2^16) + odd degree-11
+// polynomial on [-pi/2, pi/2]; ~16 VALU instructions, error < 1.5 ulp for |x| < 1e5 (libm's sinf carries a
+// Payne-Hanek large-argument path that costs ~5x as much in straight-line code).  Larger arguments fall back to sinf.
+__device__ __forceinline__ float pf_sin(float x) {
+    if (!(fabsf(x) < 1.0e5f)) return sinf(x);
+    const float k = rintf(x * 0.318309886183790671538f);
+    float r = fmaf(-k, 3.140625f, x);
+    r = fmaf(-k, 9.67502593994140625e-4f, r);
+    r = fmaf(-k, 1.509957990978376432e-7f, r);
+    const float r2 = r * r;
+    float p = fmaf(r2, -2.50521083854417187751e-8f, 2.75573192239858906526e-6f);
+    p = fmaf(r2, p, -1.98412698412698412698e-4f);
+    p = fmaf(r2, p, 8.33333333333333333333e-3f);
+    p = fmaf(r2, p, -1.66666666666666666667e-1f);
+    float sres = fmaf(r * r2, p, r);
+    return ((int)k & 1) ? -sres : sres;
+}
 __device__ __forceinline__ double pf_sin(double x) { return sin(x); }
+// exp for importance weights: float -> v_exp_f32 based (relative error ~|x| * 6e-8, irrelevant next to the fp32
+// rounding of the weights themselves); double -> libm
+__device__ __forceinline__ float pf_exp_w(float x) { return __expf(x); }
+__device__ __forceinline__ double pf_exp_w(double x) { return exp(x); }
 __device__ __forceinline__ float pf_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double pf_abs(double x) { return fabs(x); }
 
@@ -49,30 +69,72 @@ __device__ __forceinline__ double pf_abs(double x) { return fabs(x); }
 __device__ __forceinline__ double exp_diff(double a, double b) {
     return (a == -__builtin_huge_val()) ? 0.0 : exp(a - b);
 }
+// the same evaluated in the filter's arithmetic type T (a, b are tile maxima, i.e. T values carried as doubles):
+// float filters use the fast float exp here - these factors are evaluated per tile per workgroup
+template <typename T> __device__ __forceinline__ double exp_diff_t(double a, double b) {
+    return (a == -__builtin_huge_val()) ? 0.0 : (double)pf_exp_w((T)(a - b));
+}
 
 // ---------------------------------------------------------------------------------------------------------------
-// wave64 shuffles
+// wave64 cross-lane primitives on DPP (data-parallel primitives: the lane permutation rides on a VALU move, ~10x
+// cheaper than the LDS-crossbar ds_bpermute that __shfl_* lowers to).  Within a row of 16 lanes:
+//   quad_perm [1,0,3,2] (xor 1), quad_perm [2,3,0,1] (xor 2), row_half_mirror, row_mirror  -> all-reduce of the row;
+//   row_shr:1,2,4,8                                                                       -> inclusive scan of the row;
+// across the four rows: v_readlane (reductions) / row_bcast15 + row_bcast31 (scan) - the gfx9 wave64 idiom.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        T other = __shfl_xor(v, o, PF_WAVE);
-        v = (other > v) ? other : v;
-    }
-    return v;
+#define PF_DPP_QUAD_XOR1 0xB1
+#define PF_DPP_QUAD_XOR2 0x4E
+#define PF_DPP_ROW_HALF_MIRROR 0x141
+#define PF_DPP_ROW_MIRROR 0x140
+#define PF_DPP_ROW_SHR(n) (0x110 + (n))
+#define PF_DPP_ROW_BCAST15 0x142
+#define PF_DPP_ROW_BCAST31 0x143
+
+// source lane's value where the DPP pattern has a valid, enabled source; `ident` elsewhere
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_get(float v, float ident) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_get(double v, double ident) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_get(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_get(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, PF_WAVE);
-    return v;
+    v += dpp_get<PF_DPP_QUAD_XOR1>(v, T(0));
+    v += dpp_get<PF_DPP_QUAD_XOR2>(v, T(0));
+    v += dpp_get<PF_DPP_ROW_HALF_MIRROR>(v, T(0));
+    v += dpp_get<PF_DPP_ROW_MIRROR>(v, T(0));
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+template <typename T> __device__ __forceinline__ T wave_max(T v) {
+    // NaN-free inputs (maxima of sanitised log-weights); the comparison form keeps -inf working
+    T o = dpp_get<PF_DPP_QUAD_XOR1>(v, v);
+    v = (o > v) ? o : v;
+    o = dpp_get<PF_DPP_QUAD_XOR2>(v, v);
+    v = (o > v) ? o : v;
+    o = dpp_get<PF_DPP_ROW_HALF_MIRROR>(v, v);
+    v = (o > v) ? o : v;
+    o = dpp_get<PF_DPP_ROW_MIRROR>(v, v);
+    v = (o > v) ? o : v;
+    const T a = lane_get(v, 0), b = lane_get(v, 16), c = lane_get(v, 32), d = lane_get(v, 48);
+    const T ab = (a > b) ? a : b, cd = (c > d) ? c : d;
+    return (ab > cd) ? ab : cd;
 }
 // inclusive scan across the 64 lanes of a wave
-template <typename T> __device__ __forceinline__ T wave_scan_incl(T v, int lane) {
-#pragma unroll
-    for (int o = 1; o < PF_WAVE; o <<= 1) {
-        T up = __shfl_up(v, o, PF_WAVE);
-        if (lane >= o) v += up;
-    }
+template <typename T> __device__ __forceinline__ T wave_scan_incl(T v, int /*lane*/) {
+    v += dpp_get<PF_DPP_ROW_SHR(1)>(v, T(0));
+    v += dpp_get<PF_DPP_ROW_SHR(2)>(v, T(0));
+    v += dpp_get<PF_DPP_ROW_SHR(4)>(v, T(0));
+    v += dpp_get<PF_DPP_ROW_SHR(8)>(v, T(0));
+    v += dpp_get<PF_DPP_ROW_BCAST15, 0xA>(v, T(0));  // lane 15 -> row 1, lane 47 -> row 3
+    v += dpp_get<PF_DPP_ROW_BCAST31, 0xC>(v, T(0));  // lane 31 -> rows 2, 3
     return v;
 }
 
@@ -158,11 +220,11 @@ template <typename T> struct OnlineLse {
     __device__ __forceinline__ void push(T v, double& rescale, double& e) {
         rescale = 1.0;
         if (v > m) {
-            rescale = (m == -Lim<T>::inf()) ? 0.0 : (double)pf_exp(m - v);
+            rescale = (m == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(m - v);
             s *= rescale;
             m = v;
         }
-        e = (v == -Lim<T>::inf()) ? 0.0 : (double)pf_exp(v - m);
+        e = (v == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(v - m);
         if (v != v) e = v;  // NaN propagates (an un-sanitised input); sanitised inputs never hit this
         s += e;
     }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/pf_amd.h"
@@ -21,7 +22,7 @@ namespace pf {
 // ---------------------------------------------------------------------------------------------------------------
 // geometry
 // ---------------------------------------------------------------------------------------------------------------
-#define PF_MAX_TILES 512
+#define PF_MAX_TILES 1024
 
 struct Geom {
     int64_t N;
@@ -40,7 +41,7 @@ static inline Geom make_geom(int64_t N, int64_t B) {
     g.vec = (N % 4 == 0) ? 4 : 1;
     g.round_elems = PF_BLOCK * g.vec;
     const int64_t rounds_total = (N + g.round_elems - 1) / g.round_elems;
-    const int min_r = (g.vec == 4) ? 2 : 8;  // >= 2048-particle tiles
+    const int min_r = (g.vec == 4) ? 1 : 4;  // >= 1024-particle tiles
     int64_t r = (rounds_total + PF_MAX_TILES - 1) / PF_MAX_TILES;
     if (r < min_r) r = min_r;
     g.rounds_per_tile = (int)r;
@@ -64,7 +65,9 @@ struct WsLayout {
     size_t off_part;   // double partials[(5 + 2D)][B][tiles]
     size_t off_stat;   // ColStat[B]
     size_t off_poison; // int32 [2][B]
-    size_t off_ctr;    // int32 [4]
+    size_t off_ctr;    // int32 [4] (reserved)
+    size_t off_j0;     // int32 [B][tiles]: ancestor of the first grid position of every position tile
+    size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
     size_t total;
 };
 
@@ -81,6 +84,10 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     o = align256(o + sizeof(int32_t) * 2 * (size_t)g.B);
     w.off_ctr = o;
     o = align256(o + 64);
+    w.off_j0 = o;
+    o = align256(o + sizeof(int32_t) * (size_t)g.B * g.tiles);
+    w.off_dbg = o;
+    o = align256(o + 256);
     w.total = o;
     return w;
 }
@@ -138,38 +145,74 @@ template <typename T, int VEC> struct SearchWin {
     static constexpr int WIN = 2 * PF_BLOCK * VEC;
 };
 
+// lower_bound of p in the LDS window, starting from a guess: gallop away from it with doubling steps, then bisect.
+// Invariant on entry: none.  Returns a in [0, WIN] (WIN = not inside the window).
+template <typename T, int WIN> __device__ __forceinline__ int window_lower_bound(const T* win, int guess, T p) {
+    int a, b;
+    if (win[guess] < p) {  // answer is to the right of guess
+        a = guess + 1;
+        b = a;
+        int step = 1;
+        while (b < WIN && win[b] < p) {
+            a = b + 1;
+            b += step;
+            step <<= 1;
+        }
+        if (b > WIN) b = WIN;
+    } else {  // answer is at or to the left of guess
+        b = guess;
+        a = b;
+        int step = 1;
+        while (a > 0 && !(win[a - 1] < p)) {
+            b = a - 1;
+            a -= step;
+            step <<= 1;
+        }
+        if (a < 0) a = 0;
+    }
+    while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (win[mid] < p) a = mid + 1; else b = mid;
+    }
+    return a;
+}
+
 template <typename T, int VEC>
 __device__ __forceinline__ void systematic_round(const T* __restrict__ cdf_col, int N, int64_t i0, T u,
                                                  const T* __restrict__ u_elem, T* win, int* sh_j0, int (&idx)[VEC]) {
-    constexpr int WIN = SearchWin<T, VEC>::WIN;
+    constexpr int WIN = SearchWin<T, VEC>::WIN;  // 2 * 256 * VEC cdf values cover the round's 256 * VEC positions
     const int tid = threadIdx.x;
     const int j0 = *sh_j0;
-    // stage the window (coalesced), pad with +inf beyond the column
-    for (int k = tid; k < WIN; k += PF_BLOCK) {
-        const int j = j0 + k;
-        win[k] = (j < N) ? cdf_col[j] : Lim<T>::inf();
+    const int ws = j0 - (j0 % VEC);  // window start, aligned to the vector width (N % VEC == 0)
+    // stage the window: two vector loads per thread, both issued before the first LDS store; +inf beyond the column
+    {
+        T v0[VEC], v1[VEC];
+        const int ja = ws + tid * VEC, jb = ws + (PF_BLOCK + tid) * VEC;
+        const bool ina = ja < N, inb = jb < N;
+        if (ina) { if (VEC == 1) v0[0] = cdf_col[ja]; else load_vec<T, VEC>(cdf_col + ja, v0); }
+        if (inb) { if (VEC == 1) v1[0] = cdf_col[jb]; else load_vec<T, VEC>(cdf_col + jb, v1); }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (!ina) v0[j] = Lim<T>::inf();
+            if (!inb) v1[j] = Lim<T>::inf();
+        }
+        if (VEC == 1) { win[tid] = v0[0]; win[PF_BLOCK + tid] = v1[0]; }
+        else { store_vec<T, VEC>(win + tid * VEC, v0); store_vec<T, VEC>(win + (PF_BLOCK + tid) * VEC, v1); }
     }
     __syncthreads();
     const T nT = T(N);
-    int lo = 0;
+    // on average one ancestor per position: thread t's first position lands near window offset (j0 - ws) + t * VEC
+    int guess = (j0 - ws) + tid * VEC;
+    if (guess > WIN - 1) guess = WIN - 1;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int64_t i = i0 + j;
         int res = N - 1;
         if (i < N) {
             const T p = grid_position<T>(i, u_elem ? u_elem[i] : u, nT);
-            // lower_bound in the window, starting from the previous hit
-            int a = lo, b = WIN;
-            while (a < b) {
-                const int mid = (a + b) >> 1;
-                if (win[mid] < p) a = mid + 1; else b = mid;
-            }
-            lo = a;
-            if (a < WIN) {
-                res = j0 + a;
-            } else {
-                res = thread_lower_bound<T>(cdf_col, j0 + WIN, N, p);
-            }
+            const int a = window_lower_bound<T, WIN>(win, guess, p);
+            guess = a < WIN ? a : WIN - 1;
+            res = (a < WIN) ? ws + a : thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
             if (res > N - 1) res = N - 1;
         }
         idx[j] = res;
@@ -336,7 +379,7 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             double ej = 0.0;
-            if (on) ej = FROM_W ? (double)v[j] : ((v[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp(v[j] - tile_max));
+            if (on) ej = FROM_W ? (double)v[j] : ((v[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(v[j] - tile_max));
             local += ej;
             e[j] = local;  // thread-local inclusive
         }
@@ -386,7 +429,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
                                                      int u_per_elem, const T* __restrict__ v, int multinomial, uint64_t seed,
                                                      uint32_t step, const uint8_t* colmask, int32_t* __restrict__ idx,
                                                      Geom g) {
-    __shared__ T win[SearchWin<T, VEC>::WIN];
+    __shared__ __attribute__((aligned(32))) T win[SearchWin<T, VEC>::WIN];
     __shared__ int sh_j0;
     const int b = blockIdx.y, k = blockIdx.x;
     if (colmask && !colmask[b]) return;
@@ -555,11 +598,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_pre_weight(ModelDesc md, const T* 
     const int NP = 4 * D + O * D + 2 * O;
     ColParams<T, D> cp;
     cp.load(params + (int64_t)b * NP, O, y + (int64_t)(y_rows == 1 ? 0 : b) * O);
+    ColConsts<T, D> cc;
+    cc.prepare(md, cp);
     for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * PF_BLOCK) {
         T xv[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) xv[d] = x[((int64_t)d * B + b) * N + i];
-        out[(int64_t)b * N + i] = pre_weight<T, D>(md, proposal, cp, xv);
+        out[(int64_t)b * N + i] = pre_weight<T, D>(md, proposal, cp, cc, xv);
     }
 }
 
@@ -586,12 +631,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sample_and_weight(ModelDesc md, co
     const int NP = 4 * D + O * D + 2 * O;
     ColParams<T, D> cp;
     cp.load(params + (int64_t)b * NP, O, (weigh && y) ? y + (int64_t)(y_rows == 1 ? 0 : b) * O : nullptr);
+    ColConsts<T, D> cc;
+    cc.prepare(md, cp);
     for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * PF_BLOCK) {
         T xv[D], zv[D], xn[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) xv[d] = x[((int64_t)d * B + b) * N + i];
         draw_z<T, D>(z, seed, step, N, B, b, i, zv);
-        const T w = sample_and_weight<T, D>(md, weigh ? proposal : PF_PROP_BOOTSTRAP, cp, xv, zv, xn);
+        const T w = sample_and_weight<T, D>(md, weigh ? proposal : PF_PROP_BOOTSTRAP, cp, cc, xv, zv, xn);
 #pragma unroll
         for (int d = 0; d < D; ++d) x_out[((int64_t)d * B + b) * N + i] = xn[d];
         if (weigh && w_out) w_out[(int64_t)b * N + i] = w;
@@ -604,412 +651,25 @@ __global__ __launch_bounds__(PF_BLOCK) void k_initial_sample(double m0a, double 
                                                              uint64_t seed, T* __restrict__ x, int64_t N, int B,
                                                              int D) {
     const int b = blockIdx.y;
-    const double m0[3] = {m0a, m0b, m0c}, s0[3] = {s0a, s0b, s0c};
     for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * PF_BLOCK) {
-        T zv[4];
+        T zv[4] = {T(0), T(0), T(0), T(0)};
         if (!z) NormalDraw<T, 4>::draw(seed, PF_STREAM_INIT, 0u, (uint64_t)((int64_t)b * N + i), zv);
-        for (int d = 0; d < D; ++d) {
-            const int64_t o = ((int64_t)d * B + b) * N + i;
-            const T zz = z ? z[o] : zv[d];
-            x[o] = (T)m0[d] + (T)s0[d] * zz;
+#pragma unroll
+        for (int d = 0; d < PF_MAXD; ++d) {
+            if (d < D) {
+                const int64_t o = ((int64_t)d * B + b) * N + i;
+                const T zz = z ? z[o] : zv[d];
+                x[o] = (T)(d == 0 ? m0a : (d == 1 ? m0b : m0c)) + (T)(d == 0 ? s0a : (d == 1 ? s0b : s0c)) * zz;
+            }
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// fused filter step: K1 reduce -> K2 finalize + scan -> K3 resample + gather + propagate + weight
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T> struct FusedArgs {
-    ModelDesc md;
-    const T* params;
-    int filter, proposal, resampler;
-    Geom g;
-    double thr_abs;  // ess_threshold * N
-    double logN;
-    uint64_t seed;
-    T* x[2];
-    T* logw[2];
-    int32_t* anc;
-    T* cdf;
-    const T* y;
-    int y_rows;
-    const uint8_t* observed;
-    const T* z_tape;
-    const T* u_tape;
-    T* means;
-    T* vars;
-    T* ll_steps;
-    T* ll_total;
-    double* part;
-    ColStat* stat;
-    int32_t* poison;  // [2][B]
-    int32_t* ctr;     // ctr[0]: step read by K1/K2, ctr[1]: step read by K3
-    int finalize_only;
-};
+}  // namespace pf
 
-// K1: one pass over (logw, x): per-tile partials of
-//   (m1, S1, Q1)  online max / sum exp / sum exp^2 of the log-weights   -> lse, ESS, normalised weights
-//   MX[d], MXX[d] sum e x_d, sum e x_d^2                                -> filter mean / variance of the current state
-//   (m2, S2)      APF only: the same for rw = sanitize(pre_weight(x, y) + logw)   -> first-stage resampling weights
-template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
-    __shared__ double red[(3 + 2 * D) * PF_NWAVES];
-    __shared__ T redm[PF_NWAVES];
-    const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
-    const int step = a.ctr[0];
-    const int slot = step & 1;
-    const bool obs = !a.finalize_only && a.observed[step] != 0;
-    const bool apf = obs && a.filter == PF_FILTER_APF;
+#include "pf_fused.hpp"
 
-    const int O = a.md.obs_dim;
-    const int NP = 4 * D + O * D + 2 * O;
-    ColParams<T, D> cp;
-    cp.load(a.params + (int64_t)b * NP, O, apf ? a.y + ((int64_t)step * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O : nullptr);
-
-    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
-    const T* x_base = a.x[slot];
-
-    OnlineLse<T> a1, a2;
-    a1.init();
-    a2.init();
-    double q1 = 0.0, mx[D], mxx[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) mx[d] = mxx[d] = 0.0;
-    bool poison = false;
-
-    const int64_t base = (int64_t)k * g.tile_elems;
-    for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t i0 = base + (int64_t)r * g.round_elems + threadIdx.x * VEC;
-        if (i0 >= g.N) break;
-        T lw[VEC], xv[D][VEC];
-        if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
-            if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            double rs, e;
-            a1.push(lw[j], rs, e);
-            q1 = q1 * rs * rs + e * e;
-            T xj[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                xj[d] = xv[d][j];
-                const double xd = (double)xj[d];
-                mx[d] = mx[d] * rs + e * xd;
-                mxx[d] = mxx[d] * rs + e * xd * xd;
-            }
-            if (apf) {
-                const T pre = pre_weight<T, D>(a.md, a.proposal, cp, xj);
-                if (pre != pre || pre == Lim<T>::inf()) poison = true;
-                double rs2, e2;
-                a2.push(sanitize_logw(pre + lw[j]), rs2, e2);
-            }
-        }
-    }
-
-    const T M1 = block_max<T>(a1.m, redm);
-    const double f1 = exp_diff((double)a1.m, (double)M1);
-    double sums[3 + 2 * D];
-    sums[0] = a1.s * f1;
-    sums[1] = q1 * f1 * f1;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        sums[3 + d] = mx[d] * f1;
-        sums[3 + D + d] = mxx[d] * f1;
-    }
-    T M2 = -Lim<T>::inf();
-    sums[2] = 0.0;
-    if (apf) {  // uniform branch
-        M2 = block_max<T>(a2.m, redm);
-        sums[2] = a2.s * exp_diff((double)a2.m, (double)M2);
-    }
-    block_sum<3 + 2 * D>(sums, red);
-
-    if (poison) atomicOr(&a.poison[(step & 1) * g.B + b], 1);
-    if (threadIdx.x == 0) {
-        const int64_t stride = (int64_t)g.B * g.tiles;
-        const int64_t o = (int64_t)b * g.tiles + k;
-        a.part[PQ_M1 * stride + o] = (double)M1;
-        a.part[PQ_S1 * stride + o] = sums[0];
-        a.part[PQ_Q1 * stride + o] = sums[1];
-        a.part[PQ_M2 * stride + o] = (double)M2;
-        a.part[PQ_S2 * stride + o] = sums[2];
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            a.part[(PQ_MX + d) * stride + o] = sums[3 + d];
-            a.part[(PQ_MX + D + d) * stride + o] = sums[3 + D + d];
-        }
-    }
-}
-
-// K2: re-reduce the column's partials; tile 0 finalises the bookkeeping of the *current* state (moments row `step`,
-// log-likelihood increment of step-1, resampling decision); then - if the column resamples - scan this tile into cdf.
-template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
-    __shared__ double red[4 * PF_NWAVES];
-    __shared__ double redm[PF_NWAVES];
-    __shared__ double red2[2 * D * PF_NWAVES];
-    const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
-    const int step = a.ctr[0];
-    const int slot = step & 1;
-    const bool obs = !a.finalize_only && a.observed[step] != 0;
-    const bool apf = a.filter == PF_FILTER_APF;
-    if (k == 0 && b == 0 && threadIdx.x == 0) a.ctr[1] = step;
-
-    const ColLse c1 = combine_partials(a.part, PQ_M1, PQ_S1, PQ_Q1, b, k, g.B, g.tiles, red, redm);
-    const double lse_w = c1.M + log(c1.S);
-    const double ess = c1.S * c1.S / c1.Q;
-    ColLse c2 = c1;
-    if (apf && obs) c2 = combine_partials(a.part, PQ_M2, PQ_S2, -1, b, k, g.B, g.tiles, red, redm);
-
-    bool resample;
-    if (apf) resample = obs;                       // APF resamples every weighted step (apf.py:29-31)
-    else resample = ess < a.thr_abs;               // SISR: ess < ess_threshold * N (sisr.py:18-19)
-    if (a.finalize_only) resample = false;
-
-    if (k == 0) {
-        // moments of the current state (row `step` of filter_means / filter_variance)
-        const int64_t stride = (int64_t)g.B * g.tiles;
-        double mv[2 * D];
-#pragma unroll
-        for (int q = 0; q < 2 * D; ++q) {
-            mv[q] = 0.0;
-            for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-                mv[q] += a.part[(PQ_MX + q) * stride + (int64_t)b * g.tiles + t] *
-                         exp_diff(a.part[PQ_M1 * stride + (int64_t)b * g.tiles + t], c1.M);
-        }
-        block_sum<2 * D>(mv, red2);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const double mu = mv[d] / c1.S;
-                double var = mv[D + d] / c1.S - mu * mu;
-                if (var < 0.0) var = 0.0;
-                a.means[((int64_t)step * g.B + b) * D + d] = (T)mu;
-                a.vars[((int64_t)step * g.B + b) * D + d] = (T)var;
-            }
-            ColStat st = a.stat[b];
-            // log-likelihood increment of the previous step: ll = lse(logw') - base_lse   (0 for unweighted steps)
-            if (step > 0 && !st.ll_done) {
-                double ll = 0.0;
-                const int pslot = (step - 1) & 1;
-                if (st.prev_observed) {
-                    ll = lse_w - st.base_lse;
-                    if (a.poison[pslot * g.B + b]) ll = __builtin_nan("");
-                }
-                a.poison[pslot * g.B + b] = 0;
-                a.ll_steps[(int64_t)(step - 1) * g.B + b] = (T)ll;
-                a.ll_total[b] = (T)((double)a.ll_total[b] + ll);
-            }
-            st.lse_w = lse_w;
-            st.resample = resample ? 1 : 0;
-            st.ll_done = a.finalize_only ? 1 : 0;
-            if (a.finalize_only) {
-                a.stat[b] = st;
-            } else {
-            st.prev_observed = obs ? 1 : 0;
-            if (apf) {
-                // ll_t = [lse(w') - log N] + [lse(rw) - lse(w)]   (apf.py:44)
-                st.base_lse = a.logN - ((c2.M + log(c2.S)) - lse_w);
-            } else {
-                // ll_t = lse(wi + log W): W = 1/N after resampling, else the carried normalised weights (sisr.py:52-55)
-                st.base_lse = resample ? a.logN : lse_w;
-            }
-            a.stat[b] = st;
-            }
-        }
-    }
-    if (!resample) return;
-
-    const int64_t stride = (int64_t)g.B * g.tiles;
-    const int sm = (apf ? PQ_M2 : PQ_M1), ss = (apf ? PQ_S2 : PQ_S1);
-    const double mk = a.part[sm * stride + (int64_t)b * g.tiles + k];
-    const double sk = a.part[ss * stride + (int64_t)b * g.tiles + k];
-    const double fk = exp_diff(mk, c2.M) / c2.S;
-    const double Pk = c2.prefix / c2.S;
-    const double Pnext = Pk + sk * fk;
-
-    T* cdf_col = a.cdf + (int64_t)b * g.N;
-    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
-    if (!apf) {
-        scan_tile<T, VEC, false>(lw_col, cdf_col, g, k, (T)mk, Pk, fk, Pnext, red);
-        return;
-    }
-
-    // APF: the scanned weights are rw = sanitize(pre_weight(x, y) + logw), recomputed in registers (never stored)
-    const int O = a.md.obs_dim;
-    const int NP = 4 * D + O * D + 2 * O;
-    ColParams<T, D> cp;
-    cp.load(a.params + (int64_t)b * NP, O, a.y + ((int64_t)step * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O);
-    const T* x_base = a.x[slot];
-    const T tile_max = (T)mk;
-    double carry = 0.0;
-    const int64_t base = (int64_t)k * g.tile_elems;
-    for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t r0 = base + (int64_t)r * g.round_elems;
-        if (r0 >= g.N) break;
-        const int64_t i0 = r0 + threadIdx.x * VEC;
-        const bool on = i0 < g.N;
-        T lw[VEC], xv[D][VEC];
-        if (on) {
-            if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
-                if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
-            }
-        }
-        double e[VEC], local = 0.0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            double ej = 0.0;
-            if (on) {
-                T xj[D];
-#pragma unroll
-                for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-                const T rw = sanitize_logw(pre_weight<T, D>(a.md, a.proposal, cp, xj) + lw[j]);
-                ej = (rw == -Lim<T>::inf()) ? 0.0 : (double)pf_exp(rw - tile_max);
-            }
-            local += ej;
-            e[j] = local;
-        }
-        double total;
-        const double excl = block_scan_excl(local, red, total);
-        if (on) {
-            T outv[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                double cc = Pk + fk * (carry + excl + e[j]);
-                if (cc > Pnext) cc = Pnext;
-                outv[j] = (i0 + j == g.N - 1) ? T(1) : (T)cc;
-            }
-            if (VEC == 1) cdf_col[i0] = outv[0]; else store_vec<T, VEC>(cdf_col + i0, outv);
-        }
-        carry += total;
-    }
-}
-
-// K3: ancestors (systematic window search | multinomial) -> gather x[anc] -> propagate (Philox or tape) -> weight
-template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_fused_step(FusedArgs<T> a) {
-    __shared__ T win[SearchWin<T, VEC>::WIN];
-    __shared__ int sh_j0;
-    const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
-    const int step = a.ctr[1];
-    const int slot = step & 1;
-    const bool obs = a.observed[step] != 0;
-    const bool apf = a.filter == PF_FILTER_APF;
-    const bool resample = a.stat[b].resample != 0;
-    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
-    const int N = (int)g.N;
-    if (k == 0 && b == 0 && threadIdx.x == 0) a.ctr[0] = step + 1;
-
-    const int O = a.md.obs_dim;
-    const int NP = 4 * D + O * D + 2 * O;
-    ColParams<T, D> cp;
-    cp.load(a.params + (int64_t)b * NP, O, obs ? a.y + ((int64_t)step * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O : nullptr);
-
-    const T* x_in = a.x[slot];
-    T* x_out = a.x[slot ^ 1];
-    const T* lw_in = a.logw[slot] + (int64_t)b * g.N;
-    T* lw_out = a.logw[slot ^ 1] + (int64_t)b * g.N;
-    const T* cdf_col = a.cdf + (int64_t)b * g.N;
-    int32_t* anc_col = a.anc + (int64_t)b * g.N;
-    const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
-
-    const int64_t base = (int64_t)k * g.tile_elems;
-    T ub = T(0);
-    if (resample && !multinomial) {
-        ub = a.u_tape ? a.u_tape[(int64_t)step * g.B + b] : uniform_draw<T>(a.seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
-        if (threadIdx.x < PF_WAVE) {
-            const int j0 = wave_lower_bound<T>(cdf_col, N, grid_position<T>(base, ub, T(N)), threadIdx.x & 63);
-            if ((threadIdx.x & 63) == 0) sh_j0 = j0;
-        }
-        __syncthreads();
-    }
-    bool poison = false;
-
-    for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t r0 = base + (int64_t)r * g.round_elems;
-        if (r0 >= g.N) break;
-        const int64_t i0 = r0 + threadIdx.x * VEC;
-        const bool on = i0 < g.N;
-        int idx[VEC];
-        if (resample) {
-            if (!multinomial) {
-                systematic_round<T, VEC>(cdf_col, N, i0, ub, nullptr, win, &sh_j0, idx);
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    idx[j] = N - 1;
-                    if (i0 + j < g.N) {
-                        const T p = uniform_draw<T>(a.seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0 + j));
-                        const int q = thread_lower_bound<T>(cdf_col, 0, N, p);
-                        idx[j] = q > N - 1 ? N - 1 : q;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) idx[j] = (int)((i0 + j < g.N) ? (i0 + j) : (g.N - 1));
-        }
-        if (!on) continue;
-
-        T lw_old[VEC];
-        if (!resample) {
-            if (VEC == 1) lw_old[0] = lw_in[i0]; else load_vec<T, VEC>(lw_in + i0, lw_old);
-        }
-        T xo[D][VEC], lwo[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            T xr[D], zv[D], xn[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) xr[d] = x_in[((int64_t)d * g.B + b) * g.N + idx[j]];
-            draw_z<T, D>(z_step, a.seed, (uint32_t)step, g.N, g.B, b, i0 + j, zv);
-            T w_new;
-            if (obs) {
-                const T wi = sample_and_weight<T, D>(a.md, a.proposal, cp, xr, zv, xn);
-                if (apf) {
-                    // second-stage weight: ws - pre_weight(x[anc])   (apf.py:43), the pre-weight recomputed in registers
-                    w_new = wi - pre_weight<T, D>(a.md, a.proposal, cp, xr);
-                    if (w_new != w_new || w_new == Lim<T>::inf()) poison = true;
-                } else {
-                    if (wi != wi || wi == Lim<T>::inf()) poison = true;
-                    w_new = resample ? wi : (wi + lw_old[j]);
-                }
-            } else {
-                // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
-                sample_and_weight<T, D>(a.md, PF_PROP_BOOTSTRAP, cp, xr, zv, xn);
-                w_new = resample ? T(0) : lw_old[j];
-            }
-            lwo[j] = sanitize_logw(w_new);
-#pragma unroll
-            for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            T* xc = x_out + ((int64_t)d * g.B + b) * g.N + i0;
-            if (VEC == 1) xc[0] = xo[d][0]; else store_vec<T, VEC>(xc, xo[d]);
-        }
-        if (VEC == 1) lw_out[i0] = lwo[0]; else store_vec<T, VEC>(lw_out + i0, lwo);
-        if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
-            if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
-        }
-    }
-    if (poison) atomicOr(&a.poison[(step & 1) * g.B + b], 1);
-}
-
-__global__ void k_set_counter(int32_t* ctr, int v) {
-    ctr[0] = v;
-    ctr[1] = v;
-}
-
+namespace pf {
 }  // namespace pf
 
 // =================================================================================================================
@@ -1035,7 +695,14 @@ extern "C" const char* pf_error_string(int code) {
     }
 }
 
+
 static inline bool bad_shape(int64_t N, int64_t B) { return N < 1 || B < 1 || N > (int64_t)1 << 30 || B > 65535; }
+
+extern "C" int pf_debug_offset(int64_t N, int64_t B, size_t* off) {
+    if (!off || bad_shape(N, B)) return PF_EINVAL;
+    *off = make_ws(make_geom(N, B), PF_MAXD).off_dbg;
+    return PF_OK;
+}
 
 extern "C" int pf_workspace_bytes(int64_t N, int64_t B, int64_t D, size_t* bytes) {
     if (!bytes || bad_shape(N, B) || D < 1 || D > PF_MAXD) return PF_EINVAL;
@@ -1284,7 +951,6 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.cdf = (T*)A->cdf;
     a.y = (const T*)A->y;
     a.y_rows = (int)A->y_rows;
-    a.observed = A->observed;
     a.z_tape = (const T*)A->z_tape;
     a.u_tape = (const T*)A->u_tape;
     a.means = (T*)A->means;
@@ -1294,52 +960,64 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.part = (double*)((char*)A->ws + wl.off_part);
     a.stat = (ColStat*)((char*)A->ws + wl.off_stat);
     a.poison = (int32_t*)((char*)A->ws + wl.off_poison);
-    a.ctr = A->step_counter;
+    a.j0 = (int32_t*)((char*)A->ws + wl.off_j0);
+    a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
     a.finalize_only = 0;
+    {
+        const char* dc = getenv("PF_DEBUG_CUT");
+        a.debug_cut = dc ? atoi(dc) : 0;
+    }
+    const uint8_t* observed = A->observed;  // host array
 
     const dim3 grid(g.tiles, g.B), block(PF_BLOCK);
-    hipLaunchKernelGGL(k_set_counter, dim3(1), dim3(1), 0, st, a.ctr, (int)t0);
     if (t0 == 0) {
         // fresh filter: no previous step to account for
         hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
         if (e != hipSuccess) return (int)e;
     }
+    // partials of the incoming state (afterwards every step kernel leaves the partials of the state it wrote)
+    a.step = (int)t0;
+    a.obs = n_steps > 0 ? (observed[t0] != 0) : 0;
+    a.obs_next = 0;
+    hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
+
+    std::vector<hipEvent_t> ev;
     if (kernel_ms) {
-        // profiling variant: bracket every launch with HIP events on the caller's stream (serialises the stream
-        // slightly; never used for the throughput number) and report the average duration of each of the 3 kernels
-        std::vector<hipEvent_t> ev((size_t)n_steps * 4);
+        // measurement variant: bracket every launch with HIP events on the caller's stream
+        ev.resize((size_t)n_steps * 3);
         for (auto& e : ev)
             if (hipEventCreate(&e) != hipSuccess) return (int)hipGetLastError();
-        for (int64_t s = 0; s < n_steps; ++s) {
-            (void)hipEventRecord(ev[4 * s + 0], st);
-            hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
-            (void)hipEventRecord(ev[4 * s + 1], st);
-            hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid, block, 0, st, a);
-            (void)hipEventRecord(ev[4 * s + 2], st);
-            hipLaunchKernelGGL((k_fused_step<T, D, VEC>), grid, block, 0, st, a);
-            (void)hipEventRecord(ev[4 * s + 3], st);
-        }
-        hipError_t se = hipStreamSynchronize(st);
-        if (se != hipSuccess) return (int)se;
-        double acc[3] = {0, 0, 0};
-        for (int64_t s = 0; s < n_steps; ++s)
-            for (int q = 0; q < 3; ++q) {
-                float ms = 0.f;
-                (void)hipEventElapsedTime(&ms, ev[4 * s + q], ev[4 * s + q + 1]);
-                acc[q] += ms;
-            }
-        for (int q = 0; q < 3; ++q) kernel_ms[q] = n_steps > 0 ? (float)(acc[q] / (double)n_steps) : 0.f;
-        for (auto& e : ev) (void)hipEventDestroy(e);
-    } else
+    }
     for (int64_t s = 0; s < n_steps; ++s) {
-        hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
+        const int64_t t = t0 + s;
+        a.step = (int)t;
+        a.obs = observed[t] != 0;
+        a.obs_next = (s + 1 < n_steps) ? (observed[t + 1] != 0) : 0;
+        if (kernel_ms) (void)hipEventRecord(ev[3 * s + 0], st);
         hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid, block, 0, st, a);
+        if (kernel_ms) (void)hipEventRecord(ev[3 * s + 1], st);
         hipLaunchKernelGGL((k_fused_step<T, D, VEC>), grid, block, 0, st, a);
+        if (kernel_ms) (void)hipEventRecord(ev[3 * s + 2], st);
     }
     if (finalize) {
+        a.step = (int)(t0 + n_steps);
+        a.obs = a.obs_next = 0;
         a.finalize_only = 1;
-        hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
         hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid, block, 0, st, a);
+    }
+    if (kernel_ms) {
+        hipError_t se = hipStreamSynchronize(st);
+        if (se != hipSuccess) return (int)se;
+        double acc[2] = {0, 0};
+        for (int64_t s = 0; s < n_steps; ++s)
+            for (int q = 0; q < 2; ++q) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, ev[3 * s + q], ev[3 * s + q + 1]);
+                acc[q] += ms;
+            }
+        kernel_ms[0] = 0.f;  // the reduce kernel only runs once per call now
+        for (int q = 0; q < 2; ++q) kernel_ms[1 + q] = n_steps > 0 ? (float)(acc[q] / (double)n_steps) : 0.f;
+        for (auto& e : ev) (void)hipEventDestroy(e);
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PF_OK : (int)e;
@@ -1365,7 +1043,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (rc) return rc;
     if (bad_shape(A->N, A->B) || t0 < 0 || n_steps < 0) return PF_EINVAL;
     if (!A->x[0] || !A->x[1] || !A->logw[0] || !A->logw[1] || !A->anc || !A->cdf || !A->means || !A->vars ||
-        !A->ll_steps || !A->ll_total || !A->step_counter || !A->ws)
+        !A->ll_steps || !A->ll_total || !A->ws)
         return PF_EINVAL;
     if (n_steps > 0 && (!A->y || !A->observed)) return PF_EINVAL;
     if (A->y_rows != 1 && A->y_rows != A->B) return PF_EINVAL;

@@ -114,6 +114,71 @@ __device__ __forceinline__ void mean_scale(const ModelDesc& md, const ColParams<
     }
 }
 
+// Per-column constants for the closed-form fast path: scalar state (D = 1), scalar linear-Gaussian observation and a
+// state-independent transition scale (every built-in kind except Verhulst).  Everything that does not depend on the
+// particle - reciprocals, logs, the optimal-proposal gain - is evaluated once per thread, leaving ~30 flops + one sine
+// per particle (the reference spends ~40 aten ops and a batched LU here: SURVEY.md section 8(a) a14).
+template <typename T, int D> struct ColConsts {
+    bool fast;
+    T g, inv_g, inc, yb, a;
+    T i2s, ks;               // observation: 1 / (2 s^2), log s + log sqrt(2 pi)
+    T i2inc, kt;             // transition:  1 / (2 inc^2), log inc + log sqrt(2 pi) + log |g|
+    T c_loc, c_y, kstd, kq;  // LinearGaussianObservations kernel: mean = c_loc * loc + c_y, std, log std + log sqrt(2 pi)
+    T i2c, kc;               // LGO pre-weight: 1 / (2 (s^2 + a^2 g^2)), log sqrt(s^2 + a^2 g^2) + log sqrt(2 pi)
+    T ou_e;                  // exp(-kappa dt) for the OU kind
+
+    __device__ __forceinline__ void prepare(const ModelDesc& md, const ColParams<T, D>& cp) {
+        fast = false;
+        if constexpr (D == 1) {
+            if (md.obs_kind != PF_OBS_LINEAR || md.hid_kind == PF_HID_VERHULST_EM) return;
+            fast = true;
+            const T dt = (T)md.dt;
+            switch (md.hid_kind) {
+                case PF_HID_LINEAR: g = cp.hp[2][0]; break;
+                case PF_HID_SINE_EM: g = cp.hp[1][0]; break;
+                case PF_HID_LORENZ63_EM: g = cp.hp[3][0]; break;
+                default: {  // OU
+                    const T kappa = cp.hp[0][0];
+                    g = cp.hp[2][0] * pf_sqrt((T(1) - pf_exp(T(-2) * kappa * dt)) / (T(2) * kappa));
+                    break;
+                }
+            }
+            ou_e = (md.hid_kind == PF_HID_OU) ? pf_exp(-cp.hp[0][0] * dt) : T(0);
+            inv_g = T(1) / g;
+            inc = (T)md.inc_scale;
+            a = cp.A[0][0];
+            const T s = cp.os[0];
+            yb = cp.y[0] - cp.ob[0];
+            i2s = T(1) / (T(2) * s * s);
+            ks = pf_log(s) + T(PF_LOG_SQRT_2PI);
+            i2inc = T(1) / (T(2) * inc * inc);
+            kt = pf_log(inc) + T(PF_LOG_SQRT_2PI) + pf_log(pf_abs(g));
+            const T hvi = T(1) / (g * g), ovi = T(1) / (s * s);
+            const T cov = T(1) / (hvi + a * ovi * a);
+            c_loc = cov * hvi;
+            c_y = cov * (a * (ovi * yb));
+            kstd = pf_sqrt(cov);
+            kq = pf_log(kstd) + T(PF_LOG_SQRT_2PI);
+            const T cvar = s * s + a * (g * g) * a;
+            i2c = T(1) / (T(2) * cvar);
+            kc = pf_log(pf_sqrt(cvar)) + T(PF_LOG_SQRT_2PI);
+        }
+    }
+
+    // one-step mean of the scalar state (the scale is `g`)
+    __device__ __forceinline__ T loc1(const ModelDesc& md, const ColParams<T, D>& cp, T x) const {
+        switch (md.hid_kind) {
+            case PF_HID_LINEAR: return cp.hp[0][0] + cp.hp[1][0] * x;
+            case PF_HID_SINE_EM: return x + pf_sin(x - cp.hp[0][0]) * (T)md.dt;
+            default: return cp.hp[1][0] + (x - cp.hp[1][0]) * ou_e;  // OU
+        }
+    }
+    __device__ __forceinline__ T obs_lp(T x) const {
+        const T r = yb - a * x;
+        return -(r * r) * i2s - ks;
+    }
+};
+
 template <typename T> __device__ __forceinline__ T normal_logpdf(T y, T loc, T scale) {
     const T r = y - loc;
     return -(r * r) / (T(2) * scale * scale) - pf_log(scale) - T(PF_LOG_SQRT_2PI);
@@ -208,7 +273,14 @@ template <typename T, int K> __device__ __forceinline__ void spd_inverse(const T
 // APF first-stage weight  (proposal.pre_weight(y, x))
 template <typename T, int D>
 __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
-                                        const T (&x)[D]) {
+                                        const ColConsts<T, D>& cc, const T (&x)[D]) {
+    if constexpr (D == 1) {
+        if (cc.fast) {
+            if (proposal == PF_PROP_BOOTSTRAP) return cc.obs_lp(cc.loc1(md, cp, x[0]));  // log p(y | E[x_t | x_{t-1}])
+            const T r = cc.yb - cc.a * x[0];                                           // LGO: evaluated at x_{t-1} itself
+            return -(r * r) * cc.i2c - cc.kc;
+        }
+    }
     T loc[D], scale[D];
     mean_scale<T, D>(md, cp, x, loc, scale);
     if (proposal == PF_PROP_BOOTSTRAP) return obs_logpdf<T, D>(md, cp, loc);
@@ -254,7 +326,21 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
 // proposal.sample_and_weight(y, prediction): new state and importance weight given the draws z
 template <typename T, int D>
 __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
-                                               const T (&x)[D], const T (&z)[D], T (&xn)[D]) {
+                                               const ColConsts<T, D>& cc, const T (&x)[D], const T (&z)[D], T (&xn)[D]) {
+    if constexpr (D == 1) {
+        if (cc.fast) {
+            const T loc = cc.loc1(md, cp, x[0]);
+            if (proposal == PF_PROP_BOOTSTRAP) {
+                xn[0] = loc + cc.g * (z[0] * cc.inc);
+                return cc.obs_lp(xn[0]);
+            }
+            const T km = cc.c_loc * loc + cc.c_y;
+            xn[0] = km + cc.kstd * z[0];
+            const T eps = (xn[0] - loc) * cc.inv_g;
+            // log p(y | x') + log p(x' | x) - log q(x')
+            return cc.obs_lp(xn[0]) + (-(eps * eps) * cc.i2inc - cc.kt) - (-T(0.5) * z[0] * z[0] - cc.kq);
+        }
+    }
     T loc[D], scale[D];
     mean_scale<T, D>(md, cp, x, loc, scale);
     if (proposal == PF_PROP_BOOTSTRAP) {

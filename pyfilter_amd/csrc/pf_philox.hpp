@@ -48,57 +48,78 @@ __device__ __forceinline__ double u01_d(uint32_t a, uint32_t b) {
     return (double)v * (1.0 / 9007199254740992.0);
 }
 
+// float Box-Muller on the hardware transcendentals: v_log_f32, v_sqrt_f32 and v_sin_f32 / v_cos_f32, whose argument is
+// in revolutions - exactly the 2*pi*u2 of Box-Muller.  ~10 VALU instructions per pair (the libm versions cost ~150).
 __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
-    const float r = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.28318530717958647692f * u2, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));
+    z0 = r * __builtin_amdgcn_cosf(u2);
+    z1 = r * __builtin_amdgcn_sinf(u2);
 }
 __device__ __forceinline__ void box_muller(double u1, double u2, double& z0, double& z1) {
     const double r = sqrt(-2.0 * log(u1));
-    double s, c;
-    sincos(6.28318530717958647692 * u2, &s, &c);
-    z0 = r * c;
-    z1 = r * s;
+    const double a = 6.28318530717958647692 * u2;
+    z0 = r * cos(a);
+    z1 = r * sin(a);
 }
 
-// D (<= 4) standard normals for element `elem` of step `step`.
-template <typename T, int D> struct NormalDraw;
-
-template <int D> struct NormalDraw<float, D> {
-    __device__ __forceinline__ static void draw(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem,
-                                                float (&z)[D]) {
-        const Philox4 r = philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), step, stream, (uint32_t)seed,
-                                        (uint32_t)(seed >> 32));
-        float a, b;
-        box_muller(u01_open0(r.x), u01(r.y), a, b);
-        z[0] = a;
-        if (D > 1) z[1] = b;
-        if (D > 2) {
-            box_muller(u01_open0(r.z), u01(r.w), a, b);
-            z[2] = a;
-            if (D > 3) z[3] = b;
-        }
+// Standard normals are addressed by a flat index n = elem * D + d.  One Philox call yields NPC of them (4 for float,
+// 2 for double), so the VEC consecutive particles a thread owns share calls: D = 1, float, VEC = 4 -> one call per
+// thread per round instead of four.
+template <typename T> struct NormalCall;
+template <> struct NormalCall<float> {
+    static constexpr int NPC = 4;
+    __device__ __forceinline__ static void call(uint64_t seed, uint32_t stream, uint32_t step, uint64_t c, float (&z)[4]) {
+        const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+        box_muller(u01_open0(r.x), u01(r.y), z[0], z[1]);
+        box_muller(u01_open0(r.z), u01(r.w), z[2], z[3]);
+    }
+};
+template <> struct NormalCall<double> {
+    static constexpr int NPC = 2;
+    __device__ __forceinline__ static void call(uint64_t seed, uint32_t stream, uint32_t step, uint64_t c, double (&z)[2]) {
+        const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+        box_muller(u01_open0_d(r.x, r.y), u01_d(r.z, r.w), z[0], z[1]);
     }
 };
 
-template <int D> struct NormalDraw<double, D> {
-    __device__ __forceinline__ static void draw(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem,
-                                                double (&z)[D]) {
-        Philox4 r = philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), step, stream, (uint32_t)seed,
-                                  (uint32_t)(seed >> 32));
-        double a, b;
-        box_muller(u01_open0_d(r.x, r.y), u01_d(r.z, r.w), a, b);
-        z[0] = a;
-        if (D > 1) z[1] = b;
-        if (D > 2) {
-            r = philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), step, stream | 0x100u, (uint32_t)seed,
-                              (uint32_t)(seed >> 32));
-            box_muller(u01_open0_d(r.x, r.y), u01_d(r.z, r.w), a, b);
-            z[2] = a;
-            if (D > 3) z[3] = b;
+// z[j][d] for the VEC consecutive particles elem0 .. elem0 + VEC - 1
+template <typename T, int D, int VEC>
+__device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem0, T (&z)[VEC][D]) {
+    constexpr int NPC = NormalCall<T>::NPC;
+    const uint64_t n0 = elem0 * D;
+    if ((VEC * D) % NPC == 0 && (n0 % NPC) == 0) {
+        // aligned: exactly VEC * D / NPC calls, every normal used
+#pragma unroll
+        for (int c = 0; c < (VEC * D) / NPC; ++c) {
+            T zz[NPC];
+            NormalCall<T>::call(seed, stream, step, n0 / NPC + c, zz);
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int n = c * NPC + q;
+                z[n / D][n % D] = zz[q];
+            }
         }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < VEC * D; ++n) {
+        T zz[NPC];
+        NormalCall<T>::call(seed, stream, step, (n0 + n) / NPC, zz);
+        const int q = (int)((n0 + n) % NPC);
+        T v = zz[0];
+#pragma unroll
+        for (int k = 1; k < NPC; ++k) v = (q == k) ? zz[k] : v;
+        z[n / D][n % D] = v;
+    }
+}
+
+// D (<= 4) standard normals for the single element `elem`
+template <typename T, int D> struct NormalDraw {
+    __device__ __forceinline__ static void draw(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem, T (&z)[D]) {
+        T zz[1][D];
+        draw_normals<T, D, 1>(seed, stream, step, elem, zz);
+#pragma unroll
+        for (int d = 0; d < D; ++d) z[d] = zz[0][d];
     }
 };
 

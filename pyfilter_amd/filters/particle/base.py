@@ -292,7 +292,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.x[0], a.x[1] = x_a.data_ptr(), x_b.data_ptr()
         a.logw[0], a.logw[1] = lw_a.data_ptr(), lw_b.data_ptr()
         a.anc, a.cdf = anc.data_ptr(), cdf.data_ptr()
-        a.y, a.y_rows, a.observed = y_steps.data_ptr(), rows, observed.data_ptr()
+        observed_host = observed.cpu().contiguous()  # the launch loop reads the flags on the host (one sync per call)
+        a.y, a.y_rows, a.observed = y_steps.data_ptr(), rows, observed_host.data_ptr()
         z_tape = u_tape = None
         if ctx.z_tape is not None:
             z_tape = ctx.z_tape[t_start:t_start + steps].contiguous()
@@ -312,7 +313,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             self.kernel_ms = tuple(kms)
         else:
             L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
-        self._last_run = dict(x=(x_a, x_b), logw=(lw_a, lw_b), anc=anc, cdf=cdf, y=y_steps, observed=observed,
+        self._last_run = dict(x=(x_a, x_b), logw=(lw_a, lw_b), anc=anc, cdf=cdf, y=y_steps, observed=observed_host,
                               z=z_tape, u=u_tape, ctr=ctr, ws=ws, ll_steps=ll_steps)  # keep device buffers alive
 
         # ---- hand the results over in the reference's shapes -------------------------------------------------------

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Kernel-level micro-benchmark of the fused step: prints the HIP-event average duration of the step kernels for a
+matrix of configurations.  Usage: python tools/kbench.py [name ...]   (development tool; bench.py is the contract)."""
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from pyfilter_amd import resampling, timeseries as ts  # noqa: E402
+from pyfilter_amd.filters.particle import APF, SISR, proposals  # noqa: E402
+from pyfilter_amd.timeseries import models  # noqa: E402
+
+dev = "cuda"
+
+
+def t(v, dtype=torch.float32):
+    return torch.tensor(v, dtype=dtype, device=dev)
+
+
+def make(model, filt, prop, n, b, dtype=torch.float32, resampler="systematic"):
+    if model == "sine":
+        ssm = ts.LinearStateSpaceModel(models.SineDiffusion(t(0.0, dtype), t(1.0, dtype), dt=0.1), (t(1.0, dtype), t(0.1, dtype)))
+        o = ()
+    elif model == "lg":
+        ssm = ts.LinearStateSpaceModel(models.AR(t(0.0, dtype), t(0.99, dtype), t(0.05, dtype)), (t(1.0, dtype), t(0.15, dtype)))
+        o = ()
+    elif model == "lorenz":
+        hidden = models.Lorenz63(t(10.0, dtype), t(28.0, dtype), t(8.0 / 3.0, dtype), t(1.0, dtype), dt=0.01)
+        a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]], dtype)
+        ssm = ts.LinearStateSpaceModel(hidden, (a, t([0.0], dtype), t([math.sqrt(0.1)], dtype)), torch.Size([2]))
+        o = (2,)
+    cls = {"sisr": SISR, "apf": APF}[filt]
+    p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
+    rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[resampler]
+    f = cls(ssm, n, proposal=p, resampling=rs)
+    if b > 1:
+        f.set_batch_shape(torch.Size([b]))
+    return f, o
+
+
+CONFIGS = {
+    "apf_lgo_1m": ("sine", "apf", "lgo", 1 << 20, 1),
+    "apf_boot_1m": ("sine", "apf", "bootstrap", 1 << 20, 1),
+    "sisr_boot_1m": ("sine", "sisr", "bootstrap", 1 << 20, 1),
+    "sisr_boot_lg_1m": ("lg", "sisr", "bootstrap", 1 << 20, 1),
+    "apf_lgo_4m": ("sine", "apf", "lgo", 1 << 22, 1),
+    "apf_lgo_64x64k": ("sine", "apf", "lgo", 65536, 64),
+    "apf_lgo_1024x8k": ("sine", "apf", "lgo", 8192, 1024),
+    "apf_lgo_256k": ("sine", "apf", "lgo", 1 << 18, 1),
+    "sisr_lorenz_4m": ("lorenz", "sisr", "bootstrap", 1 << 22, 1),
+    "sisr_lorenz_4m_mn": ("lorenz", "sisr", "bootstrap", 1 << 22, 1, "multinomial"),
+}
+
+
+def main():
+    names = sys.argv[1:] or ["apf_lgo_1m", "apf_boot_1m", "sisr_boot_1m"]
+    T = int(os.environ.get("KB_T", 100))
+    for name in names:
+        cfg = CONFIGS[name]
+        f, o = make(*cfg[:5], resampler=(cfg[5] if len(cfg) > 5 else "systematic"))
+        g = torch.Generator().manual_seed(0)
+        y = (0.3 * torch.randn((T,) + o, generator=g)).cumsum(0).to(dev) if not o else torch.randn((T,) + o, generator=g).to(dev)
+        f.batch_filter(y, bar=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            res = f.batch_filter(y, bar=False)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        f._time_kernels = True
+        f.batch_filter(y, bar=False)
+        k = f.kernel_ms
+        n, b = cfg[3], cfg[4]
+        if int(os.environ.get("PF_DEBUG_CUT", "0")) < 0:
+            import ctypes as C
+            from pyfilter_amd import _lib as L
+            off = C.c_size_t(0)
+            lib = L.load()
+            lib.pf_debug_offset.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]
+            lib.pf_debug_offset(cfg[3], cfg[4], C.byref(off))
+            ws = f._last_run["ws"]
+            st = ws[off.value:off.value + 256].view(torch.int64).cpu().tolist()
+            sc = [st[i] - st[0] for i in range(0, 7)]
+            sp = [st[i] - st[8] for i in range(8, 16)]
+            print("   scan stamps (cycles from start: combine_done, finalize_done, pre-loop, pre-blockscan, post-blockscan, round_end):", sc[1:])
+            print("   step stamps (cycles from start: params, pre-loop, search_done, compute_done, push_done, pre-finish, end):", sp[1:])
+        print(f"{name:22s} us/step {1e6 * wall / T:8.2f}  particle-steps/s {n * b * T / wall:10.3e}  kernels(us, event-bracketed) "
+              f"scan {1e3 * k[1]:7.2f} step {1e3 * k[2]:7.2f}  ll {res.loglikelihood.reshape(-1)[0].item():.3f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
