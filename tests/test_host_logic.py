@@ -1,0 +1,176 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol ``include/pf_amd.h`` declares, the host
+logic (parameter packing, layouts, containers, step schedule) behaves, the product refuses to run without a GPU, and
+the plain-C oracle agrees with the reference's golden vectors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as ge
+
+    ge.build()
+
+
+def test_library_exports_every_declared_symbol():
+    from pyfilter_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "pf_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(pf_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in pf_amd.h but not exported by libpfamd.so"
+    assert declared <= set(_lib.EXPORTS) | {"pf_debug_offset"}, declared - set(_lib.EXPORTS)
+    assert b"gfx950" in lib.pf_version()
+    assert lib.pf_error_string(-2) == b"workspace too small"
+    n = C.c_size_t(0)
+    assert lib.pf_workspace_bytes(1 << 20, 1, 1, C.byref(n)) == 0 and n.value > 0
+    assert lib.pf_workspace_bytes(0, 1, 1, C.byref(n)) == _lib_einval()
+
+
+def _lib_einval():
+    return -1
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected before anything is launched (safe to call on a CPU-only box)."""
+    from pyfilter_amd import _lib
+
+    lib = _lib.load()
+    assert lib.pf_normalize(None, None, None, None, 10, 1, 0, None, 0, None) == -1
+    assert lib.pf_filter_run(None, 0, 1, 0, None) == -1
+    m = _lib.PfModel()
+    m.hid_kind, m.obs_kind, m.dim, m.obs_dim, m.params = 3, 0, 1, 1, 1  # Lorenz needs D = 3
+    assert lib.pf_pre_weight(C.byref(m), 0, 1, 1, 1, 1, 8, 1, 0, None) == -3
+
+
+def test_no_cpu_fallback():
+    import pyfilter_amd
+    from pyfilter_amd import _lib
+
+    with pytest.raises(_lib.PfAmdError):
+        pyfilter_amd.utils.normalize(torch.zeros(8))
+    with pytest.raises(_lib.PfAmdError):
+        pyfilter_amd.resampling.systematic(torch.zeros(8))
+
+
+def test_pack_params_layout():
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.timeseries import models
+
+    t = torch.tensor
+    kappa, gamma, sigma = t([0.1, 0.2, 0.3]), t([1.0, 1.1, 1.2]), t([0.5, 0.6, 0.7])
+    ssm = ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(kappa, gamma, sigma, dt=1.0), (t(2.0), t(0.25)))
+    rows = models.pack_params(ssm, 3, torch.float64, "cpu")
+    assert rows.shape == (3, 4 * 1 + 1 + 2)  # [hp0 hp1 hp2 hp3 | A | b | s]
+    assert torch.equal(rows[:, 0], kappa.double()) and torch.equal(rows[:, 2], sigma.double())
+    assert torch.equal(rows[:, 4], torch.full((3,), 2.0, dtype=torch.float64))
+    assert torch.equal(rows[:, 5], torch.zeros(3, dtype=torch.float64)) and torch.equal(rows[:, 6], torch.full((3,), 0.25, dtype=torch.float64))
+    k = ssm.kernel_kind
+    assert (k.hid_kind, k.obs_kind, k.dim, k.obs_dim) == (4, 0, 1, 1)
+
+    hidden = models.Lorenz63(t(10.0), t(28.0), t(8.0 / 3.0), t(1.0))
+    a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]])
+    ssm3 = ts.LinearStateSpaceModel(hidden, (a, t([0.0]), t([0.3])), torch.Size([2]))
+    rows = models.pack_params(ssm3, 2, torch.float32, "cpu")
+    assert rows.shape == (2, 4 * 3 + 2 * 3 + 2 * 2)
+    assert torch.equal(rows[0, 12:18], a.reshape(-1)) and torch.allclose(rows[1, 20:22], t([0.3, 0.3]))
+    assert ssm3.kernel_kind.dim == 3 and ssm3.kernel_kind.obs_dim == 2 and abs(ssm3.kernel_kind.inc_scale - 0.1) < 1e-12
+
+    sv = models.StochasticVolatilityModel(models.Verhulst(t(0.05), t(1.0), t(0.1), dt=0.2), t(0.0))
+    assert sv.kernel_kind.obs_kind == 1
+    with pytest.raises(Exception):
+        models.pack_params(ts.StateSpaceModel(ts.AffineProcess(lambda x, s: (x.value, s), (t(1.0),), None, None), None, ()), 1, torch.float32, "cpu")
+
+
+def test_layout_views_round_trip_without_copies():
+    from pyfilter_amd import ops
+
+    soa = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)  # (D, B, N)
+    v = ops.from_soa(soa, True, True)
+    assert v.shape == (5, 3, 2) and ops.to_soa(v, True, True).data_ptr() == soa.data_ptr()
+    cols = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    w = ops.from_cols(cols, True)
+    assert w.shape == (4, 3) and ops.to_cols(w).data_ptr() == cols.data_ptr()
+    one = torch.zeros(1, 4)
+    assert ops.from_cols(one, False).shape == (4,)
+    s1 = torch.zeros(1, 1, 6)
+    assert ops.from_soa(s1, False, False).shape == (6,) and ops.to_soa(ops.from_soa(s1, False, False), False, False).data_ptr() == s1.data_ptr()
+
+
+def test_tensor_container_state_dict_keys():
+    from pyfilter_amd.container import TensorContainer, make_dequeue
+
+    tc = TensorContainer()
+    tc.make_deque("filter_means", maxlen=True)
+    tc.make_deque("last", maxlen=False)
+    tc.make_deque("five", maxlen=5)
+    for i in range(7):
+        for k in ("filter_means", "last", "five"):
+            tc[k].append(torch.full((2,), float(i)))
+    sd = tc.state_dict()
+    assert set(sd) == {"tensor_deque_None__filter_means", "tensor_deque_1__last", "tensor_deque_5__five"}
+    assert sd["tensor_deque_None__filter_means"].shape == (7, 2) and sd["tensor_deque_1__last"].shape == (1, 2)
+    assert sd["tensor_deque_5__five"][0, 0] == 2.0
+    tc2 = TensorContainer()
+    tc2.load_state_dict(dict(sd))
+    assert torch.equal(tc2.get_as_tensor("five"), tc.get_as_tensor("five")) and tc2["five"].maxlen == 5
+    assert make_dequeue(False).maxlen == 1 and make_dequeue(True).maxlen is None
+
+
+def test_api_surface_matches_reference_names():
+    from pyfilter_amd.filters import BaseFilter, FilterResult
+    from pyfilter_amd.filters.particle import APF, SISR, ParticleFilter, proposals
+    from pyfilter_amd.resampling import multinomial, systematic  # noqa: F401
+    from pyfilter_amd.utils import get_ess, normalize  # noqa: F401
+
+    for m in ("set_batch_shape", "initialize", "predict", "correct", "filter", "batch_filter", "copy", "increase_particles"):
+        assert hasattr(SISR, m) and hasattr(APF, m), m
+    for m in ("filter_means", "filter_variance", "loglikelihood", "latest_state", "states", "state_dict",
+              "load_state_dict", "resample", "exchange", "copy"):
+        assert hasattr(FilterResult, m), m
+    for cls in (proposals.Bootstrap, proposals.LinearGaussianObservations):
+        for m in ("set_model", "sample_and_weight", "pre_weight", "copy"):
+            assert hasattr(cls, m)
+    assert issubclass(SISR, ParticleFilter) and issubclass(ParticleFilter, BaseFilter)
+    f = SISR(lambda ctx: None, 100, ess_threshold=0.5)
+    f.set_batch_shape(torch.Size([7]))
+    assert f.particles == torch.Size([100, 7]) and f._resample_threshold == 50.0
+    f.increase_particles(2)
+    assert f.particles == torch.Size([200, 7]) and f._resample_threshold == 100.0
+    g = f.copy()
+    assert g.particles == f.particles and g._resample_threshold == 100.0 * 200  # the reference's copy() quirk
+    with pytest.raises(NotImplementedError):
+        f.set_batch_shape(torch.Size([2, 3]))
+
+
+# ---- the plain-C oracle against the reference's golden vectors -----------------------------------------------------
+@pytest.mark.parametrize("dt,ct,suf", [("f32", np.float32, "f32"), ("f64", np.float64, "f64")])
+def test_c_oracle_against_reference_golden(dt, ct, suf):
+    so = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libpforacle.so"))
+    with np.load(os.path.join(ROOT, "tests", "golden", f"primitives_{dt}.npz")) as f:
+        g = {k: f[k] for k in f.files}
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for nm in "abc":
+        lw = np.ascontiguousarray(g[f"norm_{nm}_in"].T)  # (B, N) column layout
+        b, n = lw.shape
+        W = np.empty_like(lw)
+        getattr(so, f"oracle_normalize_{suf}")(ptr(lw), ptr(W), C.c_int64(n), C.c_int64(b))
+        assert np.array_equal(lw.T, g[f"norm_{nm}_inplace"], equal_nan=True)  # in-place sanitisation: exact
+        np.testing.assert_allclose(W.T, g[f"norm_{nm}_W"], rtol=1e-12 if dt == "f64" else 5e-5, atol=0)
+        # sequential systematic walk on the reference's own W and u: exact ancestors
+        Wref = np.ascontiguousarray(g[f"norm_{nm}_W"].T)
+        ok = ~np.isnan(Wref).any(axis=1)
+        u = np.ascontiguousarray(g[f"norm_{nm}_u"].reshape(-1))
+        idx = np.empty((b, n), dtype=np.int64)
+        getattr(so, f"oracle_systematic_{suf}")(ptr(Wref), ptr(u), ptr(idx), C.c_int64(n), C.c_int64(b))
+        assert np.array_equal(idx[ok].T, g[f"norm_{nm}_idx"][:, ok])
