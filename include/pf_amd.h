@@ -169,7 +169,8 @@ typedef struct pf_filter_args {
     void* vars;      /* (T+1, B, D) */
     void* ll_steps;  /* (T, B) per-step log-likelihood increments */
     void* ll_total;  /* (B) running sum, updated in place */
-    int32_t* step_counter; /* reserved (unused) */
+    int32_t* step_counter; /* optional device uint64 "epoch" added to `seed` by every kernel (NULL = 0): lets a captured
+                            * graph draw fresh Philox numbers on every replay */
     void* ws;
     size_t ws_bytes;
 } pf_filter_args;
@@ -178,6 +179,15 @@ typedef struct pf_filter_args {
  * step (scan, then resample+propagate+weight+reduce) plus one reduce launch for the incoming state.
  * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps). */
 int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
+
+/* hipGraph variant: captures the launch sequence pf_filter_run would issue (every pointer, the step flags and the
+ * observation offsets are baked into the kernel nodes) and returns an opaque handle OWNED BY THE CALLER; replaying it
+ * costs one host call instead of 2 T launches (an eager launch costs the host ~5 us, a graph kernel node ~1.5 us).
+ * The buffers named in `args` must stay alive and in place for the handle's lifetime; `y`'s contents may change. */
+int pf_filter_graph_create(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
+                           void** handle);
+int pf_filter_graph_launch(void* handle, void* stream);
+int pf_filter_graph_destroy(void* handle);
 
 /* Measurement variant of pf_filter_run: brackets every kernel launch with HIP events on `stream`, synchronises the
  * stream and returns the average duration in ms of the step kernels in kernel_ms[0..2] =

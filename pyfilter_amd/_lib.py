@@ -26,7 +26,8 @@ MAX_O = 3
 EXPORTS = (
     "pf_version", "pf_error_string", "pf_workspace_bytes", "pf_normalize", "pf_systematic", "pf_systematic_logw",
     "pf_multinomial", "pf_gather", "pf_loglik", "pf_moments", "pf_pre_weight", "pf_sample_and_weight",
-    "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed",
+    "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed", "pf_filter_graph_create", "pf_filter_graph_launch",
+    "pf_filter_graph_destroy",
 )
 
 
@@ -89,6 +90,9 @@ def load() -> C.CDLL:
     lib.pf_initial_sample.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), vp, u64, vp, i64, i64, i64, i32, vp]
     lib.pf_filter_run.argtypes = [C.POINTER(PfFilterArgs), i64, i64, i32, vp]
     lib.pf_filter_run_timed.argtypes = [C.POINTER(PfFilterArgs), i64, i64, i32, vp, C.POINTER(C.c_float)]
+    lib.pf_filter_graph_create.argtypes = [C.POINTER(PfFilterArgs), i64, i64, i32, vp, C.POINTER(vp)]
+    lib.pf_filter_graph_launch.argtypes = [vp, vp]
+    lib.pf_filter_graph_destroy.argtypes = [vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("pf_version", "pf_error_string"):

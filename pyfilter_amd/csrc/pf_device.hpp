@@ -62,6 +62,14 @@ __device__ __forceinline__ double pf_sin(double x) { return sin(x); }
 // rounding of the weights themselves); double -> libm
 __device__ __forceinline__ float pf_exp_w(float x) { return __expf(x); }
 __device__ __forceinline__ double pf_exp_w(double x) { return exp(x); }
+// per-column constants (evaluated once per thread, on the critical path of every workgroup): hardware log / rcp /
+// sqrt for float (1 ulp class), libm for double
+__device__ __forceinline__ float pf_log_c(float x) { return __logf(x); }
+__device__ __forceinline__ double pf_log_c(double x) { return log(x); }
+__device__ __forceinline__ float pf_rcp_c(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double pf_rcp_c(double x) { return 1.0 / x; }
+__device__ __forceinline__ float pf_sqrt_c(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double pf_sqrt_c(double x) { return sqrt(x); }
 __device__ __forceinline__ float pf_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double pf_abs(double x) { return fabs(x); }
 

@@ -1,8 +1,8 @@
 // pf_fused.hpp - the fused SISR / APF time step: TWO kernels per step.
 //
-//   k_fused_scan   (grid tiles x B)  re-reduces the column's per-tile partials, tile 0 finalises the bookkeeping of the
-//                                    current state (moments row, log-likelihood of the previous step, resampling
-//                                    decision); if the column resamples: scans this tile of resampling weights into the
+//   k_fused_scan   (grid tiles+1 x B) re-reduces the column's per-tile partials; the extra workgroup per column does the
+//                                    bookkeeping of the current state (moments row, log-likelihood of the previous step,
+//                                    resampling decision); if the column resamples: scans this tile of resampling weights into the
 //                                    cdf (fp64 carry, rounded per element) and emits j0[tile'] = the ancestor of the first
 //                                    grid position of every position tile whose start falls into this tile's cdf range.
 //   k_fused_step   (grid tiles x B)  ancestors of this tile's grid positions (LDS window search from j0) -> gather
@@ -20,7 +20,8 @@ namespace pf {
 
 #define PF_STAMP(a, slot)                                                                       \
     do {                                                                                        \
-        if ((a).debug_cut < 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)        \
+        if ((a).debug_cut < 0 && !(a).finalize_only && blockIdx.x == (unsigned)(-(a).debug_cut - 1) &&  \
+            blockIdx.y == 0 && threadIdx.x == 0)                                                \
             (a).dbg[slot] = (unsigned long long)clock64();                                      \
     } while (0)
 
@@ -32,6 +33,7 @@ template <typename T> struct FusedArgs {
     double thr_abs;  // ess_threshold * N
     double logN;
     uint64_t seed;
+    const uint64_t* seed_dev;  // optional device word added to `seed` (lets a captured graph draw fresh numbers per replay)
     T* x[2];
     T* logw[2];
     int32_t* anc;
@@ -127,34 +129,54 @@ template <typename T, int D> struct PartialAcc {
             for (int j = 0; j < VEC; ++j) a2.s += (rw[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(rw[j] - a2.m);
         }
     }
-    // workgroup reduction + store; `red` >= (3 + 2D) * PF_NWAVES doubles, `redm` >= PF_NWAVES Ts
+    // workgroup reduction + store in two LDS exchanges (maxima, then every rescaled sum); `red` >= (3 + 2D) * PF_NWAVES
+    // doubles, `redm` >= 2 * PF_NWAVES Ts, neither used by anything still in flight
     __device__ __forceinline__ void finish(double* part, int b, int k, int B, int tiles, bool pre_on, double* red, T* redm,
                                            int32_t* poison_slot) {
-        const T M1 = block_max<T>(a1.m, redm);
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        const T w1 = wave_max<T>(a1.m), w2 = wave_max<T>(a2.m);
+        if (lane == 0) {
+            redm[wid] = w1;
+            redm[PF_NWAVES + wid] = w2;
+        }
+        __syncthreads();
+        T M1 = redm[0], M2 = redm[PF_NWAVES];
+#pragma unroll
+        for (int w = 1; w < PF_NWAVES; ++w) {
+            M1 = (redm[w] > M1) ? redm[w] : M1;
+            M2 = (redm[PF_NWAVES + w] > M2) ? redm[PF_NWAVES + w] : M2;
+        }
         const double f1 = exp_diff_t<T>((double)a1.m, (double)M1);
         double sums[3 + 2 * D];
         sums[0] = a1.s * f1;
         sums[1] = q1 * f1 * f1;
+        sums[2] = pre_on ? a2.s * exp_diff_t<T>((double)a2.m, (double)M2) : 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             sums[3 + d] = mx[d] * f1;
             sums[3 + D + d] = mxx[d] * f1;
         }
-        T M2 = -Lim<T>::inf();
-        sums[2] = 0.0;
-        if (pre_on) {  // uniform
-            M2 = block_max<T>(a2.m, redm);
-            sums[2] = a2.s * exp_diff_t<T>((double)a2.m, (double)M2);
+#pragma unroll
+        for (int q = 0; q < 3 + 2 * D; ++q) {
+            const double ws = wave_sum(sums[q]);
+            if (lane == 0) red[q * PF_NWAVES + wid] = ws;
         }
-        block_sum<3 + 2 * D>(sums, red);
         if (poison) atomicOr(poison_slot, 1);
+        __syncthreads();
         if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < 3 + 2 * D; ++q) {
+                double r = red[q * PF_NWAVES];
+#pragma unroll
+                for (int w = 1; w < PF_NWAVES; ++w) r += red[q * PF_NWAVES + w];
+                sums[q] = r;
+            }
             const int64_t stride = (int64_t)B * tiles;
             const int64_t o = (int64_t)b * tiles + k;
             part[PQ_M1 * stride + o] = (double)M1;
             part[PQ_S1 * stride + o] = sums[0];
             part[PQ_Q1 * stride + o] = sums[1];
-            part[PQ_M2 * stride + o] = (double)M2;
+            part[PQ_M2 * stride + o] = pre_on ? (double)M2 : -__builtin_huge_val();
             part[PQ_S2 * stride + o] = sums[2];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -169,7 +191,7 @@ template <typename T, int D> struct PartialAcc {
 template <typename T, int D, int VEC>
 __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     __shared__ double red[(3 + 2 * D) * PF_NWAVES];
-    __shared__ T redm[PF_NWAVES];
+    __shared__ T redm[2 * PF_NWAVES];
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int slot = a.step & 1;
@@ -232,11 +254,100 @@ __device__ __forceinline__ void emit_j0(T c_prev, T c, int64_t i, T u, int64_t N
     }
 }
 
+// Combined column statistics from the per-tile partials.  The first PF_BLOCK tiles' values are passed in registers
+// (`early`, loaded at the very top of the kernel so their latency overlaps the tile's own work); further tiles are
+// read in the loops.  Two LDS exchanges: maxima, then every rescaled sum.
+struct ColCombine {
+    double m1, m2, S1, Q1, S2, prefK, prefK1;
+};
+#define PF_COMBINE_ITERS (PF_MAX_TILES / PF_BLOCK)  // partial records per thread
+struct EarlyPartials {
+    double m1[PF_COMBINE_ITERS], s1[PF_COMBINE_ITERS], q1[PF_COMBINE_ITERS], m2[PF_COMBINE_ITERS], s2[PF_COMBINE_ITERS];
+};
+template <typename T>
+__device__ __forceinline__ void load_early_partials(const FusedArgs<T>& a, int64_t cb, int64_t stride, bool two,
+                                                    EarlyPartials& e) {
+#pragma unroll
+    for (int it = 0; it < PF_COMBINE_ITERS; ++it) {
+        const int t = threadIdx.x + it * PF_BLOCK;
+        e.m1[it] = e.m2[it] = -__builtin_huge_val();
+        e.s1[it] = e.q1[it] = e.s2[it] = 0.0;
+        if (t < a.g.tiles) {
+            e.m1[it] = a.part[PQ_M1 * stride + cb + t];
+            e.s1[it] = a.part[PQ_S1 * stride + cb + t];
+            e.q1[it] = a.part[PQ_Q1 * stride + cb + t];
+            if (two) {
+                e.m2[it] = a.part[PQ_M2 * stride + cb + t];
+                e.s2[it] = a.part[PQ_S2 * stride + cb + t];
+            }
+        }
+    }
+}
+template <typename T>
+__device__ __forceinline__ ColCombine combine_column(const FusedArgs<T>& a, const EarlyPartials& e, int64_t cb,
+                                                     int64_t stride, int k, bool two, double* red, double* redm) {
+    const Geom& g = a.g;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double m1 = e.m1[0], m2 = e.m2[0];
+#pragma unroll
+    for (int it = 1; it < PF_COMBINE_ITERS; ++it) {
+        m1 = fmax(m1, e.m1[it]);
+        m2 = fmax(m2, e.m2[it]);
+    }
+    m1 = wave_max(m1);
+    m2 = wave_max(m2);
+    if (lane == 0) {
+        redm[wid] = m1;
+        redm[PF_NWAVES + wid] = m2;
+    }
+    __syncthreads();
+    m1 = redm[0];
+    m2 = redm[PF_NWAVES];
+#pragma unroll
+    for (int w = 1; w < PF_NWAVES; ++w) {
+        m1 = fmax(m1, redm[w]);
+        m2 = fmax(m2, redm[PF_NWAVES + w]);
+    }
+    // S1, Q1, S2 and the resampling-weight prefix below tile k / below tile k+1.  Both prefixes use the same masked
+    // loop + reduction tree, so tile k's "next" prefix is bit-identical to what tile k+1 computes as its own.
+    double v[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < PF_COMBINE_ITERS; ++it) {
+        const int t = threadIdx.x + it * PF_BLOCK;
+        if (t < g.tiles) {
+            const double f = exp_diff_t<T>(e.m1[it], m1);
+            const double s = e.s1[it] * f;
+            v[0] += s;
+            v[1] += e.q1[it] * f * f;
+            double sr = s;
+            if (two) {
+                sr = e.s2[it] * exp_diff_t<T>(e.m2[it], m2);
+                v[2] += sr;
+            }
+            if (t < k) v[3] += sr;
+            if (t < k + 1) v[4] += sr;
+        }
+    }
+    block_sum<5>(v, red);
+    ColCombine c;
+    c.m1 = m1;
+    c.m2 = m2;
+    c.S1 = v[0];
+    c.Q1 = v[1];
+    c.S2 = v[2];
+    c.prefK = v[3];
+    c.prefK1 = v[4];
+    return c;
+}
+
+// grid (tiles + 1, B): workgroups k < tiles scan their tile; the extra workgroup k == tiles is the column's bookkeeper
+// (moments row, log-likelihood increment, resampling decision) - kept off the scanning workgroups' critical path.
 template <typename T, int D, int VEC>
 __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
     __shared__ double red[6 * PF_NWAVES];
     __shared__ double redm[2 * PF_NWAVES];
     __shared__ double red2[2 * D * PF_NWAVES];
+    __shared__ double reds[PF_NWAVES];
     __shared__ T lastv[PF_BLOCK + 1];  // every thread's last cdf value of the round (+ the previous round's last one)
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -249,86 +360,29 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
     const int64_t cb = (int64_t)b * g.tiles;
     if (a.debug_cut == 1) return;
     PF_STAMP(a, 0);
+    EarlyPartials early;
+    load_early_partials<T>(a, cb, stride, two, early);
 
-    // prefetch round 0 of this tile (log-weights, and the particles the APF's in-register pre-weight needs) so the
-    // loads are in flight while the partials are combined
-    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
-    const T* x_base = a.x[slot];
-    const int64_t base = (int64_t)k * g.tile_elems;
-    T lw[VEC], xv[D][VEC];
-    {
-        const int64_t i0 = base + threadIdx.x * VEC;
-        if (!a.finalize_only && i0 < g.N) {
-            if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
-            if (two) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
-                    if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
-                }
-            }
-        }
-    }
-
-    // ---- one pass over the column's partials: both maxima, then both sums + this tile's prefix ----------------------
-    double m1 = -__builtin_huge_val(), m2 = -__builtin_huge_val();
-    for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK) {
-        m1 = fmax(m1, a.part[PQ_M1 * stride + cb + t]);
-        if (two) m2 = fmax(m2, a.part[PQ_M2 * stride + cb + t]);
-    }
-    {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        m1 = wave_max(m1);
-        m2 = wave_max(m2);
-        if (lane == 0) { redm[wid] = m1; redm[PF_NWAVES + wid] = m2; }
-        __syncthreads();
-        m1 = redm[0];
-        m2 = redm[PF_NWAVES];
-#pragma unroll
-        for (int w = 1; w < PF_NWAVES; ++w) { m1 = fmax(m1, redm[w]); m2 = fmax(m2, redm[PF_NWAVES + w]); }
-    }
-    // S1, Q1, S2, and the resampling-weight prefix below this tile / below the next tile.  Both prefixes use the same
-    // masked loop + reduction tree, so tile k's "next" prefix is bit-identical to what tile k+1 computes as its own.
-    double v[6] = {0, 0, 0, 0, 0, 0};  // S1, Q1, S2, prefix(k), prefix(k+1), -
-    for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK) {
-        const double f = exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], m1);
-        const double s = a.part[PQ_S1 * stride + cb + t] * f;
-        v[0] += s;
-        v[1] += a.part[PQ_Q1 * stride + cb + t] * f * f;
-        double sr = s;
-        if (two) {
-            sr = a.part[PQ_S2 * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M2 * stride + cb + t], m2);
-            v[2] += sr;
-        }
-        if (t < k) v[3] += sr;
-        if (t < k + 1) v[4] += sr;
-    }
-    block_sum<6>(v, red);
-    PF_STAMP(a, 1);
-    const double S1 = v[0], Q1 = v[1];
-    const double lse_w = m1 + log(S1);
-    const double ess = S1 * S1 / Q1;
-
-    bool resample;
-    if (apf) resample = obs;            // APF resamples every weighted step (apf.py:29-31)
-    else resample = ess < a.thr_abs;    // SISR: ess < ess_threshold * N (sisr.py:18-19)
-    if (a.finalize_only) resample = false;
-
-    if (k == 0) {
-        // moments of the current state -> row `step` of filter_means / filter_variance
+    if (k == g.tiles) {
+        // ------------------------------------------------ bookkeeper ------------------------------------------------------
+        const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
+        const double lse_w = c.m1 + log(c.S1);
+        const double ess = c.S1 * c.S1 / c.Q1;
+        bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
+        if (a.finalize_only) resample = false;
         double mv[2 * D];
 #pragma unroll
         for (int q = 0; q < 2 * D; ++q) {
             mv[q] = 0.0;
             for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-                mv[q] += a.part[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], m1);
+                mv[q] += a.part[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], c.m1);
         }
         block_sum<2 * D>(mv, red2);
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const double mu = mv[d] / S1;
-                double var = mv[D + d] / S1 - mu * mu;
+            for (int d = 0; d < D; ++d) {  // moments of the current state -> row `step` of filter_means / filter_variance
+                const double mu = mv[d] / c.S1;
+                double var = mv[D + d] / c.S1 - mu * mu;
                 if (var < 0.0) var = 0.0;
                 a.means[((int64_t)step * g.B + b) * D + d] = (T)mu;
                 a.vars[((int64_t)step * g.B + b) * D + d] = (T)var;
@@ -351,28 +405,26 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
             st.ll_done = a.finalize_only ? 1 : 0;
             if (!a.finalize_only) {
                 st.prev_observed = obs ? 1 : 0;
-                if (apf) {
-                    // ll_t = [lse(w') - log N] + [lse(rw) - lse(w)]   (apf.py:44)
-                    st.base_lse = a.logN - ((m2 + log(v[2])) - lse_w);
-                } else {
-                    // ll_t = lse(wi + log W): W = 1/N after resampling, else the carried weights (sisr.py:52-55)
-                    st.base_lse = resample ? a.logN : lse_w;
-                }
+                // ll_t = [lse(w') - log N] + [lse(rw) - lse(w)] (apf.py:44) | lse(wi + log W), W = 1/N after resampling
+                // else the carried weights (sisr.py:52-55)
+                st.base_lse = apf ? a.logN - ((c.m2 + log(c.S2)) - lse_w) : (resample ? a.logN : lse_w);
             }
             a.stat[b] = st;
         }
+        return;
     }
-    PF_STAMP(a, 2);
-    if (!resample || a.debug_cut == 2) return;
+    if (a.finalize_only) return;
 
-    // ---- scan this tile of resampling weights: SISR scans logw, APF scans rw = sanitize(pre_weight(x, y) + logw) ------
-    const double MR = two ? m2 : m1, SR = two ? v[2] : S1;
+    // ---------------------------------------------------- scanner ---------------------------------------------------------
+    // 1. everything that does not need the column totals: this tile's log-weights (and particles for the APF's
+    //    in-register pre-weight), its own maximum, the exponentials and the workgroup-local scan (one round per tile is
+    //    the common case; multi-round tiles take the generic loop below)
+    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
+    const T* x_base = a.x[slot];
+    const int64_t base = (int64_t)k * g.tile_elems;
+    const int64_t tile_last = (base + g.tile_elems < g.N ? base + g.tile_elems : g.N) - 1;
     const double mk = a.part[(two ? PQ_M2 : PQ_M1) * stride + cb + k];
-    const double fk = exp_diff_t<T>(mk, MR) / SR;
-    const double Pk = v[3] / SR;
-    const double Pnext = v[4] / SR;
     const T tile_max = (T)mk;
-
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
     cc.fast = false;
@@ -381,21 +433,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
         cc.prepare(a.md, cp);
     }
     const bool sys = a.resampler == PF_RESAMPLE_SYSTEMATIC;
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const T ub = !sys ? T(0)
                       : (a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
-                                  : uniform_draw<T>(a.seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b));
-
+                                  : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b));
     T* cdf_col = a.cdf + (int64_t)b * g.N;
     int32_t* j0_col = a.j0 + cb;
-    double carry = 0.0;
-    PF_STAMP(a, 3);
-    const int64_t tile_last = (base + g.tile_elems < g.N ? base + g.tile_elems : g.N) - 1;
-    for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t r0 = base + (int64_t)r * g.round_elems;
-        if (r0 >= g.N) break;
-        const int64_t i0 = r0 + threadIdx.x * VEC;
-        const bool on = i0 < g.N;
-        if (on && r > 0) {
+
+    auto tile_exponentials = [&](int64_t i0, bool on, double (&e)[VEC]) -> double {
+        T lw[VEC], xv[D][VEC];
+        if (on) {
             if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
             if (two) {
 #pragma unroll
@@ -405,13 +452,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
                 }
             }
         }
-        double e[VEC], local = 0.0;
+        double local = 0.0;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             double ej = 0.0;
             if (on) {
                 T rw = lw[j];
-                if (two) {
+                if (two) {  // APF: rw = sanitize(pre_weight(x, y) + logw), recomputed in registers, never stored
                     T xj[D];
 #pragma unroll
                     for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
@@ -420,19 +467,20 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
                 ej = (rw == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(rw - tile_max);
             }
             local += ej;
-            e[j] = local;
+            e[j] = local;  // thread-local inclusive
         }
-        PF_STAMP(a, 4);
-        double total;
-        const double excl = block_scan_excl(local, red, total);
-        PF_STAMP(a, 5);
+        return local;
+    };
+    // cdf values of one round from the scanned exponentials; stores them and emits the position-tile starts
+    auto write_round = [&](int r, int64_t i0, bool on, const double (&e)[VEC], double offset, double Pk, double fk,
+                           double Pnext) {
         T outv[VEC];
         if (on) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                double cc = Pk + fk * (carry + excl + e[j]);
-                if (cc > Pnext) cc = Pnext;
-                T c = (T)cc;
+                double cc_ = Pk + fk * (offset + e[j]);
+                if (cc_ > Pnext) cc_ = Pnext;
+                T c = (T)cc_;
                 // the tile's last element is pinned to T(prefix(k+1)) - the value tile k+1 starts from - and the column's
                 // last element to 1 (cumsum[..., -1] = 1, resampling.py:49)
                 if (i0 + j == tile_last) c = (i0 + j == g.N - 1) ? T(1) : (T)Pnext;
@@ -456,38 +504,85 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
             __syncthreads();
             if (threadIdx.x == 0) lastv[0] = lastv[PF_BLOCK];
         }
+    };
+
+    const bool single = g.rounds_per_tile == 1;
+    double e0[VEC], excl0 = 0.0;
+    const int64_t i00 = base + threadIdx.x * VEC;
+    if (single) {
+        double total;
+        const double local = tile_exponentials(i00, i00 < g.N, e0);
+        excl0 = block_scan_excl(local, reds, total);
+    }
+    PF_STAMP(a, 1);
+
+    // 2. the column totals
+    const ColCombine c = combine_column<T>(a, early, cb, stride, k, two, red, redm);
+    PF_STAMP(a, 2);
+    const bool resample = apf ? obs : (c.S1 * c.S1 / c.Q1 < a.thr_abs);
+    if (!resample || a.debug_cut == 2) return;
+    const double MR = two ? c.m2 : c.m1, SR = two ? c.S2 : c.S1;
+    const double fk = exp_diff_t<T>(mk, MR) / SR;
+    const double Pk = c.prefK / SR;
+    const double Pnext = c.prefK1 / SR;
+    PF_STAMP(a, 3);
+
+    // 3. cdf = P_k + f_k * (scan), rounded per element
+    if (single) {
+        write_round(0, i00, i00 < g.N, e0, excl0, Pk, fk, Pnext);
         PF_STAMP(a, 6);
+        return;
+    }
+    double carry = 0.0;
+    for (int r = 0; r < g.rounds_per_tile; ++r) {
+        const int64_t r0 = base + (int64_t)r * g.round_elems;
+        if (r0 >= g.N) break;
+        const int64_t i0 = r0 + threadIdx.x * VEC;
+        const bool on = i0 < g.N;
+        double e[VEC], total;
+        const double local = tile_exponentials(i0, on, e);
+        const double excl = block_scan_excl(local, reds, total);
+        write_round(r, i0, on, e, carry + excl, Pk, fk, Pnext);
         carry += total;
     }
 }
 
 template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_fused_step(FusedArgs<T> a) {
-    __shared__ __attribute__((aligned(32))) T win[SearchWin<T, VEC>::WIN];
+__global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_step(FusedArgs<T> a) {
+    constexpr int WIN = SearchWin<T, VEC>::WIN;
+    // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
+    // ancestor gather is an LDS read instead of a second dependent global round trip
+    constexpr bool XWIN = (sizeof(T) * D <= 8);
+    __shared__ __attribute__((aligned(32))) T win[WIN];
+    __shared__ __attribute__((aligned(32))) T xwin[XWIN ? D * WIN : VEC];
     __shared__ int sh_j0;
     __shared__ double red[(3 + 2 * D) * PF_NWAVES];
-    __shared__ T redm[PF_NWAVES];
+    __shared__ T redm[2 * PF_NWAVES];
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
+    const int tid = threadIdx.x;
     const int step = a.step;
     const int slot = step & 1;
     const bool obs = a.obs != 0;
     const bool apf = a.filter == PF_FILTER_APF;
     const bool resample = a.stat[b].resample != 0;
     const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
+    const bool windowed = resample && !multinomial;
     const bool pre_next = a.obs_next && apf;
     const int N = (int)g.N;
     PF_STAMP(a, 8);
+    if (a.debug_cut == 1) return;
 
-    ColParams<T, D> cp, cpn;
-    ColConsts<T, D> cc, ccn;
+    // uniform loads first: the window start and the column's parameter rows
+    int j0 = windowed ? a.j0[(int64_t)b * g.tiles + k] : 0;
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    ColParams<T, D> cp;
+    ColConsts<T, D> cc;
     load_col_params<T, D>(a, b, step, obs, cp);
-    cc.prepare(a.md, cp);
-    ccn.fast = false;
-    if (pre_next) {
-        load_col_params<T, D>(a, b, step + 1, true, cpn);
-        ccn.prepare(a.md, cpn);
-    }
+    if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
+    const T ub = !windowed ? T(0)
+                           : (a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
+                                       : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b));
 
     const T* x_in = a.x[slot];
     T* x_out = a.x[slot ^ 1];
@@ -496,39 +591,116 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_step(FusedArgs<T> a) {
     const T* cdf_col = a.cdf + (int64_t)b * g.N;
     int32_t* anc_col = a.anc + (int64_t)b * g.N;
     const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
-
     const int64_t base = (int64_t)k * g.tile_elems;
-    T ub = T(0);
-    if (a.debug_cut == 1) return;
-    PF_STAMP(a, 9);
-    if (resample && !multinomial) {
-        ub = a.u_tape ? a.u_tape[(int64_t)step * g.B + b] : uniform_draw<T>(a.seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
-        if (threadIdx.x == 0) sh_j0 = a.j0[(int64_t)b * g.tiles + k];
-        __syncthreads();
-    }
+    const T nT = T(N);
+
     bool poison = false;
     PartialAcc<T, D> acc;
     acc.init();
-    PF_STAMP(a, 10);
+    PF_STAMP(a, 9);
 
     for (int r = 0; r < g.rounds_per_tile; ++r) {
         const int64_t r0 = base + (int64_t)r * g.round_elems;
         if (r0 >= g.N) break;
-        const int64_t i0 = r0 + threadIdx.x * VEC;
+        const int64_t i0 = r0 + tid * VEC;
         const bool on = i0 < g.N;
-        int idx[VEC];
-        if (resample) {
-            if (!multinomial) {
-                systematic_round<T, VEC>(cdf_col, N, i0, ub, nullptr, win, &sh_j0, idx);
-            } else {
+
+        // ---- 1. issue the window loads (cdf, and the particles behind it) ------------------------------------------
+        const int ws = j0 - (j0 % VEC);
+        T c0[VEC], c1[VEC], xa[D][VEC], xb[D][VEC];
+        const int ja = ws + tid * VEC, jb = ws + (PF_BLOCK + tid) * VEC;
+        const bool ina = windowed && ja < N, inb = windowed && jb < N;
+        if (ina) {
+            if (VEC == 1) c0[0] = cdf_col[ja]; else load_vec<T, VEC>(cdf_col + ja, c0);
+            if (XWIN) {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    idx[j] = N - 1;
-                    if (i0 + j < g.N) {
-                        const T p = uniform_draw<T>(a.seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0 + j));
-                        const int q = thread_lower_bound<T>(cdf_col, 0, N, p);
-                        idx[j] = q > N - 1 ? N - 1 : q;
-                    }
+                for (int d = 0; d < D; ++d) {
+                    const T* xc = x_in + ((int64_t)d * g.B + b) * g.N + ja;
+                    if (VEC == 1) xa[d][0] = xc[0]; else load_vec<T, VEC>(xc, xa[d]);
+                }
+            }
+        }
+        if (inb) {
+            if (VEC == 1) c1[0] = cdf_col[jb]; else load_vec<T, VEC>(cdf_col + jb, c1);
+            if (XWIN) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const T* xc = x_in + ((int64_t)d * g.B + b) * g.N + jb;
+                    if (VEC == 1) xb[d][0] = xc[0]; else load_vec<T, VEC>(xc, xb[d]);
+                }
+            }
+        }
+        T lw_old[VEC];
+        if (on && !resample) {
+            if (VEC == 1) lw_old[0] = lw_in[i0]; else load_vec<T, VEC>(lw_in + i0, lw_old);
+        }
+
+        // ---- 2. work that does not need the window, while those loads are in flight --------------------------------
+        if (r == 0) cc.prepare(a.md, cp);
+        T zt[VEC][D];
+        if (on) {
+            if (z_step) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    T zr[VEC];
+                    const T* zc = z_step + ((int64_t)d * g.B + b) * g.N + i0;
+                    if (VEC == 1) zr[0] = zc[0]; else load_vec<T, VEC>(zc, zr);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) zt[j][d] = zr[j];
+                }
+            } else {
+                draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), zt);
+            }
+        }
+        PF_STAMP(a, 10);
+
+        // ---- 3. ancestors ---------------------------------------------------------------------------------------------
+        int idx[VEC];
+        if (windowed) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (!ina) c0[j] = Lim<T>::inf();
+                if (!inb) c1[j] = Lim<T>::inf();
+            }
+            if (VEC == 1) { win[tid] = c0[0]; win[PF_BLOCK + tid] = c1[0]; }
+            else { store_vec<T, VEC>(win + tid * VEC, c0); store_vec<T, VEC>(win + (PF_BLOCK + tid) * VEC, c1); }
+            if (XWIN) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (ina) { if (VEC == 1) xwin[d * WIN + tid] = xa[d][0]; else store_vec<T, VEC>(xwin + d * WIN + tid * VEC, xa[d]); }
+                    if (inb) { if (VEC == 1) xwin[d * WIN + PF_BLOCK + tid] = xb[d][0]; else store_vec<T, VEC>(xwin + d * WIN + (PF_BLOCK + tid) * VEC, xb[d]); }
+                }
+            }
+            __syncthreads();
+            // on average one ancestor per position: thread t's first position lands near offset (j0 - ws) + t * VEC
+            int guess = (j0 - ws) + tid * VEC;
+            if (guess > WIN - 1) guess = WIN - 1;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int64_t i = i0 + j;
+                int res = N - 1;
+                if (i < N) {
+                    const T p = grid_position<T>(i, ub, nT);
+                    const int q = window_lower_bound<T, WIN>(win, guess, p);
+                    guess = q < WIN ? q : WIN - 1;
+                    res = (q < WIN) ? ws + q : thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
+                    if (res > N - 1) res = N - 1;
+                }
+                idx[j] = res;
+            }
+            if (r + 1 < g.rounds_per_tile) {  // the next round's window starts at this round's last ancestor
+                if (tid == PF_BLOCK - 1) sh_j0 = idx[VEC - 1];
+                __syncthreads();
+                j0 = sh_j0;
+            }
+        } else if (resample) {  // multinomial: iid uniforms, global binary search
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                idx[j] = N - 1;
+                if (i0 + j < g.N) {
+                    const T p = uniform_draw<T>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0 + j));
+                    const int q = thread_lower_bound<T>(cdf_col, 0, N, p);
+                    idx[j] = q > N - 1 ? N - 1 : q;
                 }
             }
         } else {
@@ -536,68 +708,72 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_step(FusedArgs<T> a) {
             for (int j = 0; j < VEC; ++j) idx[j] = (int)((i0 + j < g.N) ? (i0 + j) : (g.N - 1));
         }
         PF_STAMP(a, 11);
-        if (!on) continue;
-        if (a.debug_cut == 2) {
+        if (on && a.debug_cut == 2) {
             if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
-            continue;
         }
 
-        T lw_old[VEC];
-        if (!resample) {
-            if (VEC == 1) lw_old[0] = lw_in[i0]; else load_vec<T, VEC>(lw_in + i0, lw_old);
-        }
-        T xo[D][VEC], lwo[VEC], pre_n[VEC], zt[VEC][D];
-        if (z_step) {
+        // ---- 4. gather, propagate, weight -------------------------------------------------------------------------------
+        T xo[D][VEC], lwo[VEC], pre_n[VEC];
+        if (on && a.debug_cut != 2) {
+            T xr[VEC][D];
+            if (!resample) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                T zr[VEC];
-                const T* zc = z_step + ((int64_t)d * g.B + b) * g.N + i0;
-                if (VEC == 1) zr[0] = zc[0]; else load_vec<T, VEC>(zc, zr);
+                for (int d = 0; d < D; ++d) {
+                    T xv[VEC];
+                    const T* xc = x_in + ((int64_t)d * g.B + b) * g.N + i0;
+                    if (VEC == 1) xv[0] = xc[0]; else load_vec<T, VEC>(xc, xv);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) zt[j][d] = zr[j];
-            }
-        } else {
-            draw_normals<T, D, VEC>(a.seed, PF_STREAM_NORMAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), zt);
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            T xr[D], xn[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) xr[d] = x_in[((int64_t)d * g.B + b) * g.N + idx[j]];
-            T w_new;
-            if (obs) {
-                const T wi = sample_and_weight<T, D>(a.md, a.proposal, cp, cc, xr, zt[j], xn);
-                if (apf) {
-                    // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
-                    w_new = wi - pre_weight<T, D>(a.md, a.proposal, cp, cc, xr);
-                    if (w_new != w_new || w_new == Lim<T>::inf()) poison = true;
-                } else {
-                    if (wi != wi || wi == Lim<T>::inf()) poison = true;
-                    w_new = resample ? wi : (wi + lw_old[j]);
+                    for (int j = 0; j < VEC; ++j) xr[j][d] = xv[j];
                 }
             } else {
-                // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
-                sample_and_weight<T, D>(a.md, PF_PROP_BOOTSTRAP, cp, cc, xr, zt[j], xn);
-                w_new = resample ? T(0) : lw_old[j];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int q = idx[j] - ws;
+                    const bool in_lds = XWIN && windowed && q >= 0 && q < WIN;
+#pragma unroll
+                    for (int d = 0; d < D; ++d)
+                        xr[j][d] = in_lds ? xwin[d * WIN + q] : x_in[((int64_t)d * g.B + b) * g.N + idx[j]];
+                }
             }
-            lwo[j] = sanitize_logw(w_new);
 #pragma unroll
-            for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
-            // first-stage weight of the next step, while the new particle is still in registers
-            pre_n[j] = pre_next ? pre_weight<T, D>(a.md, a.proposal, cpn, ccn, xn) : T(0);
-        }
-        PF_STAMP(a, 12);
-        acc.template push_round<VEC>(lwo, xo, pre_next, pre_n);
-        PF_STAMP(a, 13);
+            for (int j = 0; j < VEC; ++j) {
+                T xn[D];
+                T w_new;
+                if (obs) {
+                    const T wi = sample_and_weight<T, D>(a.md, a.proposal, cp, cc, xr[j], zt[j], xn);
+                    if (apf) {
+                        // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
+                        w_new = wi - pre_weight<T, D>(a.md, a.proposal, cp, cc, xr[j]);
+                        if (w_new != w_new || w_new == Lim<T>::inf()) poison = true;
+                    } else {
+                        if (wi != wi || wi == Lim<T>::inf()) poison = true;
+                        w_new = resample ? wi : (wi + lw_old[j]);
+                    }
+                } else {
+                    // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
+                    sample_and_weight<T, D>(a.md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
+                    w_new = resample ? T(0) : lw_old[j];
+                }
+                lwo[j] = sanitize_logw(w_new);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            T* xc = x_out + ((int64_t)d * g.B + b) * g.N + i0;
-            if (VEC == 1) xc[0] = xo[d][0]; else store_vec<T, VEC>(xc, xo[d]);
+                for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
+                // first-stage weight of the next step, while the new particle is still in registers
+                pre_n[j] = pre_next ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xn, true) : T(0);
+            }
+            PF_STAMP(a, 12);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                T* xc = x_out + ((int64_t)d * g.B + b) * g.N + i0;
+                if (VEC == 1) xc[0] = xo[d][0]; else store_vec<T, VEC>(xc, xo[d]);
+            }
+            if (VEC == 1) lw_out[i0] = lwo[0]; else store_vec<T, VEC>(lw_out + i0, lwo);
+            if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
+                if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
+            }
+            acc.template push_round<VEC>(lwo, xo, pre_next, pre_n);
+            PF_STAMP(a, 13);
         }
-        if (VEC == 1) lw_out[i0] = lwo[0]; else store_vec<T, VEC>(lw_out + i0, lwo);
-        if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
-            if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
-        }
+        if (windowed && r + 1 < g.rounds_per_tile) __syncthreads();  // the window is rewritten by the next round
     }
     if (poison) atomicOr(&a.poison[(step & 1) * g.B + b], 1);
     if (a.debug_cut == 3) return;

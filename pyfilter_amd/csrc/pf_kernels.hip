@@ -943,6 +943,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.thr_abs = A->ess_threshold * (double)A->N;
     a.logN = log((double)A->N);
     a.seed = A->seed;
+    a.seed_dev = (const uint64_t*)A->step_counter;
     a.x[0] = (T*)A->x[0];
     a.x[1] = (T*)A->x[1];
     a.logw[0] = (T*)A->logw[0];
@@ -969,7 +970,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     }
     const uint8_t* observed = A->observed;  // host array
 
-    const dim3 grid(g.tiles, g.B), block(PF_BLOCK);
+    const dim3 grid(g.tiles, g.B), grid_scan(g.tiles + 1, g.B), block(PF_BLOCK);
     if (t0 == 0) {
         // fresh filter: no previous step to account for
         hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
@@ -994,7 +995,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.obs = observed[t] != 0;
         a.obs_next = (s + 1 < n_steps) ? (observed[t + 1] != 0) : 0;
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 0], st);
-        hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 1], st);
         hipLaunchKernelGGL((k_fused_step<T, D, VEC>), grid, block, 0, st, a);
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 2], st);
@@ -1003,7 +1004,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.step = (int)(t0 + n_steps);
         a.obs = a.obs_next = 0;
         a.finalize_only = 1;
-        hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
     }
     if (kernel_ms) {
         hipError_t se = hipStreamSynchronize(st);
@@ -1034,6 +1035,62 @@ extern "C" int pf_filter_run_timed(const pf_filter_args* A, int64_t t0, int64_t 
                                    float* kernel_ms) {
     if (!kernel_ms) return PF_EINVAL;
     return filter_run_checked(A, t0, n_steps, finalize, stream, kernel_ms);
+}
+
+// ---- hipGraph variant: the whole launch sequence of a run captured once, replayed with one host call -----------------
+struct PfGraph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+extern "C" int pf_filter_graph_create(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
+                                      void** handle) {
+    if (!handle) return PF_EINVAL;
+    *handle = nullptr;
+    (void)stream;
+    // capture on a private stream (the caller's may be the legacy default stream, which cannot capture); the graph is
+    // replayed on whatever stream pf_filter_graph_launch is given
+    hipStream_t st = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) return (int)e;
+    e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(st);
+        return (int)e;
+    }
+    const int rc = filter_run_checked(A, t0, n_steps, finalize, (void*)st, nullptr);
+    hipGraph_t graph = nullptr;
+    e = hipStreamEndCapture(st, &graph);
+    (void)hipStreamDestroy(st);
+    if (rc != PF_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (e != hipSuccess) return (int)e;
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return (int)e;
+    }
+    PfGraph* g = new PfGraph{graph, exec};
+    *handle = g;
+    return PF_OK;
+}
+
+extern "C" int pf_filter_graph_launch(void* handle, void* stream) {
+    if (!handle) return PF_EINVAL;
+    const hipError_t e = hipGraphLaunch(((PfGraph*)handle)->exec, (hipStream_t)stream);
+    return e == hipSuccess ? PF_OK : (int)e;
+}
+
+extern "C" int pf_filter_graph_destroy(void* handle) {
+    if (!handle) return PF_OK;
+    PfGraph* g = (PfGraph*)handle;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return PF_OK;
 }
 
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,

@@ -31,7 +31,8 @@ template <typename T, int D> struct ColParams {
     T A[MAXO][D];
     T ob[MAXO];
     T os[MAXO];
-    T y[MAXO];
+    T y[MAXO];   // observation of this step
+    T yn[MAXO];  // observation of the next step (APF: its first-stage weights are prepared one kernel early)
     int O;
 
     __device__ __forceinline__ void load(const T* __restrict__ row, int O_, const T* __restrict__ yrow) {
@@ -49,7 +50,12 @@ template <typename T, int D> struct ColParams {
             ob[o] = on ? a[O_ * D + o] : T(0);
             os[o] = on ? a[O_ * D + O_ + o] : T(1);
             y[o] = (on && yrow) ? yrow[o] : T(0);
+            yn[o] = T(0);
         }
+    }
+    __device__ __forceinline__ void load_next(const T* __restrict__ yrow) {
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) yn[o] = (o < O && yrow) ? yrow[o] : T(0);
     }
 };
 
@@ -120,7 +126,7 @@ __device__ __forceinline__ void mean_scale(const ModelDesc& md, const ColParams<
 // per particle (the reference spends ~40 aten ops and a batched LU here: SURVEY.md section 8(a) a14).
 template <typename T, int D> struct ColConsts {
     bool fast;
-    T g, inv_g, inc, yb, a;
+    T g, inv_g, inc, yb, ybn, a;  // yb / ybn: y - b for this / the next observation
     T i2s, ks;               // observation: 1 / (2 s^2), log s + log sqrt(2 pi)
     T i2inc, kt;             // transition:  1 / (2 inc^2), log inc + log sqrt(2 pi) + log |g|
     T c_loc, c_y, kstd, kq;  // LinearGaussianObservations kernel: mean = c_loc * loc + c_y, std, log std + log sqrt(2 pi)
@@ -144,24 +150,25 @@ template <typename T, int D> struct ColConsts {
                 }
             }
             ou_e = (md.hid_kind == PF_HID_OU) ? pf_exp(-cp.hp[0][0] * dt) : T(0);
-            inv_g = T(1) / g;
+            inv_g = pf_rcp_c(g);
             inc = (T)md.inc_scale;
             a = cp.A[0][0];
             const T s = cp.os[0];
             yb = cp.y[0] - cp.ob[0];
-            i2s = T(1) / (T(2) * s * s);
-            ks = pf_log(s) + T(PF_LOG_SQRT_2PI);
-            i2inc = T(1) / (T(2) * inc * inc);
-            kt = pf_log(inc) + T(PF_LOG_SQRT_2PI) + pf_log(pf_abs(g));
-            const T hvi = T(1) / (g * g), ovi = T(1) / (s * s);
-            const T cov = T(1) / (hvi + a * ovi * a);
+            ybn = cp.yn[0] - cp.ob[0];
+            const T ovi = pf_rcp_c(s * s), hvi = inv_g * inv_g;
+            i2s = T(0.5) * ovi;
+            ks = pf_log_c(s) + T(PF_LOG_SQRT_2PI);
+            i2inc = T(0.5) * pf_rcp_c(inc * inc);
+            kt = pf_log_c(inc * pf_abs(g)) + T(PF_LOG_SQRT_2PI);
+            const T cov = pf_rcp_c(hvi + a * ovi * a);
             c_loc = cov * hvi;
             c_y = cov * (a * (ovi * yb));
-            kstd = pf_sqrt(cov);
-            kq = pf_log(kstd) + T(PF_LOG_SQRT_2PI);
+            kstd = pf_sqrt_c(cov);
+            kq = T(0.5) * pf_log_c(cov) + T(PF_LOG_SQRT_2PI);
             const T cvar = s * s + a * (g * g) * a;
-            i2c = T(1) / (T(2) * cvar);
-            kc = pf_log(pf_sqrt(cvar)) + T(PF_LOG_SQRT_2PI);
+            i2c = T(0.5) * pf_rcp_c(cvar);
+            kc = T(0.5) * pf_log_c(cvar) + T(PF_LOG_SQRT_2PI);
         }
     }
 
@@ -173,8 +180,8 @@ template <typename T, int D> struct ColConsts {
             default: return cp.hp[1][0] + (x - cp.hp[1][0]) * ou_e;  // OU
         }
     }
-    __device__ __forceinline__ T obs_lp(T x) const {
-        const T r = yb - a * x;
+    __device__ __forceinline__ T obs_lp(T x, bool next = false) const {
+        const T r = (next ? ybn : yb) - a * x;
         return -(r * r) * i2s - ks;
     }
 };
@@ -186,8 +193,8 @@ template <typename T> __device__ __forceinline__ T normal_logpdf(T y, T loc, T s
 
 // model.build_density(x).log_prob(y)
 template <typename T, int D>
-__device__ __forceinline__ T obs_logpdf(const ModelDesc& md, const ColParams<T, D>& cp, const T (&x)[D]) {
-    if (md.obs_kind == PF_OBS_SV) return normal_logpdf(cp.y[0], cp.ob[0], x[0]);
+__device__ __forceinline__ T obs_logpdf(const ModelDesc& md, const ColParams<T, D>& cp, const T (&x)[D], bool next = false) {
+    if (md.obs_kind == PF_OBS_SV) return normal_logpdf(next ? cp.yn[0] : cp.y[0], cp.ob[0], x[0]);
     T lp = T(0);
 #pragma unroll
     for (int o = 0; o < ColParams<T, D>::MAXO; ++o) {
@@ -195,7 +202,7 @@ __device__ __forceinline__ T obs_logpdf(const ModelDesc& md, const ColParams<T, 
             T loc = cp.ob[o];
 #pragma unroll
             for (int d = 0; d < D; ++d) loc += cp.A[o][d] * x[d];
-            lp += normal_logpdf(cp.y[o], loc, cp.os[o]);
+            lp += normal_logpdf(next ? cp.yn[o] : cp.y[o], loc, cp.os[o]);
         }
     }
     return lp;
@@ -273,17 +280,17 @@ template <typename T, int K> __device__ __forceinline__ void spd_inverse(const T
 // APF first-stage weight  (proposal.pre_weight(y, x))
 template <typename T, int D>
 __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
-                                        const ColConsts<T, D>& cc, const T (&x)[D]) {
+                                        const ColConsts<T, D>& cc, const T (&x)[D], bool next = false) {
     if constexpr (D == 1) {
         if (cc.fast) {
-            if (proposal == PF_PROP_BOOTSTRAP) return cc.obs_lp(cc.loc1(md, cp, x[0]));  // log p(y | E[x_t | x_{t-1}])
-            const T r = cc.yb - cc.a * x[0];                                           // LGO: evaluated at x_{t-1} itself
+            if (proposal == PF_PROP_BOOTSTRAP) return cc.obs_lp(cc.loc1(md, cp, x[0]), next);  // log p(y | E[x_t | x_{t-1}])
+            const T r = (next ? cc.ybn : cc.yb) - cc.a * x[0];                               // LGO: evaluated at x_{t-1} itself
             return -(r * r) * cc.i2c - cc.kc;
         }
     }
     T loc[D], scale[D];
     mean_scale<T, D>(md, cp, x, loc, scale);
-    if (proposal == PF_PROP_BOOTSTRAP) return obs_logpdf<T, D>(md, cp, loc);
+    if (proposal == PF_PROP_BOOTSTRAP) return obs_logpdf<T, D>(md, cp, loc, next);
 
     // LinearGaussianObservations.pre_weight: N(y; b + A x_{t-1}, diag(s^2) + A diag(g^2) A^T)  (linear.py:57-86)
     constexpr int MO = ColParams<T, D>::MAXO;
@@ -294,7 +301,7 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
         T lo = cp.ob[o];
 #pragma unroll
         for (int d = 0; d < D; ++d) lo += cp.A[o][d] * x[d];
-        r[o] = on ? (cp.y[o] - lo) : T(0);
+        r[o] = on ? ((next ? cp.yn[o] : cp.y[o]) - lo) : T(0);
 #pragma unroll
         for (int p = 0; p < MO; ++p) {
             T c = (o == p) ? (on ? cp.os[o] * cp.os[o] : T(1)) : T(0);

@@ -9,6 +9,7 @@ route through ``predict`` / ``correct`` - which still calls the HIP primitives f
 moments and evaluates only the user's model callables with PyTorch-ROCm ops.
 """
 import ctypes as C
+import os
 from typing import Callable, Optional, Union
 
 import torch
@@ -60,6 +61,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._z_tape = None
         self._u_tape = None
         self._z0 = None
+        self._plans = {}
 
     # ------------------------------------------------------------------------------------------------------------
     @property
@@ -249,7 +251,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             steps = t_obs
             y_steps = y_dev
             observed = (~y_nan).to(torch.uint8)
-            obs_rows = torch.arange(1, steps + 1, device=device)
+            obs_rows = None
         else:
             sched, t = [], t_start
             for k in range(t_obs):
@@ -266,34 +268,29 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             observed = torch.zeros(steps, dtype=torch.uint8, device=device)
             observed[is_obs] = (~y_nan).to(torch.uint8)
             obs_rows = torch.nonzero(is_obs).reshape(-1) + 1
-        y_steps = y_steps.contiguous()
-
-        # ---- buffers --------------------------------------------------------------------------------------------
-        x_a = ops.to_soa(x0, self._batched, self._has_event).clone()
-        x_b = torch.empty_like(x_a)
-        lw_a = ops.to_cols(state.weights).clone()
-        lw_b = torch.empty_like(lw_a)
-        anc = ops.to_cols(state.previous_indices.to(torch.int32)).contiguous().clone()
-        cdf = torch.empty_like(lw_a)
-        means = torch.empty((steps + 1, b, d), device=device, dtype=dtype)
-        variances = torch.empty_like(means)
-        ll_steps = torch.zeros((steps, b), device=device, dtype=dtype)
-        ll_total = torch.zeros(b, device=device, dtype=dtype)
-        ctr = torch.zeros(4, device=device, dtype=torch.int32)
-        ws = L.new_workspace(n, b, device)
-
-        a = L.PfFilterArgs()
-        a.model = ops.make_model_struct(kind, ctx.params)
-        a.filter, a.proposal, a.resampler = self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL, self._resampler_kind()
-        a.dtype = L.dtype_code(dtype)
-        a.N, a.B = n, b
-        a.ess_threshold = float(self._resample_threshold) / float(n)
-        a.seed = self._seed
-        a.x[0], a.x[1] = x_a.data_ptr(), x_b.data_ptr()
-        a.logw[0], a.logw[1] = lw_a.data_ptr(), lw_b.data_ptr()
-        a.anc, a.cdf = anc.data_ptr(), cdf.data_ptr()
         observed_host = observed.cpu().contiguous()  # the launch loop reads the flags on the host (one sync per call)
-        a.y, a.y_rows, a.observed = y_steps.data_ptr(), rows, observed_host.data_ptr()
+
+        taped = ctx.z_tape is not None or ctx.u_tape is not None
+        use_graph = (not taped) and not getattr(self, "_time_kernels", False) and os.environ.get("PF_NO_GRAPH", "0") != "1"
+        key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
+               self._resampler_kind(), self._seed, float(self._resample_threshold), bytes(observed_host.numpy().tobytes()))
+        plan = self._plans.get(key) if use_graph else None
+        if plan is None:
+            plan = _FusedPlan(self, kind, n, b, d, o, steps, rows, dtype, device, observed_host)
+            if use_graph:
+                if len(self._plans) >= 4:  # a handful of (shape, schedule) combinations at most
+                    self._plans.pop(next(iter(self._plans))).destroy()
+                self._plans[key] = plan
+
+        # ---- load the inputs into the plan's (persistent) buffers -------------------------------------------------------
+        plan.params.copy_(ctx.params)
+        plan.x[0].copy_(ops.to_soa(x0, self._batched, self._has_event))
+        plan.logw[0].copy_(ops.to_cols(state.weights))
+        plan.anc.copy_(ops.to_cols(state.previous_indices.to(torch.int32)))
+        plan.y.copy_(y_steps)
+        plan.ll_total.zero_()
+        plan.epoch.add_(1)  # fresh Philox draws for every call (the base seed is baked into the launch arguments)
+        a = plan.args
         z_tape = u_tape = None
         if ctx.z_tape is not None:
             z_tape = ctx.z_tape[t_start:t_start + steps].contiguous()
@@ -301,23 +298,28 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + steps].contiguous()
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)
-        a.means, a.vars = means.data_ptr(), variances.data_ptr()
-        a.ll_steps, a.ll_total = ll_steps.data_ptr(), ll_total.data_ptr()
-        a.step_counter = ctr.data_ptr()
-        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
 
         # NB the kernels index tapes / observations by the *local* step 0..steps-1 and draw Philox numbers by it too
+        lib = L.load()
         if getattr(self, "_time_kernels", False):
             kms = (C.c_float * 3)()
-            L.check(L.load().pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")
+            L.check(lib.pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")
             self.kernel_ms = tuple(kms)
+        elif use_graph:
+            if plan.graph is None:
+                h = C.c_void_p(None)
+                L.check(lib.pf_filter_graph_create(C.byref(a), 0, steps, 1, L.stream_ptr(), C.byref(h)), "pf_filter_graph_create")
+                plan.graph = h
+            L.check(lib.pf_filter_graph_launch(plan.graph, L.stream_ptr()), "pf_filter_graph_launch")
         else:
-            L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
-        self._last_run = dict(x=(x_a, x_b), logw=(lw_a, lw_b), anc=anc, cdf=cdf, y=y_steps, observed=observed_host,
-                              z=z_tape, u=u_tape, ctr=ctr, ws=ws, ll_steps=ll_steps)  # keep device buffers alive
+            L.check(lib.pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
+        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws)  # keep device buffers alive
 
-        # ---- hand the results over in the reference's shapes -------------------------------------------------------
-        x_fin, lw_fin = (x_a, lw_a) if steps % 2 == 0 else (x_b, lw_b)
+        # ---- hand the results over in the reference's shapes (copies: a cached plan's buffers are reused) ------------
+        slot = steps % 2
+        x_fin, lw_fin = plan.x[slot].clone(), plan.logw[slot].clone()
+        means, variances, ll_steps = plan.means.clone(), plan.vars.clone(), plan.ll_steps.clone()
+        ll_total, anc = plan.ll_total.clone(), plan.anc.clone()
         final_x = TimeseriesState(t_start + steps, ops.from_soa(x_fin, self._batched, self._has_event),
                                   self._model.hidden.event_shape)
         shape_md = (lambda t: t if self._batched else t[:, 0])
@@ -327,6 +329,58 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             final_x, ops.from_cols(lw_fin, self._batched), ll_last, ops.from_cols(anc, self._batched).long(),
             _moments=(means_v[-1], vars_v[-1]),
         )
-        sel = obs_rows
+        sel = slice(1, None) if obs_rows is None else obs_rows
         result._extend_fused(means_v[sel], vars_v[sel], ll_total if self._batched else ll_total[0], last)
         return result
+
+
+class _FusedPlan:
+    """Persistent device buffers + launch arguments (+ the captured hipGraph) of one fused-run configuration.  Keeping
+    them across ``batch_filter`` calls means repeated runs (PMMH / SMC^2 re-filter the same data many times,
+    ``inference/batch/mcmc/utils.py:55``) replay one graph instead of issuing 2 T kernel launches from the host."""
+
+    def __init__(self, filt, kind, n, b, d, o, steps, rows, dtype, device, observed_host):
+        self.x = (torch.empty((d, b, n), device=device, dtype=dtype), torch.empty((d, b, n), device=device, dtype=dtype))
+        self.logw = (torch.empty((b, n), device=device, dtype=dtype), torch.empty((b, n), device=device, dtype=dtype))
+        self.anc = torch.empty((b, n), device=device, dtype=torch.int32)
+        self.cdf = torch.empty((b, n), device=device, dtype=dtype)
+        self.y = torch.empty((steps, rows, o), device=device, dtype=dtype)
+        self.means = torch.empty((steps + 1, b, d), device=device, dtype=dtype)
+        self.vars = torch.empty_like(self.means)
+        self.ll_steps = torch.zeros((steps, b), device=device, dtype=dtype)
+        self.ll_total = torch.zeros(b, device=device, dtype=dtype)
+        self.epoch = torch.zeros(1, device=device, dtype=torch.int64)
+        self.params = torch.empty_like(filt._ctx.params)
+        self.ws = L.new_workspace(n, b, device)
+        self.observed_host = observed_host
+        self.graph = None
+
+        a = L.PfFilterArgs()
+        a.model = ops.make_model_struct(kind, self.params)
+        a.filter, a.proposal, a.resampler = filt._FILTER_KIND, filt._proposal._KERNEL_PROPOSAL, filt._resampler_kind()
+        a.dtype = L.dtype_code(dtype)
+        a.N, a.B = n, b
+        a.ess_threshold = float(filt._resample_threshold) / float(n)
+        a.seed = filt._seed
+        a.x[0], a.x[1] = self.x[0].data_ptr(), self.x[1].data_ptr()
+        a.logw[0], a.logw[1] = self.logw[0].data_ptr(), self.logw[1].data_ptr()
+        a.anc, a.cdf = self.anc.data_ptr(), self.cdf.data_ptr()
+        a.y, a.y_rows, a.observed = self.y.data_ptr(), rows, observed_host.data_ptr()
+        a.z_tape, a.u_tape = None, None
+        a.means, a.vars = self.means.data_ptr(), self.vars.data_ptr()
+        a.ll_steps, a.ll_total = self.ll_steps.data_ptr(), self.ll_total.data_ptr()
+        a.step_counter = self.epoch.data_ptr()
+        a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.args = a
+
+    def destroy(self):
+        if self.graph is not None:
+            torch.cuda.synchronize()
+            L.load().pf_filter_graph_destroy(self.graph)
+            self.graph = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -87,7 +87,7 @@ def main():
             st = ws[off.value:off.value + 256].view(torch.int64).cpu().tolist()
             sc = [st[i] - st[0] for i in range(0, 7)]
             sp = [st[i] - st[8] for i in range(8, 16)]
-            print("   scan stamps (cycles from start: combine_done, finalize_done, pre-loop, pre-blockscan, post-blockscan, round_end):", sc[1:])
+            print("   scan stamps (cycles from start: combine_done, finalize_done, pre-loop, pre-blockscan, post-blockscan, round_end):", sc[1:], " (PF_DEBUG_CUT=-(tile+1) selects the stamped tile)")
             print("   step stamps (cycles from start: params, pre-loop, search_done, compute_done, push_done, pre-finish, end):", sp[1:])
         print(f"{name:22s} us/step {1e6 * wall / T:8.2f}  particle-steps/s {n * b * T / wall:10.3e}  kernels(us, event-bracketed) "
               f"scan {1e3 * k[1]:7.2f} step {1e3 * k[2]:7.2f}  ll {res.loglikelihood.reshape(-1)[0].item():.3f}", flush=True)
