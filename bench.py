@@ -166,6 +166,48 @@ def cpu_baseline(name, w, seconds_budget=15.0):
     }
 
 
+def pmc_traffic(kernel_substr, workload, dtype_name, t_len=20):
+    """HBM bytes per launch of one kernel from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md (HBM section)
+    prescribes: FETCH_SIZE and WRITE_SIZE in *separate* --pmc passes (TCC slots), kernel-trace only; both are in KiB;
+    on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled
+    (WRITE_SIZE is uncalibrated and taken as is).  Returns None when the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="pf_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
+               sys.executable, os.path.abspath(__file__), "--_inner", "--workload", workload, "--dtype", dtype_name,
+               "--T", str(t_len), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+        env = dict(os.environ, TMPDIR="/tmp", PF_NO_GRAPH="1")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            tot, n = 0.0, 0
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        tot += float(row["Counter_Value"])
+                        n += 1
+            if n == 0:
+                return None
+            vals[counter] = tot / n
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return {"bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "FETCH_SIZE_KiB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": vals["WRITE_SIZE"],
+            "note": "FETCH_SIZE doubled (gfx950 wide-read correction); counters see fabric requests, so reads served "
+                    "by the per-XCD L2 (the whole working set of this workload fits in L2 + Infinity Cache) do not appear"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +217,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--T", type=int, default=None, help="override the number of observations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--_inner", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -229,6 +273,9 @@ def main():
     units_per_pass = w["N"] * w["B"] * w["T"] * world
     value = units_per_pass * args.steps / elapsed
 
+    if args._inner:  # profiled child of pmc_traffic(): the timed passes above are all it needs
+        return
+
     # ---- per-kernel durations (HIP events on the launch stream) in a separate instrumented pass ------------------
     filt._time_kernels = True
     filt.batch_filter(y, bar=False)
@@ -249,6 +296,12 @@ def main():
         "step_alg_bytes_per_particle": sum(alg_bytes_per_particle(w, k, esz) for k in names),
         "whole_step_GBs": sum(alg_bytes_per_particle(w, k, esz) for k in names) * value / world / 1e9,
     }
+
+    if rank == 0 and world == 1 and not args.no_traffic:
+        tr = pmc_traffic(f"k_fused_{dom}", args.workload, args.dtype)
+        if tr is not None:
+            roofline["traffic"] = tr["bytes_per_launch"]
+            roofline["traffic_detail"] = tr
 
     if rank == 0:
         cpu = None

@@ -343,7 +343,7 @@ __device__ __forceinline__ ColCombine combine_column(const FusedArgs<T>& a, cons
 // grid (tiles + 1, B): workgroups k < tiles scan their tile; the extra workgroup k == tiles is the column's bookkeeper
 // (moments row, log-likelihood increment, resampling decision) - kept off the scanning workgroups' critical path.
 template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_scan(FusedArgs<T> a) {
     __shared__ double red[6 * PF_NWAVES];
     __shared__ double redm[2 * PF_NWAVES];
     __shared__ double red2[2 * D * PF_NWAVES];
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_scan(FusedArgs<T> a) {
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
     cc.fast = false;
+    cc.lin_fast = false;
     if (two) {
         load_col_params<T, D>(a, b, step, true, cp);
         cc.prepare(a.md, cp);

@@ -23,6 +23,7 @@ namespace pf {
 // geometry
 // ---------------------------------------------------------------------------------------------------------------
 #define PF_MAX_TILES 1024
+#define PF_TARGET_WGS 1024
 
 struct Geom {
     int64_t N;
@@ -41,8 +42,15 @@ static inline Geom make_geom(int64_t N, int64_t B) {
     g.vec = (N % 4 == 0) ? 4 : 1;
     g.round_elems = PF_BLOCK * g.vec;
     const int64_t rounds_total = (N + g.round_elems - 1) / g.round_elems;
-    const int min_r = (g.vec == 4) ? 1 : 4;  // >= 1024-particle tiles
-    int64_t r = (rounds_total + PF_MAX_TILES - 1) / PF_MAX_TILES;
+    // Tile size: every workgroup pays a fixed price (column combine, constants, reductions), so tiles grow until the
+    // grid is down to ~PF_TARGET_WGS workgroups (4 per CU) - but never more than PF_MAX_TILES tiles per column.
+    int min_r = (g.vec == 4) ? 1 : 4;  // >= 1024-particle tiles
+    int64_t target = PF_TARGET_WGS;
+    if (const char* ev = getenv("PF_TARGET_WGS")) target = atoll(ev) > 0 ? atoll(ev) : target;  // development knob
+    int64_t r = (rounds_total * B) / target;
+    if (r > rounds_total) r = rounds_total;
+    const int64_t r_cap = (rounds_total + PF_MAX_TILES - 1) / PF_MAX_TILES;
+    if (r < r_cap) r = r_cap;
     if (r < min_r) r = min_r;
     g.rounds_per_tile = (int)r;
     g.tile_elems = g.rounds_per_tile * g.round_elems;

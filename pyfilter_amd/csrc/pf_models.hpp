@@ -125,6 +125,11 @@ __device__ __forceinline__ void mean_scale(const ModelDesc& md, const ColParams<
 // particle - reciprocals, logs, the optimal-proposal gain - is evaluated once per thread, leaving ~30 flops + one sine
 // per particle (the reference spends ~40 aten ops and a batched LU here: SURVEY.md section 8(a) a14).
 template <typename T, int D> struct ColConsts {
+    // D-generic part: linear observation + state-independent transition scale -> Bootstrap needs no per-particle
+    // division / log (`lin_fast`); the scalar closed forms below additionally cover LinearGaussianObservations
+    static constexpr int MAXO = ObsDim<D>::MAXO;
+    bool lin_fast;
+    T oi2s[MAXO], oks;          // 1 / (2 s_o^2) per observation component, sum_o (log s_o + log sqrt(2 pi))
     bool fast;
     T g, inv_g, inc, yb, ybn, a;  // yb / ybn: y - b for this / the next observation
     T i2s, ks;               // observation: 1 / (2 s^2), log s + log sqrt(2 pi)
@@ -135,6 +140,16 @@ template <typename T, int D> struct ColConsts {
 
     __device__ __forceinline__ void prepare(const ModelDesc& md, const ColParams<T, D>& cp) {
         fast = false;
+        lin_fast = (D > 1) && md.obs_kind == PF_OBS_LINEAR && md.hid_kind != PF_HID_VERHULST_EM;  // D = 1: scalar forms below
+        if (lin_fast) {
+            oks = T(0);
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o) {
+                const bool on = o < cp.O;
+                oi2s[o] = on ? T(0.5) * pf_rcp_c(cp.os[o] * cp.os[o]) : T(0);
+                oks += on ? pf_log_c(cp.os[o]) + T(PF_LOG_SQRT_2PI) : T(0);
+            }
+        }
         if constexpr (D == 1) {
             if (md.obs_kind != PF_OBS_LINEAR || md.hid_kind == PF_HID_VERHULST_EM) return;
             fast = true;
@@ -179,6 +194,20 @@ template <typename T, int D> struct ColConsts {
             case PF_HID_SINE_EM: return x + pf_sin(x - cp.hp[0][0]) * (T)md.dt;
             default: return cp.hp[1][0] + (x - cp.hp[1][0]) * ou_e;  // OU
         }
+    }
+    // log N(y; b + A x, diag(s^2)) with the reciprocals / logs hoisted (any D)
+    __device__ __forceinline__ T obs_lp_lin(const ColParams<T, D>& cp, const T (&x)[D], bool next) const {
+        T lp = -oks;
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            if (o < cp.O) {
+                T r = (next ? cp.yn[o] : cp.y[o]) - cp.ob[o];
+#pragma unroll
+                for (int d = 0; d < D; ++d) r -= cp.A[o][d] * x[d];
+                lp -= (r * r) * oi2s[o];
+            }
+        }
+        return lp;
     }
     __device__ __forceinline__ T obs_lp(T x, bool next = false) const {
         const T r = (next ? ybn : yb) - a * x;
@@ -290,7 +319,7 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
     }
     T loc[D], scale[D];
     mean_scale<T, D>(md, cp, x, loc, scale);
-    if (proposal == PF_PROP_BOOTSTRAP) return obs_logpdf<T, D>(md, cp, loc, next);
+    if (proposal == PF_PROP_BOOTSTRAP) return cc.lin_fast ? cc.obs_lp_lin(cp, loc, next) : obs_logpdf<T, D>(md, cp, loc, next);
 
     // LinearGaussianObservations.pre_weight: N(y; b + A x_{t-1}, diag(s^2) + A diag(g^2) A^T)  (linear.py:57-86)
     constexpr int MO = ColParams<T, D>::MAXO;
@@ -354,7 +383,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
         const T inc = (T)md.inc_scale;
 #pragma unroll
         for (int d = 0; d < D; ++d) xn[d] = loc[d] + scale[d] * (z[d] * inc);
-        return obs_logpdf<T, D>(md, cp, xn);
+        return cc.lin_fast ? cc.obs_lp_lin(cp, xn, false) : obs_logpdf<T, D>(md, cp, xn);
     }
 
     // optimal proposal for linear-Gaussian observations (find_optimal_density, proposals/utils.py:219-267):

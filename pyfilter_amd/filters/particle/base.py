@@ -297,6 +297,13 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             assert z_tape.shape[0] == steps, "z tape shorter than the number of steps"
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + steps].contiguous()
+        elif self._resampler_kind() == L.RESAMPLE_SYSTEMATIC:
+            # one uniform per (step, filter): T x B numbers drawn up front (a device generator seeded by (seed, call)),
+            # so no kernel spends a Philox chain on a per-column scalar
+            plan.u_gen.manual_seed((self._seed * 1000003 + int(plan.calls)) & 0x7FFFFFFFFFFFFFFF)
+            plan.u.uniform_(generator=plan.u_gen)
+            u_tape = plan.u
+        plan.calls += 1
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)
 
         # NB the kernels index tapes / observations by the *local* step 0..steps-1 and draw Philox numbers by it too
@@ -350,6 +357,9 @@ class _FusedPlan:
         self.ll_steps = torch.zeros((steps, b), device=device, dtype=dtype)
         self.ll_total = torch.zeros(b, device=device, dtype=dtype)
         self.epoch = torch.zeros(1, device=device, dtype=torch.int64)
+        self.u = torch.empty((steps, b), device=device, dtype=dtype)
+        self.u_gen = torch.Generator(device=device)
+        self.calls = 0
         self.params = torch.empty_like(filt._ctx.params)
         self.ws = L.new_workspace(n, b, device)
         self.observed_host = observed_host
