@@ -258,3 +258,75 @@ def test_observe_every_step_and_state_dict():
     fresh.load_state_dict(sd)
     torch.testing.assert_close(fresh.filter_means, rf.filter_means)
     torch.testing.assert_close(fresh.latest_state.timeseries_state.value, rf.latest_state.timeseries_state.value)
+
+
+# ---- BASELINE.json sizes -------------------------------------------------------------------------------------------
+def _full_size_case(model, filt_name, prop, n, b, t_len, seed, ess=0.9):
+    case = dict(name="full", model=model, filter=filt_name, proposal=prop, N=n, B=b, T=t_len, ess_threshold=ess, seed=seed)
+    spec = build_spec(case, torch.float64)
+    gen = torch.Generator().manual_seed(seed)
+    d = (spec.dim,) if spec.dim > 0 else ()
+    z = torch.randn((t_len, n, b) + d, generator=gen, dtype=torch.float32)
+    u = torch.rand(t_len, b, generator=gen, dtype=torch.float32)
+    z0 = torch.randn((n, b) + d, generator=gen, dtype=torch.float32)
+    from oracle.cases import simulate
+
+    y = simulate(case, spec, torch.float64)
+    return case, spec, dict(z_tape=z, u_tape=u, z0=z0), y
+
+
+@pytest.mark.parametrize("model,filt_name,prop,n,b,t_len", [
+    ("sine", "apf", "lgo", 1 << 20, 1, 8),            # configs[1]: 1 048 576-particle APF + LinearGaussianObservations
+    ("sv_batched", "apf", "bootstrap", 65536, 8, 6),   # configs[2] shape (65 536 particles per series, 8 of the 64 series)
+    ("lorenz", "sisr", "bootstrap", 1 << 20, 1, 6),    # configs[3] model / filter (systematic; 2^20 of the 2^22 particles)
+    ("ou_batched", "apf", "bootstrap", 8192, 16, 8),   # configs[4]: theta on the batch dim, 8 192 state particles
+    ("lg1d", "sisr", "bootstrap", 1000, 1, 50),        # configs[0]
+])
+def test_fp64_parity_at_benchmark_sizes(model, filt_name, prop, n, b, t_len):
+    """BASELINE.json shapes in float64, identical draws: filter_means / log-likelihood within 1e-9 of the oracle (bar:
+    1e-5) and the final ancestors identical - at 2^20 particles there are ~10^7 searchsorted decisions per step."""
+    case, spec, g, y = _full_size_case(model, filt_name, prop, n, b, t_len, seed=900 + n % 97)
+    x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
+    ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=0.9)
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    res = filt.batch_filter(y.cuda(), bar=False)
+    torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(res.filter_variance.cpu(), ref["filter_variance"], rtol=1e-7, atol=1e-11)
+    torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9)
+    mism = (res.latest_state.previous_indices.cpu() != ref["prev_inds"]).sum().item()
+    assert mism <= 2, f"{mism} of {n * b} final ancestors differ"
+
+
+def test_fp32_full_size_invariants():
+    """configs[1] at full size in float32 with Philox draws: invariants that do not need an oracle run - finite
+    outputs, ancestors sorted and in range, means inside the particle cloud, ll close to the fp64 tape run's scale,
+    two different seeds agree within Monte-Carlo error, the same seed reproduces bit for bit."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device="cuda")  # noqa: E731
+    ssm = ts.LinearStateSpaceModel(models.SineDiffusion(t(0.0), t(1.0), dt=0.1), (t(1.0), t(0.1)))
+    gen = torch.Generator().manual_seed(5)
+    x, ys = 0.3, []
+    for _ in range(40):
+        x = x + math.sin(x) * 0.1 + math.sqrt(0.1) * torch.randn((), generator=gen).item()
+        ys.append(x + 0.1 * torch.randn((), generator=gen).item())
+    y = torch.tensor(ys, device="cuda")
+    n = 1 << 20
+
+    def run(seed):
+        f = APF(ssm, n, proposal=proposals.LinearGaussianObservations(), seed=seed)
+        return f.batch_filter(y, bar=False)
+
+    r1, r2, r1b = run(1), run(2), run(1)
+    for r in (r1, r2):
+        assert torch.isfinite(r.filter_means).all() and torch.isfinite(r.loglikelihood).all()
+        idx = r.latest_state.previous_indices
+        assert (idx[1:] >= idx[:-1]).all() and idx.min() >= 0 and idx.max() <= n - 1
+        xs = r.latest_state.timeseries_state.value
+        assert xs.min() <= r.filter_means[-1, 0] <= xs.max()
+    assert torch.equal(r1.filter_means, r1b.filter_means) and torch.equal(r1.loglikelihood, r1b.loglikelihood)
+    se = (r1.filter_variance[1:] / n).sqrt()
+    assert ((r1.filter_means[1:] - r2.filter_means[1:]).abs() <= 8.0 * se + 1e-5).all()
+    assert abs((r1.loglikelihood - r2.loglikelihood).item()) < 0.05
