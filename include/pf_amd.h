@@ -54,7 +54,9 @@ extern "C" {
 #define PF_FILTER_APF 1
 /* resamplers (pyfilter/resampling.py) */
 #define PF_RESAMPLE_SYSTEMATIC 0
-#define PF_RESAMPLE_MULTINOMIAL 1
+#define PF_RESAMPLE_MULTINOMIAL 1 /* in pf_filter_run: N iid draws realised as their order statistics (sorted uniforms from
+                                   * normalised Exp(1) spacings, scanned by the same kernels) -> the ancestors come out
+                                   * SORTED; torch.multinomial returns the same multiset in iid order */
 
 /* Closed description of a state-space model (the "kernel_id" view of a stochproc StateSpaceModel). */
 typedef struct pf_model {
@@ -155,6 +157,7 @@ typedef struct pf_filter_args {
     void* logw[2];  /* (B,N)   */
     int32_t* anc;   /* (B,N) ancestors of the latest step (SISR keeps them when no resampling happened) */
     void* cdf;      /* (B,N) scratch */
+    void* pos;      /* (B,N) scratch: sorted resampling positions (PF_RESAMPLE_MULTINOMIAL only, else NULL) */
     /* observations */
     const void* y;            /* (T, y_rows, O) */
     int64_t y_rows;           /* 1 or B */

@@ -46,7 +46,7 @@ class PfFilterArgs(C.Structure):
         ("ess_threshold", C.c_double),
         ("seed", C.c_uint64),
         ("x", C.c_void_p * 2), ("logw", C.c_void_p * 2),
-        ("anc", C.c_void_p), ("cdf", C.c_void_p),
+        ("anc", C.c_void_p), ("cdf", C.c_void_p), ("pos", C.c_void_p),
         ("y", C.c_void_p), ("y_rows", C.c_int64), ("observed", C.c_void_p),
         ("z_tape", C.c_void_p), ("u_tape", C.c_void_p),
         ("means", C.c_void_p), ("vars", C.c_void_p), ("ll_steps", C.c_void_p), ("ll_total", C.c_void_p),

@@ -38,6 +38,7 @@ template <typename T> struct FusedArgs {
     T* logw[2];
     int32_t* anc;
     T* cdf;
+    T* pos;      // (B, N) sorted resampling positions (multinomial)
     const T* y;  // (T, y_rows, O)
     int y_rows;
     const T* z_tape;
@@ -71,11 +72,13 @@ __device__ __forceinline__ void load_col_params(const FusedArgs<T>& a, int b, in
 template <typename T, int D> struct PartialAcc {
     OnlineLse<T> a1, a2;
     double q1, mx[D], mxx[D];
+    double es;  // sum of the Exp(1) spacings the next step's sorted-uniform multinomial will use for these particles
     bool poison;
     __device__ __forceinline__ void init() {
         a1.init();
         a2.init();
         q1 = 0.0;
+        es = 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) mx[d] = mxx[d] = 0.0;
         poison = false;
@@ -129,7 +132,7 @@ template <typename T, int D> struct PartialAcc {
             for (int j = 0; j < VEC; ++j) a2.s += (rw[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(rw[j] - a2.m);
         }
     }
-    // workgroup reduction + store in two LDS exchanges (maxima, then every rescaled sum); `red` >= (3 + 2D) * PF_NWAVES
+    // workgroup reduction + store in two LDS exchanges (maxima, then every rescaled sum); `red` >= (4 + 2D) * PF_NWAVES
     // doubles, `redm` >= 2 * PF_NWAVES Ts, neither used by anything still in flight
     __device__ __forceinline__ void finish(double* part, int b, int k, int B, int tiles, bool pre_on, double* red, T* redm,
                                            int32_t* poison_slot) {
@@ -147,7 +150,7 @@ template <typename T, int D> struct PartialAcc {
             M2 = (redm[PF_NWAVES + w] > M2) ? redm[PF_NWAVES + w] : M2;
         }
         const double f1 = exp_diff_t<T>((double)a1.m, (double)M1);
-        double sums[3 + 2 * D];
+        double sums[4 + 2 * D];
         sums[0] = a1.s * f1;
         sums[1] = q1 * f1 * f1;
         sums[2] = pre_on ? a2.s * exp_diff_t<T>((double)a2.m, (double)M2) : 0.0;
@@ -156,8 +159,9 @@ template <typename T, int D> struct PartialAcc {
             sums[3 + d] = mx[d] * f1;
             sums[3 + D + d] = mxx[d] * f1;
         }
+        sums[3 + 2 * D] = es;
 #pragma unroll
-        for (int q = 0; q < 3 + 2 * D; ++q) {
+        for (int q = 0; q < 4 + 2 * D; ++q) {
             const double ws = wave_sum(sums[q]);
             if (lane == 0) red[q * PF_NWAVES + wid] = ws;
         }
@@ -165,7 +169,7 @@ template <typename T, int D> struct PartialAcc {
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
-            for (int q = 0; q < 3 + 2 * D; ++q) {
+            for (int q = 0; q < 4 + 2 * D; ++q) {
                 double r = red[q * PF_NWAVES];
 #pragma unroll
                 for (int w = 1; w < PF_NWAVES; ++w) r += red[q * PF_NWAVES + w];
@@ -178,6 +182,7 @@ template <typename T, int D> struct PartialAcc {
             part[PQ_Q1 * stride + o] = sums[1];
             part[PQ_M2 * stride + o] = pre_on ? (double)M2 : -__builtin_huge_val();
             part[PQ_S2 * stride + o] = sums[2];
+            part[PQ_E * stride + o] = sums[3 + 2 * D];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 part[(PQ_MX + d) * stride + o] = sums[3 + d];
@@ -190,7 +195,7 @@ template <typename T, int D> struct PartialAcc {
 // partials of the state in slot (step & 1) - only needed for the first state of a run
 template <typename T, int D, int VEC>
 __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
-    __shared__ double red[(3 + 2 * D) * PF_NWAVES];
+    __shared__ double red[(4 + 2 * D) * PF_NWAVES];
     __shared__ T redm[2 * PF_NWAVES];
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -225,6 +230,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
             pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) : T(0);
         }
         acc.template push_round<VEC>(lw, xv, pre_on, pre);
+        if (a.resampler == PF_RESAMPLE_MULTINOMIAL) {
+            T ev[VEC];
+            draw_exponentials<T, VEC>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_MULTINOMIAL, (uint32_t)a.step,
+                                      (uint64_t)((int64_t)b * g.N + i0), ev);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
+        }
     }
     acc.finish(a.part, b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 1) * g.B + b]);
 }
@@ -233,13 +245,21 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 // c_prev < p_t <= c  (searchsorted side=left).  The intervals (c_prev, c] of consecutive elements partition (-1, 1], so
 // every tile start is claimed by exactly one element.  Candidates come from the real-valued inverse of p_t (cheap early
 // out: almost no element contains a tile start), membership from the exact fp test of resampling.py:44-51.
+// One heavy particle (degenerate weights) can own the first grid position of hundreds of position tiles; such wide
+// intervals are queued in LDS and expanded by the whole workgroup instead of one thread looping over them.
+#define PF_WIDE_MAX 32
+template <typename T> struct WideEntry {
+    T c_prev, c;
+    int i, ta, tb;
+};
 template <typename T>
 __device__ __forceinline__ void emit_j0(T c_prev, T c, int64_t i, T u, int64_t N, int tile_elems, int tiles,
-                                        int32_t* __restrict__ j0_col) {
-    // evaluated in T: the products carry a relative error of eps, i.e. <= eps * N / tile (< 0.07 at N = 2^30, tile >= 1024)
-    // in tile units - covered by delta
+                                        int32_t* __restrict__ j0_col, WideEntry<T>* wide, int* wide_cnt) {
+    // evaluated in T: c * N carries a relative error of eps, i.e. <= eps * N / tile = eps * tiles in tile units; the fp
+    // grid formula itself adds as much again.  delta covers both with a wide margin and is still << 1, so only the rare
+    // element whose interval really comes close to a tile start runs the exact test below.
     const T inv = T(1) / T(tile_elems);
-    const T delta = T(0.25);
+    const T delta = T(8) * T(tiles) * (sizeof(T) == 4 ? T(1.1920929e-7) : T(2.220446e-16)) + T(1e-4);
     const T lo = (c_prev * T(N) - u) * inv - delta;
     const T hi = (c * T(N) - u) * inv + delta;
     const T th = floor(hi);
@@ -247,10 +267,33 @@ __device__ __forceinline__ void emit_j0(T c_prev, T c, int64_t i, T u, int64_t N
     int64_t ta = (int64_t)ceil(lo), tb = (int64_t)th;
     if (ta < 0) ta = 0;
     if (tb > tiles - 1) tb = tiles - 1;
+    if (tb - ta >= 8) {
+        const int slot = atomicAdd(wide_cnt, 1);
+        if (slot < PF_WIDE_MAX) {
+            wide[slot].c_prev = c_prev;
+            wide[slot].c = c;
+            wide[slot].i = (int)i;
+            wide[slot].ta = (int)ta;
+            wide[slot].tb = (int)tb;
+            return;
+        }
+    }
     const T nT = T(N);
     for (int64_t t = ta; t <= tb; ++t) {
         const T p = grid_position<T>(t * tile_elems, u, nT);
         if (c_prev < p && p <= c) j0_col[t] = (int32_t)i;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void emit_wide(const WideEntry<T>* wide, int n, T u, int64_t N, int tile_elems,
+                                          int32_t* __restrict__ j0_col) {
+    const T nT = T(N);
+    for (int e = 0; e < n; ++e) {
+        const WideEntry<T> w = wide[e];
+        for (int t = w.ta + (int)threadIdx.x; t <= w.tb; t += PF_BLOCK) {
+            const T p = grid_position<T>((int64_t)t * tile_elems, u, nT);
+            if (w.c_prev < p && p <= w.c) j0_col[t] = w.i;
+        }
     }
 }
 
@@ -259,11 +302,26 @@ __device__ __forceinline__ void emit_j0(T c_prev, T c, int64_t i, T u, int64_t N
 // read in the loops.  Two LDS exchanges: maxima, then every rescaled sum.
 struct ColCombine {
     double m1, m2, S1, Q1, S2, prefK, prefK1;
+    double TE, prefE;  // multinomial: total / prefix (tiles below k) of the Exp(1) spacings
 };
 #define PF_COMBINE_ITERS (PF_MAX_TILES / PF_BLOCK)  // partial records per thread
 struct EarlyPartials {
     double m1[PF_COMBINE_ITERS], s1[PF_COMBINE_ITERS], q1[PF_COMBINE_ITERS], m2[PF_COMBINE_ITERS], s2[PF_COMBINE_ITERS];
 };
+// the Exp(1)-spacing prefix for the sorted-uniform multinomial (its own small reduction; systematic runs skip it)
+template <typename T>
+__device__ __forceinline__ void combine_spacings(const FusedArgs<T>& a, int64_t cb, int64_t stride, int k, double* red,
+                                                 double& total, double& prefix) {
+    double v[2] = {0.0, 0.0};
+    for (int t = threadIdx.x; t < a.g.tiles; t += PF_BLOCK) {
+        const double e = a.part[PQ_E * stride + cb + t];
+        v[0] += e;
+        if (t < k) v[1] += e;
+    }
+    block_sum<2>(v, red);
+    total = v[0];
+    prefix = v[1];
+}
 template <typename T>
 __device__ __forceinline__ void load_early_partials(const FusedArgs<T>& a, int64_t cb, int64_t stride, bool two,
                                                     EarlyPartials& e) {
@@ -343,12 +401,14 @@ __device__ __forceinline__ ColCombine combine_column(const FusedArgs<T>& a, cons
 // grid (tiles + 1, B): workgroups k < tiles scan their tile; the extra workgroup k == tiles is the column's bookkeeper
 // (moments row, log-likelihood increment, resampling decision) - kept off the scanning workgroups' critical path.
 template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_scan(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan(FusedArgs<T> a) {
     __shared__ double red[6 * PF_NWAVES];
     __shared__ double redm[2 * PF_NWAVES];
     __shared__ double red2[2 * D * PF_NWAVES];
     __shared__ double reds[PF_NWAVES];
     __shared__ T lastv[PF_BLOCK + 1];  // every thread's last cdf value of the round (+ the previous round's last one)
+    __shared__ WideEntry<T> wide[PF_WIDE_MAX];
+    __shared__ int wide_cnt;
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int step = a.step;
@@ -492,18 +552,24 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         if (sys) {
             // the *stored* cdf value preceding this thread's first element: previous thread's last value (LDS)
             lastv[threadIdx.x + 1] = on ? outv[VEC - 1] : T(1);
-            if (r == 0 && threadIdx.x == 0) lastv[0] = (k == 0) ? T(-1) : (T)Pk;
+            if (threadIdx.x == 0) {
+                wide_cnt = 0;
+                if (r == 0) lastv[0] = (k == 0) ? T(-1) : (T)Pk;
+            }
             __syncthreads();
             if (on) {
                 T c_prev = lastv[threadIdx.x];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    emit_j0<T>(c_prev, outv[j], i0 + j, ub, g.N, g.tile_elems, g.tiles, j0_col);
+                    emit_j0<T>(c_prev, outv[j], i0 + j, ub, g.N, g.tile_elems, g.tiles, j0_col, wide, &wide_cnt);
                     c_prev = outv[j];
                 }
             }
             __syncthreads();
+            const int nw = wide_cnt < PF_WIDE_MAX ? wide_cnt : PF_WIDE_MAX;
+            if (nw > 0) emit_wide<T>(wide, nw, ub, g.N, g.tile_elems, j0_col);
             if (threadIdx.x == 0) lastv[0] = lastv[PF_BLOCK];
+            if (nw > 0) __syncthreads();
         }
     };
 
@@ -516,6 +582,39 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         excl0 = block_scan_excl(local, reds, total);
     }
     PF_STAMP(a, 1);
+    if (!sys) {
+        // sorted-uniform multinomial: position i = (sum of Exp(1) spacings up to i) / (sum of all N + 1 spacings) - the
+        // order statistics of N iid uniforms; the spacings are regenerated from Philox, scanned like the weights
+        double TE, prefE;
+        combine_spacings<T>(a, cb, stride, k, red, TE, prefE);
+        T tail[1];
+        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)g.B * g.N + b), tail);
+        const double inv = 1.0 / (TE + (double)tail[0]);
+        double carryE = 0.0;
+        T* pos_col = a.pos + (int64_t)b * g.N;
+        for (int r = 0; r < g.rounds_per_tile; ++r) {
+            const int64_t r0 = base + (int64_t)r * g.round_elems;
+            if (r0 >= g.N) break;
+            const int64_t i0 = r0 + threadIdx.x * VEC;
+            const bool on = i0 < g.N;
+            T ev[VEC];
+            double incl[VEC], local = 0.0, total;
+            if (on) draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), ev);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                local += on ? (double)ev[j] : 0.0;
+                incl[j] = local;
+            }
+            const double excl = block_scan_excl(local, reds, total);
+            if (on) {
+                T pv[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pv[j] = (T)((prefE + carryE + excl + incl[j]) * inv);
+                if (VEC == 1) pos_col[i0] = pv[0]; else store_vec<T, VEC>(pos_col + i0, pv);
+            }
+            carryE += total;
+        }
+    }
 
     // 2. the column totals
     const ColCombine c = combine_column<T>(a, early, cb, stride, k, two, red, redm);
@@ -557,7 +656,7 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     __shared__ __attribute__((aligned(32))) T win[WIN];
     __shared__ __attribute__((aligned(32))) T xwin[XWIN ? D * WIN : VEC];
     __shared__ int sh_j0;
-    __shared__ double red[(3 + 2 * D) * PF_NWAVES];
+    __shared__ double red[(4 + 2 * D) * PF_NWAVES];
     __shared__ T redm[2 * PF_NWAVES];
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -568,20 +667,20 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     const bool apf = a.filter == PF_FILTER_APF;
     const bool resample = a.stat[b].resample != 0;
     const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
-    const bool windowed = resample && !multinomial;
+    const bool windowed = resample;  // both resamplers search an LDS window of the cdf (their positions are sorted)
     const bool pre_next = a.obs_next && apf;
     const int N = (int)g.N;
     PF_STAMP(a, 8);
     if (a.debug_cut == 1) return;
 
     // uniform loads first: the window start and the column's parameter rows
-    int j0 = windowed ? a.j0[(int64_t)b * g.tiles + k] : 0;
+    int j0 = (windowed && !multinomial) ? a.j0[(int64_t)b * g.tiles + k] : 0;
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
     load_col_params<T, D>(a, b, step, obs, cp);
     if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
-    const T ub = !windowed ? T(0)
+    const T ub = (!windowed || multinomial) ? T(0)
                            : (a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
                                        : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b));
 
@@ -599,12 +698,26 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     PartialAcc<T, D> acc;
     acc.init();
     PF_STAMP(a, 9);
+    const T* pos_col = multinomial ? a.pos + (int64_t)b * g.N : nullptr;
+    if (windowed && multinomial) {
+        // no position-tile table for the sorted uniforms: one wave finds the window start with a 64-ary search
+        if (tid < PF_WAVE) {
+            const int q = wave_lower_bound<T>(cdf_col, N, pos_col[base], tid & 63);
+            if ((tid & 63) == 0) sh_j0 = q;
+        }
+        __syncthreads();
+        j0 = sh_j0;
+    }
 
     for (int r = 0; r < g.rounds_per_tile; ++r) {
         const int64_t r0 = base + (int64_t)r * g.round_elems;
         if (r0 >= g.N) break;
         const int64_t i0 = r0 + tid * VEC;
         const bool on = i0 < g.N;
+        T pv[VEC];
+        if (multinomial && windowed && on) {
+            if (VEC == 1) pv[0] = pos_col[i0]; else load_vec<T, VEC>(pos_col + i0, pv);
+        }
 
         // ---- 1. issue the window loads (cdf, and the particles behind it) ------------------------------------------
         const int ws = j0 - (j0 % VEC);
@@ -681,7 +794,7 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 const int64_t i = i0 + j;
                 int res = N - 1;
                 if (i < N) {
-                    const T p = grid_position<T>(i, ub, nT);
+                    const T p = multinomial ? pv[j] : grid_position<T>(i, ub, nT);
                     const int q = window_lower_bound<T, WIN>(win, guess, p);
                     guess = q < WIN ? q : WIN - 1;
                     res = (q < WIN) ? ws + q : thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
@@ -693,16 +806,6 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 if (tid == PF_BLOCK - 1) sh_j0 = idx[VEC - 1];
                 __syncthreads();
                 j0 = sh_j0;
-            }
-        } else if (resample) {  // multinomial: iid uniforms, global binary search
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                idx[j] = N - 1;
-                if (i0 + j < g.N) {
-                    const T p = uniform_draw<T>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0 + j));
-                    const int q = thread_lower_bound<T>(cdf_col, 0, N, p);
-                    idx[j] = q > N - 1 ? N - 1 : q;
-                }
             }
         } else {
 #pragma unroll
@@ -772,6 +875,12 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
             }
             acc.template push_round<VEC>(lwo, xo, pre_next, pre_n);
+            if (multinomial) {
+                T ev[VEC];
+                draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)(step + 1), (uint64_t)((int64_t)b * g.N + i0), ev);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
+            }
             PF_STAMP(a, 13);
         }
         if (windowed && r + 1 < g.rounds_per_tile) __syncthreads();  // the window is rewritten by the next round

@@ -70,7 +70,7 @@ struct ColStat {
 
 // workspace carve-up (all offsets 256-byte aligned)
 struct WsLayout {
-    size_t off_part;   // double partials[(5 + 2D)][B][tiles]
+    size_t off_part;   // double partials[(6 + 2D)][B][tiles]
     size_t off_stat;   // ColStat[B]
     size_t off_poison; // int32 [2][B]
     size_t off_ctr;    // int32 [4] (reserved)
@@ -85,7 +85,7 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     WsLayout w;
     size_t o = 0;
     w.off_part = o;
-    o = align256(o + sizeof(double) * (size_t)(5 + 2 * D) * g.B * g.tiles);
+    o = align256(o + sizeof(double) * (size_t)(6 + 2 * D) * g.B * g.tiles);
     w.off_stat = o;
     o = align256(o + sizeof(ColStat) * (size_t)g.B);
     w.off_poison = o;
@@ -101,7 +101,8 @@ static inline WsLayout make_ws(const Geom& g, int D) {
 }
 
 // partial slots
-enum { PQ_M1 = 0, PQ_S1 = 1, PQ_Q1 = 2, PQ_M2 = 3, PQ_S2 = 4, PQ_MX = 5 };  // MX[d] at 5+d, MXX[d] at 5+D+d
+// E: sum of the tile's Exp(1) spacings (sorted-uniform multinomial); MX[d] at 6+d, MXX[d] at 6+D+d
+enum { PQ_M1 = 0, PQ_S1 = 1, PQ_Q1 = 2, PQ_M2 = 3, PQ_S2 = 4, PQ_E = 5, PQ_MX = 6 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // wave-cooperative lower_bound over a non-decreasing array: first j in [0, n) with c[j] >= p (clamped to n-1).
@@ -958,6 +959,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.logw[1] = (T*)A->logw[1];
     a.anc = A->anc;
     a.cdf = (T*)A->cdf;
+    a.pos = (T*)A->pos;
     a.y = (const T*)A->y;
     a.y_rows = (int)A->y_rows;
     a.z_tape = (const T*)A->z_tape;
@@ -1114,6 +1116,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (A->y_rows != 1 && A->y_rows != A->B) return PF_EINVAL;
     if (A->proposal == PF_PROP_LGO && A->model.obs_kind != PF_OBS_LINEAR) return PF_EUNSUPPORTED;
     if (A->filter != PF_FILTER_SISR && A->filter != PF_FILTER_APF) return PF_EUNSUPPORTED;
+    if (A->resampler == PF_RESAMPLE_MULTINOMIAL && !A->pos) return PF_EINVAL;
     const Geom g = make_geom(A->N, A->B);
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;

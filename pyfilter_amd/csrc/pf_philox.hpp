@@ -123,6 +123,43 @@ template <typename T, int D> struct NormalDraw {
     }
 };
 
+// Exp(1) draws for the sorted-uniform (exponential spacings) multinomial resampler, VEC consecutive elements.
+template <typename T, int VEC>
+__device__ __forceinline__ void draw_exponentials(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem0, T (&e)[VEC]);
+template <> __device__ __forceinline__ void draw_exponentials<float, 4>(uint64_t seed, uint32_t stream, uint32_t step,
+                                                                        uint64_t elem0, float (&e)[4]) {
+    const uint64_t c = elem0 >> 2;  // elem0 % 4 == 0: one call serves the four elements
+    const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream | 0x200u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    e[0] = -__logf(u01_open0(r.x));
+    e[1] = -__logf(u01_open0(r.y));
+    e[2] = -__logf(u01_open0(r.z));
+    e[3] = -__logf(u01_open0(r.w));
+}
+template <> __device__ __forceinline__ void draw_exponentials<float, 1>(uint64_t seed, uint32_t stream, uint32_t step,
+                                                                        uint64_t elem0, float (&e)[1]) {
+    const uint64_t c = elem0 >> 2;
+    const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream | 0x200u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint32_t q = (uint32_t)(elem0 & 3);
+    const uint32_t w = q == 0 ? r.x : (q == 1 ? r.y : (q == 2 ? r.z : r.w));
+    e[0] = -__logf(u01_open0(w));
+}
+template <> __device__ __forceinline__ void draw_exponentials<double, 4>(uint64_t seed, uint32_t stream, uint32_t step,
+                                                                         uint64_t elem0, double (&e)[4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t c = (elem0 >> 1) + h;
+        const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream | 0x200u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        e[2 * h] = -log(u01_open0_d(r.x, r.y));
+        e[2 * h + 1] = -log(u01_open0_d(r.z, r.w));
+    }
+}
+template <> __device__ __forceinline__ void draw_exponentials<double, 1>(uint64_t seed, uint32_t stream, uint32_t step,
+                                                                         uint64_t elem0, double (&e)[1]) {
+    const uint64_t c = elem0 >> 1;
+    const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream | 0x200u, (uint32_t)seed, (uint32_t)(seed >> 32));
+    e[0] = (elem0 & 1) ? -log(u01_open0_d(r.z, r.w)) : -log(u01_open0_d(r.x, r.y));
+}
+
 template <typename T> __device__ __forceinline__ T uniform_draw(uint64_t seed, uint32_t stream, uint32_t step,
                                                                uint64_t elem);
 template <> __device__ __forceinline__ float uniform_draw<float>(uint64_t seed, uint32_t stream, uint32_t step,

@@ -351,6 +351,7 @@ class _FusedPlan:
         self.logw = (torch.empty((b, n), device=device, dtype=dtype), torch.empty((b, n), device=device, dtype=dtype))
         self.anc = torch.empty((b, n), device=device, dtype=torch.int32)
         self.cdf = torch.empty((b, n), device=device, dtype=dtype)
+        self.pos = torch.empty((b, n), device=device, dtype=dtype) if filt._resampler_kind() == L.RESAMPLE_MULTINOMIAL else None
         self.y = torch.empty((steps, rows, o), device=device, dtype=dtype)
         self.means = torch.empty((steps + 1, b, d), device=device, dtype=dtype)
         self.vars = torch.empty_like(self.means)
@@ -374,7 +375,7 @@ class _FusedPlan:
         a.seed = filt._seed
         a.x[0], a.x[1] = self.x[0].data_ptr(), self.x[1].data_ptr()
         a.logw[0], a.logw[1] = self.logw[0].data_ptr(), self.logw[1].data_ptr()
-        a.anc, a.cdf = self.anc.data_ptr(), self.cdf.data_ptr()
+        a.anc, a.cdf, a.pos = self.anc.data_ptr(), self.cdf.data_ptr(), L.ptr(self.pos)
         a.y, a.y_rows, a.observed = self.y.data_ptr(), rows, observed_host.data_ptr()
         a.z_tape, a.u_tape = None, None
         a.means, a.vars = self.means.data_ptr(), self.vars.data_ptr()
