@@ -141,13 +141,19 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             z0 = None
             if self._z0 is not None:
                 z0 = ops.to_soa(self._z0.to(device=device, dtype=dtype), self._batched, self._has_event)
-            m0 = hidden.init_mean.reshape(-1).expand(d) if hidden.init_mean.numel() in (1, d) else None
-            s0 = hidden.init_scale.reshape(-1).expand(d) if hidden.init_scale.numel() in (1, d) else None
-            if m0 is not None and s0 is not None:
+            im, isd = hidden.init_mean.to(device=device, dtype=dtype), hidden.init_scale.to(device=device, dtype=dtype)
+            if im.numel() in (1, d) and isd.numel() in (1, d):
+                m0, s0 = im.reshape(-1).expand(d), isd.reshape(-1).expand(d)
                 soa = ops.initial_sample_soa(m0.tolist(), s0.tolist(), n, b, d, dtype, device, self._seed, z0)
-                x = TimeseriesState(0, ops.from_soa(soa, self._batched, self._has_event), hidden.event_shape)
             else:
-                x = hidden.initial_sample(self.particles)
+                # per-filter initial parameters (theta on the batch dim): standard draws from the kernel, then the
+                # column-wise affine map (once per run)
+                soa = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, device, self._seed, z0)
+                from ...timeseries.models import _expand
+                mb = _expand(im, b, (d,), dtype, device).t().unsqueeze(-1)  # (D, B, 1)
+                sb = _expand(isd, b, (d,), dtype, device).t().unsqueeze(-1)
+                soa = mb + sb * soa
+            x = TimeseriesState(0, ops.from_soa(soa, self._batched, self._has_event), hidden.event_shape)
         else:
             x = hidden.initial_sample(self.particles)
             if x.value.device != device:

@@ -330,3 +330,22 @@ def test_fp32_full_size_invariants():
     se = (r1.filter_variance[1:] / n).sqrt()
     assert ((r1.filter_means[1:] - r2.filter_means[1:]).abs() <= 8.0 * se + 1e-5).all()
     assert abs((r1.loglikelihood - r2.loglikelihood).item()) < 0.05
+
+
+def test_per_filter_initial_parameters():
+    """theta on the batch dim also parameterises the initial distribution (OU: N(gamma_b, sigma_b / sqrt(2 kappa_b)))."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device="cuda")  # noqa: E731
+    kappa, gamma, sigma = t([0.5, 1.0, 2.0]), t([-3.0, 0.0, 5.0]), t([0.1, 0.5, 1.0])
+    ssm = ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(kappa, gamma, sigma, dt=1.0), (t(1.0), t(0.05)))
+    filt = APF(ssm, 200_000, seed=3)
+    filt.set_batch_shape(torch.Size([3]))
+    x0 = filt.initialize().timeseries_state.value
+    assert x0.shape == (200_000, 3)
+    torch.testing.assert_close(x0.mean(0), gamma, atol=0.01, rtol=0)
+    torch.testing.assert_close(x0.std(0), sigma / (2 * kappa).sqrt(), atol=0.01, rtol=0.02)
+    res = filt.batch_filter(torch.zeros(5, device="cuda"), bar=False)
+    assert res.filter_means.shape == (6, 3, 1) and torch.isfinite(res.loglikelihood).all()
