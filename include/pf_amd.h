@@ -156,8 +156,8 @@ typedef struct pf_filter_args {
     void* x[2];     /* (D,B,N) */
     void* logw[2];  /* (B,N)   */
     int32_t* anc;   /* (B,N) ancestors of the latest step (SISR keeps them when no resampling happened) */
-    void* cdf;      /* (B,N) scratch */
-    void* pos;      /* (B,N) scratch: sorted resampling positions (PF_RESAMPLE_MULTINOMIAL only, else NULL) */
+    void* cdf;      /* (B,N) scratch: tile-local weight scans of even steps (systematic) | the cdf (multinomial) */
+    void* pos;      /* (B,N) scratch: tile-local weight scans of odd steps (systematic) | sorted positions (multinomial) */
     /* observations */
     const void* y;            /* (T, y_rows, O) */
     int64_t y_rows;           /* 1 or B */

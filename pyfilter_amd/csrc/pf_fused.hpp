@@ -51,6 +51,11 @@ template <typename T> struct FusedArgs {
     ColStat* stat;
     int32_t* poison;  // [2][B]
     int32_t* j0;      // [B][tiles]
+    double* ptab;     // [B][tiles + 1] normalised exclusive prefix of the tiles' resampling mass (P_0 = 0 ... P_tiles ~ 1)
+    double* ftab;     // [B][tiles]     exp(m_t - M) / S: scale of tile t's local (max-shifted) sums
+    int t0;           // first step of this run: the partials of state t0 are taken about pivot 0, later ones about the
+                      // previous state's mean (row q - 1 of `means`)
+    int from_local;   // systematic pipeline: `cdf` holds per-tile local scans L_i, the cdf is P_k + f_k * L_i
     // per launch
     int step;       // local step index: slot = step & 1 is read, the other written
     int obs;        // this step weighs against y[step]
@@ -68,48 +73,51 @@ __device__ __forceinline__ void load_col_params(const FusedArgs<T>& a, int b, in
             with_y ? a.y + ((int64_t)step * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O : nullptr);
 }
 
-// Accumulates the per-tile partials of a state from registers.
+// Accumulates the per-tile partials of a state from registers.  Per-thread accumulators are of the filter's type T: a
+// thread sums at most 4 R terms, the workgroup / column sums above it are fp64.  The weighted moments are taken about a
+// per-column pivot c (the previous state's mean) - sum e (x - c), sum e (x - c)^2 - so the variance never cancels.
 template <typename T, int D> struct PartialAcc {
-    OnlineLse<T> a1, a2;
-    double q1, mx[D], mxx[D];
-    double es;  // sum of the Exp(1) spacings the next step's sorted-uniform multinomial will use for these particles
+    T m1, m2;          // running maxima of logw / rw
+    T s1, s2, q1;      // sum e, sum e_rw, sum e^2
+    T mx[D], mxx[D];   // sum e (x - c), sum e (x - c)^2
+    double es;         // sum of the Exp(1) spacings the next step's sorted-uniform multinomial will use for these particles
     bool poison;
     __device__ __forceinline__ void init() {
-        a1.init();
-        a2.init();
-        q1 = 0.0;
+        m1 = m2 = -Lim<T>::inf();
+        s1 = s2 = q1 = T(0);
         es = 0.0;
 #pragma unroll
-        for (int d = 0; d < D; ++d) mx[d] = mxx[d] = 0.0;
+        for (int d = 0; d < D; ++d) mx[d] = mxx[d] = T(0);
         poison = false;
     }
     // One round of VEC particles: lw sanitised log-weights, x particles, pre (if pre_on) first-stage log-weights of the
     // next step.  The running maxima move at most once per round, so there is one exp per element (+ one per rescale).
     template <int VEC>
-    __device__ __forceinline__ void push_round(const T (&lw)[VEC], const T (&x)[D][VEC], bool pre_on, const T (&pre)[VEC]) {
+    __device__ __forceinline__ void push_round(const T (&lw)[VEC], const T (&x)[D][VEC], bool pre_on, const T (&pre)[VEC],
+                                               const T (&piv)[D]) {
         T m = lw[0];
 #pragma unroll
         for (int j = 1; j < VEC; ++j) m = (lw[j] > m) ? lw[j] : m;
-        if (m > a1.m) {
-            const double rs = (a1.m == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(a1.m - m);
-            a1.s *= rs;
+        if (m > m1) {
+            const T rs = (m1 == -Lim<T>::inf()) ? T(0) : pf_exp_w(m1 - m);
+            s1 *= rs;
             q1 *= rs * rs;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 mx[d] *= rs;
                 mxx[d] *= rs;
             }
-            a1.m = m;
+            m1 = m;
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            double e = (lw[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(lw[j] - a1.m);
-            if (lw[j] != lw[j]) e = (double)lw[j];
-            a1.s += e;
+            T e = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - m1);
+            if (lw[j] != lw[j]) e = lw[j];
+            s1 += e;
             q1 += e * e;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const double xd = (double)x[d][j];
+                const T xd = x[d][j] - piv[d];
                 mx[d] += e * xd;
                 mxx[d] += e * xd * xd;
             }
@@ -121,23 +129,23 @@ template <typename T, int D> struct PartialAcc {
                 if (pre[j] != pre[j] || pre[j] == Lim<T>::inf()) poison = true;
                 rw[j] = sanitize_logw(pre[j] + lw[j]);
             }
-            T m2 = rw[0];
+            T mm = rw[0];
 #pragma unroll
-            for (int j = 1; j < VEC; ++j) m2 = (rw[j] > m2) ? rw[j] : m2;
-            if (m2 > a2.m) {
-                a2.s *= (a2.m == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(a2.m - m2);
-                a2.m = m2;
+            for (int j = 1; j < VEC; ++j) mm = (rw[j] > mm) ? rw[j] : mm;
+            if (mm > m2) {
+                s2 *= (m2 == -Lim<T>::inf()) ? T(0) : pf_exp_w(m2 - mm);
+                m2 = mm;
             }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) a2.s += (rw[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(rw[j] - a2.m);
+            for (int j = 0; j < VEC; ++j) s2 += (rw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(rw[j] - m2);
         }
     }
     // workgroup reduction + store in two LDS exchanges (maxima, then every rescaled sum); `red` >= (4 + 2D) * PF_NWAVES
     // doubles, `redm` >= 2 * PF_NWAVES Ts, neither used by anything still in flight
     __device__ __forceinline__ void finish(double* part, int b, int k, int B, int tiles, bool pre_on, double* red, T* redm,
-                                           int32_t* poison_slot) {
+                                           int32_t* poison_slot, T& M1_out, T& M2_out) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        const T w1 = wave_max<T>(a1.m), w2 = wave_max<T>(a2.m);
+        const T w1 = wave_max<T>(m1), w2 = wave_max<T>(m2);
         if (lane == 0) {
             redm[wid] = w1;
             redm[PF_NWAVES + wid] = w2;
@@ -149,15 +157,17 @@ template <typename T, int D> struct PartialAcc {
             M1 = (redm[w] > M1) ? redm[w] : M1;
             M2 = (redm[PF_NWAVES + w] > M2) ? redm[PF_NWAVES + w] : M2;
         }
-        const double f1 = exp_diff_t<T>((double)a1.m, (double)M1);
+        M1_out = M1;
+        M2_out = M2;
+        const double f1 = exp_diff_t<T>((double)m1, (double)M1);
         double sums[4 + 2 * D];
-        sums[0] = a1.s * f1;
-        sums[1] = q1 * f1 * f1;
-        sums[2] = pre_on ? a2.s * exp_diff_t<T>((double)a2.m, (double)M2) : 0.0;
+        sums[0] = (double)s1 * f1;
+        sums[1] = (double)q1 * f1 * f1;
+        sums[2] = pre_on ? (double)s2 * exp_diff_t<T>((double)m2, (double)M2) : 0.0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            sums[3 + d] = mx[d] * f1;
-            sums[3 + D + d] = mxx[d] * f1;
+            sums[3 + d] = (double)mx[d] * f1;
+            sums[3 + D + d] = (double)mxx[d] * f1;
         }
         sums[3 + 2 * D] = es;
 #pragma unroll
@@ -191,6 +201,101 @@ template <typename T, int D> struct PartialAcc {
         }
     }
 };
+
+// cdf value of particle i from its tile-local scan L_i: P_k + f_k * L_i in fp64, clamped to the next tile's prefix,
+// rounded once to T; a tile's last element is pinned to T(P_{k+1}) and the column's last one to 1 (resampling.py:49).
+// The planning kernel (j0 search) and the step kernel (window staging) both go through this one function.
+template <typename T>
+__device__ __forceinline__ T cdf_from_local(T L, double Pk, double fk, double Pnext, bool tile_last, bool col_last) {
+    double c = Pk + fk * (double)L;
+    if (c > Pnext) c = Pnext;
+    T r = (T)c;
+    if (tile_last) r = col_last ? T(1) : (T)Pnext;
+    return r;
+}
+template <typename T> struct CdfView {  // random access to the implied cdf of one column (slow path / searches)
+    const T* L;
+    const double* ptab;  // this column's (tiles + 1) prefixes
+    const double* ftab;
+    int64_t N;
+    int tile_elems;
+    __device__ __forceinline__ T at(int64_t i) const {
+        const int kt = (int)(i / tile_elems);
+        const int64_t last = ((int64_t)(kt + 1) * tile_elems < N ? (int64_t)(kt + 1) * tile_elems : N) - 1;
+        return cdf_from_local<T>(L[i], ptab[kt], ftab[kt], ptab[kt + 1], i == last, i == N - 1);
+    }
+    __device__ __forceinline__ int lower_bound(int lo, int hi, T p) const {
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (at(mid) < p) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    }
+};
+
+// Tile-local inclusive scan of the resampling weights of the state in slot `slot`, relative to the tile maximum MR:
+// L_i = sum_{j <= i, j in tile} exp(rw_j - MR), fp64 accumulation, stored as T in `a.cdf`.  rw = logw (SISR) or
+// sanitize(pre_weight(x, y) + logw) (APF, `two`; `next` selects the observation the pre-weight is taken against).
+// Single-round tiles pass the round's values in registers (have_regs), otherwise they are re-read (L2-hot).
+template <typename T, int D, int VEC>
+__device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int b, int k, int slot, T* l_out, bool two, bool next,
+                                                T MR, const ColParams<T, D>& cp, const ColConsts<T, D>& cc, bool have_regs,
+                                                const T (&lw_reg)[VEC], const T (&pre_reg)[VEC], double* reds) {
+    const Geom& g = a.g;
+    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
+    const T* x_base = a.x[slot];
+    T* l_col = l_out + (int64_t)b * g.N;
+    const int64_t base = (int64_t)k * g.tile_elems;
+    double carry = 0.0;
+    for (int r = 0; r < g.rounds_per_tile; ++r) {
+        const int64_t r0 = base + (int64_t)r * g.round_elems;
+        if (r0 >= g.N) break;
+        const int64_t i0 = r0 + threadIdx.x * VEC;
+        const bool on = i0 < g.N;
+        T rw[VEC];
+        if (on) {
+            if (have_regs) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) rw[j] = two ? sanitize_logw(pre_reg[j] + lw_reg[j]) : lw_reg[j];
+            } else {
+                T lw[VEC];
+                if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
+                if (two) {
+                    T xv[D][VEC];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
+                        if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        T xj[D];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
+                        rw[j] = sanitize_logw(pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, next) + lw[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) rw[j] = lw[j];
+                }
+            }
+        }
+        double e[VEC], local = 0.0, total;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            local += (on && rw[j] != -Lim<T>::inf()) ? (double)pf_exp_w(rw[j] - MR) : 0.0;
+            e[j] = local;
+        }
+        const double excl = block_scan_excl(local, reds, total);
+        if (on) {
+            T outv[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) outv[j] = (T)(carry + excl + e[j]);
+            if (VEC == 1) l_col[i0] = outv[0]; else store_vec<T, VEC>(l_col + i0, outv);
+        }
+        carry += total;
+    }
+}
 
 // partials of the state in slot (step & 1) - only needed for the first state of a run
 template <typename T, int D, int VEC>
@@ -229,7 +334,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
             for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
             pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) : T(0);
         }
-        acc.template push_round<VEC>(lw, xv, pre_on, pre);
+        T piv0[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) piv0[d] = T(0);
+        acc.template push_round<VEC>(lw, xv, pre_on, pre, piv0);
         if (a.resampler == PF_RESAMPLE_MULTINOMIAL) {
             T ev[VEC];
             draw_exponentials<T, VEC>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_MULTINOMIAL, (uint32_t)a.step,
@@ -238,7 +346,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
             for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
         }
     }
-    acc.finish(a.part, b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 1) * g.B + b]);
+    T M1, M2;
+    acc.finish(a.part, b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 1) * g.B + b], M1, M2);
+    if (a.from_local) {
+        __shared__ double reds[PF_NWAVES];
+        T dummy[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dummy[j] = T(0);
+        // local scans are double buffered like the state: step s reads buffer s & 1 while it writes the next one
+        tile_local_scan<T, D, VEC>(a, b, k, slot, (a.step & 1) ? a.pos : a.cdf, pre_on, false, pre_on ? M2 : M1, cp, cc, false,
+                                   dummy, dummy, reds);
+    }
 }
 
 // Emits j0[t] = i for every position tile t whose first grid position p_t = (t * tile + u) / N satisfies
@@ -398,6 +516,64 @@ __device__ __forceinline__ ColCombine combine_column(const FusedArgs<T>& a, cons
     return c;
 }
 
+// The column's bookkeeping, run by one extra workgroup per column: moments of the current state (row `step` of
+// filter_means / filter_variance), the log-likelihood increment of the previous step, the resampling decision.
+template <typename T, int D>
+__device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const EarlyPartials& early, int b, int64_t cb,
+                                                    int64_t stride, bool obs, bool apf, bool two, double* red, double* redm,
+                                                    double* red2) {
+    const Geom& g = a.g;
+    const int step = a.step;
+    const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
+    const double lse_w = c.m1 + log(c.S1);
+    const double ess = c.S1 * c.S1 / c.Q1;
+    bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
+    if (a.finalize_only) resample = false;
+    double mv[2 * D];
+#pragma unroll
+    for (int q = 0; q < 2 * D; ++q) {
+        mv[q] = 0.0;
+        for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
+            mv[q] += a.part[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], c.m1);
+    }
+    block_sum<2 * D>(mv, red2);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {  // moments of the current state -> row `step` of filter_means / filter_variance
+            // the partials were taken about the pivot c = previous row's mean (0 for the run's first state)
+            const double piv = (step > a.t0) ? (double)a.means[((int64_t)(step - 1) * g.B + b) * D + d] : 0.0;
+            const double dm = mv[d] / c.S1;
+            double var = mv[D + d] / c.S1 - dm * dm;
+            if (var < 0.0) var = 0.0;
+            a.means[((int64_t)step * g.B + b) * D + d] = (T)(piv + dm);
+            a.vars[((int64_t)step * g.B + b) * D + d] = (T)var;
+        }
+        ColStat st = a.stat[b];
+        // log-likelihood increment of the previous step: ll = lse(logw') - base_lse   (0 for unweighted steps)
+        if (step > 0 && !st.ll_done) {
+            double ll = 0.0;
+            const int pslot = (step - 1) & 1;
+            if (st.prev_observed) {
+                ll = lse_w - st.base_lse;
+                if (a.poison[pslot * g.B + b]) ll = __builtin_nan("");
+            }
+            a.poison[pslot * g.B + b] = 0;
+            a.ll_steps[(int64_t)(step - 1) * g.B + b] = (T)ll;
+            a.ll_total[b] = (T)((double)a.ll_total[b] + ll);
+        }
+        st.lse_w = lse_w;
+        st.resample = resample ? 1 : 0;
+        st.ll_done = a.finalize_only ? 1 : 0;
+        if (!a.finalize_only) {
+            st.prev_observed = obs ? 1 : 0;
+            // ll_t = [lse(w') - log N] + [lse(rw) - lse(w)] (apf.py:44) | lse(wi + log W), W = 1/N after resampling
+            // else the carried weights (sisr.py:52-55)
+            st.base_lse = apf ? a.logN - ((c.m2 + log(c.S2)) - lse_w) : (resample ? a.logN : lse_w);
+        }
+        a.stat[b] = st;
+    }
+}
+
 // grid (tiles + 1, B): workgroups k < tiles scan their tile; the extra workgroup k == tiles is the column's bookkeeper
 // (moments row, log-likelihood increment, resampling decision) - kept off the scanning workgroups' critical path.
 template <typename T, int D, int VEC>
@@ -424,53 +600,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
     load_early_partials<T>(a, cb, stride, two, early);
 
     if (k == g.tiles) {
-        // ------------------------------------------------ bookkeeper ------------------------------------------------------
-        const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
-        const double lse_w = c.m1 + log(c.S1);
-        const double ess = c.S1 * c.S1 / c.Q1;
-        bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
-        if (a.finalize_only) resample = false;
-        double mv[2 * D];
-#pragma unroll
-        for (int q = 0; q < 2 * D; ++q) {
-            mv[q] = 0.0;
-            for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-                mv[q] += a.part[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], c.m1);
-        }
-        block_sum<2 * D>(mv, red2);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {  // moments of the current state -> row `step` of filter_means / filter_variance
-                const double mu = mv[d] / c.S1;
-                double var = mv[D + d] / c.S1 - mu * mu;
-                if (var < 0.0) var = 0.0;
-                a.means[((int64_t)step * g.B + b) * D + d] = (T)mu;
-                a.vars[((int64_t)step * g.B + b) * D + d] = (T)var;
-            }
-            ColStat st = a.stat[b];
-            // log-likelihood increment of the previous step: ll = lse(logw') - base_lse   (0 for unweighted steps)
-            if (step > 0 && !st.ll_done) {
-                double ll = 0.0;
-                const int pslot = (step - 1) & 1;
-                if (st.prev_observed) {
-                    ll = lse_w - st.base_lse;
-                    if (a.poison[pslot * g.B + b]) ll = __builtin_nan("");
-                }
-                a.poison[pslot * g.B + b] = 0;
-                a.ll_steps[(int64_t)(step - 1) * g.B + b] = (T)ll;
-                a.ll_total[b] = (T)((double)a.ll_total[b] + ll);
-            }
-            st.lse_w = lse_w;
-            st.resample = resample ? 1 : 0;
-            st.ll_done = a.finalize_only ? 1 : 0;
-            if (!a.finalize_only) {
-                st.prev_observed = obs ? 1 : 0;
-                // ll_t = [lse(w') - log N] + [lse(rw) - lse(w)] (apf.py:44) | lse(wi + log W), W = 1/N after resampling
-                // else the carried weights (sisr.py:52-55)
-                st.base_lse = apf ? a.logN - ((c.m2 + log(c.S2)) - lse_w) : (resample ? a.logN : lse_w);
-            }
-            a.stat[b] = st;
-        }
+        column_bookkeeping<T, D>(a, early, b, cb, stride, obs, apf, two, red, redm, red2);
         return;
     }
     if (a.finalize_only) return;
@@ -647,7 +777,111 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
     }
 }
 
-template <typename T, int D, int VEC>
+// Planning kernel of the systematic pipeline.  grid (ceil(tiles / 4) + 1, B): every workgroup re-reduces the column's
+// partials into the tile-prefix table (workgroup 0 publishes it: ptab / ftab), each of its 4 waves then finds j0 for one
+// position tile - the tile via the table, the element inside it with a 64-ary search over the local scans; the extra
+// workgroup does the column's bookkeeping.  No per-particle pass: the per-particle scan was done by the previous step
+// kernel (tile_local_scan) while the weights were in registers.
+template <typename T, int D>
+__global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
+    __shared__ double red[6 * PF_NWAVES];
+    __shared__ double redm[2 * PF_NWAVES];
+    __shared__ double red2[2 * D * PF_NWAVES];
+    __shared__ double reds[PF_NWAVES];
+    __shared__ double ptl[PF_MAX_TILES + 1];
+    const Geom& g = a.g;
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int nplan = (g.tiles + PF_NWAVES - 1) / PF_NWAVES;
+    const int step = a.step;
+    const bool obs = !a.finalize_only && a.obs;
+    const bool apf = a.filter == PF_FILTER_APF;
+    const bool two = apf && obs;
+    const int64_t stride = (int64_t)g.B * g.tiles;
+    const int64_t cb = (int64_t)b * g.tiles;
+    EarlyPartials early;
+    load_early_partials<T>(a, cb, stride, two, early);
+    if (k == nplan) {
+        column_bookkeeping<T, D>(a, early, b, cb, stride, obs, apf, two, red, redm, red2);
+        return;
+    }
+    if (a.finalize_only) return;
+    const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
+    const bool resample = apf ? obs : (c.S1 * c.S1 / c.Q1 < a.thr_abs);
+    if (!resample) return;
+    const double MR = two ? c.m2 : c.m1, SR = two ? c.S2 : c.S1;
+    const int slot_m = two ? PQ_M2 : PQ_M1, slot_s = two ? PQ_S2 : PQ_S1;
+
+    // tile-prefix table: thread t owns the IT consecutive tiles [t * IT, (t + 1) * IT)
+    const int IT = (g.tiles + PF_BLOCK - 1) / PF_BLOCK;
+    double incl[PF_COMBINE_ITERS], run = 0.0, total;
+#pragma unroll
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        const int t = threadIdx.x * IT + q;
+        if (q < IT && t < g.tiles)
+            run += a.part[slot_s * stride + cb + t] * exp_diff_t<T>(a.part[slot_m * stride + cb + t], MR);
+        incl[q] = run;
+    }
+    const double excl = block_scan_excl(run, reds, total);
+    if (threadIdx.x == 0) ptl[0] = 0.0;
+#pragma unroll
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        const int t = threadIdx.x * IT + q;
+        if (q < IT && t < g.tiles) ptl[t + 1] = (excl + incl[q]) / SR;
+    }
+    __syncthreads();
+    if (k == 0) {
+        for (int t = threadIdx.x; t <= g.tiles; t += PF_BLOCK) a.ptab[(int64_t)b * (g.tiles + 1) + t] = ptl[t];
+        for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
+            a.ftab[cb + t] = exp_diff_t<T>(a.part[slot_m * stride + cb + t], MR) / SR;
+    }
+
+    // j0 of position tile t: one wave each
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int t = k * PF_NWAVES + wid;
+    if (t >= g.tiles) return;
+    const T ub = a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
+                          : uniform_draw<T>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
+    const T p = grid_position<T>((int64_t)t * g.tile_elems, ub, T(g.N));
+    // the tile holding the ancestor: first kt whose end value T(P_{kt+1}) (1 for the last tile) is >= p
+    int lo = 0, hi = g.tiles - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((T)ptl[mid + 1] < p) lo = mid + 1; else hi = mid;
+    }
+    const int kt = lo;
+    const double Pk = ptl[kt], Pn = ptl[kt + 1];
+    const double fk = exp_diff_t<T>(a.part[slot_m * stride + cb + kt], MR) / SR;
+    const int64_t first = (int64_t)kt * g.tile_elems;
+    const int64_t last = (first + g.tile_elems < g.N ? first + g.tile_elems : g.N) - 1;
+    const T* l_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;
+    // 64-ary search for the first i in [first, last] with cdf(i) >= p (cdf(last) >= p by the choice of kt)
+    int64_t slo = first, shi = last + 1;
+    while (shi - slo > PF_WAVE) {
+        const int64_t len = shi - slo;
+        const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
+        int64_t probe = slo + (lane + 1) * st - 1;
+        if (probe > shi - 1) probe = shi - 1;
+        const bool ge = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1) >= p;
+        const unsigned long long bal = __ballot(ge);
+        if (bal == 0ull) { slo = shi - 1; shi = slo + 1; break; }
+        const int f = __ffsll((long long)bal) - 1;
+        int64_t nhi = slo + (int64_t)(f + 1) * st;
+        if (nhi > shi) nhi = shi;
+        slo = slo + (int64_t)f * st;
+        shi = nhi;
+    }
+    const int64_t i = slo + lane;
+    const bool ge = (i < shi) ? (cdf_from_local<T>(l_col[i], Pk, fk, Pn, i == last, i == g.N - 1) >= p) : true;
+    const unsigned long long bal = __ballot(ge);
+    const int f = __ffsll((long long)bal) - 1;
+    int64_t res = slo + f;
+    if (res > last) res = last;
+    if (lane == 0) a.j0[cb + t] = (int32_t)res;
+}
+
+// MODE 0: systematic pipeline (planning kernel + local scans); MODE 1: multinomial (sorted positions, explicit cdf from
+// k_fused_scan).  Compile-time so that neither variant carries the other's registers.
+template <typename T, int D, int VEC, int MODE>
 __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_step(FusedArgs<T> a) {
     constexpr int WIN = SearchWin<T, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
@@ -657,6 +891,7 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     __shared__ __attribute__((aligned(32))) T xwin[XWIN ? D * WIN : VEC];
     __shared__ int sh_j0;
     __shared__ double red[(4 + 2 * D) * PF_NWAVES];
+    __shared__ double reds[PF_NWAVES];
     __shared__ T redm[2 * PF_NWAVES];
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -666,7 +901,7 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     const bool obs = a.obs != 0;
     const bool apf = a.filter == PF_FILTER_APF;
     const bool resample = a.stat[b].resample != 0;
-    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
+    constexpr bool multinomial = MODE == 1;
     const bool windowed = resample;  // both resamplers search an LDS window of the cdf (their positions are sorted)
     const bool pre_next = a.obs_next && apf;
     const int N = (int)g.N;
@@ -688,7 +923,8 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     T* x_out = a.x[slot ^ 1];
     const T* lw_in = a.logw[slot] + (int64_t)b * g.N;
     T* lw_out = a.logw[slot ^ 1] + (int64_t)b * g.N;
-    const T* cdf_col = a.cdf + (int64_t)b * g.N;
+    // multinomial / two-kernel pipeline: the cdf itself; systematic pipeline: the local scans of this step's parity
+    const T* cdf_col = ((MODE == 0 && (step & 1)) ? a.pos : a.cdf) + (int64_t)b * g.N;
     int32_t* anc_col = a.anc + (int64_t)b * g.N;
     const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
     const int64_t base = (int64_t)k * g.tile_elems;
@@ -699,6 +935,15 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     acc.init();
     PF_STAMP(a, 9);
     const T* pos_col = multinomial ? a.pos + (int64_t)b * g.N : nullptr;
+    constexpr bool from_local = MODE == 0;  // `cdf` holds tile-local scans; the cdf is implied by the table
+    const double* ptab_col = a.ptab + (int64_t)b * (g.tiles + 1);
+    const double* ftab_col = a.ftab + (int64_t)b * g.tiles;
+    CdfView<T> view;
+    view.L = cdf_col;
+    view.ptab = ptab_col;
+    view.ftab = ftab_col;
+    view.N = g.N;
+    view.tile_elems = g.tile_elems;
     if (windowed && multinomial) {
         // no position-tile table for the sorted uniforms: one wave finds the window start with a 64-ary search
         if (tid < PF_WAVE) {
@@ -709,6 +954,9 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         j0 = sh_j0;
     }
 
+    T lwo[VEC], pre_n[VEC];  // the last round's new log-weights / next-step pre-weights (reused by the local scan)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) lwo[j] = pre_n[j] = T(0);
     for (int r = 0; r < g.rounds_per_tile; ++r) {
         const int64_t r0 = base + (int64_t)r * g.round_elems;
         if (r0 >= g.N) break;
@@ -750,7 +998,6 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         }
 
         // ---- 2. work that does not need the window, while those loads are in flight --------------------------------
-        if (r == 0) cc.prepare(a.md, cp);
         T zt[VEC][D];
         if (on) {
             if (z_step) {
@@ -771,6 +1018,18 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         // ---- 3. ancestors ---------------------------------------------------------------------------------------------
         int idx[VEC];
         if (windowed) {
+            if (from_local) {  // local scans -> cdf values (a staged vector never straddles a tile: tile % VEC == 0)
+                const int kta = ina ? ja / g.tile_elems : 0, ktb = inb ? jb / g.tile_elems : 0;
+                const double tPa = ptab_col[kta], tNa = ptab_col[kta + 1], tFa = ftab_col[kta];
+                const double tPb = ptab_col[ktb], tNb = ptab_col[ktb + 1], tFb = ftab_col[ktb];
+                const int64_t la = ((int64_t)(kta + 1) * g.tile_elems < g.N ? (int64_t)(kta + 1) * g.tile_elems : g.N) - 1;
+                const int64_t lb = ((int64_t)(ktb + 1) * g.tile_elems < g.N ? (int64_t)(ktb + 1) * g.tile_elems : g.N) - 1;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (ina) c0[j] = cdf_from_local<T>(c0[j], tPa, tFa, tNa, ja + j == la, ja + j == g.N - 1);
+                    if (inb) c1[j] = cdf_from_local<T>(c1[j], tPb, tFb, tNb, jb + j == lb, jb + j == g.N - 1);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 if (!ina) c0[j] = Lim<T>::inf();
@@ -797,7 +1056,9 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                     const T p = multinomial ? pv[j] : grid_position<T>(i, ub, nT);
                     const int q = window_lower_bound<T, WIN>(win, guess, p);
                     guess = q < WIN ? q : WIN - 1;
-                    res = (q < WIN) ? ws + q : thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
+                    if (q < WIN) res = ws + q;
+                    else if (from_local) res = view.lower_bound(ws + WIN < N ? ws + WIN : N, N, p);
+                    else res = thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
                     if (res > N - 1) res = N - 1;
                 }
                 idx[j] = res;
@@ -817,7 +1078,8 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         }
 
         // ---- 4. gather, propagate, weight -------------------------------------------------------------------------------
-        T xo[D][VEC], lwo[VEC], pre_n[VEC];
+        if (r == 0) cc.prepare(a.md, cp);  // per-column constants: computed here so they are not live across the search
+        T xo[D][VEC];
         if (on && a.debug_cut != 2) {
             T xr[VEC][D];
             if (!resample) {
@@ -874,7 +1136,10 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
             if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
                 if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
             }
-            acc.template push_round<VEC>(lwo, xo, pre_next, pre_n);
+            T piv[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) piv[d] = a.means[((int64_t)step * g.B + b) * D + d];
+            acc.template push_round<VEC>(lwo, xo, pre_next, pre_n, piv);
             if (multinomial) {
                 T ev[VEC];
                 draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)(step + 1), (uint64_t)((int64_t)b * g.N + i0), ev);
@@ -888,7 +1153,12 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     if (poison) atomicOr(&a.poison[(step & 1) * g.B + b], 1);
     if (a.debug_cut == 3) return;
     PF_STAMP(a, 14);
-    acc.finish(a.part, b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 1) * g.B + b]);
+    T M1, M2;
+    acc.finish(a.part, b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 1) * g.B + b], M1, M2);
+    // the next step's resampling weights, scanned per tile while they are at hand (their cdf = table + these local scans)
+    if (from_local && (!apf || pre_next))
+        tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, true, pre_next ? M2 : M1, cp, cc,
+                                   g.rounds_per_tile == 1, lwo, pre_n, reds);
     PF_STAMP(a, 15);
 }
 

@@ -76,6 +76,8 @@ struct WsLayout {
     size_t off_ctr;    // int32 [4] (reserved)
     size_t off_j0;     // int32 [B][tiles]: ancestor of the first grid position of every position tile
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
+    size_t off_ptab;   // double [B][tiles + 1]
+    size_t off_ftab;   // double [B][tiles]
     size_t total;
 };
 
@@ -96,6 +98,10 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     o = align256(o + sizeof(int32_t) * (size_t)g.B * g.tiles);
     w.off_dbg = o;
     o = align256(o + 256);
+    w.off_ptab = o;
+    o = align256(o + sizeof(double) * (size_t)g.B * (g.tiles + 1));
+    w.off_ftab = o;
+    o = align256(o + sizeof(double) * (size_t)g.B * g.tiles);
     w.total = o;
     return w;
 }
@@ -973,7 +979,13 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.poison = (int32_t*)((char*)A->ws + wl.off_poison);
     a.j0 = (int32_t*)((char*)A->ws + wl.off_j0);
     a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
+    a.ptab = (double*)((char*)A->ws + wl.off_ptab);
+    a.ftab = (double*)((char*)A->ws + wl.off_ftab);
+    {
+        a.from_local = (A->resampler == PF_RESAMPLE_SYSTEMATIC) ? 1 : 0;
+    }
     a.finalize_only = 0;
+    a.t0 = (int)t0;
     {
         const char* dc = getenv("PF_DEBUG_CUT");
         a.debug_cut = dc ? atoi(dc) : 0;
@@ -981,6 +993,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const uint8_t* observed = A->observed;  // host array
 
     const dim3 grid(g.tiles, g.B), grid_scan(g.tiles + 1, g.B), block(PF_BLOCK);
+    const dim3 grid_plan((g.tiles + PF_NWAVES - 1) / PF_NWAVES + 1, g.B);
     if (t0 == 0) {
         // fresh filter: no previous step to account for
         hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
@@ -1005,16 +1018,19 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.obs = observed[t] != 0;
         a.obs_next = (s + 1 < n_steps) ? (observed[t + 1] != 0) : 0;
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 0], st);
-        hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
+        if (a.from_local) hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
+        else hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 1], st);
-        hipLaunchKernelGGL((k_fused_step<T, D, VEC>), grid, block, 0, st, a);
+        if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1>), grid, block, 0, st, a);
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 2], st);
     }
     if (finalize) {
         a.step = (int)(t0 + n_steps);
         a.obs = a.obs_next = 0;
         a.finalize_only = 1;
-        hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
+        if (a.from_local) hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
+        else hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
     }
     if (kernel_ms) {
         hipError_t se = hipStreamSynchronize(st);
@@ -1116,7 +1132,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (A->y_rows != 1 && A->y_rows != A->B) return PF_EINVAL;
     if (A->proposal == PF_PROP_LGO && A->model.obs_kind != PF_OBS_LINEAR) return PF_EUNSUPPORTED;
     if (A->filter != PF_FILTER_SISR && A->filter != PF_FILTER_APF) return PF_EUNSUPPORTED;
-    if (A->resampler == PF_RESAMPLE_MULTINOMIAL && !A->pos) return PF_EINVAL;
+    if (!A->pos) return PF_EINVAL;
     const Geom g = make_geom(A->N, A->B);
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;

@@ -357,7 +357,7 @@ class _FusedPlan:
         self.logw = (torch.empty((b, n), device=device, dtype=dtype), torch.empty((b, n), device=device, dtype=dtype))
         self.anc = torch.empty((b, n), device=device, dtype=torch.int32)
         self.cdf = torch.empty((b, n), device=device, dtype=dtype)
-        self.pos = torch.empty((b, n), device=device, dtype=dtype) if filt._resampler_kind() == L.RESAMPLE_MULTINOMIAL else None
+        self.pos = torch.empty((b, n), device=device, dtype=dtype)
         self.y = torch.empty((steps, rows, o), device=device, dtype=dtype)
         self.means = torch.empty((steps + 1, b, d), device=device, dtype=dtype)
         self.vars = torch.empty_like(self.means)
