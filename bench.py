@@ -113,13 +113,17 @@ def build_problem(name, dtype, device, world, rank, t_override=None):
 
 
 def alg_bytes_per_particle(w, kernel, e=4):
-    """Algorithmic HBM bytes per particle per launch (with int32 ancestors: 4 B instead of 8; the
-    separate reduce pass of §8(d) no longer exists - the step kernel reduces the state it writes from registers):
-    scan 8 (+4D for the APF's in-register pre-weight) | step 4 (cdf) + 4D (x[anc]) + 4D (x') + 4 (logw') + 4 (anc)."""
-    d = w["D"]  # e = bytes per state / weight element (4 for fp32)
-    if kernel == "scan":
-        return e * 2 + (e * d if w["filter"] == "apf" else 0)
-    return e * (2 + 2 * d) + 4
+    """Algorithmic HBM bytes per particle per launch (e = bytes per state / weight element, ancestors
+    are int32).  Systematic pipeline: the planning kernel touches no per-particle data (tile partials + a few probes);
+    the step kernel reads the local scans L (e) and x[anc] (e D), writes x' (e D), logw' (e), the next L (e), anc (4).
+    Multinomial pipeline: scan reads logw (e) [+ x (e D) for the APF] and writes cdf (e) + sorted positions (e); step
+    reads cdf (e) + positions (e) + x[anc] (e D), writes x' (e D), logw' (e), anc (4)."""
+    d = w["D"]
+    if w["resampler"] == "systematic":
+        return 0 if kernel == "plan" else e * (3 + 2 * d) + 4
+    if kernel == "plan":  # = k_fused_scan here
+        return e * 3 + (e * d if w["filter"] == "apf" else 0)
+    return e * (3 + 2 * d) + 4
 
 
 def cpu_baseline(name, w, seconds_budget=15.0):
@@ -281,24 +285,25 @@ def main():
     filt.batch_filter(y, bar=False)
     torch.cuda.synchronize()
     filt._time_kernels = False
-    kms = dict(zip(("scan", "step"), filt.kernel_ms[1:3]))  # two kernels per time step
-    names = ("scan", "step")
+    kms = dict(zip(("plan", "step"), filt.kernel_ms[1:3]))  # two kernels per time step
+    names = ("plan", "step")
+    kname = {"plan": "k_fused_plan" if w["resampler"] == "systematic" else "k_fused_scan", "step": "k_fused_step"}
     dom = max(names, key=lambda k: kms[k])
     esz = 8 if dtype == torch.float64 else 4
     launch_bytes = {k: alg_bytes_per_particle(w, k, esz) * w["N"] * w["B"] for k in names}
     achieved = launch_bytes[dom] / (kms[dom] * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": f"k_fused_{dom}", "achieved": achieved,
+        "bound": "hbm", "kernel": kname[dom], "achieved": achieved,
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "bytes_per_launch": launch_bytes[dom],
-        "kernel_us": {k: 1e3 * kms[k] for k in names},
-        "all_kernels_GBs": {k: launch_bytes[k] / (kms[k] * 1e-3) / 1e9 for k in names},
+        "kernel_us": {kname[k]: 1e3 * kms[k] for k in names},
+        "all_kernels_GBs": {kname[k]: launch_bytes[k] / (kms[k] * 1e-3) / 1e9 for k in names},
         "step_alg_bytes_per_particle": sum(alg_bytes_per_particle(w, k, esz) for k in names),
         "whole_step_GBs": sum(alg_bytes_per_particle(w, k, esz) for k in names) * value / world / 1e9,
     }
 
     if rank == 0 and world == 1 and not args.no_traffic:
-        tr = pmc_traffic(f"k_fused_{dom}", args.workload, args.dtype)
+        tr = pmc_traffic(kname[dom], args.workload, args.dtype)
         if tr is not None:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_detail"] = tr

@@ -238,8 +238,8 @@ template <typename T> struct CdfView {  // random access to the implied cdf of o
 // sanitize(pre_weight(x, y) + logw) (APF, `two`; `next` selects the observation the pre-weight is taken against).
 // Single-round tiles pass the round's values in registers (have_regs), otherwise they are re-read (L2-hot).
 template <typename T, int D, int VEC>
-__device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int b, int k, int slot, T* l_out, bool two, bool next,
-                                                T MR, const ColParams<T, D>& cp, const ColConsts<T, D>& cc, bool have_regs,
+__device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int proposal, int b, int k, int slot, T* l_out, bool two,
+                                                bool next, T MR, const ColParams<T, D>& cp, const ColConsts<T, D>& cc, bool have_regs,
                                                 const T (&lw_reg)[VEC], const T (&pre_reg)[VEC], double* reds) {
     const Geom& g = a.g;
     const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int b, in
                         T xj[D];
 #pragma unroll
                         for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-                        rw[j] = sanitize_logw(pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, next) + lw[j]);
+                        rw[j] = sanitize_logw(pre_weight<T, D>(a.md, proposal, cp, cc, xj, next) + lw[j]);
                     }
                 } else {
 #pragma unroll
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dummy[j] = T(0);
         // local scans are double buffered like the state: step s reads buffer s & 1 while it writes the next one
-        tile_local_scan<T, D, VEC>(a, b, k, slot, (a.step & 1) ? a.pos : a.cdf, pre_on, false, pre_on ? M2 : M1, cp, cc, false,
+        tile_local_scan<T, D, VEC>(a, a.proposal, b, k, slot, (a.step & 1) ? a.pos : a.cdf, pre_on, false, pre_on ? M2 : M1, cp, cc, false,
                                    dummy, dummy, reds);
     }
 }
@@ -881,8 +881,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
 
 // MODE 0: systematic pipeline (planning kernel + local scans); MODE 1: multinomial (sorted positions, explicit cdf from
 // k_fused_scan).  Compile-time so that neither variant carries the other's registers.
-template <typename T, int D, int VEC, int MODE>
+// PROP: the proposal as a compile-time constant (0 Bootstrap, 1 LinearGaussianObservations) or -1 = run-time switch.
+// For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
+template <typename T, int D, int VEC, int MODE, int PROP>
 __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_step(FusedArgs<T> a) {
+    const int proposal = (PROP >= 0) ? PROP : a.proposal;
     constexpr int WIN = SearchWin<T, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
     // ancestor gather is an LDS read instead of a second dependent global round trip
@@ -1106,10 +1109,10 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 T xn[D];
                 T w_new;
                 if (obs) {
-                    const T wi = sample_and_weight<T, D>(a.md, a.proposal, cp, cc, xr[j], zt[j], xn);
+                    const T wi = sample_and_weight<T, D>(a.md, proposal, cp, cc, xr[j], zt[j], xn);
                     if (apf) {
                         // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
-                        w_new = wi - pre_weight<T, D>(a.md, a.proposal, cp, cc, xr[j]);
+                        w_new = wi - pre_weight<T, D>(a.md, proposal, cp, cc, xr[j]);
                         if (w_new != w_new || w_new == Lim<T>::inf()) poison = true;
                     } else {
                         if (wi != wi || wi == Lim<T>::inf()) poison = true;
@@ -1124,7 +1127,7 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
 #pragma unroll
                 for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
                 // first-stage weight of the next step, while the new particle is still in registers
-                pre_n[j] = pre_next ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xn, true) : T(0);
+                pre_n[j] = pre_next ? pre_weight<T, D>(a.md, proposal, cp, cc, xn, true) : T(0);
             }
             PF_STAMP(a, 12);
 #pragma unroll
@@ -1157,7 +1160,7 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     acc.finish(a.part, b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 1) * g.B + b], M1, M2);
     // the next step's resampling weights, scanned per tile while they are at hand (their cdf = table + these local scans)
     if (from_local && (!apf || pre_next))
-        tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, true, pre_next ? M2 : M1, cp, cc,
+        tile_local_scan<T, D, VEC>(a, proposal, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, true, pre_next ? M2 : M1, cp, cc,
                                    g.rounds_per_tile == 1, lwo, pre_n, reds);
     PF_STAMP(a, 15);
 }

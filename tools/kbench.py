@@ -61,9 +61,15 @@ def main():
     T = int(os.environ.get("KB_T", 100))
     for name in names:
         cfg = CONFIGS[name]
-        f, o = make(*cfg[:5], resampler=(cfg[5] if len(cfg) > 5 else "systematic"))
-        g = torch.Generator().manual_seed(0)
-        y = (0.3 * torch.randn((T,) + o, generator=g)).cumsum(0).to(dev) if not o else torch.randn((T,) + o, generator=g).to(dev)
+        if cfg[0] == "lorenz":  # data simulated from the model (bench.py's generator), not noise
+            import bench
+            from pyfilter_amd import resampling as rs_
+            f, y, w = bench.build_problem("lorenz_mn", torch.float32, torch.device(dev), 1, 0, T)
+            f._resampler = {"systematic": rs_.systematic, "multinomial": rs_.multinomial}[cfg[5] if len(cfg) > 5 else "systematic"]
+        else:
+            f, o = make(*cfg[:5], resampler=(cfg[5] if len(cfg) > 5 else "systematic"))
+            g = torch.Generator().manual_seed(0)
+            y = (0.3 * torch.randn((T,) + o, generator=g)).cumsum(0).to(dev) if not o else torch.randn((T,) + o, generator=g).to(dev)
         f.batch_filter(y, bar=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
