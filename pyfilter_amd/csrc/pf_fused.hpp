@@ -1,19 +1,20 @@
-// pf_fused.hpp - the fused SISR / APF time step: TWO kernels per step.
+// pf_fused.hpp - the fused SISR / APF time step: two kernel launches per step, one of them light.
 //
-//   k_fused_scan   (grid tiles+1 x B) re-reduces the column's per-tile partials; the extra workgroup per column does the
-//                                    bookkeeping of the current state (moments row, log-likelihood of the previous step,
-//                                    resampling decision); if the column resamples: scans this tile of resampling weights into the
-//                                    cdf (fp64 carry, rounded per element) and emits j0[tile'] = the ancestor of the first
-//                                    grid position of every position tile whose start falls into this tile's cdf range.
-//   k_fused_step   (grid tiles x B)  ancestors of this tile's grid positions (LDS window search from j0) -> gather
-//                                    x[anc] -> propagate (Philox / tape) -> weight -> write x', logw', anc -> and, while
-//                                    the new state is still in registers, the per-tile partials of the NEXT step
-//                                    (online max / sum-exp / sum-exp^2, weighted moments, and - for the APF - the
-//                                    first-stage weights against the next observation).
+// Systematic resampling (the default):
+//   k_fused_plan  (grid ceil(tiles/4)+1 x B)  no per-particle pass.  Re-reduces the column's per-tile partials into the
+//                 tile-prefix table (P_t, f_t); each wave finds j0 for one position tile (tile via the table, element via
+//                 a 64-ary search over the tile-local scans); one extra workgroup per column does the bookkeeping
+//                 (moments row, log-likelihood increment of the previous step, resampling decision).
+//   k_fused_step  (grid tiles x B)  stages a window of local scans L_i, maps them to cdf values (P_k + f_k L_i, fp64,
+//                 rounded once), LDS searchsorted from j0, gathers x[anc] (from LDS when small), propagates
+//                 (Philox / tape), weighs, stores x', logw', anc - and, while the new state is in registers: the next
+//                 step's per-tile partials (max / sum exp / sum exp^2, pivoted weighted moments, the APF's first-stage
+//                 weights against y_{t+1}) and the tile-local inclusive scan L'_i of the next resampling weights.
+// Multinomial resampling: k_fused_scan (explicit cdf + sorted positions from Exp(1) spacings) + k_fused_step<MODE 1>.
 //
-// k_fused_reduce produces the partials of the very first state only.  A kernel boundary is the only inter-workgroup
-// synchronisation; the step index, "observed" flags and observation rows are kernel arguments set by the host loop, so a
-// launch has no dependent-load prologue.
+// k_fused_reduce produces the partials / local scans of the very first state only.  A kernel boundary is the only
+// inter-workgroup synchronisation; the step index, "observed" flags and observation rows are kernel arguments set by
+// the host loop (or baked into a captured hipGraph), so a launch has no dependent flag-load prologue.
 #pragma once
 
 namespace pf {
@@ -51,6 +52,7 @@ template <typename T> struct FusedArgs {
     ColStat* stat;
     int32_t* poison;  // [2][B]
     int32_t* j0;      // [B][tiles]
+    int32_t* k0;      // [B][tiles] tile index of j0
     double* ptab;     // [B][tiles + 1] normalised exclusive prefix of the tiles' resampling mass (P_0 = 0 ... P_tiles ~ 1)
     double* ftab;     // [B][tiles]     exp(m_t - M) / S: scale of tile t's local (max-shifted) sums
     int t0;           // first step of this run: the partials of state t0 are taken about pivot 0, later ones about the
@@ -359,62 +361,6 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     }
 }
 
-// Emits j0[t] = i for every position tile t whose first grid position p_t = (t * tile + u) / N satisfies
-// c_prev < p_t <= c  (searchsorted side=left).  The intervals (c_prev, c] of consecutive elements partition (-1, 1], so
-// every tile start is claimed by exactly one element.  Candidates come from the real-valued inverse of p_t (cheap early
-// out: almost no element contains a tile start), membership from the exact fp test of resampling.py:44-51.
-// One heavy particle (degenerate weights) can own the first grid position of hundreds of position tiles; such wide
-// intervals are queued in LDS and expanded by the whole workgroup instead of one thread looping over them.
-#define PF_WIDE_MAX 32
-template <typename T> struct WideEntry {
-    T c_prev, c;
-    int i, ta, tb;
-};
-template <typename T>
-__device__ __forceinline__ void emit_j0(T c_prev, T c, int64_t i, T u, int64_t N, int tile_elems, int tiles,
-                                        int32_t* __restrict__ j0_col, WideEntry<T>* wide, int* wide_cnt) {
-    // evaluated in T: c * N carries a relative error of eps, i.e. <= eps * N / tile = eps * tiles in tile units; the fp
-    // grid formula itself adds as much again.  delta covers both with a wide margin and is still << 1, so only the rare
-    // element whose interval really comes close to a tile start runs the exact test below.
-    const T inv = T(1) / T(tile_elems);
-    const T delta = T(8) * T(tiles) * (sizeof(T) == 4 ? T(1.1920929e-7) : T(2.220446e-16)) + T(1e-4);
-    const T lo = (c_prev * T(N) - u) * inv - delta;
-    const T hi = (c * T(N) - u) * inv + delta;
-    const T th = floor(hi);
-    if (th < lo) return;  // no integer in [lo, hi]
-    int64_t ta = (int64_t)ceil(lo), tb = (int64_t)th;
-    if (ta < 0) ta = 0;
-    if (tb > tiles - 1) tb = tiles - 1;
-    if (tb - ta >= 8) {
-        const int slot = atomicAdd(wide_cnt, 1);
-        if (slot < PF_WIDE_MAX) {
-            wide[slot].c_prev = c_prev;
-            wide[slot].c = c;
-            wide[slot].i = (int)i;
-            wide[slot].ta = (int)ta;
-            wide[slot].tb = (int)tb;
-            return;
-        }
-    }
-    const T nT = T(N);
-    for (int64_t t = ta; t <= tb; ++t) {
-        const T p = grid_position<T>(t * tile_elems, u, nT);
-        if (c_prev < p && p <= c) j0_col[t] = (int32_t)i;
-    }
-}
-template <typename T>
-__device__ __forceinline__ void emit_wide(const WideEntry<T>* wide, int n, T u, int64_t N, int tile_elems,
-                                          int32_t* __restrict__ j0_col) {
-    const T nT = T(N);
-    for (int e = 0; e < n; ++e) {
-        const WideEntry<T> w = wide[e];
-        for (int t = w.ta + (int)threadIdx.x; t <= w.tb; t += PF_BLOCK) {
-            const T p = grid_position<T>((int64_t)t * tile_elems, u, nT);
-            if (w.c_prev < p && p <= w.c) j0_col[t] = w.i;
-        }
-    }
-}
-
 // Combined column statistics from the per-tile partials.  The first PF_BLOCK tiles' values are passed in registers
 // (`early`, loaded at the very top of the kernel so their latency overlaps the tile's own work); further tiles are
 // read in the loops.  Two LDS exchanges: maxima, then every rescaled sum.
@@ -574,17 +520,15 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
     }
 }
 
-// grid (tiles + 1, B): workgroups k < tiles scan their tile; the extra workgroup k == tiles is the column's bookkeeper
-// (moments row, log-likelihood increment, resampling decision) - kept off the scanning workgroups' critical path.
+// Scan kernel of the MULTINOMIAL pipeline (the systematic one uses k_fused_plan).  grid (tiles + 1, B): workgroups
+// k < tiles scan their tile of resampling weights into the explicit cdf and their tile of Exp(1) spacings into the sorted
+// resampling positions; the extra workgroup k == tiles is the column's bookkeeper.
 template <typename T, int D, int VEC>
 __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan(FusedArgs<T> a) {
     __shared__ double red[6 * PF_NWAVES];
     __shared__ double redm[2 * PF_NWAVES];
     __shared__ double red2[2 * D * PF_NWAVES];
     __shared__ double reds[PF_NWAVES];
-    __shared__ T lastv[PF_BLOCK + 1];  // every thread's last cdf value of the round (+ the previous round's last one)
-    __shared__ WideEntry<T> wide[PF_WIDE_MAX];
-    __shared__ int wide_cnt;
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int step = a.step;
@@ -623,13 +567,8 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
         load_col_params<T, D>(a, b, step, true, cp);
         cc.prepare(a.md, cp);
     }
-    const bool sys = a.resampler == PF_RESAMPLE_SYSTEMATIC;
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    const T ub = !sys ? T(0)
-                      : (a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
-                                  : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b));
     T* cdf_col = a.cdf + (int64_t)b * g.N;
-    int32_t* j0_col = a.j0 + cb;
 
     auto tile_exponentials = [&](int64_t i0, bool on, double (&e)[VEC]) -> double {
         T lw[VEC], xv[D][VEC];
@@ -679,28 +618,6 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
             }
             if (VEC == 1) cdf_col[i0] = outv[0]; else store_vec<T, VEC>(cdf_col + i0, outv);
         }
-        if (sys) {
-            // the *stored* cdf value preceding this thread's first element: previous thread's last value (LDS)
-            lastv[threadIdx.x + 1] = on ? outv[VEC - 1] : T(1);
-            if (threadIdx.x == 0) {
-                wide_cnt = 0;
-                if (r == 0) lastv[0] = (k == 0) ? T(-1) : (T)Pk;
-            }
-            __syncthreads();
-            if (on) {
-                T c_prev = lastv[threadIdx.x];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    emit_j0<T>(c_prev, outv[j], i0 + j, ub, g.N, g.tile_elems, g.tiles, j0_col, wide, &wide_cnt);
-                    c_prev = outv[j];
-                }
-            }
-            __syncthreads();
-            const int nw = wide_cnt < PF_WIDE_MAX ? wide_cnt : PF_WIDE_MAX;
-            if (nw > 0) emit_wide<T>(wide, nw, ub, g.N, g.tile_elems, j0_col);
-            if (threadIdx.x == 0) lastv[0] = lastv[PF_BLOCK];
-            if (nw > 0) __syncthreads();
-        }
     };
 
     const bool single = g.rounds_per_tile == 1;
@@ -712,7 +629,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
         excl0 = block_scan_excl(local, reds, total);
     }
     PF_STAMP(a, 1);
-    if (!sys) {
+    {
         // sorted-uniform multinomial: position i = (sum of Exp(1) spacings up to i) / (sum of all N + 1 spacings) - the
         // order statistics of N iid uniforms; the spacings are regenerated from Philox, scanned like the weights
         double TE, prefE;
@@ -876,7 +793,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     const int f = __ffsll((long long)bal) - 1;
     int64_t res = slo + f;
     if (res > last) res = last;
-    if (lane == 0) a.j0[cb + t] = (int32_t)res;
+    if (lane == 0) {
+        a.j0[cb + t] = (int32_t)res;
+        a.k0[cb + t] = kt;
+    }
 }
 
 // MODE 0: systematic pipeline (planning kernel + local scans); MODE 1: multinomial (sorted positions, explicit cdf from
@@ -913,7 +833,10 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
 
     // uniform loads first: the window start and the column's parameter rows
     int j0 = (windowed && !multinomial) ? a.j0[(int64_t)b * g.tiles + k] : 0;
+    int kt0 = (MODE == 0 && windowed) ? a.k0[(int64_t)b * g.tiles + k] : 0;  // tile index of j0 (no integer division here)
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
+
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
     load_col_params<T, D>(a, b, step, obs, cp);
@@ -929,7 +852,6 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     // multinomial / two-kernel pipeline: the cdf itself; systematic pipeline: the local scans of this step's parity
     const T* cdf_col = ((MODE == 0 && (step & 1)) ? a.pos : a.cdf) + (int64_t)b * g.N;
     int32_t* anc_col = a.anc + (int64_t)b * g.N;
-    const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
     const int64_t base = (int64_t)k * g.tile_elems;
     const T nT = T(N);
 
@@ -1022,7 +944,17 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         int idx[VEC];
         if (windowed) {
             if (from_local) {  // local scans -> cdf values (a staged vector never straddles a tile: tile % VEC == 0)
-                const int kta = ina ? ja / g.tile_elems : 0, ktb = inb ? jb / g.tile_elems : 0;
+                // tile of each staged vector: kt0 is the tile of j0 (from the planning kernel / carried between rounds); a
+                // window spans at most a few tiles, so two compares replace the integer divisions
+                while ((int64_t)(kt0 + 1) * g.tile_elems <= ws) ++kt0;  // uniform; only advances between rounds
+                int kta = kt0, ktb = kt0;
+                {
+                    const int64_t e1 = (int64_t)(kt0 + 1) * g.tile_elems, e2 = e1 + g.tile_elems, e3 = e2 + g.tile_elems;
+                    kta += (ja >= e1) + (ja >= e2) + (ja >= e3);
+                    ktb += (jb >= e1) + (jb >= e2) + (jb >= e3);
+                    if (!ina) kta = kt0;
+                    if (!inb) ktb = kt0;
+                }
                 const double tPa = ptab_col[kta], tNa = ptab_col[kta + 1], tFa = ftab_col[kta];
                 const double tPb = ptab_col[ktb], tNb = ptab_col[ktb + 1], tFb = ftab_col[ktb];
                 const int64_t la = ((int64_t)(kta + 1) * g.tile_elems < g.N ? (int64_t)(kta + 1) * g.tile_elems : g.N) - 1;

@@ -74,7 +74,7 @@ struct WsLayout {
     size_t off_stat;   // ColStat[B]
     size_t off_poison; // int32 [2][B]
     size_t off_ctr;    // int32 [4] (reserved)
-    size_t off_j0;     // int32 [B][tiles]: ancestor of the first grid position of every position tile
+    size_t off_j0;     // int32 [2][B][tiles]: ancestor of the first grid position of every position tile + its tile index
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
     size_t off_ptab;   // double [B][tiles + 1]
     size_t off_ftab;   // double [B][tiles]
@@ -95,7 +95,7 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.off_ctr = o;
     o = align256(o + 64);
     w.off_j0 = o;
-    o = align256(o + sizeof(int32_t) * (size_t)g.B * g.tiles);
+    o = align256(o + sizeof(int32_t) * 2 * (size_t)g.B * g.tiles);
     w.off_dbg = o;
     o = align256(o + 256);
     w.off_ptab = o;
@@ -978,6 +978,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.stat = (ColStat*)((char*)A->ws + wl.off_stat);
     a.poison = (int32_t*)((char*)A->ws + wl.off_poison);
     a.j0 = (int32_t*)((char*)A->ws + wl.off_j0);
+    a.k0 = a.j0 + (size_t)g.B * g.tiles;
     a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
     a.ptab = (double*)((char*)A->ws + wl.off_ptab);
     a.ftab = (double*)((char*)A->ws + wl.off_ftab);
