@@ -803,7 +803,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
 // k_fused_scan).  Compile-time so that neither variant carries the other's registers.
 // PROP: the proposal as a compile-time constant (0 Bootstrap, 1 LinearGaussianObservations) or -1 = run-time switch.
 // For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
-template <typename T, int D, int VEC, int MODE, int PROP>
+// FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
+// generic per-particle arithmetic (and its registers) from the fast instantiation and vice versa.
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST>
 __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_step(FusedArgs<T> a) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     constexpr int WIN = SearchWin<T, VEC>::WIN;
@@ -1013,7 +1015,10 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         }
 
         // ---- 4. gather, propagate, weight -------------------------------------------------------------------------------
-        if (r == 0) cc.prepare(a.md, cp);  // per-column constants: computed here so they are not live across the search
+        if (r == 0) {  // per-column constants: computed here so they are not live across the search
+            cc.prepare(a.md, cp);
+            __builtin_assume(cc.fast == FAST);
+        }
         T xo[D][VEC];
         if (on && a.debug_cut != 2) {
             T xr[VEC][D];
@@ -1060,6 +1065,9 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
                 // first-stage weight of the next step, while the new particle is still in registers
                 pre_n[j] = pre_next ? pre_weight<T, D>(a.md, proposal, cp, cc, xn, true) : T(0);
+                // keep the scheduler from interleaving all VEC particles' arithmetic: that is what pushes the kernel
+                // over its register budget (spills cost real HBM traffic: PMC WRITE_SIZE)
+                if (j & 1) __builtin_amdgcn_sched_barrier(0);
             }
             PF_STAMP(a, 12);
 #pragma unroll

@@ -1022,15 +1022,21 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         if (a.from_local) hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
         else hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 1], st);
-        if constexpr (D == 1) {  // scalar state: the closed forms are cheap, the proposal stays a run-time switch
-            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, -1>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, -1>), grid, block, 0, st, a);
+        if constexpr (D == 1) {  // scalar state: the proposal stays a run-time switch, the closed-form path a template flag
+            const bool fast = a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM;
+            if (fast) {
+                if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, -1, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, -1, true>), grid, block, 0, st, a);
+            } else {
+                if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, -1, false>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, -1, false>), grid, block, 0, st, a);
+            }
         } else if (a.proposal == PF_PROP_BOOTSTRAP) {
-            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PF_PROP_BOOTSTRAP>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PF_PROP_BOOTSTRAP>), grid, block, 0, st, a);
+            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PF_PROP_BOOTSTRAP, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PF_PROP_BOOTSTRAP, false>), grid, block, 0, st, a);
         } else {
-            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PF_PROP_LGO>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PF_PROP_LGO>), grid, block, 0, st, a);
+            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PF_PROP_LGO, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PF_PROP_LGO, false>), grid, block, 0, st, a);
         }
         if (kernel_ms) (void)hipEventRecord(ev[3 * s + 2], st);
     }
