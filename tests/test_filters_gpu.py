@@ -349,3 +349,35 @@ def test_per_filter_initial_parameters():
     torch.testing.assert_close(x0.std(0), sigma / (2 * kappa).sqrt(), atol=0.01, rtol=0.02)
     res = filt.batch_filter(torch.zeros(5, device="cuda"), bar=False)
     assert res.filter_means.shape == (6, 3, 1) and torch.isfinite(res.loglikelihood).all()
+
+
+@pytest.mark.parametrize("filt_name,prop", [("apf", "bootstrap"), ("sisr", "bootstrap"), ("apf", "lgo")])
+def test_weight_collapse_paths(filt_name, prop):
+    """Outlier observations collapse the weights onto a handful of particles: grid positions then fall far outside the
+    LDS window (global fallback search through the implied cdf), one ancestor owns many position tiles, most tiles
+    carry ~zero mass.  float64, identical draws: ancestors and moments must still match the oracle."""
+    n, b, t_len = 65536, 2, 6
+    case = dict(name="collapse", model="sine", filter=filt_name, proposal=prop, N=n, B=b, T=t_len, ess_threshold=0.9, seed=77)
+    spec = build_spec(case, torch.float64)
+    gen = torch.Generator().manual_seed(77)
+    z = torch.randn((t_len, n, b), generator=gen, dtype=torch.float32)
+    u = torch.rand(t_len, b, generator=gen, dtype=torch.float32)
+    z0 = torch.randn((n, b), generator=gen, dtype=torch.float32)
+    y = torch.tensor([0.1, 4.5, -5.0, 0.0, 6.0, 5.9], dtype=torch.float64)  # far in the tails of the particle cloud
+    g = dict(z_tape=z, u_tape=u, z0=z0)
+    x0 = cpu_ref.M.initial_sample(spec, z0.double())
+    ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, z.double(), u.double(), ess_threshold=0.9, record_steps=True)
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    res = filt.batch_filter(y.cuda(), bar=False)
+    torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-8, atol=1e-10)
+    # the reference evaluates the APF's second likelihood term unshifted, log sum W exp(pre) (apf.py:44): with
+    # pre ~ -1000 every exp underflows and the reference reports -inf; the kernels use the max-shifted form (equal
+    # whenever the reference's value is finite) and stay finite
+    ll, ll_ref = res.loglikelihood.cpu(), ref["loglikelihood"]
+    fin = torch.isfinite(ll_ref)
+    torch.testing.assert_close(ll[fin], ll_ref[fin], rtol=1e-8, atol=1e-8)
+    assert torch.isfinite(ll[~fin]).all()
+    assert torch.equal(res.latest_state.previous_indices.cpu(), ref["prev_inds"])
+    # the collapse really happened: at some step fewer than 1 % of the particles survive resampling
+    uniq = min(torch.unique(ref["step_idx"][t][:, 0]).numel() for t in range(t_len))
+    assert uniq < n // 100, uniq
