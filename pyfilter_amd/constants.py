@@ -1,12 +1,20 @@
-"""Mirror of ``pyfilter/constants.py:5-11``."""
-from math import sqrt
+"""Numeric constants of the default floating-point type, evaluated at import like ``pyfilter.constants`` does
+(so they follow ``torch.set_default_dtype`` only if it is called before the import)."""
+import math
 
 import torch
 
-INFTY = float("inf")
-_info = torch.finfo(torch.get_default_dtype())
 
-EPS = sqrt(_info.eps)
-EPS2 = _info.eps
+def _default_finfo() -> torch.finfo:
+    return torch.finfo(torch.get_default_dtype())
 
-MAX = _info.max
+
+_fi = _default_finfo()
+
+#: positive infinity (log-weights of impossible particles are ``-INFTY``)
+INFTY = math.inf
+#: machine epsilon of the default dtype and its square root
+EPS2 = float(_fi.eps)
+EPS = math.sqrt(EPS2)
+#: largest finite value of the default dtype (``normalize`` maps ``-inf`` to ``-MAX``, see ``utils.normalize``)
+MAX = float(_fi.max)
