@@ -64,6 +64,7 @@ template <typename T> struct FusedArgs {
     int obs_next;   // the next step exists and is a weighted step (its first-stage weights are prepared here)
     int finalize_only;
     unsigned long long* dbg;
+    int replay;     // measurement replays: the bookkeeper computes but does not publish (results stay untouched)
     int debug_cut;  // development knob (env PF_DEBUG_CUT): kernels return early after stage n; 0 = off
 };
 
@@ -483,7 +484,7 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
             mv[q] += a.part[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], c.m1);
     }
     block_sum<2 * D>(mv, red2);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !a.replay) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {  // moments of the current state -> row `step` of filter_means / filter_variance
             // the partials were taken about the pivot c = previous row's mean (0 for the run's first state)
@@ -508,7 +509,7 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
             a.ll_total[b] = (T)((double)a.ll_total[b] + ll);
         }
         st.lse_w = lse_w;
-        st.resample = resample ? 1 : 0;
+        if (!a.finalize_only) st.resample = resample ? 1 : 0;
         st.ll_done = a.finalize_only ? 1 : 0;
         if (!a.finalize_only) {
             st.prev_observed = obs ? 1 : 0;
