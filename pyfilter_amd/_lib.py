@@ -67,12 +67,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("PF_AMD_LIB", LIB_PATH)  # development: an instrumented build of the same sources
+    if not os.path.exists(path):
         raise PfAmdError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  pyfilter_amd has no CPU / eager fallback."
         )
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.pf_version.restype = C.c_char_p
     lib.pf_error_string.restype = C.c_char_p
     lib.pf_error_string.argtypes = [C.c_int]

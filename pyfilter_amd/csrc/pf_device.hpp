@@ -25,13 +25,16 @@ template <> struct Lim<double> {
     __host__ __device__ static constexpr double lowest() { return -1.79769313486231570815e+308; }
 };
 
+__device__ __forceinline__ bool is_nan_or_posinf(float v) { return __builtin_amdgcn_classf(v, 0x203); }
+__device__ __forceinline__ bool is_nan_or_posinf(double v) { return __builtin_amdgcn_class(v, 0x203); }
+
 // torch.nan_to_num_(w, nan=-inf, posinf=-inf) as pyfilter/utils.py:57 calls it: NaN -> -inf, +inf -> -inf and -
 // because ``neginf`` is left at its default - -inf -> the lowest finite value of the dtype.
 template <typename T> __device__ __forceinline__ T sanitize_logw(T v) {
-    if (v != v) return -Lim<T>::inf();
-    if (v == Lim<T>::inf()) return -Lim<T>::inf();
-    if (v == -Lim<T>::inf()) return Lim<T>::lowest();
-    return v;
+    // v_cmp_class: one test for {sNaN, qNaN, +inf} (bits 0, 1, 9), one compare for -inf
+    const bool bad = is_nan_or_posinf(v);
+    T r = bad ? -Lim<T>::inf() : v;
+    return (v == -Lim<T>::inf()) ? Lim<T>::lowest() : r;
 }
 
 __device__ __forceinline__ float pf_exp(float x) { return expf(x); }
@@ -58,13 +61,16 @@ __device__ __forceinline__ float pf_sin(float x) {
     return ((int)k & 1) ? -sres : sres;
 }
 __device__ __forceinline__ double pf_sin(double x) { return sin(x); }
-// exp for importance weights: float -> v_exp_f32 based (relative error ~|x| * 6e-8, irrelevant next to the fp32
-// rounding of the weights themselves); double -> libm
-__device__ __forceinline__ float pf_exp_w(float x) { return __expf(x); }
+// exp for importance weights: float -> the bare v_exp_f32 (2^x) on x * log2(e): two instructions (clang's __expf
+// expands to 13 with its range handling).  Relative error ~|x| * 6e-8, irrelevant next to the fp32 rounding of the
+// weights themselves; results below 2^-126 flush to zero, exp(-inf) = 0.  double -> libm
+__device__ __forceinline__ float pf_exp_w(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ double pf_exp_w(double x) { return exp(x); }
 // per-column constants (evaluated once per thread, on the critical path of every workgroup): hardware log / rcp /
 // sqrt for float (1 ulp class), libm for double
-__device__ __forceinline__ float pf_log_c(float x) { return __logf(x); }
+__device__ __forceinline__ float pf_log_c(float x) {  // bare v_log_f32 (log2); arguments here are normal numbers
+    return __builtin_amdgcn_logf(x) * 0.693147180559945309417f;
+}
 __device__ __forceinline__ double pf_log_c(double x) { return log(x); }
 __device__ __forceinline__ float pf_rcp_c(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double pf_rcp_c(double x) { return 1.0 / x; }
@@ -143,6 +149,26 @@ template <typename T> __device__ __forceinline__ T wave_scan_incl(T v, int /*lan
     v += dpp_get<PF_DPP_ROW_SHR(8)>(v, T(0));
     v += dpp_get<PF_DPP_ROW_BCAST15, 0xA>(v, T(0));  // lane 15 -> row 1, lane 47 -> row 3
     v += dpp_get<PF_DPP_ROW_BCAST31, 0xC>(v, T(0));  // lane 31 -> rows 2, 3
+    return v;
+}
+
+// previous lane's value (lane 0 gets `ident`): the gfx9 whole-wave DPP shift
+#define PF_DPP_WAVE_SHR1 0x138
+__device__ __forceinline__ int wave_prev(int v, int ident) {
+    return __builtin_amdgcn_update_dpp(ident, v, PF_DPP_WAVE_SHR1, 0xF, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ int dpp_get_i(int v, int ident) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+// inclusive running maximum of non-negative ints across the 64 lanes
+__device__ __forceinline__ int wave_scan_max(int v) {
+    v = imax(v, dpp_get_i<PF_DPP_ROW_SHR(1)>(v, 0));
+    v = imax(v, dpp_get_i<PF_DPP_ROW_SHR(2)>(v, 0));
+    v = imax(v, dpp_get_i<PF_DPP_ROW_SHR(4)>(v, 0));
+    v = imax(v, dpp_get_i<PF_DPP_ROW_SHR(8)>(v, 0));
+    v = imax(v, dpp_get_i<PF_DPP_ROW_BCAST15, 0xA>(v, 0));
+    v = imax(v, dpp_get_i<PF_DPP_ROW_BCAST31, 0xC>(v, 0));
     return v;
 }
 

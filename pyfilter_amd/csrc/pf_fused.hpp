@@ -19,12 +19,24 @@
 
 namespace pf {
 
+// Development instrumentation (cycle stamps, early-exit cuts for per-stage PMC profiles) is compiled in only with
+// -DPF_DEVTOOLS (tools/pmc_stages.py builds that variant); the production kernels carry none of it.
+#ifdef PF_DEVTOOLS
+#define PF_CUT(a, n) ((a).debug_cut == (n))
 #define PF_STAMP(a, slot)                                                                       \
     do {                                                                                        \
         if ((a).debug_cut < 0 && !(a).finalize_only && blockIdx.x == (unsigned)(-(a).debug_cut - 1) &&  \
             blockIdx.y == 0 && threadIdx.x == 0)                                                \
             (a).dbg[slot] = (unsigned long long)clock64();                                      \
     } while (0)
+#else
+#define PF_CUT(a, n) false
+#ifdef PF_ISA_MARKS  // stage boundaries as comments in the ISA listing (static instruction counts; they pin the schedule)
+#define PF_STAMP(a, slot) asm volatile("; PF_MARK " #slot)
+#else
+#define PF_STAMP(a, slot) do { } while (0)
+#endif
+#endif
 
 template <typename T> struct FusedArgs {
     ModelDesc md;
@@ -48,13 +60,16 @@ template <typename T> struct FusedArgs {
     T* vars;
     T* ll_steps;
     T* ll_total;
-    double* part;
+    double* part;          // per-tile partials, two copies: state q's live in copy q & 1 (the step kernel reads the plan of
+    int64_t part_stride;   // state `step` while it writes the partials of state `step + 1`; a replayed step stays exact)
     ColStat* stat;
     int32_t* poison;  // [2][B]
     int32_t* j0;      // [B][tiles]
     int32_t* k0;      // [B][tiles] tile index of j0
     double* ptab;     // [B][tiles + 1] normalised exclusive prefix of the tiles' resampling mass (P_0 = 0 ... P_tiles ~ 1)
     double* ftab;     // [B][tiles]     exp(m_t - M) / S: scale of tile t's local (max-shifted) sums
+    T* cpack;         // [B][PK_N] this step's closed-form constants of every column (scalar fast path; see FastCol)
+    T* ucol;          // [B] this step's systematic offset u of every column
     int t0;           // first step of this run: the partials of state t0 are taken about pivot 0, later ones about the
                       // previous state's mean (row q - 1 of `means`)
     int from_local;   // systematic pipeline: `cdf` holds per-tile local scans L_i, the cdf is P_k + f_k * L_i
@@ -64,16 +79,21 @@ template <typename T> struct FusedArgs {
     int obs_next;   // the next step exists and is a weighted step (its first-stage weights are prepared here)
     int finalize_only;
     unsigned long long* dbg;
+    __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
+    __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
     int replay;     // measurement replays: the bookkeeper computes but does not publish (results stay untouched)
     int debug_cut;  // development knob (env PF_DEBUG_CUT): kernels return early after stage n; 0 = off
 };
 
+// `late`: an opaque zero added to the row addresses (the step kernel ties it to a value computed after the ancestor
+// search, so the loads - and the registers they fill - cannot be hoisted above it)
 template <typename T, int D>
-__device__ __forceinline__ void load_col_params(const FusedArgs<T>& a, int b, int step, bool with_y, ColParams<T, D>& cp) {
+__device__ __forceinline__ void load_col_params(const FusedArgs<T>& a, int b, int step, bool with_y, ColParams<T, D>& cp,
+                                                int late = 0) {
     const int O = a.md.obs_dim;
     const int NP = 4 * D + O * D + 2 * O;
-    cp.load(a.params + (int64_t)b * NP, O,
-            with_y ? a.y + ((int64_t)step * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O : nullptr);
+    cp.load(a.params + (int64_t)b * NP + late, O,
+            with_y ? a.y + ((int64_t)step * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O + late : nullptr);
 }
 
 // Accumulates the per-tile partials of a state from registers.  Per-thread accumulators are of the filter's type T: a
@@ -95,9 +115,11 @@ template <typename T, int D> struct PartialAcc {
     }
     // One round of VEC particles: lw sanitised log-weights, x particles, pre (if pre_on) first-stage log-weights of the
     // next step.  The running maxima move at most once per round, so there is one exp per element (+ one per rescale).
+    // e_out: exp(rw_j - thread max) of this round's resampling weights rw (= lw, or lw + pre when pre_on) - for
+    // single-round tiles the tile-local scan reuses them (times finish()'s factor) instead of evaluating exp again.
     template <int VEC>
     __device__ __forceinline__ void push_round(const T (&lw)[VEC], const T (&x)[D][VEC], bool pre_on, const T (&pre)[VEC],
-                                               const T (&piv)[D]) {
+                                               const T (&piv)[D], T (&e_out)[VEC]) {
         T m = lw[0];
 #pragma unroll
         for (int j = 1; j < VEC; ++j) m = (lw[j] > m) ? lw[j] : m;
@@ -116,6 +138,7 @@ template <typename T, int D> struct PartialAcc {
         for (int j = 0; j < VEC; ++j) {
             T e = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - m1);
             if (lw[j] != lw[j]) e = lw[j];
+            e_out[j] = e;
             s1 += e;
             q1 += e * e;
 #pragma unroll
@@ -129,7 +152,7 @@ template <typename T, int D> struct PartialAcc {
             T rw[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                if (pre[j] != pre[j] || pre[j] == Lim<T>::inf()) poison = true;
+                if (is_nan_or_posinf(pre[j])) poison = true;
                 rw[j] = sanitize_logw(pre[j] + lw[j]);
             }
             T mm = rw[0];
@@ -140,13 +163,20 @@ template <typename T, int D> struct PartialAcc {
                 m2 = mm;
             }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) s2 += (rw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(rw[j] - m2);
+            for (int j = 0; j < VEC; ++j) {
+                const T e = (rw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(rw[j] - m2);
+                e_out[j] = e;
+                s2 += e;
+            }
         }
     }
     // workgroup reduction + store in two LDS exchanges (maxima, then every rescaled sum); `red` >= (4 + 2D) * PF_NWAVES
-    // doubles, `redm` >= 2 * PF_NWAVES Ts, neither used by anything still in flight
+    // doubles, `redm` >= 2 * PF_NWAVES Ts, neither used by anything still in flight.  The within-wave sums run in T (for
+    // float: 6 DPP adds per quantity instead of fp64 pairs of moves), everything above a wave is fp64.  WITH_ES: the
+    // Exp(1) spacings of the multinomial route are reduced too.  F1 / F2: this thread's factors exp(m - M).
+    template <bool WITH_ES>
     __device__ __forceinline__ void finish(double* part, int b, int k, int B, int tiles, bool pre_on, double* red, T* redm,
-                                           int32_t* poison_slot, T& M1_out, T& M2_out) {
+                                           int32_t* poison_slot, T& M1_out, T& M2_out, T& F1_out, T& F2_out) {
         const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
         const T w1 = wave_max<T>(m1), w2 = wave_max<T>(m2);
         if (lane == 0) {
@@ -162,44 +192,55 @@ template <typename T, int D> struct PartialAcc {
         }
         M1_out = M1;
         M2_out = M2;
-        const double f1 = exp_diff_t<T>((double)m1, (double)M1);
-        double sums[4 + 2 * D];
-        sums[0] = (double)s1 * f1;
-        sums[1] = (double)q1 * f1 * f1;
-        sums[2] = pre_on ? (double)s2 * exp_diff_t<T>((double)m2, (double)M2) : 0.0;
+        const T f1 = (m1 == -Lim<T>::inf()) ? T(0) : pf_exp_w(m1 - M1);
+        const T f2 = (!pre_on || m2 == -Lim<T>::inf()) ? T(0) : pf_exp_w(m2 - M2);
+        F1_out = f1;
+        F2_out = f2;
+        constexpr int NS = 3 + 2 * D;
+        T sums[NS];
+        sums[0] = s1 * f1;
+        sums[1] = q1 * f1 * f1;
+        sums[2] = pre_on ? s2 * f2 : T(0);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            sums[3 + d] = (double)mx[d] * f1;
-            sums[3 + D + d] = (double)mxx[d] * f1;
+            sums[3 + d] = mx[d] * f1;
+            sums[3 + D + d] = mxx[d] * f1;
         }
-        sums[3 + 2 * D] = es;
 #pragma unroll
-        for (int q = 0; q < 4 + 2 * D; ++q) {
-            const double ws = wave_sum(sums[q]);
-            if (lane == 0) red[q * PF_NWAVES + wid] = ws;
+        for (int q = 0; q < NS; ++q) {
+            const T ws = wave_sum(sums[q]);
+            if (lane == 0) red[q * PF_NWAVES + wid] = (double)ws;
+        }
+        if constexpr (WITH_ES) {
+            const double ws = wave_sum(es);
+            if (lane == 0) red[NS * PF_NWAVES + wid] = ws;
         }
         if (poison) atomicOr(poison_slot, 1);
         __syncthreads();
         if (threadIdx.x == 0) {
+            double tot[NS + 1];
 #pragma unroll
-            for (int q = 0; q < 4 + 2 * D; ++q) {
-                double r = red[q * PF_NWAVES];
+            for (int q = 0; q < NS + 1; ++q) {
+                double r = 0.0;
+                if (q < NS || WITH_ES) {
+                    r = red[q * PF_NWAVES];
 #pragma unroll
-                for (int w = 1; w < PF_NWAVES; ++w) r += red[q * PF_NWAVES + w];
-                sums[q] = r;
+                    for (int w = 1; w < PF_NWAVES; ++w) r += red[q * PF_NWAVES + w];
+                }
+                tot[q] = r;
             }
             const int64_t stride = (int64_t)B * tiles;
             const int64_t o = (int64_t)b * tiles + k;
             part[PQ_M1 * stride + o] = (double)M1;
-            part[PQ_S1 * stride + o] = sums[0];
-            part[PQ_Q1 * stride + o] = sums[1];
+            part[PQ_S1 * stride + o] = tot[0];
+            part[PQ_Q1 * stride + o] = tot[1];
             part[PQ_M2 * stride + o] = pre_on ? (double)M2 : -__builtin_huge_val();
-            part[PQ_S2 * stride + o] = sums[2];
-            part[PQ_E * stride + o] = sums[3 + 2 * D];
+            part[PQ_S2 * stride + o] = tot[2];
+            part[PQ_E * stride + o] = tot[NS];
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                part[(PQ_MX + d) * stride + o] = sums[3 + d];
-                part[(PQ_MX + D + d) * stride + o] = sums[3 + D + d];
+                part[(PQ_MX + d) * stride + o] = tot[3 + d];
+                part[(PQ_MX + D + d) * stride + o] = tot[3 + D + d];
             }
         }
     }
@@ -239,11 +280,12 @@ template <typename T> struct CdfView {  // random access to the implied cdf of o
 // Tile-local inclusive scan of the resampling weights of the state in slot `slot`, relative to the tile maximum MR:
 // L_i = sum_{j <= i, j in tile} exp(rw_j - MR), fp64 accumulation, stored as T in `a.cdf`.  rw = logw (SISR) or
 // sanitize(pre_weight(x, y) + logw) (APF, `two`; `next` selects the observation the pre-weight is taken against).
-// Single-round tiles pass the round's values in registers (have_regs), otherwise they are re-read (L2-hot).
-template <typename T, int D, int VEC>
-__device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int proposal, int b, int k, int slot, T* l_out, bool two,
-                                                bool next, T MR, const ColParams<T, D>& cp, const ColConsts<T, D>& cc, bool have_regs,
-                                                const T (&lw_reg)[VEC], const T (&pre_reg)[VEC], double* reds) {
+// Single-round tiles pass exp(rw - thread max) and the thread's factor exp(thread max - MR) in registers (have_regs:
+// PartialAcc::push_round / finish computed them already), otherwise the state is re-read (L2-hot).
+// `prew(xj)`: the first-stage weight of one particle (only evaluated on the re-read path of APF steps).
+template <typename T, int D, int VEC, typename PreW>
+__device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int b, int k, int slot, T* l_out, bool two, T MR,
+                                                PreW&& prew, bool have_regs, const T (&e_reg)[VEC], T f_reg, double* reds) {
     const Geom& g = a.g;
     const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
     const T* x_base = a.x[slot];
@@ -257,10 +299,7 @@ __device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int propo
         const bool on = i0 < g.N;
         T rw[VEC];
         if (on) {
-            if (have_regs) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) rw[j] = two ? sanitize_logw(pre_reg[j] + lw_reg[j]) : lw_reg[j];
-            } else {
+            if (!have_regs) {
                 T lw[VEC];
                 if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
                 if (two) {
@@ -275,7 +314,7 @@ __device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int propo
                         T xj[D];
 #pragma unroll
                         for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-                        rw[j] = sanitize_logw(pre_weight<T, D>(a.md, proposal, cp, cc, xj, next) + lw[j]);
+                        rw[j] = sanitize_logw(prew(xj) + lw[j]);
                     }
                 } else {
 #pragma unroll
@@ -286,7 +325,8 @@ __device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int propo
         double e[VEC], local = 0.0, total;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            local += (on && rw[j] != -Lim<T>::inf()) ? (double)pf_exp_w(rw[j] - MR) : 0.0;
+            if (have_regs) local += on ? (double)(e_reg[j] * f_reg) : 0.0;
+            else local += (on && rw[j] != -Lim<T>::inf()) ? (double)pf_exp_w(rw[j] - MR) : 0.0;
             e[j] = local;
         }
         const double excl = block_scan_excl(local, reds, total);
@@ -340,7 +380,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
         T piv0[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) piv0[d] = T(0);
-        acc.template push_round<VEC>(lw, xv, pre_on, pre, piv0);
+        T e_unused[VEC];
+        acc.template push_round<VEC>(lw, xv, pre_on, pre, piv0, e_unused);
         if (a.resampler == PF_RESAMPLE_MULTINOMIAL) {
             T ev[VEC];
             draw_exponentials<T, VEC>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_MULTINOMIAL, (uint32_t)a.step,
@@ -349,16 +390,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
             for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
         }
     }
-    T M1, M2;
-    acc.finish(a.part, b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 1) * g.B + b], M1, M2);
+    T M1, M2, F1, F2;
+    acc.template finish<true>(a.part_w(a.step), b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 1) * g.B + b], M1, M2, F1, F2);
     if (a.from_local) {
         __shared__ double reds[PF_NWAVES];
         T dummy[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dummy[j] = T(0);
         // local scans are double buffered like the state: step s reads buffer s & 1 while it writes the next one
-        tile_local_scan<T, D, VEC>(a, a.proposal, b, k, slot, (a.step & 1) ? a.pos : a.cdf, pre_on, false, pre_on ? M2 : M1, cp, cc, false,
-                                   dummy, dummy, reds);
+        tile_local_scan<T, D, VEC>(a, b, k, slot, (a.step & 1) ? a.pos : a.cdf, pre_on, pre_on ? M2 : M1,
+                                   [&](const T (&xj)[D]) { return pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, false); }, false,
+                                   dummy, T(0), reds);
     }
 }
 
@@ -379,7 +421,7 @@ __device__ __forceinline__ void combine_spacings(const FusedArgs<T>& a, int64_t 
                                                  double& total, double& prefix) {
     double v[2] = {0.0, 0.0};
     for (int t = threadIdx.x; t < a.g.tiles; t += PF_BLOCK) {
-        const double e = a.part[PQ_E * stride + cb + t];
+        const double e = a.part_r()[PQ_E * stride + cb + t];
         v[0] += e;
         if (t < k) v[1] += e;
     }
@@ -396,12 +438,12 @@ __device__ __forceinline__ void load_early_partials(const FusedArgs<T>& a, int64
         e.m1[it] = e.m2[it] = -__builtin_huge_val();
         e.s1[it] = e.q1[it] = e.s2[it] = 0.0;
         if (t < a.g.tiles) {
-            e.m1[it] = a.part[PQ_M1 * stride + cb + t];
-            e.s1[it] = a.part[PQ_S1 * stride + cb + t];
-            e.q1[it] = a.part[PQ_Q1 * stride + cb + t];
+            e.m1[it] = a.part_r()[PQ_M1 * stride + cb + t];
+            e.s1[it] = a.part_r()[PQ_S1 * stride + cb + t];
+            e.q1[it] = a.part_r()[PQ_Q1 * stride + cb + t];
             if (two) {
-                e.m2[it] = a.part[PQ_M2 * stride + cb + t];
-                e.s2[it] = a.part[PQ_S2 * stride + cb + t];
+                e.m2[it] = a.part_r()[PQ_M2 * stride + cb + t];
+                e.s2[it] = a.part_r()[PQ_S2 * stride + cb + t];
             }
         }
     }
@@ -471,6 +513,23 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
                                                     double* red2) {
     const Geom& g = a.g;
     const int step = a.step;
+    if (threadIdx.x == PF_BLOCK - 1 && !a.finalize_only) {
+        // this step's per-column records for the step kernel: the systematic offset and (scalar closed-form models) the
+        // constants of FastCol - evaluated once here instead of once per thread there
+        if (a.resampler == PF_RESAMPLE_SYSTEMATIC)
+            a.ucol[b] = a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
+                                 : uniform_draw<T>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
+        if constexpr (D == 1) {
+            if (a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM) {
+                ColParams<T, 1> cp;
+                ColConsts<T, 1> cc;
+                load_col_params<T, 1>(a, b, step, obs, cp);
+                if (a.obs_next && apf) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
+                cc.prepare(a.md, cp);
+                write_col_pack<T>(a.md, cp, cc, a.cpack + (int64_t)b * PK_N);
+            }
+        }
+    }
     const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
     const double lse_w = c.m1 + log(c.S1);
     const double ess = c.S1 * c.S1 / c.Q1;
@@ -481,7 +540,7 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
     for (int q = 0; q < 2 * D; ++q) {
         mv[q] = 0.0;
         for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-            mv[q] += a.part[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part[PQ_M1 * stride + cb + t], c.m1);
+            mv[q] += a.part_r()[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part_r()[PQ_M1 * stride + cb + t], c.m1);
     }
     block_sum<2 * D>(mv, red2);
     if (threadIdx.x == 0 && !a.replay) {
@@ -539,7 +598,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
     const bool two = apf && obs;  // a second (m2, S2) set of partials is live
     const int64_t stride = (int64_t)g.B * g.tiles;
     const int64_t cb = (int64_t)b * g.tiles;
-    if (a.debug_cut == 1) return;
+    if (PF_CUT(a, 1)) return;
     PF_STAMP(a, 0);
     EarlyPartials early;
     load_early_partials<T>(a, cb, stride, two, early);
@@ -558,7 +617,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
     const T* x_base = a.x[slot];
     const int64_t base = (int64_t)k * g.tile_elems;
     const int64_t tile_last = (base + g.tile_elems < g.N ? base + g.tile_elems : g.N) - 1;
-    const double mk = a.part[(two ? PQ_M2 : PQ_M1) * stride + cb + k];
+    const double mk = a.part_r()[(two ? PQ_M2 : PQ_M1) * stride + cb + k];
     const T tile_max = (T)mk;
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
@@ -668,7 +727,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan
     const ColCombine c = combine_column<T>(a, early, cb, stride, k, two, red, redm);
     PF_STAMP(a, 2);
     const bool resample = apf ? obs : (c.S1 * c.S1 / c.Q1 < a.thr_abs);
-    if (!resample || a.debug_cut == 2) return;
+    if (!resample || PF_CUT(a, 2)) return;
     const double MR = two ? c.m2 : c.m1, SR = two ? c.S2 : c.S1;
     const double fk = exp_diff_t<T>(mk, MR) / SR;
     const double Pk = c.prefK / SR;
@@ -736,7 +795,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         const int t = threadIdx.x * IT + q;
         if (q < IT && t < g.tiles)
-            run += a.part[slot_s * stride + cb + t] * exp_diff_t<T>(a.part[slot_m * stride + cb + t], MR);
+            run += a.part_r()[slot_s * stride + cb + t] * exp_diff_t<T>(a.part_r()[slot_m * stride + cb + t], MR);
         incl[q] = run;
     }
     const double excl = block_scan_excl(run, reds, total);
@@ -750,7 +809,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     if (k == 0) {
         for (int t = threadIdx.x; t <= g.tiles; t += PF_BLOCK) a.ptab[(int64_t)b * (g.tiles + 1) + t] = ptl[t];
         for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-            a.ftab[cb + t] = exp_diff_t<T>(a.part[slot_m * stride + cb + t], MR) / SR;
+            a.ftab[cb + t] = exp_diff_t<T>(a.part_r()[slot_m * stride + cb + t], MR) / SR;
     }
 
     // j0 of position tile t: one wave each
@@ -768,7 +827,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     }
     const int kt = lo;
     const double Pk = ptl[kt], Pn = ptl[kt + 1];
-    const double fk = exp_diff_t<T>(a.part[slot_m * stride + cb + kt], MR) / SR;
+    const double fk = exp_diff_t<T>(a.part_r()[slot_m * stride + cb + kt], MR) / SR;
     const int64_t first = (int64_t)kt * g.tile_elems;
     const int64_t last = (first + g.tile_elems < g.N ? first + g.tile_elems : g.N) - 1;
     const T* l_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;
@@ -800,14 +859,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     }
 }
 
-// MODE 0: systematic pipeline (planning kernel + local scans); MODE 1: multinomial (sorted positions, explicit cdf from
-// k_fused_scan).  Compile-time so that neither variant carries the other's registers.
+// MODE 0: systematic pipeline (planning kernel + local scans), ancestors from the inverted grid (grid_count);
+// MODE 1: multinomial (sorted positions, explicit cdf from k_fused_scan), ancestors by searching the staged window;
+// MODE 2: systematic pipeline with the searching ancestor stage - float grids beyond 2^22 positions, where the closed
+// form of MODE 0 is not exact.  Compile-time so that no variant carries another's registers.
 // PROP: the proposal as a compile-time constant (0 Bootstrap, 1 LinearGaussianObservations) or -1 = run-time switch.
 // For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
 // FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
 // generic per-particle arithmetic (and its registers) from the fast instantiation and vice versa.
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST>
-__global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void k_fused_step(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == PF_PROP_LGO ? 2 : 3)) : 1) void k_fused_step(FusedArgs<T> a) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     constexpr int WIN = SearchWin<T, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
@@ -816,9 +877,11 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     __shared__ __attribute__((aligned(32))) T win[WIN];
     __shared__ __attribute__((aligned(32))) T xwin[XWIN ? D * WIN : VEC];
     __shared__ int sh_j0;
+    __shared__ int sh_cl[2 * PF_NWAVES], sh_wm[PF_NWAVES];
     __shared__ double red[(4 + 2 * D) * PF_NWAVES];
     __shared__ double reds[PF_NWAVES];
     __shared__ T redm[2 * PF_NWAVES];
+    int* hd = reinterpret_cast<int*>(win);  // systematic route: heads of the offspring ranges (the cdf window is not staged)
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int tid = threadIdx.x;
@@ -832,38 +895,43 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
     const bool pre_next = a.obs_next && apf;
     const int N = (int)g.N;
     PF_STAMP(a, 8);
-    if (a.debug_cut == 1) return;
+    if (PF_CUT(a, 1)) return;
 
     // uniform loads first: the window start and the column's parameter rows
     int j0 = (windowed && !multinomial) ? a.j0[(int64_t)b * g.tiles + k] : 0;
-    int kt0 = (MODE == 0 && windowed) ? a.k0[(int64_t)b * g.tiles + k] : 0;  // tile index of j0 (no integer division here)
+    int kt0 = (MODE != 1 && windowed) ? a.k0[(int64_t)b * g.tiles + k] : 0;  // tile index of j0 (no integer division here)
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
 
+    // FAST: the column's closed-form constants come from the record the bookkeeper wrote (FastCol, loaded right before
+    // they are used); otherwise the parameter rows are loaded and reduced here
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
-    load_col_params<T, D>(a, b, step, obs, cp);
-    if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
-    const T ub = (!windowed || multinomial) ? T(0)
-                           : (a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
-                                       : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b));
+    FastCol<T> fc;
+    if constexpr (!FAST && D > 1) {
+        load_col_params<T, D>(a, b, step, obs, cp);
+        if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
+    }
+    const T ub = (!windowed || multinomial) ? T(0) : a.ucol[b];
 
     const T* x_in = a.x[slot];
     T* x_out = a.x[slot ^ 1];
     const T* lw_in = a.logw[slot] + (int64_t)b * g.N;
     T* lw_out = a.logw[slot ^ 1] + (int64_t)b * g.N;
     // multinomial / two-kernel pipeline: the cdf itself; systematic pipeline: the local scans of this step's parity
-    const T* cdf_col = ((MODE == 0 && (step & 1)) ? a.pos : a.cdf) + (int64_t)b * g.N;
+    const T* cdf_col = ((MODE != 1 && (step & 1)) ? a.pos : a.cdf) + (int64_t)b * g.N;
     int32_t* anc_col = a.anc + (int64_t)b * g.N;
     const int64_t base = (int64_t)k * g.tile_elems;
     const T nT = T(N);
+    const T rcN = T(1) / nT;
+    const bool pow2 = (N & (N - 1)) == 0;                  // then the grid division is an exact multiplication
 
     bool poison = false;
     PartialAcc<T, D> acc;
     acc.init();
     PF_STAMP(a, 9);
     const T* pos_col = multinomial ? a.pos + (int64_t)b * g.N : nullptr;
-    constexpr bool from_local = MODE == 0;  // `cdf` holds tile-local scans; the cdf is implied by the table
+    constexpr bool from_local = MODE != 1;  // `cdf` holds tile-local scans; the cdf is implied by the table
     const double* ptab_col = a.ptab + (int64_t)b * (g.tiles + 1);
     const double* ftab_col = a.ftab + (int64_t)b * g.tiles;
     CdfView<T> view;
@@ -882,14 +950,20 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         j0 = sh_j0;
     }
 
-    T lwo[VEC], pre_n[VEC];  // the last round's new log-weights / next-step pre-weights (reused by the local scan)
+    T e_rw[VEC];  // the last round's exp(rw - thread max) of the next resampling weights (reused by the local scan)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) lwo[j] = pre_n[j] = T(0);
+    for (int j = 0; j < VEC; ++j) e_rw[j] = T(0);
     for (int r = 0; r < g.rounds_per_tile; ++r) {
         const int64_t r0 = base + (int64_t)r * g.round_elems;
         if (r0 >= g.N) break;
         const int64_t i0 = r0 + tid * VEC;
         const bool on = i0 < g.N;
+        if (MODE == 0 && windowed) {  // no head anywhere yet (ordered against the scatter by the barrier below)
+            int zero[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) zero[j] = 0;
+            if (VEC == 1) hd[tid] = 0; else store_vec<int, VEC>(hd + tid * VEC, zero);
+        }
         T pv[VEC];
         if (multinomial && windowed && on) {
             if (VEC == 1) pv[0] = pos_col[i0]; else load_vec<T, VEC>(pos_col + i0, pv);
@@ -942,6 +1016,10 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
             }
         }
         PF_STAMP(a, 10);
+        if (PF_CUT(a, 4)) {  // development: keep the draws alive, stop here
+            if (on) lw_out[i0] = zt[0][0] + zt[VEC - 1][D - 1];
+            return;
+        }
 
         // ---- 3. ancestors ---------------------------------------------------------------------------------------------
         int idx[VEC];
@@ -973,8 +1051,6 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 if (!ina) c0[j] = Lim<T>::inf();
                 if (!inb) c1[j] = Lim<T>::inf();
             }
-            if (VEC == 1) { win[tid] = c0[0]; win[PF_BLOCK + tid] = c1[0]; }
-            else { store_vec<T, VEC>(win + tid * VEC, c0); store_vec<T, VEC>(win + (PF_BLOCK + tid) * VEC, c1); }
             if (XWIN) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -982,24 +1058,98 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                     if (inb) { if (VEC == 1) xwin[d * WIN + PF_BLOCK + tid] = xb[d][0]; else store_vec<T, VEC>(xwin + d * WIN + (PF_BLOCK + tid) * VEC, xb[d]); }
                 }
             }
-            __syncthreads();
-            // on average one ancestor per position: thread t's first position lands near offset (j0 - ws) + t * VEC
-            int guess = (j0 - ws) + tid * VEC;
-            if (guess > WIN - 1) guess = WIN - 1;
+            if constexpr (MODE != 0) {
+                if (VEC == 1) { win[tid] = c0[0]; win[PF_BLOCK + tid] = c1[0]; }
+                else { store_vec<T, VEC>(win + tid * VEC, c0); store_vec<T, VEC>(win + (PF_BLOCK + tid) * VEC, c1); }
+                __syncthreads();
+                // on average one ancestor per position: thread t's first position lands near offset (j0 - ws) + t * VEC
+                int guess = (j0 - ws) + tid * VEC;
+                if (guess > WIN - 1) guess = WIN - 1;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const int64_t i = i0 + j;
-                int res = N - 1;
-                if (i < N) {
-                    const T p = multinomial ? pv[j] : grid_position<T>(i, ub, nT);
-                    const int q = window_lower_bound<T, WIN>(win, guess, p);
-                    guess = q < WIN ? q : WIN - 1;
-                    if (q < WIN) res = ws + q;
-                    else if (from_local) res = view.lower_bound(ws + WIN < N ? ws + WIN : N, N, p);
-                    else res = thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
-                    if (res > N - 1) res = N - 1;
+                for (int j = 0; j < VEC; ++j) {
+                    const int64_t i = i0 + j;
+                    int res = N - 1;
+                    if (i < N) {
+                        const T p = multinomial ? pv[j] : grid_position<T>(i, ub, nT);
+                        const int q = window_lower_bound<T, WIN>(win, guess, p);
+                        guess = q < WIN ? q : WIN - 1;
+                        if (q < WIN) res = ws + q;
+                        else if (from_local) res = view.lower_bound(ws + WIN < N ? ws + WIN : N, N, p);
+                        else res = thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
+                        if (res > N - 1) res = N - 1;
+                    }
+                    idx[j] = res;
                 }
-                idx[j] = res;
+            } else {
+                // Systematic grid, inverted (grid_count): every staged cdf entry computes how many of the round's positions
+                // lie at or below it; entry q owns positions [K_{q-1}, K_q) and writes its index at the head of that
+                // range; a running maximum over the round's positions spreads the heads.  No search, no divergence.
+                const int RE = g.round_elems, r0i = (int)r0;
+                int cn0[VEC], cn1[VEC];
+                if (pow2) {
+                    grid_counts_local<T, VEC, true>(c0, ub, nT, rcN, N, r0i, RE, cn0);
+                    grid_counts_local<T, VEC, true>(c1, ub, nT, rcN, N, r0i, RE, cn1);
+                } else {
+                    grid_counts_local<T, VEC, false>(c0, ub, nT, rcN, N, r0i, RE, cn0);
+                    grid_counts_local<T, VEC, false>(c1, ub, nT, rcN, N, r0i, RE, cn1);
+                }
+                const int lane = tid & 63, wid = tid >> 6;
+                if (lane == 63) {
+                    sh_cl[wid] = cn0[VEC - 1];
+                    sh_cl[PF_NWAVES + wid] = cn1[VEC - 1];
+                }
+                __syncthreads();  // the wave-boundary counts are visible; `hd` is zeroed (top of the round)
+                int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[VEC - 1], 0);
+                if (lane == 0) {
+                    pv0 = wid ? sh_cl[wid - 1] : 0;  // entries before the window own no position of this round
+                    pv1 = sh_cl[PF_NWAVES + wid - 1];  // wave 0: the first half's last entry
+                }
+                const int covered = sh_cl[2 * PF_NWAVES - 1];  // positions of this round the window accounts for
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
+                    if (cn0[j] > lo0) hd[lo0] = tid * VEC + j + 1;
+                    if (cn1[j] > lo1) hd[lo1] = (PF_BLOCK + tid) * VEC + j + 1;
+                }
+                __syncthreads();
+                int h[VEC];
+                if (VEC == 1) h[0] = hd[tid]; else load_vec<int, VEC>(hd + tid * VEC, h);
+#ifdef PF_DEVTOOLS
+                if (tid == 0) {
+                    atomicAdd(&a.dbg[22], 1ull);                       // rounds
+                    if (h[0] == 0) atomicAdd(&a.dbg[23], 1ull);        // rounds without a head at position 0
+                    if (covered == 0) atomicAdd(&a.dbg[24], 1ull);
+                    if (covered < RE) atomicAdd(&a.dbg[25], 1ull);
+                    if (h[0] == 0 && b == 0 && atomicAdd(&a.dbg[26], 1ull) == 0) {
+                        a.dbg[27] = (unsigned long long)k; a.dbg[28] = (unsigned long long)j0; a.dbg[29] = (unsigned long long)cn0[0];
+                        a.dbg[30] = (unsigned long long)cn0[VEC - 1]; a.dbg[31] = (unsigned long long)__float_as_uint((float)c0[VEC - 1]);
+                    }
+                }
+#endif
+#pragma unroll
+                for (int j = 1; j < VEC; ++j) h[j] = imax(h[j], h[j - 1]);
+                const int inc = wave_scan_max(h[VEC - 1]);
+                if (lane == 63) sh_wm[wid] = inc;
+                __syncthreads();
+                int carry = wave_prev(inc, 0);
+#pragma unroll
+                for (int w = 0; w < PF_NWAVES - 1; ++w) carry = (w < wid) ? imax(carry, sh_wm[w]) : carry;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int64_t i = i0 + j;
+                    const int q = imax(carry, h[j]);
+                    int res = ws + q - 1;
+                    if (i < N && (tid * VEC + j >= covered || q == 0)) {
+                        // the window ended before this position (a stretch of negligible weights) - or, defensively, no
+                        // head precedes it: binary search in the implied cdf
+                        const int from = (q == 0) ? 0 : (ws + WIN < N ? ws + WIN : N);
+#ifdef PF_DEVTOOLS
+                        atomicAdd(&a.dbg[q == 0 ? 21 : 20], 1ull);
+#endif
+                        res = view.lower_bound(from, N, grid_position<T>(i, ub, nT));
+                    }
+                    idx[j] = (i < N && res < N) ? res : N - 1;
+                }
             }
             if (r + 1 < g.rounds_per_tile) {  // the next round's window starts at this round's last ancestor
                 if (tid == PF_BLOCK - 1) sh_j0 = idx[VEC - 1];
@@ -1011,17 +1161,30 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
             for (int j = 0; j < VEC; ++j) idx[j] = (int)((i0 + j < g.N) ? (i0 + j) : (g.N - 1));
         }
         PF_STAMP(a, 11);
-        if (on && a.debug_cut == 2) {
+        if (on && PF_CUT(a, 2)) {
             if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
         }
 
         // ---- 4. gather, propagate, weight -------------------------------------------------------------------------------
-        if (r == 0) {  // per-column constants: computed here so they are not live across the search
+        // the column's constants are fetched only now - their address is tied to the ancestors by an opaque zero - so
+        // they occupy registers for the arithmetic below and not across the search
+        int late;
+        asm volatile("v_readfirstlane_b32 %0, %1\n\ts_and_b32 %0, %0, 0" : "=s"(late) : "v"(idx[0]) : "scc");
+        if constexpr (FAST) {
+            // scalar loads of the record the bookkeeper wrote: 20 SGPRs
+            fc.load((const_ptr<T>)(uintptr_t)(a.cpack + (int64_t)b * PK_N) + late);
+        } else if constexpr (D == 1) {
+            load_col_params<T, D>(a, b, step, obs, cp, late);
+            if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim + late);
+            cc.prepare(a.md, cp);
+            __builtin_assume(cc.fast == FAST);
+        } else if (r == 0) {  // D > 1: the rows were loaded up front (register room, and no exposed latency here)
             cc.prepare(a.md, cp);
             __builtin_assume(cc.fast == FAST);
         }
         T xo[D][VEC];
-        if (on && a.debug_cut != 2) {
+        if (on && !PF_CUT(a, 2)) {
+            T lwo[VEC], pre_n[VEC];  // this round's new log-weights / first-stage weights of the next step
             T xr[VEC][D];
             if (!resample) {
 #pragma unroll
@@ -1047,25 +1210,30 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
                 T xn[D];
                 T w_new;
                 if (obs) {
-                    const T wi = sample_and_weight<T, D>(a.md, proposal, cp, cc, xr[j], zt[j], xn);
+                    T wi;
+                    if constexpr (FAST) wi = fc.sample_and_weight(proposal, xr[j][0], zt[j][0], xn[0]);
+                    else wi = sample_and_weight<T, D>(a.md, proposal, cp, cc, xr[j], zt[j], xn);
                     if (apf) {
                         // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
-                        w_new = wi - pre_weight<T, D>(a.md, proposal, cp, cc, xr[j]);
-                        if (w_new != w_new || w_new == Lim<T>::inf()) poison = true;
+                        if constexpr (FAST) w_new = wi - fc.pre_weight(proposal, xr[j][0]);
+                        else w_new = wi - pre_weight<T, D>(a.md, proposal, cp, cc, xr[j]);
+                        if (is_nan_or_posinf(w_new)) poison = true;
                     } else {
-                        if (wi != wi || wi == Lim<T>::inf()) poison = true;
+                        if (is_nan_or_posinf(wi)) poison = true;
                         w_new = resample ? wi : (wi + lw_old[j]);
                     }
                 } else {
                     // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
-                    sample_and_weight<T, D>(a.md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
+                    if constexpr (FAST) fc.sample_and_weight(PF_PROP_BOOTSTRAP, xr[j][0], zt[j][0], xn[0]);
+                    else sample_and_weight<T, D>(a.md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
                     w_new = resample ? T(0) : lw_old[j];
                 }
                 lwo[j] = sanitize_logw(w_new);
 #pragma unroll
                 for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
                 // first-stage weight of the next step, while the new particle is still in registers
-                pre_n[j] = pre_next ? pre_weight<T, D>(a.md, proposal, cp, cc, xn, true) : T(0);
+                if constexpr (FAST) pre_n[j] = pre_next ? fc.pre_weight(proposal, xn[0], true) : T(0);
+                else pre_n[j] = pre_next ? pre_weight<T, D>(a.md, proposal, cp, cc, xn, true) : T(0);
                 // keep the scheduler from interleaving all VEC particles' arithmetic: that is what pushes the kernel
                 // over its register budget (spills cost real HBM traffic: PMC WRITE_SIZE)
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);
@@ -1080,10 +1248,14 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
             if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
                 if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
             }
+            if (PF_CUT(a, 5)) {
+                if (pre_next) { if (VEC == 1) lw_out[i0] = pre_n[0]; else store_vec<T, VEC>(lw_out + i0, pre_n); }
+                return;
+            }
             T piv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) piv[d] = a.means[((int64_t)step * g.B + b) * D + d];
-            acc.template push_round<VEC>(lwo, xo, pre_next, pre_n, piv);
+            acc.template push_round<VEC>(lwo, xo, pre_next, pre_n, piv, e_rw);
             if (multinomial) {
                 T ev[VEC];
                 draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)(step + 1), (uint64_t)((int64_t)b * g.N + i0), ev);
@@ -1095,14 +1267,19 @@ __global__ __launch_bounds__(PF_BLOCK, (sizeof(T) == 4 && D == 1) ? 4 : 1) void 
         if (windowed && r + 1 < g.rounds_per_tile) __syncthreads();  // the window is rewritten by the next round
     }
     if (poison) atomicOr(&a.poison[(step & 1) * g.B + b], 1);
-    if (a.debug_cut == 3) return;
+    if (PF_CUT(a, 3)) return;
     PF_STAMP(a, 14);
-    T M1, M2;
-    acc.finish(a.part, b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 1) * g.B + b], M1, M2);
+    T M1, M2, F1, F2;
+    acc.template finish<MODE == 1>(a.part_w(step + 1), b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 1) * g.B + b], M1, M2, F1, F2);
+    if (PF_CUT(a, 6)) return;
     // the next step's resampling weights, scanned per tile while they are at hand (their cdf = table + these local scans)
     if (from_local && (!apf || pre_next))
-        tile_local_scan<T, D, VEC>(a, proposal, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, true, pre_next ? M2 : M1, cp, cc,
-                                   g.rounds_per_tile == 1, lwo, pre_n, reds);
+        tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, pre_next ? M2 : M1,
+                                   [&](const T (&xj)[D]) {
+                                       if constexpr (FAST) return fc.pre_weight(proposal, xj[0], true);
+                                       else return pre_weight<T, D>(a.md, proposal, cp, cc, xj, true);
+                                   },
+                                   g.rounds_per_tile == 1, e_rw, pre_next ? F2 : F1, reds);
     PF_STAMP(a, 15);
 }
 

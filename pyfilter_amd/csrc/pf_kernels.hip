@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <type_traits>
+
 #include "../../include/pf_amd.h"
 #include "pf_device.hpp"
 #include "pf_models.hpp"
@@ -70,7 +72,8 @@ struct ColStat {
 
 // workspace carve-up (all offsets 256-byte aligned)
 struct WsLayout {
-    size_t off_part;   // double partials[(6 + 2D)][B][tiles]
+    size_t off_part;   // double partials[2][(6 + 2D)][B][tiles]
+    size_t part_elems;
     size_t off_stat;   // ColStat[B]
     size_t off_poison; // int32 [2][B]
     size_t off_ctr;    // int32 [4] (reserved)
@@ -78,6 +81,8 @@ struct WsLayout {
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
     size_t off_ptab;   // double [B][tiles + 1]
     size_t off_ftab;   // double [B][tiles]
+    size_t off_cpack;  // T [B][PK_N] (sized for double)
+    size_t off_ucol;   // T [B]
     size_t total;
 };
 
@@ -86,8 +91,9 @@ static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 static inline WsLayout make_ws(const Geom& g, int D) {
     WsLayout w;
     size_t o = 0;
-    w.off_part = o;
-    o = align256(o + sizeof(double) * (size_t)(6 + 2 * D) * g.B * g.tiles);
+    w.off_part = o;  // two copies (the fused pipeline double-buffers them by state parity)
+    w.part_elems = (size_t)(6 + 2 * D) * g.B * g.tiles;
+    o = align256(o + 2 * sizeof(double) * w.part_elems);
     w.off_stat = o;
     o = align256(o + sizeof(ColStat) * (size_t)g.B);
     w.off_poison = o;
@@ -102,6 +108,10 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     o = align256(o + sizeof(double) * (size_t)g.B * (g.tiles + 1));
     w.off_ftab = o;
     o = align256(o + sizeof(double) * (size_t)g.B * g.tiles);
+    w.off_cpack = o;
+    o = align256(o + sizeof(double) * (size_t)g.B * 24);
+    w.off_ucol = o;
+    o = align256(o + sizeof(double) * (size_t)g.B);
     w.total = o;
     return w;
 }
@@ -149,6 +159,38 @@ template <typename T> __device__ __forceinline__ int thread_lower_bound(const T*
 
 // searchsorted position of the systematic grid: (i + u) / N evaluated exactly as resampling.py:44-46 does in T
 template <typename T> __device__ __forceinline__ T grid_position(int64_t i, T u, T n_as_t) { return (T(i) + u) / n_as_t; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The systematic grid inverted: K(c) = #{ i in [0, N) : grid_position(i) <= c }.  With it the ancestor of position i is
+// the entry j with K(cdf_{j-1}) <= i < K(cdf_j) - the same relation searchsorted(side=left) defines - and no search
+// is needed: every cdf entry computes its own offspring range in closed form (branch-free, so weight degeneracy does
+// not make lanes diverge).  Exactness: the candidate floor(c N - u) + 1 is at most one off the true K (both the fma
+// and the rounding of grid_position move the decision for at most one i while N * eps <= 1/4, i.e. N <= 2^22 in
+// float, any N in double), so evaluating the grid position - with exactly the arithmetic of grid_position - at the two
+// neighbouring indices settles it.  Larger float grids walk from the candidate to the exact boundary (step kernel).
+// POW2: N is a power of two - the division is an exact multiplication by `rcN` = 1 / N.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T, bool POW2> __device__ __forceinline__ T grid_value(T x_plus_u, T nT, T rcN) {
+    return POW2 ? x_plus_u * rcN : x_plus_u / nT;
+}
+template <typename T, bool POW2> __device__ __forceinline__ int grid_count(T c, T u, T nT, T rcN, int N) {
+    T t = __builtin_fma(c, nT, -u);
+    t = __builtin_fmin(__builtin_fmax(t, T(-1)), nT);  // +inf (beyond the column) -> N; NaN -> -1
+    const T fl = __builtin_floor(t);
+    const T pa = grid_value<T, POW2>(fl + u, nT, rcN), pb = grid_value<T, POW2>((fl + T(1)) + u, nT, rcN);
+    const int K = (int)fl + ((pa <= c) ? 1 : 0) + ((pb <= c) ? 1 : 0);
+    return K < 0 ? 0 : (K > N ? N : K);
+}
+// offspring counts relative to the round's first position r0, clamped to the round: [0, RE]
+template <typename T, int VEC, bool POW2>
+__device__ __forceinline__ void grid_counts_local(const T (&c)[VEC], T u, T nT, T rcN, int N, int r0, int RE,
+                                                  int (&out)[VEC]) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int k = grid_count<T, POW2>(c[j], u, nT, rcN, N) - r0;
+        out[j] = k < 0 ? 0 : (k > RE ? RE : k);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Window search shared by the stand-alone resampler and the fused step kernel.
@@ -975,6 +1017,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.ll_steps = (T*)A->ll_steps;
     a.ll_total = (T*)A->ll_total;
     a.part = (double*)((char*)A->ws + wl.off_part);
+    a.part_stride = (int64_t)wl.part_elems;
     a.stat = (ColStat*)((char*)A->ws + wl.off_stat);
     a.poison = (int32_t*)((char*)A->ws + wl.off_poison);
     a.j0 = (int32_t*)((char*)A->ws + wl.off_j0);
@@ -982,6 +1025,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
     a.ptab = (double*)((char*)A->ws + wl.off_ptab);
     a.ftab = (double*)((char*)A->ws + wl.off_ftab);
+    a.cpack = (T*)((char*)A->ws + wl.off_cpack);
+    a.ucol = (T*)((char*)A->ws + wl.off_ucol);
+    static_assert(PK_N == 24, "workspace layout reserves 24 slots per column record");
     {
         a.from_local = (A->resampler == PF_RESAMPLE_SYSTEMATIC) ? 1 : 0;
     }
@@ -1011,23 +1057,29 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         if (a.from_local) hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
         else hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
     };
+    // ancestor stage of the step kernel: 0 inverted grid (systematic), 1 multinomial, 2 systematic by search - float
+    // grids beyond 2^22 positions, where the closed form is not exact (PF_FORCE_SEARCH=1 selects it for testing)
+    static const bool force_search = getenv("PF_FORCE_SEARCH") != nullptr;
+    const int mode = !a.from_local ? 1 : ((sizeof(T) == 4 && (g.N > ((int64_t)1 << 22) || force_search)) ? 2 : 0);
+    auto launch_step_as = [&](auto prop_c, auto fast_c) {
+        constexpr int PROP = decltype(prop_c)::value;
+        constexpr bool FAST = decltype(fast_c)::value;
+        if (mode == 0) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PROP, FAST>), grid, block, 0, st, a);
+        else if (mode == 1) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PROP, FAST>), grid, block, 0, st, a);
+        else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 2, PROP, FAST>), grid, block, 0, st, a);
+    };
     auto launch_step = [&]() {
-        if constexpr (D == 1) {  // scalar state: the proposal stays a run-time switch, the closed-form path a template flag
-        const bool fast = a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM;
+        // scalar closed-form models: the proposal is a run-time switch inside one lean kernel (FAST); everything else gets
+        // the proposal as a template constant so that Bootstrap runs do not carry the optimal proposal's registers
+        bool fast = false;
+        if constexpr (D == 1) fast = a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM;
         if (fast) {
-            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, -1, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, -1, true>), grid, block, 0, st, a);
+            if constexpr (D == 1) launch_step_as(std::integral_constant<int, -1>{}, std::true_type{});
+        } else if (a.proposal == PF_PROP_BOOTSTRAP) {
+            launch_step_as(std::integral_constant<int, PF_PROP_BOOTSTRAP>{}, std::false_type{});
         } else {
-            if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, -1, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, -1, false>), grid, block, 0, st, a);
+            launch_step_as(std::integral_constant<int, PF_PROP_LGO>{}, std::false_type{});
         }
-    } else if (a.proposal == PF_PROP_BOOTSTRAP) {
-        if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PF_PROP_BOOTSTRAP, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PF_PROP_BOOTSTRAP, false>), grid, block, 0, st, a);
-    } else {
-        if (a.from_local) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PF_PROP_LGO, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PF_PROP_LGO, false>), grid, block, 0, st, a);
-    }
     };
     hipEvent_t ev_loop[2] = {nullptr, nullptr};
     if (kernel_ms) {
@@ -1041,8 +1093,18 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.step = (int)t;
         a.obs = observed[t] != 0;
         a.obs_next = (s + 1 < n_steps) ? (observed[t + 1] != 0) : 0;
+#ifdef PF_DEVTOOLS
+        // stage cuts on ONE launch (the last but one step) when PF_DEBUG_CUT_AT_END is set: the state entering it is
+        // valid, so per-dispatch PMC rows of that launch profile the stages on real data
+        static const bool cut_at_end = getenv("PF_DEBUG_CUT_AT_END") != nullptr;
+        const int cut_all = a.debug_cut;
+        if (cut_at_end && cut_all > 0 && s != n_steps - 2) a.debug_cut = 0;
+#endif
         launch_plan();
         launch_step();
+#ifdef PF_DEVTOOLS
+        a.debug_cut = cut_all;
+#endif
     }
     if (kernel_ms) (void)hipEventRecord(ev_loop[1], st);
     if (finalize) {

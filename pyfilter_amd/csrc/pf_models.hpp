@@ -215,6 +215,68 @@ template <typename T, int D> struct ColConsts {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// The scalar closed forms in canonical shape, one record per column and time step.  The column's bookkeeper (planning /
+// scan kernel) evaluates ColConsts::prepare once and stores the record; the step kernel reads it with scalar loads
+// (constant address space: the values sit in SGPRs, no per-thread recomputation, nothing uniform held in VGPRs).
+//   one-step mean:  A2 == 0:  loc = A0 + (x - A3) * A1      (linear AR: A3 = 0; OU: A0 = A3 = gamma, A1 = e^{-kappa dt})
+//                   A2 != 0:  loc = x + A2 * sin(x - A3)    (sine diffusion, A2 = dt)
+// The arithmetic is the one ColConsts::loc1 / sample_and_weight / pre_weight perform (same operations, same order).
+// ---------------------------------------------------------------------------------------------------------------
+enum {
+    PK_A0 = 0, PK_A1, PK_A2, PK_A3, PK_G, PK_INC, PK_A, PK_YB, PK_YBN, PK_I2S, PK_KS, PK_CLOC, PK_CY, PK_KSTD, PK_INVG,
+    PK_I2INC, PK_KT, PK_KQ, PK_I2C, PK_KC, PK_USED, PK_N = 24
+};
+template <typename T> using const_ptr = const __attribute__((address_space(4))) T*;
+
+template <typename T> __device__ __forceinline__ void write_col_pack(const ModelDesc& md, const ColParams<T, 1>& cp,
+                                                                     const ColConsts<T, 1>& cc, T* __restrict__ q) {
+    T A0 = T(0), A1 = T(0), A2 = T(0), A3 = T(0);
+    switch (md.hid_kind) {
+        case PF_HID_LINEAR: A0 = cp.hp[0][0]; A1 = cp.hp[1][0]; break;
+        case PF_HID_SINE_EM: A2 = (T)md.dt; A3 = cp.hp[0][0]; break;
+        default: A0 = cp.hp[1][0]; A3 = cp.hp[1][0]; A1 = cc.ou_e; break;  // OU
+    }
+    q[PK_A0] = A0; q[PK_A1] = A1; q[PK_A2] = A2; q[PK_A3] = A3;
+    q[PK_G] = cc.g; q[PK_INC] = cc.inc; q[PK_A] = cc.a; q[PK_YB] = cc.yb; q[PK_YBN] = cc.ybn;
+    q[PK_I2S] = cc.i2s; q[PK_KS] = cc.ks; q[PK_CLOC] = cc.c_loc; q[PK_CY] = cc.c_y; q[PK_KSTD] = cc.kstd;
+    q[PK_INVG] = cc.inv_g; q[PK_I2INC] = cc.i2inc; q[PK_KT] = cc.kt; q[PK_KQ] = cc.kq; q[PK_I2C] = cc.i2c; q[PK_KC] = cc.kc;
+}
+
+template <typename T> struct FastCol {
+    T A0, A1, A2, A3, g, inc, a, yb, ybn, i2s, ks, c_loc, c_y, kstd, inv_g, i2inc, kt, kq, i2c, kc;
+    __device__ __forceinline__ void load(const_ptr<T> q) {
+        A0 = q[PK_A0]; A1 = q[PK_A1]; A2 = q[PK_A2]; A3 = q[PK_A3];
+        g = q[PK_G]; inc = q[PK_INC]; a = q[PK_A]; yb = q[PK_YB]; ybn = q[PK_YBN];
+        i2s = q[PK_I2S]; ks = q[PK_KS]; c_loc = q[PK_CLOC]; c_y = q[PK_CY]; kstd = q[PK_KSTD];
+        inv_g = q[PK_INVG]; i2inc = q[PK_I2INC]; kt = q[PK_KT]; kq = q[PK_KQ]; i2c = q[PK_I2C]; kc = q[PK_KC];
+    }
+    __device__ __forceinline__ T loc(T x) const {
+        if (A2 != T(0)) return x + pf_sin(x - A3) * A2;
+        return A0 + (x - A3) * A1;
+    }
+    __device__ __forceinline__ T obs_lp(T x, bool next = false) const {
+        const T r = (next ? ybn : yb) - a * x;
+        return -(r * r) * i2s - ks;
+    }
+    __device__ __forceinline__ T pre_weight(int proposal, T x, bool next = false) const {
+        if (proposal == PF_PROP_BOOTSTRAP) return obs_lp(loc(x), next);
+        const T r = (next ? ybn : yb) - a * x;
+        return -(r * r) * i2c - kc;
+    }
+    __device__ __forceinline__ T sample_and_weight(int proposal, T x, T z, T& xn) const {
+        const T l = loc(x);
+        if (proposal == PF_PROP_BOOTSTRAP) {
+            xn = l + g * (z * inc);
+            return obs_lp(xn);
+        }
+        const T km = c_loc * l + c_y;
+        xn = km + kstd * z;
+        const T eps = (xn - l) * inv_g;
+        return obs_lp(xn) + (-(eps * eps) * i2inc - kt) - (-T(0.5) * z * z - kq);
+    }
+};
+
 template <typename T> __device__ __forceinline__ T normal_logpdf(T y, T loc, T scale) {
     const T r = y - loc;
     return -(r * r) / (T(2) * scale * scale) - pf_log(scale) - T(PF_LOG_SQRT_2PI);

@@ -19,8 +19,10 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32), not a mul_hi / mul_lo pair
+        const uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
         c0 = n0;
         c1 = n1;
@@ -51,7 +53,8 @@ __device__ __forceinline__ double u01_d(uint32_t a, uint32_t b) {
 // float Box-Muller on the hardware transcendentals: v_log_f32, v_sqrt_f32 and v_sin_f32 / v_cos_f32, whose argument is
 // in revolutions - exactly the 2*pi*u2 of Box-Muller.  ~10 VALU instructions per pair (the libm versions cost ~150).
 __device__ __forceinline__ void box_muller(float u1, float u2, float& z0, float& z1) {
-    const float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u1));
+    // -2 ln u = (-2 ln 2) log2 u, u in [2^-24, 1]: the bare v_log_f32
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
     z0 = r * __builtin_amdgcn_cosf(u2);
     z1 = r * __builtin_amdgcn_sinf(u2);
 }
@@ -83,11 +86,13 @@ template <> struct NormalCall<double> {
 };
 
 // z[j][d] for the VEC consecutive particles elem0 .. elem0 + VEC - 1
+// (VEC > 1 implies N % VEC == 0 and elem0 % VEC == 0 - the geometry's rule - so the aligned branch is known statically)
 template <typename T, int D, int VEC>
 __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem0, T (&z)[VEC][D]) {
     constexpr int NPC = NormalCall<T>::NPC;
     const uint64_t n0 = elem0 * D;
-    if ((VEC * D) % NPC == 0 && (n0 % NPC) == 0) {
+    if constexpr (VEC > 1) __builtin_assume(elem0 % VEC == 0);
+    if ((VEC * D) % NPC == 0 && ((VEC > 1 && VEC % NPC == 0) || (n0 % NPC) == 0)) {
         // aligned: exactly VEC * D / NPC calls, every normal used
 #pragma unroll
         for (int c = 0; c < (VEC * D) / NPC; ++c) {
@@ -123,6 +128,9 @@ template <typename T, int D> struct NormalDraw {
     }
 };
 
+__device__ __forceinline__ float neg_log_u(uint32_t a) {  // -ln u, u in (0, 1]
+    return -0.693147180559945309417f * __builtin_amdgcn_logf(u01_open0(a));
+}
 // Exp(1) draws for the sorted-uniform (exponential spacings) multinomial resampler, VEC consecutive elements.
 template <typename T, int VEC>
 __device__ __forceinline__ void draw_exponentials(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem0, T (&e)[VEC]);
@@ -130,10 +138,10 @@ template <> __device__ __forceinline__ void draw_exponentials<float, 4>(uint64_t
                                                                         uint64_t elem0, float (&e)[4]) {
     const uint64_t c = elem0 >> 2;  // elem0 % 4 == 0: one call serves the four elements
     const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream | 0x200u, (uint32_t)seed, (uint32_t)(seed >> 32));
-    e[0] = -__logf(u01_open0(r.x));
-    e[1] = -__logf(u01_open0(r.y));
-    e[2] = -__logf(u01_open0(r.z));
-    e[3] = -__logf(u01_open0(r.w));
+    e[0] = neg_log_u(r.x);
+    e[1] = neg_log_u(r.y);
+    e[2] = neg_log_u(r.z);
+    e[3] = neg_log_u(r.w);
 }
 template <> __device__ __forceinline__ void draw_exponentials<float, 1>(uint64_t seed, uint32_t stream, uint32_t step,
                                                                         uint64_t elem0, float (&e)[1]) {
@@ -141,7 +149,7 @@ template <> __device__ __forceinline__ void draw_exponentials<float, 1>(uint64_t
     const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream | 0x200u, (uint32_t)seed, (uint32_t)(seed >> 32));
     const uint32_t q = (uint32_t)(elem0 & 3);
     const uint32_t w = q == 0 ? r.x : (q == 1 ? r.y : (q == 2 ? r.z : r.w));
-    e[0] = -__logf(u01_open0(w));
+    e[0] = neg_log_u(w);
 }
 template <> __device__ __forceinline__ void draw_exponentials<double, 4>(uint64_t seed, uint32_t stream, uint32_t step,
                                                                          uint64_t elem0, double (&e)[4]) {

@@ -78,10 +78,22 @@ def main():
             res = f.batch_filter(y, bar=False)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / reps
-        f._time_kernels = True
-        f.batch_filter(y, bar=False)
-        k = f.kernel_ms
+        k = [0.0, 0.0, 0.0]
+        if not os.environ.get("KB_NO_TIMED"):  # (the replays of the timed run would pollute a PMC profile)
+            f._time_kernels = True
+            f.batch_filter(y, bar=False)
+            k = f.kernel_ms
         n, b = cfg[3], cfg[4]
+        if os.environ.get("PF_AMD_LIB"):
+            import ctypes as C
+            from pyfilter_amd import _lib as L
+            off = C.c_size_t(0)
+            lib = L.load()
+            lib.pf_debug_offset.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]
+            lib.pf_debug_offset(cfg[3], cfg[4], C.byref(off))
+            st = f._last_run["ws"][off.value:off.value + 256].view(torch.int64).cpu().tolist()
+            print("   dev counters: fallback searches", st[20], " headless positions", st[21], " rounds", st[22], " no head at 0:", st[23],
+                  " covered==0:", st[24], " covered<RE:", st[25], " first bad (k, j0, cn0[0], cn0[3], c0[3] bits):", st[27:32])
         if int(os.environ.get("PF_DEBUG_CUT", "0")) < 0:
             import ctypes as C
             from pyfilter_amd import _lib as L
