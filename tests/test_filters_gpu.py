@@ -5,6 +5,7 @@ Tolerances: float64 runs - filter_means / variances / log-likelihood within 1e-9
 path (the north-star bar is 1e-5) and **identical ancestors**; float32 runs - within 2e-4 (the reference's own fp32
 path is only that close to exact arithmetic: BASELINE.md §2)."""
 import math
+import os
 
 import pytest
 import torch
@@ -295,6 +296,67 @@ def test_fp64_parity_at_benchmark_sizes(model, filt_name, prop, n, b, t_len):
     torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9)
     mism = (res.latest_state.previous_indices.cpu() != ref["prev_inds"]).sum().item()
     assert mism <= 2, f"{mism} of {n * b} final ancestors differ"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,filt_name,prop,n,b", [
+    ("sine", "apf", "lgo", 3000, 3),          # N % 4 == 0, not a power of two: the grid division is a true division
+    ("sine", "sisr", "bootstrap", 1001, 2),   # N % 4 != 0: the scalar (VEC = 1) instantiation
+    ("lorenz", "sisr", "bootstrap", 4100, 1),  # several partially filled tiles, D = 3
+    ("ou_batched", "apf", "lgo", 6148, 5),     # ragged last tile, per-filter parameters
+])
+def test_fp64_parity_ragged_sizes(model, filt_name, prop, n, b):
+    """Particle counts that are not powers of two / not multiples of the vector width: same bar as the benchmark sizes."""
+    case, spec, g, y = _full_size_case(model, filt_name, prop, n, b, 12, seed=77 + n)
+    x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
+    ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=0.9)
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    res = filt.batch_filter(y.cuda(), bar=False)
+    torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9)
+    assert torch.equal(res.latest_state.previous_indices.cpu(), ref["prev_inds"])
+
+
+@pytest.mark.gpu
+def test_searching_ancestor_stage_passes_the_parity_suite():
+    """Float grids beyond 2^22 positions use the searching variant of the step kernel (the closed-form inverse of the
+    systematic grid is only exact up to there).  PF_FORCE_SEARCH=1 selects that variant at every size: the float32
+    golden / teacher-forced / invariant tests must pass with it too."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, PF_FORCE_SEARCH="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_filters_gpu.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "f32 or teacher or weight_collapse or fp32_full_size"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_float32_grid_beyond_2_pow_22():
+    """8 388 608 float32 particles (the searching ancestor stage, selected by size): ancestors sorted and in range, and
+    the filter agrees with its float64 run on the same observations within float32 resolution / Monte-Carlo error."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    n = 1 << 23
+    gen = torch.Generator().manual_seed(11)
+    y = (0.2 * torch.randn(6, generator=gen)).cumsum(0)
+    out = {}
+    for dtype in (torch.float32, torch.float64):
+        t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+        ssm = ts.LinearStateSpaceModel(models.AR(t(0.0), t(0.95), t(0.3)), (t(1.0), t(0.2)))
+        f = SISR(ssm, n, proposal=proposals.Bootstrap(), ess_threshold=1.1, seed=3)  # threshold > 1: resample every step
+        r = f.batch_filter(y.to("cuda", dtype), bar=False)
+        idx = r.latest_state.previous_indices
+        assert (idx[1:] >= idx[:-1]).all() and idx.min() >= 0 and idx.max() <= n - 1
+        out[dtype] = r
+    se = (out[torch.float64].filter_variance[1:] / n).sqrt()
+    diff = (out[torch.float32].filter_means[1:].double() - out[torch.float64].filter_means[1:]).abs()
+    assert (diff <= 8.0 * se + 1e-4).all(), diff
+    assert abs(out[torch.float32].loglikelihood.item() - out[torch.float64].loglikelihood.item()) < 5e-3
 
 
 def test_fp32_full_size_invariants():
