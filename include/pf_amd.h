@@ -113,6 +113,18 @@ int pf_multinomial(const void* W, const void* v, uint64_t seed, uint32_t step, c
 int pf_gather(const void* x, const int32_t* idx, const uint8_t* colmask, void* out, int64_t N, int64_t B,
               int64_t D, int dtype, void* stream);
 
+/* Whole-filter moves along the batch dim - the step either side of the hot path inside SMC^2 / PMMH:
+ *   pf_columns_gather   : ParticleFilterCorrection.resample (particle/state.py:150-158), FilterResult.resample
+ *                         (result.py:97-117):   dst[p][b][:] = src[p][idx[b]][:]          (out of place, idx (B) int64)
+ *   pf_columns_exchange : ParticleFilterCorrection.exchange (particle/state.py:160-168), FilterResult.exchange
+ *                         (result.py:76-95):    dst[p][b][:] = src[p][b][:] where mask[b] (in place in dst)
+ * src / dst are `planes` stacked (B, N) arrays of `elem_bytes`-sized elements (4 or 8: float, double, int32, int64):
+ * weights / ancestors have planes = 1, a (D, B, N) state has planes = D.  Pure byte moves, dtype-agnostic. */
+int pf_columns_gather(const void* src, const int64_t* idx, void* dst, int64_t N, int64_t B, int64_t planes,
+                      int elem_bytes, void* stream);
+int pf_columns_exchange(void* dst, const void* src, const uint8_t* mask, int64_t N, int64_t B, int64_t planes,
+                        int elem_bytes, void* stream);
+
 /* pyfilter.filters.particle.utils.log_likelihood (particle/utils.py:7-22): max v + log sum W exp(v - max);
  * W == NULL means 1/N.  v (B,N) is NOT sanitised (a NaN poisons the column, as in the reference). out (B). */
 int pf_loglik(const void* v, const void* W, void* out, int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes,

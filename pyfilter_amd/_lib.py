@@ -27,7 +27,7 @@ EXPORTS = (
     "pf_version", "pf_error_string", "pf_workspace_bytes", "pf_normalize", "pf_systematic", "pf_systematic_logw",
     "pf_multinomial", "pf_gather", "pf_loglik", "pf_moments", "pf_pre_weight", "pf_sample_and_weight",
     "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed", "pf_filter_graph_create", "pf_filter_graph_launch",
-    "pf_filter_graph_destroy",
+    "pf_filter_graph_destroy", "pf_columns_gather", "pf_columns_exchange",
 )
 
 
@@ -85,6 +85,8 @@ def load() -> C.CDLL:
     lib.pf_multinomial.argtypes = [vp, vp, u64, u32, vp, vp, vp, i64, i64, i32, vp, sz, vp]
     lib.pf_gather.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.pf_loglik.argtypes = [vp, vp, vp, i64, i64, i32, vp, sz, vp]
+    lib.pf_columns_gather.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp]
+    lib.pf_columns_exchange.argtypes = [vp, vp, vp, i64, i64, i64, i32, vp]
     lib.pf_moments.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp, sz, vp]
     lib.pf_pre_weight.argtypes = [C.POINTER(PfModel), i32, vp, vp, i64, vp, i64, i64, i32, vp]
     lib.pf_sample_and_weight.argtypes = [C.POINTER(PfModel), i32, i32, vp, vp, i64, vp, u64, u32, vp, vp, i64, i64, i32, vp]

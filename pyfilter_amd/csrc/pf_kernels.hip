@@ -546,6 +546,37 @@ __global__ __launch_bounds__(PF_BLOCK) void k_gather(const T* __restrict__ x, co
     }
 }
 
+// Whole-column moves along the batch dim (FilterResult / ParticleFilterCorrection resample + exchange).  A column is a
+// contiguous run of N elements; a workgroup moves PF_COLCHUNK bytes of one column of one plane with 16-byte accesses
+// (8 / 4-byte ones when the column size or the base addresses are not 16-byte multiples).  idx == nullptr: identity
+// (exchange); mask == nullptr: every column.
+#define PF_COLCHUNK (PF_BLOCK * 16 * 4)
+template <typename V>
+__global__ __launch_bounds__(PF_BLOCK) void k_columns_move(const char* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           const uint8_t* __restrict__ mask, char* __restrict__ dst,
+                                                           int64_t col_bytes, int B) {
+    const int b = blockIdx.y, p = blockIdx.z;
+    if (mask && !mask[b]) return;
+    int64_t from = idx ? idx[b] : (int64_t)b;
+    if (from < 0) from += B;  // torch-style negative indices
+    const V* s = reinterpret_cast<const V*>(src + ((int64_t)p * B + from) * col_bytes);
+    V* d = reinterpret_cast<V*>(dst + ((int64_t)p * B + b) * col_bytes);
+    const int64_t n = col_bytes / (int64_t)sizeof(V);
+    const int64_t per_wg = PF_COLCHUNK / (int64_t)sizeof(V);
+    const int64_t lo = (int64_t)blockIdx.x * per_wg;
+    const int64_t hi = lo + per_wg < n ? lo + per_wg : n;
+    // four independent 16-byte loads in flight per thread before the first store
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 4 * PF_BLOCK) {
+        V v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i + q * PF_BLOCK < hi) v[q] = s[i + q * PF_BLOCK];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (i + q * PF_BLOCK < hi) d[i + q * PF_BLOCK] = v[q];
+    }
+}
+
 // log_likelihood partials: online max of v with companion sum W * exp(v - max)
 template <typename T>
 __global__ __launch_bounds__(PF_BLOCK) void k_loglik_part(const T* __restrict__ v, const T* __restrict__ W,
@@ -860,6 +891,34 @@ extern "C" int pf_gather(const void* x, const int32_t* idx, const uint8_t* colma
     else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;
+}
+
+static int columns_move(const void* src, const int64_t* idx, const uint8_t* mask, void* dst, int64_t N, int64_t B,
+                        int64_t planes, int elem_bytes, void* stream) {
+    if (!src || !dst || bad_shape(N, B) || planes < 1 || planes > 65535 || (elem_bytes != 4 && elem_bytes != 8)) return PF_EINVAL;
+    const int64_t col_bytes = N * elem_bytes;
+    const dim3 grid((unsigned)((col_bytes + PF_COLCHUNK - 1) / PF_COLCHUNK), (unsigned)B, (unsigned)planes);
+    hipStream_t st = (hipStream_t)stream;
+    const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)col_bytes;
+    const char* s = (const char*)src;
+    char* d = (char*)dst;
+    if ((al & 15) == 0) hipLaunchKernelGGL((k_columns_move<uint4>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
+    else if ((al & 7) == 0) hipLaunchKernelGGL((k_columns_move<uint2>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
+    else hipLaunchKernelGGL((k_columns_move<uint32_t>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_columns_gather(const void* src, const int64_t* idx, void* dst, int64_t N, int64_t B, int64_t planes,
+                                 int elem_bytes, void* stream) {
+    if (!idx || src == dst) return PF_EINVAL;  // out of place only: a gather may read columns it has already overwritten
+    return columns_move(src, idx, nullptr, dst, N, B, planes, elem_bytes, stream);
+}
+
+extern "C" int pf_columns_exchange(void* dst, const void* src, const uint8_t* mask, int64_t N, int64_t B, int64_t planes,
+                                   int elem_bytes, void* stream) {
+    if (!mask) return PF_EINVAL;
+    return columns_move(src, nullptr, mask, dst, N, B, planes, elem_bytes, stream);
 }
 
 extern "C" int pf_loglik(const void* v, const void* W, void* out, int64_t N, int64_t B, int dtype, void* ws,

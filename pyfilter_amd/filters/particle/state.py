@@ -82,20 +82,29 @@ class ParticleFilterCorrection(Correction):
         return self.timeseries_state
 
     def resample(self, indices: Tensor):
-        """Gather whole filters along the batch dim (``:150-158``)."""
+        """Gather whole filters along the batch dim (``:150-158``): the particle planes, weights
+        and ancestors move with ``pf_columns_gather`` (whole contiguous columns in the library layout)."""
+        from ... import ops
+
         ts = self.timeseries_state
-        self["_x"] = ts.copy(values=ts.value[:, indices])
-        self["_w"] = self.weights[:, indices]
+        self["_x"] = ts.copy(values=ops.gather_filters(ts.value, indices))
+        self["_w"] = ops.gather_filters(self.weights, indices)
         self["_ll"][indices] = self["_ll"][indices]
-        self["_prev_inds"] = self["_prev_inds"][:, indices]
+        self["_prev_inds"] = ops.gather_filters(self["_prev_inds"], indices)
         self["_mean"] = self["_mean"][indices]
         self["_var"] = self["_var"][indices]
 
     def exchange(self, other: "ParticleFilterCorrection", mask: Tensor):
-        self["_x"].value[:, mask] = other.timeseries_state.value[:, mask]
-        self["_w"][:, mask] = other.weights[:, mask]
+        """Overwrite the filters selected by ``mask`` with those of ``other`` (``:160-168``), ``pf_columns_exchange``."""
+        from ... import ops
+
+        ts = self.timeseries_state
+        new_x = ops.exchange_filters(ts.value, other.timeseries_state.value, mask)
+        if new_x.data_ptr() != ts.value.data_ptr():
+            self["_x"] = ts.copy(values=new_x)
+        self["_w"] = ops.exchange_filters(self["_w"], other.weights, mask)
         self["_ll"][mask] = other.get_loglikelihood()[mask]
-        self["_prev_inds"][:, mask] = other.previous_indices[:, mask]
+        self["_prev_inds"] = ops.exchange_filters(self["_prev_inds"], other.previous_indices, mask)
         self["_mean"][mask] = other["_mean"][mask]
         self["_var"][mask] = other["_var"][mask]
 

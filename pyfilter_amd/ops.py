@@ -59,6 +59,69 @@ def _mask_ptr(colmask: Optional[torch.Tensor]):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# whole-filter moves along the batch dim
+# ----------------------------------------------------------------------------------------------------------------
+def _batch_view(t: torch.Tensor):
+    """``(N, B, ...)`` reference-layout tensor -> (``(planes, B, N)`` contiguous buffer, rebuild) where ``rebuild`` maps
+    such a buffer back to the reference layout.  No copy when ``t`` already is a view of a library buffer."""
+    if t.dim() < 2:
+        raise L.PfAmdError("a batch dimension is required: tensor must be (N, B, ...)")
+    n, b, tail = t.shape[0], t.shape[1], tuple(t.shape[2:])
+    flat = t.unsqueeze(-1) if t.dim() == 2 else (t if t.dim() == 3 else t.reshape(n, b, -1))
+    buf = flat.permute(2, 1, 0).contiguous()  # (planes, B, N); a no-op for views of (D, B, N) / (B, N) buffers
+
+    def rebuild(o: torch.Tensor) -> torch.Tensor:
+        v = o.permute(2, 1, 0)
+        if len(tail) == 0:
+            return v[..., 0]
+        return v if len(tail) == 1 else v.reshape(n, b, *tail)
+
+    return buf, rebuild
+
+
+def gather_filters(t: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
+    """``t[:, indices]`` for an ``(N, B, ...)`` tensor, as a view of a freshly gathered ``(planes, B, N)`` buffer
+    (pf_columns_gather; ParticleFilterCorrection.resample, particle/state.py:150-158)."""
+    L.require_gpu(t, indices)
+    if indices.dtype == torch.bool:
+        indices = indices.nonzero().reshape(-1)
+    idx = indices.to(torch.int64).contiguous()
+    b = t.shape[1]
+    if idx.numel() != b:
+        return t[:, indices]  # a different number of filters out than in: not the in-place resample of the reference
+    lo, hi = int(idx.min()), int(idx.max())
+    if lo < -b or hi >= b:
+        raise IndexError(f"index {hi if hi >= b else lo} is out of bounds for dimension 1 with size {b}")
+    src, rebuild = _batch_view(t)
+    dst = torch.empty_like(src)
+    planes, _, n = src.shape
+    L.check(L.load().pf_columns_gather(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), n, b, planes, src.element_size(),
+                                       L.stream_ptr()), "pf_columns_gather")
+    return rebuild(dst)
+
+
+def exchange_filters(dst_t: torch.Tensor, src_t: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """``dst[:, mask] = src[:, mask]`` for ``(N, B, ...)`` tensors (pf_columns_exchange; ParticleFilterCorrection.exchange,
+    particle/state.py:160-168).  In place when ``dst_t`` is a view of a library buffer; returns the updated tensor."""
+    L.require_gpu(dst_t, src_t, mask)
+    if mask.dtype != torch.bool or mask.dim() != 1 or mask.numel() != dst_t.shape[1] or dst_t.shape != src_t.shape \
+            or dst_t.dtype != src_t.dtype:
+        dst_t[:, mask] = src_t[:, mask]
+        return dst_t
+    dst, rebuild = _batch_view(dst_t)
+    src, _ = _batch_view(src_t)
+    planes, b, n = dst.shape
+    m = mask.contiguous()
+    L.check(L.load().pf_columns_exchange(dst.data_ptr(), src.data_ptr(), m.data_ptr(), n, b, planes, dst.element_size(),
+                                         L.stream_ptr()), "pf_columns_exchange")
+    out = rebuild(dst)
+    if out.data_ptr() != dst_t.data_ptr():  # dst_t was in a foreign layout: write the result back into it
+        dst_t.copy_(out)
+        return dst_t
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------------------------------------------
 def normalize_cols(logw: torch.Tensor, want_w=True, want_lse=False, want_ess=False):

@@ -1,0 +1,106 @@
+"""Whole-filter moves along the batch dim: ``pf_columns_gather`` / ``pf_columns_exchange`` behind
+``ParticleFilterCorrection.resample/exchange`` and ``FilterResult.resample/exchange`` (reference:
+``filters/particle/state.py:150-168``, ``filters/result.py:76-117``).  Byte moves: every comparison is bit-exact against
+the torch indexing expressions the reference uses."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pyfilter_amd import ops as o
+
+    return o
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.int32, torch.int64])
+@pytest.mark.parametrize("n,b,tail", [(4096, 7, ()), (1001, 5, ()), (4098, 3, (3,)), (65536, 16, (1,)), (333, 4, (2,))])
+def test_gather_and_exchange_match_torch_indexing(ops, dtype, n, b, tail):
+    g = torch.Generator(device="cuda").manual_seed(n + b)
+    shape = (n, b) + tail
+
+    def rnd():
+        if dtype.is_floating_point:
+            return torch.randn(shape, device="cuda", dtype=dtype, generator=g)
+        return torch.randint(-2 ** 30, 2 ** 30, shape, device="cuda", dtype=dtype, generator=g)
+
+    # library layout: a view of a (planes, B, N) buffer - and a foreign (contiguous) layout
+    for layout in ("library", "foreign"):
+        t, o = rnd(), rnd()
+        if layout == "library":
+            as_lib = lambda v: (v.unsqueeze(-1) if v.dim() == 2 else v).permute(2, 1, 0).contiguous().permute(2, 1, 0)  # noqa: E731
+            t, o = as_lib(t), as_lib(o)
+            if not tail:
+                t, o = t[..., 0], o[..., 0]
+        idx = torch.randint(0, b, (b,), device="cuda", generator=g)
+        idx[0] = -1  # torch-style negative index
+        want = t[:, idx].clone()
+        got = ops.gather_filters(t, idx)
+        assert got.shape == want.shape and torch.equal(got, want)
+        mask = torch.rand(b, device="cuda", generator=g) < 0.5
+        want = t.clone()
+        want[:, mask] = o[:, mask]
+        got = ops.exchange_filters(t, o, mask)
+        assert torch.equal(got, want) and torch.equal(t, want)  # in place
+
+
+def test_gather_rejects_out_of_range(ops):
+    t = torch.zeros(64, 4, device="cuda")
+    with pytest.raises(IndexError):
+        ops.gather_filters(t, torch.tensor([0, 1, 2, 4], device="cuda"))
+
+
+def _run_filter(seed, b=6, n=2048, t_len=5):
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, device="cuda")  # noqa: E731
+    ssm = ts.LinearStateSpaceModel(models.AR(t(0.0), t(0.9), t(0.2)), (t(1.0), t(0.3)))
+    f = APF(ssm, n, proposal=proposals.Bootstrap(), seed=seed)
+    f.set_batch_shape(torch.Size([b]))
+    y = torch.linspace(-0.5, 0.5, t_len, device="cuda")
+    return f, f.batch_filter(y, bar=False)
+
+
+def _snapshot(res):
+    s = res.latest_state
+    return dict(x=s.timeseries_state.value.clone(), w=s.weights.clone(), ll=s.get_loglikelihood().clone(),
+                idx=s.previous_indices.clone(), mean=s["_mean"].clone(), var=s["_var"].clone(),
+                total=res.loglikelihood.clone(), means=res.filter_means.clone(), variances=res.filter_variance.clone())
+
+
+def test_filter_result_resample_and_exchange():
+    """The SMC^2 / PMMH moves on real filter results: resample gathers filters, exchange overwrites the masked ones."""
+    (f1, r1), (_, r2) = _run_filter(1), _run_filter(2)
+    a, b2 = _snapshot(r1), _snapshot(r2)
+    idx = torch.tensor([5, 5, 0, 3, 3, 1], device="cuda")
+    r1.resample(idx)
+    s = _snapshot(r1)
+    for k in ("x", "w", "idx"):
+        assert torch.equal(s[k], a[k][:, idx]), k
+    assert torch.equal(s["total"], a["total"][idx])
+    # reference quirk kept: the latest state's mean / variance ARE the last entries of the filter_means / variances
+    # tuples (result.py:119-133 appends the same tensor), so resample(entire_history=True) gathers them in place
+    # (result.py:111-114) and the state's own resample gathers them once more (particle/state.py:157-158)
+    for k in ("mean", "var"):
+        assert torch.equal(s[k], a[k][idx][idx]), k
+    assert torch.equal(s["means"], a["means"][:, idx]) and torch.equal(s["variances"], a["variances"][:, idx])
+    # the filter keeps running on the moved state (buffers are in the library layout again)
+    mask = torch.tensor([True, False, False, True, True, False], device="cuda")
+    before = _snapshot(r1)
+    r1.exchange(r2, mask)
+    s = _snapshot(r1)
+    for k in ("x", "w", "idx"):
+        want = before[k].clone()
+        want[:, mask] = b2[k][:, mask]
+        assert torch.equal(s[k], want), k
+    for k in ("mean", "var", "ll", "total"):
+        want = before[k].clone()
+        want[mask] = b2[k][mask]
+        assert torch.equal(s[k], want), k
+    # the filter keeps running on the moved state
+    nxt = f1.filter(torch.tensor(0.1, device="cuda"), r1.latest_state)
+    assert torch.isfinite(nxt.get_loglikelihood()).all() and nxt.timeseries_state.value.shape == s["x"].shape
