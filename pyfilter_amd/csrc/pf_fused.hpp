@@ -915,12 +915,13 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
     const T ub = (!windowed || multinomial) ? T(0) : a.ucol[b];
 
     const T* x_in = a.x[slot];
-    T* x_out = a.x[slot ^ 1];
     const T* lw_in = a.logw[slot] + (int64_t)b * g.N;
+#ifdef PF_DEVTOOLS
     T* lw_out = a.logw[slot ^ 1] + (int64_t)b * g.N;
+    int32_t* anc_col = a.anc + (int64_t)b * g.N;
+#endif
     // multinomial / two-kernel pipeline: the cdf itself; systematic pipeline: the local scans of this step's parity
     const T* cdf_col = ((MODE != 1 && (step & 1)) ? a.pos : a.cdf) + (int64_t)b * g.N;
-    int32_t* anc_col = a.anc + (int64_t)b * g.N;
     const int64_t base = (int64_t)k * g.tile_elems;
     const T nT = T(N);
     const T rcN = T(1) / nT;
@@ -1016,10 +1017,12 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
             }
         }
         PF_STAMP(a, 10);
+#ifdef PF_DEVTOOLS
         if (PF_CUT(a, 4)) {  // development: keep the draws alive, stop here
             if (on) lw_out[i0] = zt[0][0] + zt[VEC - 1][D - 1];
             return;
         }
+#endif
 
         // ---- 3. ancestors ---------------------------------------------------------------------------------------------
         int idx[VEC];
@@ -1161,15 +1164,26 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
             for (int j = 0; j < VEC; ++j) idx[j] = (int)((i0 + j < g.N) ? (i0 + j) : (g.N - 1));
         }
         PF_STAMP(a, 11);
+#ifdef PF_DEVTOOLS
         if (on && PF_CUT(a, 2)) {
             if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
         }
+#endif
 
         // ---- 4. gather, propagate, weight -------------------------------------------------------------------------------
         // the column's constants are fetched only now - their address is tied to the ancestors by an opaque zero - so
         // they occupy registers for the arithmetic below and not across the search
         int late;
         asm volatile("v_readfirstlane_b32 %0, %1\n\ts_and_b32 %0, %0, 0" : "=s"(late) : "v"(idx[0]) : "scc");
+        // the same for the output side of the argument block: re-read from the kernarg segment behind the opaque zero, so
+        // the destination pointers are not held in (spilled) SGPRs through the prologue and the ancestor stage
+        using KArgs = const __attribute__((address_space(4))) FusedArgs<T>;
+        KArgs* la = (KArgs*)((const_ptr<char>)__builtin_amdgcn_kernarg_segment_ptr() + late);
+        T* const x_out = la->x[slot ^ 1];
+#ifndef PF_DEVTOOLS
+        T* const lw_out = la->logw[slot ^ 1] + (int64_t)b * g.N;
+        int32_t* const anc_col = la->anc + (int64_t)b * g.N;
+#endif
         if constexpr (FAST) {
             // scalar loads of the record the bookkeeper wrote: 20 SGPRs
             fc.load((const_ptr<T>)(uintptr_t)(a.cpack + (int64_t)b * PK_N) + late);
@@ -1254,7 +1268,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
             }
             T piv[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) piv[d] = a.means[((int64_t)step * g.B + b) * D + d];
+            for (int d = 0; d < D; ++d) piv[d] = la->means[((int64_t)step * g.B + b) * D + d];
             acc.template push_round<VEC>(lwo, xo, pre_next, pre_n, piv, e_rw);
             if (multinomial) {
                 T ev[VEC];
