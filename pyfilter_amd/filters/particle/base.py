@@ -219,6 +219,89 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             and hasattr(self._model.hidden, "init_mean")
         )
 
+    def filter(self, y: torch.Tensor, correction: ParticleFilterCorrection, result: FilterResult = None):
+        """One filter move (``filters/base.py:188-221``).  Built-in models take the fused single-step path; anything
+        else (user callables, custom resamplers, ``observe_every_step > 1``, recorded intermediary states) the
+        reference's predict / correct sequence over the stand-alone kernels."""
+        x = correction.timeseries_state.value
+        if (not isinstance(y, torch.Tensor) or not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1
+                or os.environ.get("PF_NO_FUSED_STEP", "0") == "1"):
+            return super().filter(y, correction, result=result)
+        new = self._filter_fused_single(y, correction)
+        if result is not None:
+            result.append(new)
+        return new
+
+    def _filter_fused_single(self, y: torch.Tensor, state: ParticleFilterCorrection) -> ParticleFilterCorrection:
+        if self._ctx is None:
+            self._proposal.set_model(self.ssm)
+            self._ctx = self._build_context(*self._device_dtype())
+            self._proposal._set_context(self._ctx)
+        ctx, kind = self._ctx, self._ctx.kind
+        ts_in = state.timeseries_state
+        x_in = ops.to_soa(ts_in.value, self._batched, self._has_event)   # views of library buffers: no copies
+        lw_in = ops.to_cols(state.weights)
+        device, dtype = x_in.device, x_in.dtype
+        d, b, n = x_in.shape
+        o = kind.obs_dim
+        y_dev = y.to(device=device, dtype=dtype).reshape(1, -1, o).contiguous()
+        if y_dev.shape[1] not in (1, b):
+            raise L.PfAmdError(f"observation of shape {tuple(y.shape)} does not broadcast against batch {b}")
+        rows = y_dev.shape[1]
+        key = ("single", n, b, d, o, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
+               self._resampler_kind(), self._seed, float(self._resample_threshold))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
+            self._plans[key] = plan
+        t_start = int(ts_in.time_index)
+        observed = not bool(y_dev.isnan().all())     # the reference branches on the host here too (filters/base.py:212)
+        plan.observed[0] = 1 if observed else 0
+        plan.calls += 1
+
+        apf = self._FILTER_KIND == L.FILTER_APF
+        x_out, lw_out = torch.empty_like(x_in), torch.empty_like(lw_in)
+        if apf:
+            anc = torch.empty((b, n), device=device, dtype=torch.int32)  # every APF step writes its ancestors
+        else:  # SISR keeps the previous ancestors when it does not resample (sisr.py:25-26)
+            cached = getattr(state, "_anc32", None)  # (int32 (B, N) buffer, the int64 tensor it was widened into)
+            if cached is not None and cached[1] is state["_prev_inds"] and cached[0].shape == (b, n):
+                anc = cached[0].clone()
+            else:
+                anc = ops.to_cols(state.previous_indices.to(torch.int32))
+        stats = torch.zeros((4 * d + 2, b), device=device, dtype=dtype)  # means (2, B, D) | variances (2, B, D) | ll | total
+        means, variances = stats[:2 * d].reshape(2, b, d), stats[2 * d:4 * d].reshape(2, b, d)
+        ll_steps, ll_total = stats[4 * d].reshape(1, b), stats[4 * d + 1]
+
+        a = plan.args
+        a.model.params = ctx.params.data_ptr()
+        a.y = y_dev.data_ptr()
+        a.seed = (self._seed + 0x9E3779B97F4A7C15 * plan.calls) & 0xFFFFFFFFFFFFFFFF  # fresh Philox draws per call
+        a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
+        a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
+        a.anc = anc.data_ptr()
+        a.means, a.vars = means.data_ptr(), variances.data_ptr()
+        a.ll_steps, a.ll_total = ll_steps.data_ptr(), ll_total.data_ptr()
+        z_tape = u_tape = None
+        if ctx.z_tape is not None:
+            z_tape = ctx.z_tape[t_start:t_start + 1].contiguous()
+            assert z_tape.shape[0] == 1, "z tape shorter than the number of steps"
+        if ctx.u_tape is not None:
+            u_tape = ctx.u_tape[t_start:t_start + 1].contiguous()
+        a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: the column bookkeeper draws u (Philox)
+        L.check(L.load().pf_filter_run(C.byref(a), 0, 1, 1, L.stream_ptr()), "pf_filter_run")
+        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, keep=(x_in, lw_in, y_dev, ctx.params))
+
+        final_x = TimeseriesState(t_start + 1, ops.from_soa(x_out, self._batched, self._has_event),
+                                  self._model.hidden.event_shape)
+        shape_md = (lambda t: t if self._batched else t[0])
+        new = ParticleFilterCorrection(
+            final_x, ops.from_cols(lw_out, self._batched), shape_md(ll_steps[0]) if self._batched else ll_steps[0, 0],
+            ops.from_cols(anc, self._batched).long(), _moments=(shape_md(means[1]), shape_md(variances[1])),
+        )
+        new._anc32 = (anc, new["_prev_inds"])
+        return new
+
     def batch_filter(self, y, bar=True, init_state=None) -> FilterResult:
         assert self._model is not None, "Model has not been initialized!"
         device, _ = self._device_dtype()
@@ -345,6 +428,32 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         sel = slice(1, None) if obs_rows is None else obs_rows
         result._extend_fused(means_v[sel], vars_v[sel], ll_total if self._batched else ll_total[0], last)
         return result
+
+
+class _SingleStepPlan:
+    """Scratch + launch arguments of the fused *single-step* move behind ``filter()`` (the online / SMC^2 entry point):
+    the kernels read the incoming state's own buffers and write freshly allocated ones that become the new state -
+    no staging copies, four launches (reduce, plan | scan, step, finalise) instead of the ~10 of the step-by-step route."""
+
+    def __init__(self, filt, kind, n, b, d, o, rows, dtype, device):
+        self.cdf = torch.empty((b, n), device=device, dtype=dtype)
+        self.pos = torch.empty((b, n), device=device, dtype=dtype)
+        self.ws = L.new_workspace(n, b, device)
+        self.observed = torch.ones(1, dtype=torch.uint8)  # host
+        self.rows = rows
+        self.calls = 0
+        a = L.PfFilterArgs()
+        a.model = ops.make_model_struct(kind, filt._ctx.params)
+        a.filter, a.proposal, a.resampler = filt._FILTER_KIND, filt._proposal._KERNEL_PROPOSAL, filt._resampler_kind()
+        a.dtype = L.dtype_code(dtype)
+        a.N, a.B = n, b
+        a.ess_threshold = float(filt._resample_threshold) / float(n)
+        a.seed = filt._seed
+        a.cdf, a.pos = self.cdf.data_ptr(), self.pos.data_ptr()
+        a.y, a.y_rows, a.observed = None, rows, self.observed.data_ptr()
+        a.step_counter = None
+        a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        self.args = a
 
 
 class _FusedPlan:

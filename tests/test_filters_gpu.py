@@ -95,8 +95,10 @@ def test_float32_teacher_forced_steps(name, dt):
 
 
 @pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f64"])
-def test_step_by_step_route_matches_reference(name, dt):
-    """predict()/correct() through the stand-alone primitives: every step's state, ancestors and ll."""
+def test_step_by_step_route_matches_reference(name, dt, monkeypatch):
+    """predict()/correct() through the stand-alone primitives (the fused single-step path of ``filter()`` switched off):
+    every step's state, ancestors and ll."""
+    monkeypatch.setenv("PF_NO_FUSED_STEP", "1")
     case = next(c for c in CASES if c["name"] == name)
     g = load_golden(name, dt)
     filt = build_filter_from_case(case, g, DT[dt], "cuda")
@@ -443,3 +445,48 @@ def test_weight_collapse_paths(filt_name, prop):
     # the collapse really happened: at some step fewer than 1 % of the particles survive resampling
     uniq = min(torch.unique(ref["step_idx"][t][:, 0]).numel() for t in range(t_len))
     assert uniq < n // 100, uniq
+
+
+@pytest.mark.parametrize("name", ["sine_apf_lgo", "lg1d_sisr_boot", "sine_apf_boot_nan", "sine_sisr_boot_nan", "sv_apf_boot",
+                                  "lorenz_sisr_boot", "lorenz_apf_lgo", "ou_apf_boot_theta", "ou_sisr_lgo_theta"])
+def test_fused_single_step_filter_matches_reference(name):
+    """``filter()`` one observation at a time (the online / SMC^2 entry point) through the fused single-step path:
+    every step's particles, weights, log-likelihood and ancestors against the reference's golden run (float64,
+    identical draws) - and identical to what the step-by-step route (PF_NO_FUSED_STEP=1) produces."""
+    from oracle.cases import CASE_BY_NAME
+
+    if name not in CASE_BY_NAME:
+        pytest.skip(f"no golden case {name}")
+    case = CASE_BY_NAME[name]
+    g = load_golden(name, "f64")
+    y = g["y"].cuda()
+    outs = {}
+    for route in ("fused", "steps"):
+        os.environ["PF_NO_FUSED_STEP"] = "1" if route == "steps" else "0"
+        try:
+            filt = build_filter_from_case(case, g, torch.float64, "cuda")
+            state = filt.initialize()
+            res = filt.initialize_with_result(state)
+            rows = []
+            for t in range(y.shape[0]):
+                state = filt.filter(y[t], state, result=res)
+                rows.append((state.timeseries_state.value.clone(), state.weights.clone(), state.get_loglikelihood().clone(),
+                             state.previous_indices.clone()))
+            outs[route] = (rows, res)
+        finally:
+            os.environ.pop("PF_NO_FUSED_STEP", None)
+    rows, res = outs["fused"]
+    tol = dict(rtol=1e-9, atol=1e-11)
+    for t, (x, w, ll, idx) in enumerate(rows):
+        torch.testing.assert_close(x.cpu(), g["step_x"][t], **tol)
+        torch.testing.assert_close(w.cpu(), g["step_w"][t], equal_nan=True, **tol)
+        torch.testing.assert_close(ll.cpu(), g["step_ll"][t], rtol=1e-9, atol=1e-9)
+        assert torch.equal(idx.cpu(), g["step_idx"][t])
+    torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
+    torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], rtol=1e-9, atol=1e-9)
+    rows_s, res_s = outs["steps"]
+    torch.testing.assert_close(res.filter_means, res_s.filter_means, **tol)
+    torch.testing.assert_close(res.loglikelihood, res_s.loglikelihood, rtol=1e-9, atol=1e-9)
+    for (x, w, ll, idx), (xs, ws, lls, idxs) in zip(rows, rows_s):
+        torch.testing.assert_close(x, xs, **tol)
+        assert torch.equal(idx, idxs)
