@@ -1084,75 +1084,11 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
                     idx[j] = res;
                 }
             } else {
-                // Systematic grid, inverted (grid_count): every staged cdf entry computes how many of the round's positions
-                // lie at or below it; entry q owns positions [K_{q-1}, K_q) and writes its index at the head of that
-                // range; a running maximum over the round's positions spreads the heads.  No search, no divergence.
-                const int RE = g.round_elems, r0i = (int)r0;
-                int cn0[VEC], cn1[VEC];
-                if (pow2) {
-                    grid_counts_local<T, VEC, true>(c0, ub, nT, rcN, N, r0i, RE, cn0);
-                    grid_counts_local<T, VEC, true>(c1, ub, nT, rcN, N, r0i, RE, cn1);
-                } else {
-                    grid_counts_local<T, VEC, false>(c0, ub, nT, rcN, N, r0i, RE, cn0);
-                    grid_counts_local<T, VEC, false>(c1, ub, nT, rcN, N, r0i, RE, cn1);
-                }
-                const int lane = tid & 63, wid = tid >> 6;
-                if (lane == 63) {
-                    sh_cl[wid] = cn0[VEC - 1];
-                    sh_cl[PF_NWAVES + wid] = cn1[VEC - 1];
-                }
-                __syncthreads();  // the wave-boundary counts are visible; `hd` is zeroed (top of the round)
-                int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[VEC - 1], 0);
-                if (lane == 0) {
-                    pv0 = wid ? sh_cl[wid - 1] : 0;  // entries before the window own no position of this round
-                    pv1 = sh_cl[PF_NWAVES + wid - 1];  // wave 0: the first half's last entry
-                }
-                const int covered = sh_cl[2 * PF_NWAVES - 1];  // positions of this round the window accounts for
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
-                    if (cn0[j] > lo0) hd[lo0] = tid * VEC + j + 1;
-                    if (cn1[j] > lo1) hd[lo1] = (PF_BLOCK + tid) * VEC + j + 1;
-                }
-                __syncthreads();
-                int h[VEC];
-                if (VEC == 1) h[0] = hd[tid]; else load_vec<int, VEC>(hd + tid * VEC, h);
-#ifdef PF_DEVTOOLS
-                if (tid == 0) {
-                    atomicAdd(&a.dbg[22], 1ull);                       // rounds
-                    if (h[0] == 0) atomicAdd(&a.dbg[23], 1ull);        // rounds without a head at position 0
-                    if (covered == 0) atomicAdd(&a.dbg[24], 1ull);
-                    if (covered < RE) atomicAdd(&a.dbg[25], 1ull);
-                    if (h[0] == 0 && b == 0 && atomicAdd(&a.dbg[26], 1ull) == 0) {
-                        a.dbg[27] = (unsigned long long)k; a.dbg[28] = (unsigned long long)j0; a.dbg[29] = (unsigned long long)cn0[0];
-                        a.dbg[30] = (unsigned long long)cn0[VEC - 1]; a.dbg[31] = (unsigned long long)__float_as_uint((float)c0[VEC - 1]);
-                    }
-                }
-#endif
-#pragma unroll
-                for (int j = 1; j < VEC; ++j) h[j] = imax(h[j], h[j - 1]);
-                const int inc = wave_scan_max(h[VEC - 1]);
-                if (lane == 63) sh_wm[wid] = inc;
-                __syncthreads();
-                int carry = wave_prev(inc, 0);
-#pragma unroll
-                for (int w = 0; w < PF_NWAVES - 1; ++w) carry = (w < wid) ? imax(carry, sh_wm[w]) : carry;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    const int64_t i = i0 + j;
-                    const int q = imax(carry, h[j]);
-                    int res = ws + q - 1;
-                    if (i < N && (tid * VEC + j >= covered || q == 0)) {
-                        // the window ended before this position (a stretch of negligible weights) - or, defensively, no
-                        // head precedes it: binary search in the implied cdf
-                        const int from = (q == 0) ? 0 : (ws + WIN < N ? ws + WIN : N);
-#ifdef PF_DEVTOOLS
-                        atomicAdd(&a.dbg[q == 0 ? 21 : 20], 1ull);
-#endif
-                        res = view.lower_bound(from, N, grid_position<T>(i, ub, nT));
-                    }
-                    idx[j] = (i < N && res < N) ? res : N - 1;
-                }
+                // Systematic grid, inverted: no search (inverse_grid_round); positions the window does not reach take a
+                // binary search in the implied cdf
+                inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                                           [&](int64_t i, int from) { return view.lower_bound(from, N, grid_position<T>(i, ub, nT)); },
+                                           idx);
             }
             if (r + 1 < g.rounds_per_tile) {  // the next round's window starts at this round's last ancestor
                 if (tid == PF_BLOCK - 1) sh_j0 = idx[VEC - 1];

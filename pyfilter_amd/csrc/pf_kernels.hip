@@ -192,6 +192,67 @@ __device__ __forceinline__ void grid_counts_local(const T (&c)[VEC], T u, T nT, 
     }
 }
 
+// One round of 256 * VEC consecutive systematic grid positions [r0, r0 + RE) against the 2 * 256 * VEC cdf entries
+// starting at ws that the threads hold in registers (c0: entries ws + tid * VEC + j, c1: the same + 256 * VEC; +inf
+// beyond the column).  Every entry computes how many of the round's positions lie at or below it (grid_count); entry q
+// owns positions [K_{q-1}, K_q) and writes q + 1 at the head of that range in `hd`; a running maximum over the round's
+// positions spreads the heads.  No search, no divergence.  `hd` (RE ints) must have been zeroed by every thread before
+// the call (the first barrier inside orders that against the scatter); `fallback(i, from)` resolves positions the
+// window does not reach (from = first index not staged, or 0 when - defensively - no head precedes the position).
+// sh_cl: 2 * PF_NWAVES ints, sh_wm: PF_NWAVES ints.  Three barriers.
+template <typename T, int VEC, typename Fallback>
+__device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (&c1)[VEC], int ws, int r0i, int RE, int N,
+                                                   T ub, T nT, T rcN, bool pow2, int64_t i0, int* hd, int* sh_cl, int* sh_wm,
+                                                   Fallback&& fallback, int (&idx)[VEC]) {
+    constexpr int WIN = 2 * PF_BLOCK * VEC;
+    const int tid = threadIdx.x;
+    int cn0[VEC], cn1[VEC];
+    if (pow2) {
+        grid_counts_local<T, VEC, true>(c0, ub, nT, rcN, N, r0i, RE, cn0);
+        grid_counts_local<T, VEC, true>(c1, ub, nT, rcN, N, r0i, RE, cn1);
+    } else {
+        grid_counts_local<T, VEC, false>(c0, ub, nT, rcN, N, r0i, RE, cn0);
+        grid_counts_local<T, VEC, false>(c1, ub, nT, rcN, N, r0i, RE, cn1);
+    }
+    const int lane = tid & 63, wid = tid >> 6;
+    if (lane == 63) {
+        sh_cl[wid] = cn0[VEC - 1];
+        sh_cl[PF_NWAVES + wid] = cn1[VEC - 1];
+    }
+    __syncthreads();  // the wave-boundary counts are visible; `hd` is zeroed
+    int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[VEC - 1], 0);
+    if (lane == 0) {
+        pv0 = wid ? sh_cl[wid - 1] : 0;    // entries before the window own no position of this round
+        pv1 = sh_cl[PF_NWAVES + wid - 1];  // wave 0: the first half's last entry
+    }
+    const int covered = sh_cl[2 * PF_NWAVES - 1];  // positions of this round the window accounts for
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
+        if (cn0[j] > lo0) hd[lo0] = tid * VEC + j + 1;
+        if (cn1[j] > lo1) hd[lo1] = (PF_BLOCK + tid) * VEC + j + 1;
+    }
+    __syncthreads();
+    int h[VEC];
+    if (VEC == 1) h[0] = hd[tid]; else load_vec<int, VEC>(hd + tid * VEC, h);
+#pragma unroll
+    for (int j = 1; j < VEC; ++j) h[j] = imax(h[j], h[j - 1]);
+    const int inc = wave_scan_max(h[VEC - 1]);
+    if (lane == 63) sh_wm[wid] = inc;
+    __syncthreads();
+    int carry = wave_prev(inc, 0);
+#pragma unroll
+    for (int w = 0; w < PF_NWAVES - 1; ++w) carry = (w < wid) ? imax(carry, sh_wm[w]) : carry;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int64_t i = i0 + j;
+        const int q = imax(carry, h[j]);
+        int res = ws + q - 1;
+        if (i < N && (tid * VEC + j >= covered || q == 0)) res = fallback(i, (q == 0) ? 0 : (ws + WIN < N ? ws + WIN : N));
+        idx[j] = (i < N && res < N) ? res : N - 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Window search shared by the stand-alone resampler and the fused step kernel.
 // For one round of 256*VEC consecutive grid positions: stage cdf[j0, j0 + WIN) in LDS, every thread lower_bounds its
@@ -485,7 +546,7 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, const T* __restrict__ u,
                                                      int u_per_elem, const T* __restrict__ v, int multinomial, uint64_t seed,
                                                      uint32_t step, const uint8_t* colmask, int32_t* __restrict__ idx,
-                                                     Geom g) {
+                                                     Geom g, int force_search) {
     __shared__ __attribute__((aligned(32))) T win[SearchWin<T, VEC>::WIN];
     __shared__ int sh_j0;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -504,6 +565,47 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
             if (lane == 0) sh_j0 = j0;
         }
         __syncthreads();
+        // one u per column and a grid the closed form is exact for: ancestors from the inverted grid, no search
+        const bool inverse = !u_per_elem && !force_search && !(sizeof(T) == 4 && N > (1 << 22));
+        if (inverse) {
+            __shared__ int sh_cl[2 * PF_NWAVES], sh_wm[PF_NWAVES];
+            int* hd = reinterpret_cast<int*>(win);
+            const int tid = threadIdx.x;
+            const T nT = T(N), rcN = T(1) / nT;
+            const bool pow2 = (N & (N - 1)) == 0;
+            for (int r = 0; r < g.rounds_per_tile; ++r) {
+                const int64_t r0 = base + (int64_t)r * g.round_elems;
+                if (r0 >= g.N) break;
+                const int64_t i0 = r0 + tid * VEC;
+                const int j0 = sh_j0;
+                const int ws = j0 - (j0 % VEC);
+                {
+                    int zero[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) zero[j] = 0;
+                    if (VEC == 1) hd[tid] = 0; else store_vec<int, VEC>(hd + tid * VEC, zero);
+                }
+                T c0[VEC], c1[VEC];
+                const int ja = ws + tid * VEC, jb = ws + (PF_BLOCK + tid) * VEC;
+                if (ja < N) { if (VEC == 1) c0[0] = col[ja]; else load_vec<T, VEC>(col + ja, c0); }
+                if (jb < N) { if (VEC == 1) c1[0] = col[jb]; else load_vec<T, VEC>(col + jb, c1); }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (!(ja < N)) c0[j] = Lim<T>::inf();
+                    if (!(jb < N)) c1[j] = Lim<T>::inf();
+                }
+                int res[VEC];
+                inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                                           [&](int64_t i, int from) { return thread_lower_bound<T>(col, from, N, grid_position<T>(i, ub, nT)); },
+                                           res);
+                if (i0 < g.N) {
+                    if (VEC == 1) out[i0] = res[0]; else store_vec<int, VEC>(out + i0, res);
+                }
+                if (tid == PF_BLOCK - 1) sh_j0 = res[VEC - 1];  // next round's window starts at this round's last ancestor
+                __syncthreads();
+            }
+            return;
+        }
         for (int r = 0; r < g.rounds_per_tile; ++r) {
             const int64_t r0 = base + (int64_t)r * g.round_elems;
             if (r0 >= g.N) break;
@@ -847,7 +949,8 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
                            (const double*)part, g);                                                                  \
     }                                                                                                                \
     hipLaunchKernelGGL((k_search<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u, u_per_elem,        \
-                       (const T*)v, multinomial, seed, step, colmask, idx, g);
+                       (const T*)v, multinomial, seed, step, colmask, idx, g, force_search);
+    static const int force_search = getenv("PF_FORCE_SEARCH") != nullptr;  // testing knob: the searching variant at any size
     PF_DISPATCH_T_VEC(dtype, g.vec, CALL)
 #undef CALL
     PF_CHECK_LAUNCH();

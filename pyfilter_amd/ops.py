@@ -8,6 +8,7 @@ The reference-layout API (``(N, [B], [D])``, particles first: pyfilter/filters/p
 ``pyfilter_amd.utils`` / ``resampling`` / ``filters`` and hands *views* of these buffers to the user.
 """
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -89,9 +90,12 @@ def gather_filters(t: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
     b = t.shape[1]
     if idx.numel() != b:
         return t[:, indices]  # a different number of filters out than in: not the in-place resample of the reference
-    lo, hi = int(idx.min()), int(idx.max())
-    if lo < -b or hi >= b:
-        raise IndexError(f"index {hi if hi >= b else lo} is out of bounds for dimension 1 with size {b}")
+    # bounds check without a host round trip where torch offers the asynchronous assert (as torch's own CUDA indexing does)
+    ok = ((idx >= -b) & (idx < b)).all()
+    if hasattr(torch, "_assert_async") and os.environ.get("PF_SYNC_CHECKS", "0") != "1":
+        torch._assert_async(ok)
+    elif not bool(ok):
+        raise IndexError(f"index out of bounds for dimension 1 with size {b}")
     src, rebuild = _batch_view(t)
     dst = torch.empty_like(src)
     planes, _, n = src.shape

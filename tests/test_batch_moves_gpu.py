@@ -46,7 +46,8 @@ def test_gather_and_exchange_match_torch_indexing(ops, dtype, n, b, tail):
         assert torch.equal(got, want) and torch.equal(t, want)  # in place
 
 
-def test_gather_rejects_out_of_range(ops):
+def test_gather_rejects_out_of_range(ops, monkeypatch):
+    monkeypatch.setenv("PF_SYNC_CHECKS", "1")  # (the default check is torch's asynchronous device-side assert)
     t = torch.zeros(64, 4, device="cuda")
     with pytest.raises(IndexError):
         ops.gather_filters(t, torch.tensor([0, 1, 2, 4], device="cuda"))
