@@ -652,7 +652,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_gather(const T* __restrict__ x, co
 // contiguous run of N elements; a workgroup moves PF_COLCHUNK bytes of one column of one plane with 16-byte accesses
 // (8 / 4-byte ones when the column size or the base addresses are not 16-byte multiples).  idx == nullptr: identity
 // (exchange); mask == nullptr: every column.
-#define PF_COLCHUNK (PF_BLOCK * 16 * 4)
+#define PF_COLCHUNK (PF_BLOCK * 16 * 8)
+typedef unsigned int pf_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int pf_v2u __attribute__((ext_vector_type(2)));
 template <typename V>
 __global__ __launch_bounds__(PF_BLOCK) void k_columns_move(const char* __restrict__ src, const int64_t* __restrict__ idx,
                                                            const uint8_t* __restrict__ mask, char* __restrict__ dst,
@@ -667,15 +669,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_columns_move(const char* __restric
     const int64_t per_wg = PF_COLCHUNK / (int64_t)sizeof(V);
     const int64_t lo = (int64_t)blockIdx.x * per_wg;
     const int64_t hi = lo + per_wg < n ? lo + per_wg : n;
-    // four independent 16-byte loads in flight per thread before the first store
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 4 * PF_BLOCK) {
-        V v[4];
+    // eight independent 16-byte loads in flight per thread before the first store
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 8 * PF_BLOCK) {
+        V v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (i + q * PF_BLOCK < hi) v[q] = s[i + q * PF_BLOCK];
+        for (int q = 0; q < 8; ++q)
+            if (i + q * PF_BLOCK < hi) v[q] = __builtin_nontemporal_load(s + i + q * PF_BLOCK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (i + q * PF_BLOCK < hi) d[i + q * PF_BLOCK] = v[q];
+        for (int q = 0; q < 8; ++q)
+            if (i + q * PF_BLOCK < hi) __builtin_nontemporal_store(v[q], d + i + q * PF_BLOCK);
     }
 }
 
@@ -1005,8 +1007,8 @@ static int columns_move(const void* src, const int64_t* idx, const uint8_t* mask
     const uintptr_t al = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)col_bytes;
     const char* s = (const char*)src;
     char* d = (char*)dst;
-    if ((al & 15) == 0) hipLaunchKernelGGL((k_columns_move<uint4>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
-    else if ((al & 7) == 0) hipLaunchKernelGGL((k_columns_move<uint2>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
+    if ((al & 15) == 0) hipLaunchKernelGGL((k_columns_move<pf_v4u>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
+    else if ((al & 7) == 0) hipLaunchKernelGGL((k_columns_move<pf_v2u>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
     else hipLaunchKernelGGL((k_columns_move<uint32_t>), grid, dim3(PF_BLOCK), 0, st, s, idx, mask, d, col_bytes, (int)B);
     PF_CHECK_LAUNCH();
     return PF_OK;
