@@ -163,3 +163,46 @@ def test_gather_moments(pf, dt, n, b, d):
 def test_cpu_tensor_is_rejected(pf):
     with pytest.raises(RuntimeError):
         pf.utils.normalize(torch.zeros(10))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_residual_resampling(pf, dt):
+    """``residual`` (resampling.py:68-105): the deterministic part - floor(N W_j) copies of particle j, in order - is the
+    reference's ``repeat_interleave`` exactly; the remaining positions are multinomial draws from the residual weights
+    (checked in distribution); batched input works per column."""
+    from pyfilter_amd import resampling
+
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(3)
+    n = 4000
+    w = torch.rand(n, generator=g, dtype=torch.float64).pow(3)
+    W = (w / w.sum()).to(dtype)
+    idx = resampling.residual(W.cuda(), normalized=True, seed=11).cpu()
+    mw = W.double() * n
+    floored = mw.floor()
+    m = int(floored.sum())
+    det = torch.arange(n).repeat_interleave(floored.long())     # what the reference writes to out[:numelems]
+    assert idx.dtype == torch.int64 and idx.shape == (n,)
+    assert torch.equal(idx[:m], det)
+    # residual part: counts ~ Multinomial(n - m, res / sum(res)); pooled chi-square over 20 equal-mass bins
+    res = (mw - floored) / (mw - floored).sum()
+    order = torch.argsort(res.cumsum(0))  # identity; bins by cumulative residual mass
+    edges = torch.searchsorted(res.cumsum(0), torch.linspace(0, 1, 21)[1:-1])
+    bins = torch.bucketize(idx[m:], edges, right=True)
+    obs = torch.bincount(bins, minlength=20).double()
+    cum = torch.cat([torch.zeros(1, dtype=torch.float64), res.cumsum(0)])
+    bounds = torch.cat([torch.zeros(1, dtype=torch.long), edges, torch.tensor([n])])
+    exp = (cum[bounds[1:]] - cum[bounds[:-1]]) * (n - m)
+    chi2 = ((obs - exp) ** 2 / exp.clamp_min(1e-9)).sum().item()
+    assert chi2 < 60.0, chi2          # 19 dof: P(chi2 > 60) ~ 3e-6
+    assert order.numel() == n
+    # batched: every column's deterministic prefix
+    Wb = torch.stack([W, W.flip(0)], dim=1)
+    ib = resampling.residual(Wb.cuda(), normalized=True, seed=5).cpu()
+    assert ib.shape == (n, 2) and torch.equal(ib[:m, 0], det)
+    det2 = torch.arange(n).repeat_interleave((W.flip(0).double() * n).floor().long())
+    assert torch.equal(ib[:det2.numel(), 1], det2)
+    # all-deterministic corner: uniform weights
+    iu = resampling.residual(torch.full((256,), 1.0 / 256, dtype=dtype).cuda(), normalized=True).cpu()
+    assert torch.equal(iu, torch.arange(256))
