@@ -896,6 +896,9 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
     const int N = (int)g.N;
     PF_STAMP(a, 8);
     if (PF_CUT(a, 1)) return;
+#ifdef PF_DEVTOOLS
+    if (a.debug_cut < 0 && tid == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[16 + k / 128] = wall_clock64();
+#endif
 
     // uniform loads first: the window start and the column's parameter rows
     int j0 = (windowed && !multinomial) ? a.j0[(int64_t)b * g.tiles + k] : 0;
@@ -1231,6 +1234,9 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
                                    },
                                    g.rounds_per_tile == 1, e_rw, pre_next ? F2 : F1, reds);
     PF_STAMP(a, 15);
+#ifdef PF_DEVTOOLS
+    if (a.debug_cut < 0 && tid == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[24 + k / 128] = wall_clock64();
+#endif
 }
 
 }  // namespace pf

@@ -517,3 +517,19 @@ def test_residual_resampler_in_a_filter(filt_name):
     # fraction of n, so the run-to-run spread is several times sqrt(var / n): measured 0.04 on the first mean, 0.25 on ll)
     assert ((out["residual"].filter_means[1:] - out["systematic"].filter_means[1:]).abs() <= 8.0 * se + 0.08).all()
     assert abs((out["residual"].loglikelihood - out["systematic"].loglikelihood).item()) < 0.6
+
+
+def test_multi_round_tiles_pass_the_parity_suite():
+    """Tiles of several rounds (the geometry of the multi-million-particle configurations: a workgroup walks R rounds of
+    1024 particles, re-reads the state for the tile-local scan, chains the window start from round to round) are reached
+    at test sizes by lowering the workgroup target: PF_TARGET_WGS=2 gives R up to 16 for the float64 parity cases."""
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    for wgs in ("2", "16"):
+        env = dict(os.environ, PF_TARGET_WGS=wgs)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_filters_gpu.py"), "-m", "gpu", "-q", "-x",
+                            "-k", "benchmark_sizes or ragged or weight_collapse or matches_reference"],
+                           env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, f"PF_TARGET_WGS={wgs}\n" + r.stdout[-3000:] + r.stderr[-2000:]

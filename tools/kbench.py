@@ -84,16 +84,6 @@ def main():
             f.batch_filter(y, bar=False)
             k = f.kernel_ms
         n, b = cfg[3], cfg[4]
-        if os.environ.get("PF_AMD_LIB"):
-            import ctypes as C
-            from pyfilter_amd import _lib as L
-            off = C.c_size_t(0)
-            lib = L.load()
-            lib.pf_debug_offset.argtypes = [C.c_int64, C.c_int64, C.POINTER(C.c_size_t)]
-            lib.pf_debug_offset(cfg[3], cfg[4], C.byref(off))
-            st = f._last_run["ws"][off.value:off.value + 256].view(torch.int64).cpu().tolist()
-            print("   dev counters: fallback searches", st[20], " headless positions", st[21], " rounds", st[22], " no head at 0:", st[23],
-                  " covered==0:", st[24], " covered<RE:", st[25], " first bad (k, j0, cn0[0], cn0[3], c0[3] bits):", st[27:32])
         if int(os.environ.get("PF_DEBUG_CUT", "0")) < 0:
             import ctypes as C
             from pyfilter_amd import _lib as L
@@ -106,6 +96,9 @@ def main():
             sc = [st[i] - st[0] for i in range(0, 7)]
             sp = [st[i] - st[8] for i in range(8, 16)]
             print("   scan stamps (cycles from start: combine_done, finalize_done, pre-loop, pre-blockscan, post-blockscan, round_end):", sc[1:], " (PF_DEBUG_CUT=-(tile+1) selects the stamped tile)")
+            t0w = min(st[16:24])
+            print("   wall clock (10 ns ticks since the first of 8 sampled workgroups, tiles 0,128,..,896): start", [v - t0w for v in st[16:24]],
+                  " end", [v - t0w for v in st[24:32]])
             print("   step stamps (cycles from start: params, pre-loop, search_done, compute_done, push_done, pre-finish, end):", sp[1:])
         print(f"{name:22s} us/step {1e6 * wall / T:8.2f}  particle-steps/s {n * b * T / wall:10.3e}  kernels(us, event-bracketed) "
               f"scan {1e3 * k[1]:7.2f} step {1e3 * k[2]:7.2f}  ll {res.loglikelihood.reshape(-1)[0].item():.3f}", flush=True)
