@@ -1033,23 +1033,26 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
             if (from_local) {  // local scans -> cdf values (a staged vector never straddles a tile: tile % VEC == 0)
                 // tile of each staged vector: kt0 is the tile of j0 (from the planning kernel / carried between rounds); a
                 // window spans at most a few tiles, so two compares replace the integer divisions
-                while ((int64_t)(kt0 + 1) * g.tile_elems <= ws) ++kt0;  // uniform; only advances between rounds
+                // (indices inside a column fit 32 bits - N <= 2^30 - and unsigned compares absorb the one possible wrap)
+                const int te = g.tile_elems;
+                while ((unsigned)((kt0 + 1) * te) <= (unsigned)ws) ++kt0;  // uniform; only advances between rounds
                 int kta = kt0, ktb = kt0;
                 {
-                    const int64_t e1 = (int64_t)(kt0 + 1) * g.tile_elems, e2 = e1 + g.tile_elems, e3 = e2 + g.tile_elems;
-                    kta += (ja >= e1) + (ja >= e2) + (ja >= e3);
-                    ktb += (jb >= e1) + (jb >= e2) + (jb >= e3);
+                    const unsigned e1 = (unsigned)(kt0 + 1) * te, e2 = e1 + te, e3 = e2 + te;
+                    kta += ((unsigned)ja >= e1) + ((unsigned)ja >= e2) + ((unsigned)ja >= e3);
+                    ktb += ((unsigned)jb >= e1) + ((unsigned)jb >= e2) + ((unsigned)jb >= e3);
                     if (!ina) kta = kt0;
                     if (!inb) ktb = kt0;
                 }
                 const double tPa = ptab_col[kta], tNa = ptab_col[kta + 1], tFa = ftab_col[kta];
                 const double tPb = ptab_col[ktb], tNb = ptab_col[ktb + 1], tFb = ftab_col[ktb];
-                const int64_t la = ((int64_t)(kta + 1) * g.tile_elems < g.N ? (int64_t)(kta + 1) * g.tile_elems : g.N) - 1;
-                const int64_t lb = ((int64_t)(ktb + 1) * g.tile_elems < g.N ? (int64_t)(ktb + 1) * g.tile_elems : g.N) - 1;
+                const unsigned ea = (unsigned)(kta + 1) * te, eb = (unsigned)(ktb + 1) * te;
+                const int la = (int)(ea < (unsigned)N ? ea : (unsigned)N) - 1;
+                const int lb = (int)(eb < (unsigned)N ? eb : (unsigned)N) - 1;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    if (ina) c0[j] = cdf_from_local<T>(c0[j], tPa, tFa, tNa, ja + j == la, ja + j == g.N - 1);
-                    if (inb) c1[j] = cdf_from_local<T>(c1[j], tPb, tFb, tNb, jb + j == lb, jb + j == g.N - 1);
+                    if (ina) c0[j] = cdf_from_local<T>(c0[j], tPa, tFa, tNa, ja + j == la, ja + j == N - 1);
+                    if (inb) c1[j] = cdf_from_local<T>(c1[j], tPb, tFb, tNb, jb + j == lb, jb + j == N - 1);
                 }
             }
 #pragma unroll

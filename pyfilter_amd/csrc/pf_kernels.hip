@@ -196,7 +196,7 @@ __device__ __forceinline__ void grid_counts_local(const T (&c)[VEC], T u, T nT, 
 // starting at ws that the threads hold in registers (c0: entries ws + tid * VEC + j, c1: the same + 256 * VEC; +inf
 // beyond the column).  Every entry computes how many of the round's positions lie at or below it (grid_count); entry q
 // owns positions [K_{q-1}, K_q) and writes q + 1 at the head of that range in `hd`; a running maximum over the round's
-// positions spreads the heads.  No search, no divergence.  `hd` (RE ints) must have been zeroed by every thread before
+// positions spreads the heads.  No search, no divergence.  `hd` (RE + 64 ints) must have its first RE entries zeroed before
 // the call (the first barrier inside orders that against the scatter); `fallback(i, from)` resolves positions the
 // window does not reach (from = first index not staged, or 0 when - defensively - no head precedes the position).
 // sh_cl: 2 * PF_NWAVES ints, sh_wm: PF_NWAVES ints.  Three barriers.
@@ -226,11 +226,14 @@ __device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (
         pv1 = sh_cl[PF_NWAVES + wid - 1];  // wave 0: the first half's last entry
     }
     const int covered = sh_cl[2 * PF_NWAVES - 1];  // positions of this round the window accounts for
+    // branch-free scatter: entries without offspring in this round write to a per-lane dump slot behind the RE heads
+    // (exec-mask juggling per conditional store costs ~5 scalar instructions, a v_cndmask one vector instruction)
+    const int dump = RE + lane;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
-        if (cn0[j] > lo0) hd[lo0] = tid * VEC + j + 1;
-        if (cn1[j] > lo1) hd[lo1] = (PF_BLOCK + tid) * VEC + j + 1;
+        hd[(cn0[j] > lo0) ? lo0 : dump] = tid * VEC + j + 1;
+        hd[(cn1[j] > lo1) ? lo1 : dump] = (PF_BLOCK + tid) * VEC + j + 1;
     }
     __syncthreads();
     int h[VEC];

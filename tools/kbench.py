@@ -51,6 +51,10 @@ CONFIGS = {
     "apf_lgo_64x64k": ("sine", "apf", "lgo", 65536, 64),
     "apf_lgo_1024x8k": ("sine", "apf", "lgo", 8192, 1024),
     "apf_lgo_256k": ("sine", "apf", "lgo", 1 << 18, 1),
+    "apf_lgo_512k": ("sine", "apf", "lgo", 1 << 19, 1),
+    "apf_lgo_2m": ("sine", "apf", "lgo", 1 << 21, 1),
+    "apf_lgo_16x64k": ("sine", "apf", "lgo", 65536, 16),
+    "apf_lgo_32x64k": ("sine", "apf", "lgo", 65536, 32),
     "sisr_lorenz_4m": ("lorenz", "sisr", "bootstrap", 1 << 22, 1),
     "sisr_lorenz_4m_mn": ("lorenz", "sisr", "bootstrap", 1 << 22, 1, "multinomial"),
 }
