@@ -33,6 +33,16 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     }
     return Philox4{c0, c1, c2, c3};
 }
+// The same with the (wave-uniform) key carried in vector registers: the compiler would otherwise precompute the 20 round
+// keys in scalar registers - in the step kernel, whose scalar file is oversubscribed, each of them costs a spill and a
+// reload (v_writelane / v_readlane) on top of its s_add; two v_add per round are cheaper.
+__device__ __forceinline__ Philox4 philox4x32_10_vkey(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                      uint32_t k1) {
+    uint32_t v0, v1;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v0) : "s"(k0));
+    asm volatile("v_mov_b32 %0, %1" : "=v"(v1) : "s"(k1));
+    return philox4x32_10(c0, c1, c2, c3, v0, v1);
+}
 
 // streams
 enum { PF_STREAM_NORMAL = 0, PF_STREAM_UNIFORM = 1, PF_STREAM_INIT = 2, PF_STREAM_MULTINOMIAL = 3 };
@@ -72,7 +82,7 @@ template <typename T> struct NormalCall;
 template <> struct NormalCall<float> {
     static constexpr int NPC = 4;
     __device__ __forceinline__ static void call(uint64_t seed, uint32_t stream, uint32_t step, uint64_t c, float (&z)[4]) {
-        const Philox4 r = philox4x32_10((uint32_t)c, (uint32_t)(c >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const Philox4 r = philox4x32_10_vkey((uint32_t)c, (uint32_t)(c >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
         box_muller(u01_open0(r.x), u01(r.y), z[0], z[1]);
         box_muller(u01_open0(r.z), u01(r.w), z[2], z[3]);
     }
