@@ -257,23 +257,36 @@ __device__ __forceinline__ T cdf_from_local(T L, double Pk, double fk, double Pn
     if (tile_last) r = col_last ? T(1) : (T)Pnext;
     return r;
 }
-template <typename T> struct CdfView {  // random access to the implied cdf of one column (slow path / searches)
+template <typename T> struct CdfView {  // searches in the implied cdf of one column (slow path)
     const T* L;
     const double* ptab;  // this column's (tiles + 1) prefixes
     const double* ftab;
-    int64_t N;
+    int N;
     int tile_elems;
-    __device__ __forceinline__ T at(int64_t i) const {
-        const int kt = (int)(i / tile_elems);
-        const int64_t last = ((int64_t)(kt + 1) * tile_elems < N ? (int64_t)(kt + 1) * tile_elems : N) - 1;
-        return cdf_from_local<T>(L[i], ptab[kt], ftab[kt], ptab[kt + 1], i == last, i == N - 1);
-    }
-    __device__ __forceinline__ int lower_bound(int lo, int hi, T p) const {
+    int tiles;
+    // first i in [from, N) with cdf(i) >= p (N if none), given a tile index kt_lo at or below the tile of `from`.
+    // Two levels - the tile by its end value T(P_{kt+1}) (1 for the last tile), then the element inside that tile with
+    // the tile's (P, f) held in registers - so there is no index / tile_elems division anywhere.
+    __device__ __forceinline__ int lower_bound(int from, T p, int kt_lo) const {
+        if (from >= N) return N;
+        int lo = kt_lo, hi = tiles - 1;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (at(mid) < p) lo = mid + 1; else hi = mid;
+            if ((T)ptab[mid + 1] < p) lo = mid + 1; else hi = mid;
         }
-        return lo;
+        for (int kt = lo; kt < tiles; ++kt) {  // (one pass unless `from` lies beyond every qualifying element of tile lo)
+            const int first = kt * tile_elems;
+            const int end = first + tile_elems < N ? first + tile_elems : N;
+            int a = from > first ? from : first, b = end;
+            if (a >= b) continue;
+            const double Pk = ptab[kt], fk = ftab[kt], Pn = ptab[kt + 1];
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (cdf_from_local<T>(L[mid], Pk, fk, Pn, mid == end - 1, mid == N - 1) < p) a = mid + 1; else b = mid;
+            }
+            if (a < end) return a;
+        }
+        return N;
     }
 };
 
@@ -942,8 +955,9 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
     view.L = cdf_col;
     view.ptab = ptab_col;
     view.ftab = ftab_col;
-    view.N = g.N;
+    view.N = N;
     view.tile_elems = g.tile_elems;
+    view.tiles = g.tiles;
     if (windowed && multinomial) {
         // no position-tile table for the sorted uniforms: one wave finds the window start with a 64-ary search
         if (tid < PF_WAVE) {
@@ -1083,7 +1097,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
                         const int q = window_lower_bound<T, WIN>(win, guess, p);
                         guess = q < WIN ? q : WIN - 1;
                         if (q < WIN) res = ws + q;
-                        else if (from_local) res = view.lower_bound(ws + WIN < N ? ws + WIN : N, N, p);
+                        else if (from_local) res = view.lower_bound(ws + WIN < N ? ws + WIN : N, p, kt0);
                         else res = thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
                         if (res > N - 1) res = N - 1;
                     }
@@ -1093,7 +1107,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
                 // Systematic grid, inverted: no search (inverse_grid_round); positions the window does not reach take a
                 // binary search in the implied cdf
                 inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
-                                           [&](int64_t i, int from) { return view.lower_bound(from, N, grid_position<T>(i, ub, nT)); },
+                                           [&](int64_t i, int from) { return view.lower_bound(from, grid_position<T>(i, ub, nT), from ? kt0 : 0); },
                                            idx);
             }
             if (r + 1 < g.rounds_per_tile) {  // the next round's window starts at this round's last ancestor
