@@ -114,16 +114,11 @@ def build_problem(name, dtype, device, world, rank, t_override=None):
 
 def alg_bytes_per_particle(w, kernel, e=4):
     """Algorithmic HBM bytes per particle per launch (e = bytes per state / weight element, ancestors
-    are int32).  Systematic pipeline: the planning kernel touches no per-particle data (tile partials + a few probes);
-    the step kernel reads the local scans L (e) and x[anc] (e D), writes x' (e D), logw' (e), the next L (e), anc (4).
-    Multinomial pipeline: scan reads logw (e) [+ x (e D) for the APF] and writes cdf (e) + sorted positions (e); step
-    reads cdf (e) + positions (e) + x[anc] (e D), writes x' (e D), logw' (e), anc (4)."""
+    are int32).  The planning kernel touches no per-particle data (tile partials + a few probes); the step kernel reads
+    the local scans L (e) and x[anc] (e D), writes x' (e D), logw' (e), the next L (e), anc (4) - for both resamplers
+    (the multinomial positions are regenerated in registers)."""
     d = w["D"]
-    if w["resampler"] == "systematic":
-        return 0 if kernel == "plan" else e * (3 + 2 * d) + 4
-    if kernel == "plan":  # = k_fused_scan here
-        return e * 3 + (e * d if w["filter"] == "apf" else 0)
-    return e * (3 + 2 * d) + 4
+    return 0 if kernel == "plan" else e * (3 + 2 * d) + 4
 
 
 def cpu_baseline(name, w, seconds_budget=15.0):
@@ -287,7 +282,7 @@ def main():
     filt._time_kernels = False
     kms = dict(zip(("plan", "step"), filt.kernel_ms[1:3]))  # two kernels per time step
     names = ("plan", "step")
-    kname = {"plan": "k_fused_plan" if w["resampler"] == "systematic" else "k_fused_scan", "step": "k_fused_step"}
+    kname = {"plan": "k_fused_plan", "step": "k_fused_step"}
     dom = max(names, key=lambda k: kms[k])
     esz = 8 if dtype == torch.float64 else 4
     launch_bytes = {k: alg_bytes_per_particle(w, k, esz) * w["N"] * w["B"] for k in names}

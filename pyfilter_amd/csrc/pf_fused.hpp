@@ -10,7 +10,9 @@
 //                 (Philox / tape), weighs, stores x', logw', anc - and, while the new state is in registers: the next
 //                 step's per-tile partials (max / sum exp / sum exp^2, pivoted weighted moments, the APF's first-stage
 //                 weights against y_{t+1}) and the tile-local inclusive scan L'_i of the next resampling weights.
-// Multinomial resampling: k_fused_scan (explicit cdf + sorted positions from Exp(1) spacings) + k_fused_step<MODE 1>.
+// Multinomial resampling runs the same two kernels: the sorted resampling positions (order statistics of N iid uniforms)
+// are normalised prefix sums of Exp(1) spacings that the step kernel regenerates per round (Philox + workgroup scan);
+// the planning kernel adds a prefix table of the spacings' tile sums (reduced with the partials one step earlier).
 //
 // k_fused_reduce produces the partials / local scans of the very first state only.  A kernel boundary is the only
 // inter-workgroup synchronisation; the step index, "observed" flags and observation rows are kernel arguments set by
@@ -68,6 +70,8 @@ template <typename T> struct FusedArgs {
     int32_t* k0;      // [B][tiles] tile index of j0
     double* ptab;     // [B][tiles + 1] normalised exclusive prefix of the tiles' resampling mass (P_0 = 0 ... P_tiles ~ 1)
     double* ftab;     // [B][tiles]     exp(m_t - M) / S: scale of tile t's local (max-shifted) sums
+    double* etab;     // [B][tiles + 1] multinomial: exclusive prefix of the tiles' Exp(1) spacing sums; [tiles] = grand
+                      // total incl. the closing spacing (the sorted uniforms are prefix / total)
     T* cpack;         // [B][PK_N] this step's closed-form constants of every column (scalar fast path; see FastCol)
     T* ucol;          // [B] this step's systematic offset u of every column
     int t0;           // first step of this run: the partials of state t0 are taken about pivot 0, later ones about the
@@ -428,20 +432,6 @@ struct ColCombine {
 struct EarlyPartials {
     double m1[PF_COMBINE_ITERS], s1[PF_COMBINE_ITERS], q1[PF_COMBINE_ITERS], m2[PF_COMBINE_ITERS], s2[PF_COMBINE_ITERS];
 };
-// the Exp(1)-spacing prefix for the sorted-uniform multinomial (its own small reduction; systematic runs skip it)
-template <typename T>
-__device__ __forceinline__ void combine_spacings(const FusedArgs<T>& a, int64_t cb, int64_t stride, int k, double* red,
-                                                 double& total, double& prefix) {
-    double v[2] = {0.0, 0.0};
-    for (int t = threadIdx.x; t < a.g.tiles; t += PF_BLOCK) {
-        const double e = a.part_r()[PQ_E * stride + cb + t];
-        v[0] += e;
-        if (t < k) v[1] += e;
-    }
-    block_sum<2>(v, red);
-    total = v[0];
-    prefix = v[1];
-}
 template <typename T>
 __device__ __forceinline__ void load_early_partials(const FusedArgs<T>& a, int64_t cb, int64_t stride, bool two,
                                                     EarlyPartials& e) {
@@ -593,180 +583,6 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
     }
 }
 
-// Scan kernel of the MULTINOMIAL pipeline (the systematic one uses k_fused_plan).  grid (tiles + 1, B): workgroups
-// k < tiles scan their tile of resampling weights into the explicit cdf and their tile of Exp(1) spacings into the sorted
-// resampling positions; the extra workgroup k == tiles is the column's bookkeeper.
-template <typename T, int D, int VEC>
-__global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? 4 : 1) void k_fused_scan(FusedArgs<T> a) {
-    __shared__ double red[6 * PF_NWAVES];
-    __shared__ double redm[2 * PF_NWAVES];
-    __shared__ double red2[2 * D * PF_NWAVES];
-    __shared__ double reds[PF_NWAVES];
-    const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
-    const int step = a.step;
-    const int slot = step & 1;
-    const bool obs = !a.finalize_only && a.obs;
-    const bool apf = a.filter == PF_FILTER_APF;
-    const bool two = apf && obs;  // a second (m2, S2) set of partials is live
-    const int64_t stride = (int64_t)g.B * g.tiles;
-    const int64_t cb = (int64_t)b * g.tiles;
-    if (PF_CUT(a, 1)) return;
-    PF_STAMP(a, 0);
-    EarlyPartials early;
-    load_early_partials<T>(a, cb, stride, two, early);
-
-    if (k == g.tiles) {
-        column_bookkeeping<T, D>(a, early, b, cb, stride, obs, apf, two, red, redm, red2);
-        return;
-    }
-    if (a.finalize_only) return;
-
-    // ---------------------------------------------------- scanner ---------------------------------------------------------
-    // 1. everything that does not need the column totals: this tile's log-weights (and particles for the APF's
-    //    in-register pre-weight), its own maximum, the exponentials and the workgroup-local scan (one round per tile is
-    //    the common case; multi-round tiles take the generic loop below)
-    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
-    const T* x_base = a.x[slot];
-    const int64_t base = (int64_t)k * g.tile_elems;
-    const int64_t tile_last = (base + g.tile_elems < g.N ? base + g.tile_elems : g.N) - 1;
-    const double mk = a.part_r()[(two ? PQ_M2 : PQ_M1) * stride + cb + k];
-    const T tile_max = (T)mk;
-    ColParams<T, D> cp;
-    ColConsts<T, D> cc;
-    cc.fast = false;
-    cc.lin_fast = false;
-    if (two) {
-        load_col_params<T, D>(a, b, step, true, cp);
-        cc.prepare(a.md, cp);
-    }
-    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    T* cdf_col = a.cdf + (int64_t)b * g.N;
-
-    auto tile_exponentials = [&](int64_t i0, bool on, double (&e)[VEC]) -> double {
-        T lw[VEC], xv[D][VEC];
-        if (on) {
-            if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
-            if (two) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
-                    if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
-                }
-            }
-        }
-        double local = 0.0;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            double ej = 0.0;
-            if (on) {
-                T rw = lw[j];
-                if (two) {  // APF: rw = sanitize(pre_weight(x, y) + logw), recomputed in registers, never stored
-                    T xj[D];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-                    rw = sanitize_logw(pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) + lw[j]);
-                }
-                ej = (rw == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(rw - tile_max);
-            }
-            local += ej;
-            e[j] = local;  // thread-local inclusive
-        }
-        return local;
-    };
-    // cdf values of one round from the scanned exponentials; stores them and emits the position-tile starts
-    auto write_round = [&](int r, int64_t i0, bool on, const double (&e)[VEC], double offset, double Pk, double fk,
-                           double Pnext) {
-        T outv[VEC];
-        if (on) {
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                double cc_ = Pk + fk * (offset + e[j]);
-                if (cc_ > Pnext) cc_ = Pnext;
-                T c = (T)cc_;
-                // the tile's last element is pinned to T(prefix(k+1)) - the value tile k+1 starts from - and the column's
-                // last element to 1 (cumsum[..., -1] = 1, resampling.py:49)
-                if (i0 + j == tile_last) c = (i0 + j == g.N - 1) ? T(1) : (T)Pnext;
-                outv[j] = c;
-            }
-            if (VEC == 1) cdf_col[i0] = outv[0]; else store_vec<T, VEC>(cdf_col + i0, outv);
-        }
-    };
-
-    const bool single = g.rounds_per_tile == 1;
-    double e0[VEC], excl0 = 0.0;
-    const int64_t i00 = base + threadIdx.x * VEC;
-    if (single) {
-        double total;
-        const double local = tile_exponentials(i00, i00 < g.N, e0);
-        excl0 = block_scan_excl(local, reds, total);
-    }
-    PF_STAMP(a, 1);
-    {
-        // sorted-uniform multinomial: position i = (sum of Exp(1) spacings up to i) / (sum of all N + 1 spacings) - the
-        // order statistics of N iid uniforms; the spacings are regenerated from Philox, scanned like the weights
-        double TE, prefE;
-        combine_spacings<T>(a, cb, stride, k, red, TE, prefE);
-        T tail[1];
-        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)g.B * g.N + b), tail);
-        const double inv = 1.0 / (TE + (double)tail[0]);
-        double carryE = 0.0;
-        T* pos_col = a.pos + (int64_t)b * g.N;
-        for (int r = 0; r < g.rounds_per_tile; ++r) {
-            const int64_t r0 = base + (int64_t)r * g.round_elems;
-            if (r0 >= g.N) break;
-            const int64_t i0 = r0 + threadIdx.x * VEC;
-            const bool on = i0 < g.N;
-            T ev[VEC];
-            double incl[VEC], local = 0.0, total;
-            if (on) draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), ev);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                local += on ? (double)ev[j] : 0.0;
-                incl[j] = local;
-            }
-            const double excl = block_scan_excl(local, reds, total);
-            if (on) {
-                T pv[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) pv[j] = (T)((prefE + carryE + excl + incl[j]) * inv);
-                if (VEC == 1) pos_col[i0] = pv[0]; else store_vec<T, VEC>(pos_col + i0, pv);
-            }
-            carryE += total;
-        }
-    }
-
-    // 2. the column totals
-    const ColCombine c = combine_column<T>(a, early, cb, stride, k, two, red, redm);
-    PF_STAMP(a, 2);
-    const bool resample = apf ? obs : (c.S1 * c.S1 / c.Q1 < a.thr_abs);
-    if (!resample || PF_CUT(a, 2)) return;
-    const double MR = two ? c.m2 : c.m1, SR = two ? c.S2 : c.S1;
-    const double fk = exp_diff_t<T>(mk, MR) / SR;
-    const double Pk = c.prefK / SR;
-    const double Pnext = c.prefK1 / SR;
-    PF_STAMP(a, 3);
-
-    // 3. cdf = P_k + f_k * (scan), rounded per element
-    if (single) {
-        write_round(0, i00, i00 < g.N, e0, excl0, Pk, fk, Pnext);
-        PF_STAMP(a, 6);
-        return;
-    }
-    double carry = 0.0;
-    for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t r0 = base + (int64_t)r * g.round_elems;
-        if (r0 >= g.N) break;
-        const int64_t i0 = r0 + threadIdx.x * VEC;
-        const bool on = i0 < g.N;
-        double e[VEC], total;
-        const double local = tile_exponentials(i0, on, e);
-        const double excl = block_scan_excl(local, reds, total);
-        write_round(r, i0, on, e, carry + excl, Pk, fk, Pnext);
-        carry += total;
-    }
-}
-
 // Planning kernel of the systematic pipeline.  grid (ceil(tiles / 4) + 1, B): every workgroup re-reduces the column's
 // partials into the tile-prefix table (workgroup 0 publishes it: ptab / ftab), each of its 4 waves then finds j0 for one
 // position tile - the tile via the table, the element inside it with a 64-ary search over the local scans; the extra
@@ -779,6 +595,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     __shared__ double red2[2 * D * PF_NWAVES];
     __shared__ double reds[PF_NWAVES];
     __shared__ double ptl[PF_MAX_TILES + 1];
+    __shared__ double pel[PF_MAX_TILES + 2];  // multinomial: prefixes of the spacing sums (+ the grand total)
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int nplan = (g.tiles + PF_NWAVES - 1) / PF_NWAVES;
@@ -825,13 +642,52 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
             a.ftab[cb + t] = exp_diff_t<T>(a.part_r()[slot_m * stride + cb + t], MR) / SR;
     }
 
+    // multinomial: the resampling positions are the order statistics of N iid uniforms, built from normalised Exp(1)
+    // spacings (Philox, regenerated wherever needed); their per-tile sums were reduced with the partials, so the first
+    // position of every tile follows from a second prefix table
+    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    if (multinomial) {
+        double inclE[PF_COMBINE_ITERS], runE = 0.0, totalE;
+#pragma unroll
+        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+            const int t = threadIdx.x * IT + q;
+            if (q < IT && t < g.tiles) runE += a.part_r()[PQ_E * stride + cb + t];
+            inclE[q] = runE;
+        }
+        const double exclE = block_scan_excl(runE, reds, totalE);
+        T tail[1];
+        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)g.B * g.N + b), tail);
+        if (threadIdx.x == 0) {
+            pel[0] = 0.0;
+            pel[g.tiles + 1] = totalE + (double)tail[0];  // grand total (one slot behind the prefixes)
+        }
+#pragma unroll
+        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+            const int t = threadIdx.x * IT + q;
+            if (q < IT && t < g.tiles) pel[t + 1] = exclE + inclE[q];
+        }
+        __syncthreads();
+        if (k == 0) {
+            double* et = a.etab + (int64_t)b * (g.tiles + 1);
+            for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK) et[t] = pel[t];
+            if (threadIdx.x == 0) et[g.tiles] = pel[g.tiles + 1];
+        }
+    }
+
     // j0 of position tile t: one wave each
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int t = k * PF_NWAVES + wid;
     if (t >= g.tiles) return;
-    const T ub = a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
-                          : uniform_draw<T>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
-    const T p = grid_position<T>((int64_t)t * g.tile_elems, ub, T(g.N));
+    T p;
+    if (multinomial) {
+        T e0[1];
+        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + (int64_t)t * g.tile_elems), e0);
+        p = (T)((pel[t] + (double)e0[0]) * (1.0 / pel[g.tiles + 1]));
+    } else {
+        const T ub = a.u_tape ? a.u_tape[(int64_t)step * g.B + b] : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
+        p = grid_position<T>((int64_t)t * g.tile_elems, ub, T(g.N));
+    }
     // the tile holding the ancestor: first kt whose end value T(P_{kt+1}) (1 for the last tile) is >= p
     int lo = 0, hi = g.tiles - 1;
     while (lo < hi) {
@@ -872,10 +728,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     }
 }
 
-// MODE 0: systematic pipeline (planning kernel + local scans), ancestors from the inverted grid (grid_count);
-// MODE 1: multinomial (sorted positions, explicit cdf from k_fused_scan), ancestors by searching the staged window;
-// MODE 2: systematic pipeline with the searching ancestor stage - float grids beyond 2^22 positions, where the closed
-// form of MODE 0 is not exact.  Compile-time so that no variant carries another's registers.
+// MODE 0: systematic, ancestors from the inverted grid (grid_count);
+// MODE 1: multinomial - the sorted positions are regenerated per round from Exp(1) spacings (Philox + workgroup scan),
+//         ancestors by searching the staged window;
+// MODE 2: systematic with the searching ancestor stage - float grids beyond 2^22 positions, where the closed form of
+//         MODE 0 is not exact.  Compile-time so that no variant carries another's registers.  All three read the cdf as
+//         tile-local scans + the planning kernel's table.
 // PROP: the proposal as a compile-time constant (0 Bootstrap, 1 LinearGaussianObservations) or -1 = run-time switch.
 // For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
 // FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
@@ -914,8 +772,15 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
 #endif
 
     // uniform loads first: the window start and the column's parameter rows
-    int j0 = (windowed && !multinomial) ? a.j0[(int64_t)b * g.tiles + k] : 0;
-    int kt0 = (MODE != 1 && windowed) ? a.k0[(int64_t)b * g.tiles + k] : 0;  // tile index of j0 (no integer division here)
+    int j0 = windowed ? a.j0[(int64_t)b * g.tiles + k] : 0;
+    int kt0 = windowed ? a.k0[(int64_t)b * g.tiles + k] : 0;  // tile index of j0 (no integer division here)
+    // multinomial: this tile's offset into the running sum of the Exp(1) spacings and the reciprocal of their total
+    double offE = 0.0, invE = 0.0, carryE = 0.0;
+    if (MODE == 1 && windowed) {
+        const double* et = a.etab + (int64_t)b * (g.tiles + 1);
+        offE = et[k];
+        invE = 1.0 / et[g.tiles];
+    }
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
 
@@ -936,8 +801,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
     T* lw_out = a.logw[slot ^ 1] + (int64_t)b * g.N;
     int32_t* anc_col = a.anc + (int64_t)b * g.N;
 #endif
-    // multinomial / two-kernel pipeline: the cdf itself; systematic pipeline: the local scans of this step's parity
-    const T* cdf_col = ((MODE != 1 && (step & 1)) ? a.pos : a.cdf) + (int64_t)b * g.N;
+    const T* cdf_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;  // the local scans of this step's parity
     const int64_t base = (int64_t)k * g.tile_elems;
     const T nT = T(N);
     const T rcN = T(1) / nT;
@@ -947,8 +811,7 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
     PartialAcc<T, D> acc;
     acc.init();
     PF_STAMP(a, 9);
-    const T* pos_col = multinomial ? a.pos + (int64_t)b * g.N : nullptr;
-    constexpr bool from_local = MODE != 1;  // `cdf` holds tile-local scans; the cdf is implied by the table
+    constexpr bool from_local = true;  // `cdf` / `pos` hold tile-local scans; the cdf is implied by the table
     const double* ptab_col = a.ptab + (int64_t)b * (g.tiles + 1);
     const double* ftab_col = a.ftab + (int64_t)b * g.tiles;
     CdfView<T> view;
@@ -958,15 +821,6 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
     view.N = N;
     view.tile_elems = g.tile_elems;
     view.tiles = g.tiles;
-    if (windowed && multinomial) {
-        // no position-tile table for the sorted uniforms: one wave finds the window start with a 64-ary search
-        if (tid < PF_WAVE) {
-            const int q = wave_lower_bound<T>(cdf_col, N, pos_col[base], tid & 63);
-            if ((tid & 63) == 0) sh_j0 = q;
-        }
-        __syncthreads();
-        j0 = sh_j0;
-    }
 
     T e_rw[VEC];  // the last round's exp(rw - thread max) of the next resampling weights (reused by the local scan)
 #pragma unroll
@@ -983,8 +837,21 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
             if (VEC == 1) hd[tid] = 0; else store_vec<int, VEC>(hd + tid * VEC, zero);
         }
         T pv[VEC];
-        if (multinomial && windowed && on) {
-            if (VEC == 1) pv[0] = pos_col[i0]; else load_vec<T, VEC>(pos_col + i0, pv);
+        if (multinomial && windowed) {
+            // this round's sorted resampling positions: the Exp(1) spacings regenerated (the previous step's epilogue summed
+            // exactly these draws into the tile partial), scanned across the workgroup, normalised by the column total
+            T ev[VEC];
+            double incl[VEC], local = 0.0, total;
+            if (on) draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), ev);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                local += on ? (double)ev[j] : 0.0;
+                incl[j] = local;
+            }
+            const double excl = block_scan_excl(local, reds, total);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) pv[j] = (T)((offE + carryE + excl + incl[j]) * invE);
+            carryE += total;
         }
 
         // ---- 1. issue the window loads (cdf, and the particles behind it) ------------------------------------------
@@ -1085,20 +952,17 @@ __global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == P
                 if (VEC == 1) { win[tid] = c0[0]; win[PF_BLOCK + tid] = c1[0]; }
                 else { store_vec<T, VEC>(win + tid * VEC, c0); store_vec<T, VEC>(win + (PF_BLOCK + tid) * VEC, c1); }
                 __syncthreads();
-                // on average one ancestor per position: thread t's first position lands near offset (j0 - ws) + t * VEC
-                int guess = (j0 - ws) + tid * VEC;
-                if (guess > WIN - 1) guess = WIN - 1;
+                T pp[VEC];
+                int qq[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pp[j] = multinomial ? pv[j] : grid_position<T>(i0 + j, ub, nT);
+                window_lower_bound_flat<T, WIN, VEC>(win, pp, qq);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int64_t i = i0 + j;
                     int res = N - 1;
                     if (i < N) {
-                        const T p = multinomial ? pv[j] : grid_position<T>(i, ub, nT);
-                        const int q = window_lower_bound<T, WIN>(win, guess, p);
-                        guess = q < WIN ? q : WIN - 1;
-                        if (q < WIN) res = ws + q;
-                        else if (from_local) res = view.lower_bound(ws + WIN < N ? ws + WIN : N, p, kt0);
-                        else res = thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
+                        res = (qq[j] < WIN) ? ws + qq[j] : view.lower_bound(ws + WIN < N ? ws + WIN : N, pp[j], kt0);
                         if (res > N - 1) res = N - 1;
                     }
                     idx[j] = res;

@@ -81,6 +81,7 @@ struct WsLayout {
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
     size_t off_ptab;   // double [B][tiles + 1]
     size_t off_ftab;   // double [B][tiles]
+    size_t off_etab;   // double [B][tiles + 1]
     size_t off_cpack;  // T [B][PK_N] (sized for double)
     size_t off_ucol;   // T [B]
     size_t total;
@@ -108,6 +109,8 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     o = align256(o + sizeof(double) * (size_t)g.B * (g.tiles + 1));
     w.off_ftab = o;
     o = align256(o + sizeof(double) * (size_t)g.B * g.tiles);
+    w.off_etab = o;
+    o = align256(o + sizeof(double) * (size_t)g.B * (g.tiles + 1));
     w.off_cpack = o;
     o = align256(o + sizeof(double) * (size_t)g.B * 24);
     w.off_ucol = o;
@@ -296,6 +299,27 @@ template <typename T, int WIN> __device__ __forceinline__ int window_lower_bound
         if (win[mid] < p) a = mid + 1; else b = mid;
     }
     return a;
+}
+
+// Branch-free lower_bound of VEC values in the LDS window (WIN a power of two): log2(WIN) + 1 rounds of "probe, compare,
+// advance" with all VEC probes of a round in flight together.  The same instruction stream for every lane - no
+// exec-mask juggling (the galloping search above spends as many scalar as vector instructions on divergent loops).
+// Returns positions in [0, WIN] (WIN = beyond the window).
+template <typename T, int WIN, int VEC>
+__device__ __forceinline__ void window_lower_bound_flat(const T* win, const T (&p)[VEC], int (&out)[VEC]) {
+    static_assert((WIN & (WIN - 1)) == 0, "window size must be a power of two");
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = 0;
+#pragma unroll
+    for (int step = WIN / 2; step >= 1; step >>= 1) {
+        T v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = win[out[j] + step - 1];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) out[j] += (v[j] < p[j]) ? step : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] += (win[out[j]] < p[j]) ? 1 : 0;
 }
 
 template <typename T, int VEC>
@@ -1192,11 +1216,12 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
     a.ptab = (double*)((char*)A->ws + wl.off_ptab);
     a.ftab = (double*)((char*)A->ws + wl.off_ftab);
+    a.etab = (double*)((char*)A->ws + wl.off_etab);
     a.cpack = (T*)((char*)A->ws + wl.off_cpack);
     a.ucol = (T*)((char*)A->ws + wl.off_ucol);
     static_assert(PK_N == 24, "workspace layout reserves 24 slots per column record");
     {
-        a.from_local = (A->resampler == PF_RESAMPLE_SYSTEMATIC) ? 1 : 0;
+        a.from_local = 1;  // both resamplers run the planning pipeline (tile-local scans + prefix table)
     }
     a.finalize_only = 0;
     a.replay = 0;
@@ -1207,7 +1232,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     }
     const uint8_t* observed = A->observed;  // host array
 
-    const dim3 grid(g.tiles, g.B), grid_scan(g.tiles + 1, g.B), block(PF_BLOCK);
+    const dim3 grid(g.tiles, g.B), block(PF_BLOCK);
     const dim3 grid_plan((g.tiles + PF_NWAVES - 1) / PF_NWAVES + 1, g.B);
     if (t0 == 0) {
         // fresh filter: no previous step to account for
@@ -1221,13 +1246,14 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
 
     auto launch_plan = [&]() {
-        if (a.from_local) hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
-        else hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
+        hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
     };
     // ancestor stage of the step kernel: 0 inverted grid (systematic), 1 multinomial, 2 systematic by search - float
     // grids beyond 2^22 positions, where the closed form is not exact (PF_FORCE_SEARCH=1 selects it for testing)
     static const bool force_search = getenv("PF_FORCE_SEARCH") != nullptr;
-    const int mode = !a.from_local ? 1 : ((sizeof(T) == 4 && (g.N > ((int64_t)1 << 22) || force_search)) ? 2 : 0);
+    const int mode = (A->resampler == PF_RESAMPLE_MULTINOMIAL)
+                         ? 1
+                         : ((sizeof(T) == 4 && (g.N > ((int64_t)1 << 22) || force_search)) ? 2 : 0);
     auto launch_step_as = [&](auto prop_c, auto fast_c) {
         constexpr int PROP = decltype(prop_c)::value;
         constexpr bool FAST = decltype(fast_c)::value;
@@ -1278,8 +1304,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.step = (int)(t0 + n_steps);
         a.obs = a.obs_next = 0;
         a.finalize_only = 1;
-        if (a.from_local) hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
-        else hipLaunchKernelGGL((k_fused_scan<T, D, VEC>), grid_scan, block, 0, st, a);
+        hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
     }
     if (kernel_ms) {
         hipError_t se = hipStreamSynchronize(st);
