@@ -269,38 +269,6 @@ template <typename T, int VEC> struct SearchWin {
     static constexpr int WIN = 2 * PF_BLOCK * VEC;
 };
 
-// lower_bound of p in the LDS window, starting from a guess: gallop away from it with doubling steps, then bisect.
-// Invariant on entry: none.  Returns a in [0, WIN] (WIN = not inside the window).
-template <typename T, int WIN> __device__ __forceinline__ int window_lower_bound(const T* win, int guess, T p) {
-    int a, b;
-    if (win[guess] < p) {  // answer is to the right of guess
-        a = guess + 1;
-        b = a;
-        int step = 1;
-        while (b < WIN && win[b] < p) {
-            a = b + 1;
-            b += step;
-            step <<= 1;
-        }
-        if (b > WIN) b = WIN;
-    } else {  // answer is at or to the left of guess
-        b = guess;
-        a = b;
-        int step = 1;
-        while (a > 0 && !(win[a - 1] < p)) {
-            b = a - 1;
-            a -= step;
-            step <<= 1;
-        }
-        if (a < 0) a = 0;
-    }
-    while (a < b) {
-        const int mid = (a + b) >> 1;
-        if (win[mid] < p) a = mid + 1; else b = mid;
-    }
-    return a;
-}
-
 // Branch-free lower_bound of VEC values in the LDS window (WIN a power of two): log2(WIN) + 1 rounds of "probe, compare,
 // advance" with all VEC probes of a round in flight together.  The same instruction stream for every lane - no
 // exec-mask juggling (the galloping search above spends as many scalar as vector instructions on divergent loops).
@@ -346,18 +314,17 @@ __device__ __forceinline__ void systematic_round(const T* __restrict__ cdf_col, 
     }
     __syncthreads();
     const T nT = T(N);
-    // on average one ancestor per position: thread t's first position lands near window offset (j0 - ws) + t * VEC
-    int guess = (j0 - ws) + tid * VEC;
-    if (guess > WIN - 1) guess = WIN - 1;
+    T pp[VEC];
+    int qq[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) pp[j] = (i0 + j < N) ? grid_position<T>(i0 + j, u_elem ? u_elem[i0 + j] : u, nT) : T(0);
+    window_lower_bound_flat<T, WIN, VEC>(win, pp, qq);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int64_t i = i0 + j;
         int res = N - 1;
         if (i < N) {
-            const T p = grid_position<T>(i, u_elem ? u_elem[i] : u, nT);
-            const int a = window_lower_bound<T, WIN>(win, guess, p);
-            guess = a < WIN ? a : WIN - 1;
-            res = (a < WIN) ? ws + a : thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, p);
+            res = (qq[j] < WIN) ? ws + qq[j] : thread_lower_bound<T>(cdf_col, ws + WIN < N ? ws + WIN : N, N, pp[j]);
             if (res > N - 1) res = N - 1;
         }
         idx[j] = res;
