@@ -533,3 +533,18 @@ def test_multi_round_tiles_pass_the_parity_suite():
                             "-k", "benchmark_sizes or ragged or weight_collapse or matches_reference"],
                            env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, f"PF_TARGET_WGS={wgs}\n" + r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n,b", [(1, 1), (2, 3), (7, 2), (64, 1), (257, 2)])
+@pytest.mark.parametrize("filt_name,prop", [("sisr", "bootstrap"), ("apf", "lgo")])
+def test_tiny_particle_counts(n, b, filt_name, prop):
+    """Degenerate sizes (a single particle, fewer particles than a wavefront, one more than a workgroup round): the
+    fused route still reproduces the oracle on identical draws."""
+    case, spec, g, y = _full_size_case("sine", filt_name, prop, n, b, 6, seed=5 + n)
+    x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
+    ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=0.9)
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    res = filt.batch_filter(y.cuda(), bar=False)
+    torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9)
+    assert torch.equal(res.latest_state.previous_indices.cpu(), ref["prev_inds"])
