@@ -548,3 +548,30 @@ def test_tiny_particle_counts(n, b, filt_name, prop):
     torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11)
     torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9)
     assert torch.equal(res.latest_state.previous_indices.cpu(), ref["prev_inds"])
+
+
+@pytest.mark.parametrize("n,b", [(1 << 22, 1), (65536 + 4, 3)])
+def test_multinomial_many_tiles_against_kalman(n, b):
+    """Multinomial resampling across many tiles / several rounds per tile (the sorted positions are rebuilt per round
+    from Exp(1) spacings whose tile sums travel through the planning kernel's second prefix table): with this many
+    particles the filter must sit on the exact Kalman filter - a misplaced tile offset would show as a bias far above
+    the Monte-Carlo error - and the ancestors must come out sorted."""
+    from pyfilter_amd import resampling, timeseries as ts
+    from pyfilter_amd.filters.particle import SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device="cuda")  # noqa: E731
+    ssm = ts.LinearStateSpaceModel(models.AR(t(0.0), t(0.9), t(0.5)), (t(1.0), t(0.5)))
+    g = torch.Generator().manual_seed(21)
+    y = (0.5 * torch.randn(10, generator=g)).cumsum(0) * 0.5
+    km, kll = cpu_ref.kalman_filter_1d(y.double(), 0.0, 0.9, 0.5, 1.0, 0.0, 0.5, 0.0, 0.5 ** 2)
+    filt = SISR(ssm, n, proposal=proposals.Bootstrap(), resampling=resampling.multinomial, ess_threshold=1.1, seed=5)
+    if b > 1:
+        filt.set_batch_shape(torch.Size([b]))
+    res = filt.batch_filter(y.cuda(), bar=False)
+    means = res.filter_means[1:].cpu().double().reshape(10, -1)
+    tol = 6.0 * 0.6 / math.sqrt(n) + 2e-4
+    assert (means - km[:, None]).abs().max().item() < tol, ((means - km[:, None]).abs().max().item(), tol)
+    assert (res.loglikelihood.cpu().double().reshape(-1) - kll).abs().max().item() < 30.0 * tol
+    idx = res.latest_state.previous_indices.reshape(n, -1)
+    assert (idx[1:] >= idx[:-1]).all() and idx.min() >= 0 and idx.max() <= n - 1
