@@ -168,8 +168,8 @@ typedef struct pf_filter_args {
     void* x[2];     /* (D,B,N) */
     void* logw[2];  /* (B,N)   */
     int32_t* anc;   /* (B,N) ancestors of the latest step (SISR keeps them when no resampling happened) */
-    void* cdf;      /* (B,N) scratch: tile-local weight scans of even steps (systematic) | the cdf (multinomial) */
-    void* pos;      /* (B,N) scratch: tile-local weight scans of odd steps (systematic) | sorted positions (multinomial) */
+    void* cdf;      /* (B,N) scratch: tile-local scans of the resampling weights, even steps */
+    void* pos;      /* (B,N) scratch: the same for odd steps (double buffered like the state; required) */
     /* observations */
     const void* y;            /* (T, y_rows, O) */
     int64_t y_rows;           /* 1 or B */
@@ -191,7 +191,8 @@ typedef struct pf_filter_args {
 } pf_filter_args;
 
 /* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; two kernel launches per
- * step (scan, then resample+propagate+weight+reduce) plus one reduce launch for the incoming state.
+ * step (plan: tile-prefix table + window starts + per-column bookkeeping; step: ancestors + gather + propagate + weight
+ * + the next state's partials and tile-local scans) plus one reduce launch for the incoming state.
  * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps). */
 int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
 
@@ -206,7 +207,7 @@ int pf_filter_graph_destroy(void* handle);
 
 /* Measurement variant of pf_filter_run (synchronises the stream).  kernel_ms[0] = in-sequence duration of one step
  * (HIP events on `stream` around the whole step loop / n_steps); kernel_ms[1], kernel_ms[2] = that time apportioned to
- * the planning (or scan) kernel and the step kernel by the ratio of their back-to-back replay durations (the last
+ * the planning kernel and the step kernel by the ratio of their back-to-back replay durations (the last
  * step's launches are idempotent).  Same results as pf_filter_run; not for throughput numbers. */
 int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                         float* kernel_ms);
