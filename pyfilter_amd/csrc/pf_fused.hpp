@@ -739,7 +739,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
 // FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
 // generic per-particle arithmetic (and its registers) from the fast instantiation and vice versa.
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST>
-__global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == PF_PROP_LGO ? 2 : 3)) : 1) void k_fused_step(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == PF_PROP_LGO ? 2 : (MODE == 1 ? 4 : 3))) : 1) void k_fused_step(FusedArgs<T> a) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     constexpr int WIN = SearchWin<T, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
