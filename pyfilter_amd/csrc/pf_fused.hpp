@@ -738,8 +738,18 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
 // For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
 // FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
 // generic per-particle arithmetic (and its registers) from the fast instantiation and vice versa.
+#ifndef PF_WAVES_D1_GENERIC
+#define PF_WAVES_D1_GENERIC 4
+#endif
+// resident waves per SIMD the register allocation is tuned for (float; measured per variant, tools/kbench.py)
+template <typename T, int D, int MODE, int PROP, bool FAST> struct StepWaves {
+    static constexpr int value = sizeof(T) != 4 ? 1
+                                 : D == 1     ? (FAST ? 4 : PF_WAVES_D1_GENERIC)
+                                 : PROP == PF_PROP_LGO ? 2
+                                 : (MODE == 1 ? 4 : 3);
+};
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST>
-__global__ __launch_bounds__(PF_BLOCK, sizeof(T) == 4 ? (D == 1 ? 4 : (PROP == PF_PROP_LGO ? 2 : (MODE == 1 ? 4 : 3))) : 1) void k_fused_step(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value)) void k_fused_step(FusedArgs<T> a) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     constexpr int WIN = SearchWin<T, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
