@@ -188,6 +188,9 @@ typedef struct pf_filter_args {
                             * graph draw fresh Philox numbers on every replay */
     void* ws;
     size_t ws_bytes;
+    const uint8_t* observed_dev; /* optional DEVICE array (T) with the meaning of `observed`; when non-NULL it is used
+                                  * instead (every kernel reads its step's flag with one scalar load), so the caller
+                                  * needs no host-side knowledge of NaN observations - `filter()` runs without a sync */
 } pf_filter_args;
 
 /* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; two kernel launches per

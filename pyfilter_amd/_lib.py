@@ -52,6 +52,7 @@ class PfFilterArgs(C.Structure):
         ("means", C.c_void_p), ("vars", C.c_void_p), ("ll_steps", C.c_void_p), ("ll_total", C.c_void_p),
         ("step_counter", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("observed_dev", C.c_void_p),
     ]
 
 

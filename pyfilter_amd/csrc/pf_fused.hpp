@@ -79,8 +79,11 @@ template <typename T> struct FusedArgs {
     int from_local;   // systematic pipeline: `cdf` holds per-tile local scans L_i, the cdf is P_k + f_k * L_i
     // per launch
     int step;       // local step index: slot = step & 1 is read, the other written
-    int obs;        // this step weighs against y[step]
-    int obs_next;   // the next step exists and is a weighted step (its first-stage weights are prepared here)
+    int obs;        // this step weighs against y[step]                     (-1: read obs_dev[step])
+    int obs_next;   // the next step exists and is a weighted step (its first-stage weights are prepared here; -1: device)
+    const uint8_t* obs_dev;  // optional device flags (pf_filter_args.observed_dev)
+    __device__ __forceinline__ bool is_obs() const { return obs >= 0 ? obs != 0 : obs_dev[step] != 0; }
+    __device__ __forceinline__ bool is_obs_next() const { return obs_next >= 0 ? obs_next != 0 : obs_dev[step + 1] != 0; }
     int finalize_only;
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int slot = a.step & 1;
-    const bool pre_on = a.obs && a.filter == PF_FILTER_APF;
+    const bool pre_on = a.is_obs() && a.filter == PF_FILTER_APF;
     ColParams<T, D> cp;
     load_col_params<T, D>(a, b, a.step, pre_on, cp);
     ColConsts<T, D> cc;
@@ -527,7 +530,7 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
                 ColParams<T, 1> cp;
                 ColConsts<T, 1> cc;
                 load_col_params<T, 1>(a, b, step, obs, cp);
-                if (a.obs_next && apf) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
+                if (a.is_obs_next() && apf) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
                 cc.prepare(a.md, cp);
                 write_col_pack<T>(a.md, cp, cc, a.cpack + (int64_t)b * PK_N);
             }
@@ -600,7 +603,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     const int b = blockIdx.y, k = blockIdx.x;
     const int nplan = (g.tiles + PF_NWAVES - 1) / PF_NWAVES;
     const int step = a.step;
-    const bool obs = !a.finalize_only && a.obs;
+    const bool obs = !a.finalize_only && a.is_obs();
     const bool apf = a.filter == PF_FILTER_APF;
     const bool two = apf && obs;
     const int64_t stride = (int64_t)g.B * g.tiles;
@@ -768,12 +771,12 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
     const int tid = threadIdx.x;
     const int step = a.step;
     const int slot = step & 1;
-    const bool obs = a.obs != 0;
+    const bool obs = a.is_obs();
     const bool apf = a.filter == PF_FILTER_APF;
     const bool resample = a.stat[b].resample != 0;
     constexpr bool multinomial = MODE == 1;
     const bool windowed = resample;  // both resamplers search an LDS window of the cdf (their positions are sorted)
-    const bool pre_next = a.obs_next && apf;
+    const bool pre_next = a.is_obs_next() && apf;
     const int N = (int)g.N;
     PF_STAMP(a, 8);
     if (PF_CUT(a, 1)) return;

@@ -1208,7 +1208,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     }
     // partials of the incoming state (afterwards every step kernel leaves the partials of the state it wrote)
     a.step = (int)t0;
-    a.obs = n_steps > 0 ? (observed[t0] != 0) : 0;
+    const bool dev_flags = A->observed_dev != nullptr;  // the kernels read the flags themselves
+    a.obs_dev = A->observed_dev;
+    a.obs = n_steps > 0 ? (dev_flags ? -1 : (observed[t0] != 0)) : 0;
     a.obs_next = 0;
     hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
 
@@ -1251,8 +1253,8 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t t = t0 + s;
         a.step = (int)t;
-        a.obs = observed[t] != 0;
-        a.obs_next = (s + 1 < n_steps) ? (observed[t + 1] != 0) : 0;
+        a.obs = dev_flags ? -1 : (observed[t] != 0);
+        a.obs_next = (s + 1 < n_steps) ? (dev_flags ? -1 : (observed[t + 1] != 0)) : 0;
 #ifdef PF_DEVTOOLS
         // stage cuts on ONE launch (the last but one step) when PF_DEBUG_CUT_AT_END is set: the state entering it is
         // valid, so per-dispatch PMC rows of that launch profile the stages on real data
@@ -1294,7 +1296,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                 a.finalize_only = 0;
                 a.replay = 1;
                 a.step = (int)(t0 + n_steps - 1);
-                a.obs = observed[t0 + n_steps - 1] != 0;
+                a.obs = dev_flags ? -1 : (observed[t0 + n_steps - 1] != 0);
                 a.obs_next = 0;
                 for (int w = 0; w < 3; ++w) { launch_plan(); launch_step(); }
                 (void)hipEventRecord(e0, st);
@@ -1399,7 +1401,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (!A->x[0] || !A->x[1] || !A->logw[0] || !A->logw[1] || !A->anc || !A->cdf || !A->means || !A->vars ||
         !A->ll_steps || !A->ll_total || !A->ws)
         return PF_EINVAL;
-    if (n_steps > 0 && (!A->y || !A->observed)) return PF_EINVAL;
+    if (n_steps > 0 && (!A->y || (!A->observed && !A->observed_dev))) return PF_EINVAL;
     if (A->y_rows != 1 && A->y_rows != A->B) return PF_EINVAL;
     if (A->proposal == PF_PROP_LGO && A->model.obs_kind != PF_OBS_LINEAR) return PF_EUNSUPPORTED;
     if (A->filter != PF_FILTER_SISR && A->filter != PF_FILTER_APF) return PF_EUNSUPPORTED;

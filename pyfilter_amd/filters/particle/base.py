@@ -255,8 +255,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             plan = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
             self._plans[key] = plan
         t_start = int(ts_in.time_index)
-        observed = not bool(y_dev.isnan().all())     # the reference branches on the host here too (filters/base.py:212)
-        plan.observed[0] = 1 if observed else 0
+        # all-NaN observation -> propagate only (filters/base.py:212).  The reference branches on the host; here the flag
+        # stays on the device (pf_filter_args.observed_dev), so consecutive filter() calls never wait for the GPU
+        obs_flag = y_dev.isnan().all().logical_not().to(torch.uint8).reshape(1)
         plan.calls += 1
 
         apf = self._FILTER_KIND == L.FILTER_APF
@@ -276,6 +277,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a = plan.args
         a.model.params = ctx.params.data_ptr()
         a.y = y_dev.data_ptr()
+        a.observed_dev = obs_flag.data_ptr()
         a.seed = (self._seed + 0x9E3779B97F4A7C15 * plan.calls) & 0xFFFFFFFFFFFFFFFF  # fresh Philox draws per call
         a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
         a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
@@ -290,7 +292,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             u_tape = ctx.u_tape[t_start:t_start + 1].contiguous()
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: the column bookkeeper draws u (Philox)
         L.check(L.load().pf_filter_run(C.byref(a), 0, 1, 1, L.stream_ptr()), "pf_filter_run")
-        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, keep=(x_in, lw_in, y_dev, ctx.params))
+        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, keep=(x_in, lw_in, y_dev, ctx.params, obs_flag))
 
         final_x = TimeseriesState(t_start + 1, ops.from_soa(x_out, self._batched, self._has_event),
                                   self._model.hidden.event_shape)
