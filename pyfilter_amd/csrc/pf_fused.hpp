@@ -751,7 +751,11 @@ template <typename T, int D, int MODE, int PROP, bool FAST> struct StepWaves {
                                  : PROP == PF_PROP_LGO ? 2
                                  : (MODE == 1 ? 4 : 3);
 };
-template <typename T, int D, int VEC, int MODE, int PROP, bool FAST>
+// SPEC: the per-launch flags as compile-time constants for the two steady states of a run - known on the host when the
+// launch is issued - so their branches, registers and dead paths (propagate-only move, tape loads, the other filter's
+// weight update) leave the kernel: 0 generic (flags read at run time: NaN observations, the run's last step, tapes,
+// device-side flags), 1 APF on an observed step followed by an observed step, 2 SISR on an observed step.
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC>
 __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value)) void k_fused_step(FusedArgs<T> a) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     constexpr int WIN = SearchWin<T, VEC>::WIN;
@@ -771,12 +775,12 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
     const int tid = threadIdx.x;
     const int step = a.step;
     const int slot = step & 1;
-    const bool obs = a.is_obs();
-    const bool apf = a.filter == PF_FILTER_APF;
-    const bool resample = a.stat[b].resample != 0;
+    const bool obs = SPEC ? true : a.is_obs();
+    const bool apf = SPEC ? (SPEC == 1) : (a.filter == PF_FILTER_APF);
+    const bool resample = (SPEC == 1) ? true : (a.stat[b].resample != 0);
     constexpr bool multinomial = MODE == 1;
     const bool windowed = resample;  // both resamplers search an LDS window of the cdf (their positions are sorted)
-    const bool pre_next = a.is_obs_next() && apf;
+    const bool pre_next = SPEC ? (SPEC == 1) : (a.is_obs_next() && apf);
     const int N = (int)g.N;
     PF_STAMP(a, 8);
     if (PF_CUT(a, 1)) return;
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
         invE = 1.0 / et[g.tiles];
     }
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    const T* z_step = a.z_tape ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
+    const T* z_step = (!SPEC && a.z_tape) ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
 
     // FAST: the column's closed-form constants come from the record the bookkeeper wrote (FastCol, loaded right before
     // they are used); otherwise the parameter rows are loaded and reduced here

@@ -1223,12 +1223,34 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const int mode = (A->resampler == PF_RESAMPLE_MULTINOMIAL)
                          ? 1
                          : ((sizeof(T) == 4 && (g.N > ((int64_t)1 << 22) || force_search)) ? 2 : 0);
+    // steady-state specialisation of this launch (float only: the double kernels are the parity path): see SPEC
+    auto spec_of = [&]() -> int {
+        if (sizeof(T) != 4 || a.z_tape || a.obs != 1) return 0;
+        if (a.filter == PF_FILTER_APF) return a.obs_next == 1 ? 1 : 0;
+        return 2;
+    };
     auto launch_step_as = [&](auto prop_c, auto fast_c) {
         constexpr int PROP = decltype(prop_c)::value;
         constexpr bool FAST = decltype(fast_c)::value;
-        if (mode == 0) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 0, PROP, FAST>), grid, block, 0, st, a);
-        else if (mode == 1) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 1, PROP, FAST>), grid, block, 0, st, a);
-        else if constexpr (sizeof(T) == 4) hipLaunchKernelGGL((k_fused_step<T, D, VEC, 2, PROP, FAST>), grid, block, 0, st, a);
+        auto go = [&](auto mode_c, auto spec_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+            constexpr int SPEC = decltype(spec_c)::value;
+            hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC>), grid, block, 0, st, a);
+        };
+        auto with_mode = [&](auto mode_c) {
+            if constexpr (sizeof(T) == 4) {
+                const int sp = spec_of();
+                if (sp == 1) return go(mode_c, std::integral_constant<int, 1>{});
+                // (the SISR specialisation of the multinomial variant spills: measured slower than the generic kernel)
+                if constexpr (decltype(mode_c)::value == 0) {
+                    if (sp == 2) return go(mode_c, std::integral_constant<int, 2>{});
+                }
+            }
+            go(mode_c, std::integral_constant<int, 0>{});
+        };
+        if (mode == 0) with_mode(std::integral_constant<int, 0>{});
+        else if (mode == 1) with_mode(std::integral_constant<int, 1>{});
+        else if constexpr (sizeof(T) == 4) go(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
     };
     auto launch_step = [&]() {
         // scalar closed-form models: the proposal is a run-time switch inside one lean kernel (FAST); everything else gets
