@@ -869,6 +869,34 @@ using namespace pf;
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
 
+static inline bool bad_shape(int64_t N, int64_t B) { return N < 1 || B < 1 || N > (int64_t)1 << 30 || B > 65535; }
+
+static inline int check_model(const pf_model* m) {
+    if (!m || !m->params) return PF_EINVAL;
+    if (m->dim < 1 || m->dim > PF_MAXD || m->obs_dim < 1 || m->obs_dim > PF_MAXO) return PF_EUNSUPPORTED;
+    if (m->dim == 1 && m->obs_dim != 1) return PF_EUNSUPPORTED;
+    if (m->hid_kind < 0 || m->hid_kind > PF_HID_OU) return PF_EUNSUPPORTED;
+    if (m->hid_kind == PF_HID_LORENZ63_EM && m->dim != 3) return PF_EUNSUPPORTED;
+    if (m->obs_kind != PF_OBS_LINEAR && m->obs_kind != PF_OBS_SV) return PF_EUNSUPPORTED;
+    if (m->obs_kind == PF_OBS_SV && m->dim != 1) return PF_EUNSUPPORTED;
+    return PF_OK;
+}
+
+static inline ModelDesc to_desc(const pf_model* m) {
+    ModelDesc d;
+    d.hid_kind = m->hid_kind;
+    d.obs_kind = m->obs_kind;
+    d.obs_dim = m->obs_dim;
+    d.dt = m->dt;
+    d.inc_scale = m->inc_scale;
+    return d;
+}
+
+// The fused-run instantiation matrix compiles as two translation units (the build runs them in parallel):
+//   -DPF_TU_NO_F64   : everything except the float64 fused kernels   (the main unit: C ABI, primitives, float32 runs)
+//   -DPF_TU_F64_ONLY : only the float64 fused kernels + their entry  (pf_run_f64)
+// Without either macro the file is a single self-contained unit.
+#ifndef PF_TU_F64_ONLY
 extern "C" const char* pf_version(void) { return "pfamd 0.1.0 (gfx950)"; }
 
 extern "C" const char* pf_error_string(int code) {
@@ -882,7 +910,6 @@ extern "C" const char* pf_error_string(int code) {
 }
 
 
-static inline bool bad_shape(int64_t N, int64_t B) { return N < 1 || B < 1 || N > (int64_t)1 << 30 || B > 65535; }
 
 extern "C" int pf_debug_offset(int64_t N, int64_t B, size_t* off) {
     if (!off || bad_shape(N, B)) return PF_EINVAL;
@@ -1060,26 +1087,7 @@ extern "C" int pf_moments(const void* x, const void* W, void* mean, void* var, i
     return PF_OK;
 }
 
-static inline int check_model(const pf_model* m) {
-    if (!m || !m->params) return PF_EINVAL;
-    if (m->dim < 1 || m->dim > PF_MAXD || m->obs_dim < 1 || m->obs_dim > PF_MAXO) return PF_EUNSUPPORTED;
-    if (m->dim == 1 && m->obs_dim != 1) return PF_EUNSUPPORTED;
-    if (m->hid_kind < 0 || m->hid_kind > PF_HID_OU) return PF_EUNSUPPORTED;
-    if (m->hid_kind == PF_HID_LORENZ63_EM && m->dim != 3) return PF_EUNSUPPORTED;
-    if (m->obs_kind != PF_OBS_LINEAR && m->obs_kind != PF_OBS_SV) return PF_EUNSUPPORTED;
-    if (m->obs_kind == PF_OBS_SV && m->dim != 1) return PF_EUNSUPPORTED;
-    return PF_OK;
-}
 
-static inline ModelDesc to_desc(const pf_model* m) {
-    ModelDesc d;
-    d.hid_kind = m->hid_kind;
-    d.obs_kind = m->obs_kind;
-    d.obs_dim = m->obs_dim;
-    d.dt = m->dt;
-    d.inc_scale = m->inc_scale;
-    return d;
-}
 
 #define PF_DISPATCH_T_D(dtype, D, CALL)                                                     \
     if (dtype == PF_F32) {                                                                  \
@@ -1145,6 +1153,8 @@ extern "C" int pf_initial_sample(const double* m0, const double* s0, const void*
 // ---------------------------------------------------------------------------------------------------------------
 // fused loop
 // ---------------------------------------------------------------------------------------------------------------
+#endif  // !PF_TU_F64_ONLY
+
 template <typename T, int D, int VEC>
 static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
                            int finalize, hipStream_t st, float* kernel_ms) {
@@ -1345,6 +1355,32 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     return e == hipSuccess ? PF_OK : (int)e;
 }
 
+// one entry per arithmetic type (see the translation-unit note above)
+int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+               hipStream_t st, float* kernel_ms);
+int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+               hipStream_t st, float* kernel_ms);
+#define RUN(T, DD, V) return filter_run_impl<T, DD, V>(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
+#define RUN_D(T, V)                                       \
+    if (D == 1) { RUN(T, 1, V) } else if (D == 2) { RUN(T, 2, V) } else { RUN(T, 3, V) }
+#ifndef PF_TU_F64_ONLY
+int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+               hipStream_t st, float* kernel_ms) {
+    const int D = A->model.dim;
+    if (g.vec == 4) { RUN_D(float, 4) } else { RUN_D(float, 1) }
+}
+#endif
+#ifndef PF_TU_NO_F64
+int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+               hipStream_t st, float* kernel_ms) {
+    const int D = A->model.dim;
+    if (g.vec == 4) { RUN_D(double, 4) } else { RUN_D(double, 1) }
+}
+#endif
+#undef RUN_D
+#undef RUN
+
+#ifndef PF_TU_F64_ONLY
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms);
 
@@ -1432,14 +1468,8 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const int D = A->model.dim;
-#define RUN(T, DD, V) return filter_run_impl<T, DD, V>(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
-#define RUN_D(T, V)                                       \
-    if (D == 1) { RUN(T, 1, V) } else if (D == 2) { RUN(T, 2, V) } else { RUN(T, 3, V) }
-    if (A->dtype == PF_F32) {
-        if (g.vec == 4) { RUN_D(float, 4) } else { RUN_D(float, 1) }
-    } else if (A->dtype == PF_F64) {
-        if (g.vec == 4) { RUN_D(double, 4) } else { RUN_D(double, 1) }
-    }
+    if (A->dtype == PF_F32) return pf_run_f32(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
+    if (A->dtype == PF_F64) return pf_run_f64(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
     return PF_EINVAL;
 }
+#endif  // !PF_TU_F64_ONLY
