@@ -1268,7 +1268,10 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         bool fast = false;
         if constexpr (D == 1) fast = a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM;
         if (fast) {
-            if constexpr (D == 1) launch_step_as(std::integral_constant<int, -1>{}, std::true_type{});
+            if constexpr (D == 1) {
+                if (a.proposal == PF_PROP_BOOTSTRAP) launch_step_as(std::integral_constant<int, PF_PROP_BOOTSTRAP>{}, std::true_type{});
+                else launch_step_as(std::integral_constant<int, PF_PROP_LGO>{}, std::true_type{});
+            }
         } else if (a.proposal == PF_PROP_BOOTSTRAP) {
             launch_step_as(std::integral_constant<int, PF_PROP_BOOTSTRAP>{}, std::false_type{});
         } else {
