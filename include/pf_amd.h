@@ -210,7 +210,7 @@ int pf_filter_graph_destroy(void* handle);
 
 /* Measurement variant of pf_filter_run (synchronises the stream).  kernel_ms[0] = in-sequence duration of one step
  * (HIP events on `stream` around the whole step loop / n_steps); kernel_ms[1], kernel_ms[2] = that time apportioned to
- * the planning kernel and the step kernel by the ratio of their back-to-back replay durations (the last
+ * the planning kernel and the step kernel by the ratio of their single-kernel replay chains (the last
  * step's launches are idempotent).  Same results as pf_filter_run; not for throughput numbers. */
 int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                         float* kernel_ms);
