@@ -608,30 +608,39 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     const bool two = apf && obs;
     const int64_t stride = (int64_t)g.B * g.tiles;
     const int64_t cb = (int64_t)b * g.tiles;
-    EarlyPartials early;
-    load_early_partials<T>(a, cb, stride, two, early);
     if (k == nplan) {
+        EarlyPartials early;
+        load_early_partials<T>(a, cb, stride, two, early);
         column_bookkeeping<T, D>(a, early, b, cb, stride, obs, apf, two, red, redm, red2);
         return;
     }
-    if (a.finalize_only) return;
-    const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
-    const bool resample = apf ? obs : (c.S1 * c.S1 / c.Q1 < a.thr_abs);
-    if (!resample) return;
-    const double MR = two ? c.m2 : c.m1, SR = two ? c.S2 : c.S1;
+    // planners: nothing to do for a step that cannot resample.  A SISR step resamples when the bookkeeper's ESS test says
+    // so (stat.resample, read by the step kernel); the planners do not repeat that test - a differently ordered sum could
+    // land on the other side of the threshold - they always prepare the table (this kernel is latency-bound either way).
+    if (a.finalize_only || (apf && !obs)) return;
     const int slot_m = two ? PQ_M2 : PQ_M1, slot_s = two ? PQ_S2 : PQ_S1;
 
-    // tile-prefix table: thread t owns the IT consecutive tiles [t * IT, (t + 1) * IT)
+    // one load of the tiles' (max, sum) pairs - thread t owns the IT consecutive tiles [t * IT, (t + 1) * IT) - then two
+    // workgroup exchanges: the column maximum, and the scan whose total is the column sum
     const int IT = (g.tiles + PF_BLOCK - 1) / PF_BLOCK;
-    double incl[PF_COMBINE_ITERS], run = 0.0, total;
+    double mloc[PF_COMBINE_ITERS], sloc[PF_COMBINE_ITERS], mymax = -__builtin_huge_val();
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         const int t = threadIdx.x * IT + q;
-        if (q < IT && t < g.tiles)
-            run += a.part_r()[slot_s * stride + cb + t] * exp_diff_t<T>(a.part_r()[slot_m * stride + cb + t], MR);
+        const bool on = q < IT && t < g.tiles;
+        mloc[q] = on ? a.part_r()[slot_m * stride + cb + t] : -__builtin_huge_val();
+        sloc[q] = on ? a.part_r()[slot_s * stride + cb + t] : 0.0;
+        mymax = mloc[q] > mymax ? mloc[q] : mymax;
+    }
+    const double MR = block_max<double>(mymax, redm);
+    double incl[PF_COMBINE_ITERS], run = 0.0, total;
+#pragma unroll
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        run += sloc[q] * exp_diff_t<T>(mloc[q], MR);
         incl[q] = run;
     }
     const double excl = block_scan_excl(run, reds, total);
+    const double SR = total;
     if (threadIdx.x == 0) ptl[0] = 0.0;
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
@@ -641,8 +650,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     __syncthreads();
     if (k == 0) {
         for (int t = threadIdx.x; t <= g.tiles; t += PF_BLOCK) a.ptab[(int64_t)b * (g.tiles + 1) + t] = ptl[t];
-        for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-            a.ftab[cb + t] = exp_diff_t<T>(a.part_r()[slot_m * stride + cb + t], MR) / SR;
+#pragma unroll
+        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+            const int t = threadIdx.x * IT + q;
+            if (q < IT && t < g.tiles) a.ftab[cb + t] = exp_diff_t<T>(mloc[q], MR) / SR;
+        }
     }
 
     // multinomial: the resampling positions are the order statistics of N iid uniforms, built from normalised Exp(1)
