@@ -174,3 +174,30 @@ def test_c_oracle_against_reference_golden(dt, ct, suf):
         idx = np.empty((b, n), dtype=np.int64)
         getattr(so, f"oracle_systematic_{suf}")(ptr(Wref), ptr(u), ptr(idx), C.c_int64(n), C.c_int64(b))
         assert np.array_equal(idx[ok].T, g[f"norm_{nm}_idx"][:, ok])
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """The ctypes mirrors of ``pf_model`` / ``pf_filter_args`` have the size and field offsets the C compiler gives the
+    structs of ``include/pf_amd.h`` (an ABI drift between header and binding would corrupt every pointer after it)."""
+    import ctypes as C
+    import subprocess
+
+    from pyfilter_amd import _lib as L
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = {"pf_model": [f[0] for f in L.PfModel._fields_], "pf_filter_args": [f[0] for f in L.PfFilterArgs._fields_]}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{root}/include/pf_amd.h"', "int main(void) {"]
+    for st, names in fields.items():
+        lines.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for n in names:
+            lines.append(f'  printf("{st}.{n} %zu\\n", offsetof({st}, {n}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c11", str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for st, cls in (("pf_model", L.PfModel), ("pf_filter_args", L.PfFilterArgs)):
+        assert int(out[st]) == C.sizeof(cls), (st, out[st], C.sizeof(cls))
+        for n in fields[st]:
+            assert int(out[f"{st}.{n}"]) == getattr(cls, n).offset, (st, n, out[f"{st}.{n}"], getattr(cls, n).offset)
