@@ -1073,12 +1073,16 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
                 T xn[D];
                 T w_new;
                 if (obs) {
-                    T wi;
-                    if constexpr (FAST) wi = fc.sample_and_weight(proposal, xr[j][0], zt[j][0], xn[0]);
-                    else wi = sample_and_weight<T, D>(a.md, proposal, cp, cc, xr[j], zt[j], xn);
+                    T wi, pre_anc = T(0);
+                    if constexpr (FAST) {
+                        if (apf) wi = fc.sample_and_weight_apf(proposal, xr[j][0], zt[j][0], xn[0], pre_anc);
+                        else wi = fc.sample_and_weight(proposal, xr[j][0], zt[j][0], xn[0]);
+                    } else {
+                        wi = sample_and_weight<T, D>(a.md, proposal, cp, cc, xr[j], zt[j], xn);
+                    }
                     if (apf) {
                         // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
-                        if constexpr (FAST) w_new = wi - fc.pre_weight(proposal, xr[j][0]);
+                        if constexpr (FAST) w_new = wi - pre_anc;
                         else w_new = wi - pre_weight<T, D>(a.md, proposal, cp, cc, xr[j]);
                         if (is_nan_or_posinf(w_new)) poison = true;
                     } else {

@@ -264,6 +264,22 @@ template <typename T> struct FastCol {
         const T r = (next ? ybn : yb) - a * x;
         return -(r * r) * i2c - kc;
     }
+    // APF: the importance weight and the first-stage weight of the ancestor in one go - both need loc(x), and the
+    // compiler does not merge two pf_sin evaluations across its large-argument branch
+    __device__ __forceinline__ T sample_and_weight_apf(int proposal, T x, T z, T& xn, T& pre) const {
+        const T l = loc(x);
+        if (proposal == PF_PROP_BOOTSTRAP) {
+            pre = obs_lp(l);
+            xn = l + g * (z * inc);
+            return obs_lp(xn);
+        }
+        const T r = yb - a * x;
+        pre = -(r * r) * i2c - kc;
+        const T km = c_loc * l + c_y;
+        xn = km + kstd * z;
+        const T eps = (xn - l) * inv_g;
+        return obs_lp(xn) + (-(eps * eps) * i2inc - kt) - (-T(0.5) * z * z - kq);
+    }
     __device__ __forceinline__ T sample_and_weight(int proposal, T x, T z, T& xn) const {
         const T l = loc(x);
         if (proposal == PF_PROP_BOOTSTRAP) {
