@@ -940,19 +940,20 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
         // ---- 3. ancestors ---------------------------------------------------------------------------------------------
         int idx[VEC];
         if (windowed) {
-            if (from_local) {  // local scans -> cdf values (a staged vector never straddles a tile: tile % VEC == 0)
-                // tile of each staged vector: kt0 is the tile of j0 (from the planning kernel / carried between rounds); a
-                // window spans at most a few tiles, so two compares replace the integer divisions
-                // (indices inside a column fit 32 bits - N <= 2^30 - and unsigned compares absorb the one possible wrap)
+            // local scans -> cdf values of one staged window [w0, w0 + WIN) (a staged vector never straddles a tile:
+            // tile % VEC == 0).  kt0 is the tile of the window start (from the planning kernel, advanced as windows move
+            // on); a window spans at most a few tiles, so compares replace the integer divisions.  Indices inside a column
+            // fit 32 bits (N <= 2^30).
+            auto map_window = [&](int w0, int wja, int wjb, bool wina, bool winb, T (&m0)[VEC], T (&m1)[VEC]) {
                 const int te = g.tile_elems;
-                while ((unsigned)((kt0 + 1) * te) <= (unsigned)ws) ++kt0;  // uniform; only advances between rounds
+                while ((unsigned)((kt0 + 1) * te) <= (unsigned)w0) ++kt0;  // uniform; only ever advances
                 int kta = kt0, ktb = kt0;
                 {
                     const unsigned e1 = (unsigned)(kt0 + 1) * te, e2 = e1 + te, e3 = e2 + te;
-                    kta += ((unsigned)ja >= e1) + ((unsigned)ja >= e2) + ((unsigned)ja >= e3);
-                    ktb += ((unsigned)jb >= e1) + ((unsigned)jb >= e2) + ((unsigned)jb >= e3);
-                    if (!ina) kta = kt0;
-                    if (!inb) ktb = kt0;
+                    kta += ((unsigned)wja >= e1) + ((unsigned)wja >= e2) + ((unsigned)wja >= e3);
+                    ktb += ((unsigned)wjb >= e1) + ((unsigned)wjb >= e2) + ((unsigned)wjb >= e3);
+                    if (!wina) kta = kt0;
+                    if (!winb) ktb = kt0;
                 }
                 const double tPa = ptab_col[kta], tNa = ptab_col[kta + 1], tFa = ftab_col[kta];
                 const double tPb = ptab_col[ktb], tNb = ptab_col[ktb + 1], tFb = ftab_col[ktb];
@@ -961,15 +962,11 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
                 const int lb = (int)(eb < (unsigned)N ? eb : (unsigned)N) - 1;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    if (ina) c0[j] = cdf_from_local<T>(c0[j], tPa, tFa, tNa, ja + j == la, ja + j == N - 1);
-                    if (inb) c1[j] = cdf_from_local<T>(c1[j], tPb, tFb, tNb, jb + j == lb, jb + j == N - 1);
+                    m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
+                    m1[j] = winb ? cdf_from_local<T>(m1[j], tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
                 }
-            }
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                if (!ina) c0[j] = Lim<T>::inf();
-                if (!inb) c1[j] = Lim<T>::inf();
-            }
+            };
+            map_window(ws, ja, jb, ina, inb, c0, c1);
             if (XWIN) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -1000,6 +997,16 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
                 // Systematic grid, inverted: no search (inverse_grid_round); positions the window does not reach take a
                 // binary search in the implied cdf
                 inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                                           [&](int it, T (&d0)[VEC], T (&d1)[VEC]) -> bool {  // the window after the staged one(s)
+                                               const int w0 = ws + it * WIN;
+                                               if (w0 >= N) return false;
+                                               const int wja = w0 + tid * VEC, wjb = w0 + (PF_BLOCK + tid) * VEC;
+                                               const bool wina = wja < N, winb = wjb < N;
+                                               if (wina) { if (VEC == 1) d0[0] = cdf_col[wja]; else load_vec<T, VEC>(cdf_col + wja, d0); }
+                                               if (winb) { if (VEC == 1) d1[0] = cdf_col[wjb]; else load_vec<T, VEC>(cdf_col + wjb, d1); }
+                                               map_window(w0, wja, wjb, wina, winb, d0, d1);
+                                               return true;
+                                           },
                                            [&](int64_t i, int from) { return view.lower_bound(from, grid_position<T>(i, ub, nT), from ? kt0 : 0); },
                                            idx);
             }

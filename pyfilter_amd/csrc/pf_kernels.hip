@@ -203,40 +203,58 @@ __device__ __forceinline__ void grid_counts_local(const T (&c)[VEC], T u, T nT, 
 // the call (the first barrier inside orders that against the scatter); `fallback(i, from)` resolves positions the
 // window does not reach (from = first index not staged, or 0 when - defensively - no head precedes the position).
 // sh_cl: 2 * PF_NWAVES ints, sh_wm: PF_NWAVES ints.  Three barriers.
-template <typename T, int VEC, typename Fallback>
+#define PF_MAX_WINDOWS 8
+// `next_window(it, d0, d1)` stages the cdf entries [ws + it * WIN, ws + (it + 1) * WIN) the same way (returns false when
+// the column ends before them).  It is only called when the windows so far do not account for all RE positions - a
+// stretch of negligible weights - and lets the workgroup walk on window by window (up to PF_MAX_WINDOWS) before the
+// remaining positions fall back to per-position binary searches, whose ~20 dependent loads would set the duration of
+// the whole kernel.
+template <typename T, int VEC, typename NextWindow, typename Fallback>
 __device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (&c1)[VEC], int ws, int r0i, int RE, int N,
                                                    T ub, T nT, T rcN, bool pow2, int64_t i0, int* hd, int* sh_cl, int* sh_wm,
-                                                   Fallback&& fallback, int (&idx)[VEC]) {
+                                                   NextWindow&& next_window, Fallback&& fallback, int (&idx)[VEC]) {
     constexpr int WIN = 2 * PF_BLOCK * VEC;
     const int tid = threadIdx.x;
-    int cn0[VEC], cn1[VEC];
-    if (pow2) {
-        grid_counts_local<T, VEC, true>(c0, ub, nT, rcN, N, r0i, RE, cn0);
-        grid_counts_local<T, VEC, true>(c1, ub, nT, rcN, N, r0i, RE, cn1);
-    } else {
-        grid_counts_local<T, VEC, false>(c0, ub, nT, rcN, N, r0i, RE, cn0);
-        grid_counts_local<T, VEC, false>(c1, ub, nT, rcN, N, r0i, RE, cn1);
-    }
     const int lane = tid & 63, wid = tid >> 6;
-    if (lane == 63) {
-        sh_cl[wid] = cn0[VEC - 1];
-        sh_cl[PF_NWAVES + wid] = cn1[VEC - 1];
-    }
-    __syncthreads();  // the wave-boundary counts are visible; `hd` is zeroed
-    int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[VEC - 1], 0);
-    if (lane == 0) {
-        pv0 = wid ? sh_cl[wid - 1] : 0;    // entries before the window own no position of this round
-        pv1 = sh_cl[PF_NWAVES + wid - 1];  // wave 0: the first half's last entry
-    }
-    const int covered = sh_cl[2 * PF_NWAVES - 1];  // positions of this round the window accounts for
-    // branch-free scatter: entries without offspring in this round write to a per-lane dump slot behind the RE heads
-    // (exec-mask juggling per conditional store costs ~5 scalar instructions, a v_cndmask one vector instruction)
     const int dump = RE + lane;
+    // counts of one staged window -> heads; returns the number of positions accounted for so far
+    auto scatter_window = [&](const T (&w0)[VEC], const T (&w1)[VEC], int qbase, int covered_before) -> int {
+        int cn0[VEC], cn1[VEC];
+        if (pow2) {
+            grid_counts_local<T, VEC, true>(w0, ub, nT, rcN, N, r0i, RE, cn0);
+            grid_counts_local<T, VEC, true>(w1, ub, nT, rcN, N, r0i, RE, cn1);
+        } else {
+            grid_counts_local<T, VEC, false>(w0, ub, nT, rcN, N, r0i, RE, cn0);
+            grid_counts_local<T, VEC, false>(w1, ub, nT, rcN, N, r0i, RE, cn1);
+        }
+        if (lane == 63) {
+            sh_cl[wid] = cn0[VEC - 1];
+            sh_cl[PF_NWAVES + wid] = cn1[VEC - 1];
+        }
+        __syncthreads();  // the wave-boundary counts are visible; `hd` is zeroed
+        int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[VEC - 1], 0);
+        if (lane == 0) {
+            pv0 = wid ? sh_cl[wid - 1] : covered_before;  // entries before the first window own no position of this round
+            pv1 = sh_cl[PF_NWAVES + wid - 1];              // wave 0: the first half's last entry
+        }
+        const int covered = sh_cl[2 * PF_NWAVES - 1];
+        // branch-free scatter: entries without offspring in this round write to a per-lane dump slot behind the RE heads
+        // (exec-mask juggling per conditional store costs ~5 scalar instructions, a v_cndmask one vector instruction)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
-        hd[(cn0[j] > lo0) ? lo0 : dump] = tid * VEC + j + 1;
-        hd[(cn1[j] > lo1) ? lo1 : dump] = (PF_BLOCK + tid) * VEC + j + 1;
+        for (int j = 0; j < VEC; ++j) {
+            const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
+            hd[(cn0[j] > lo0) ? lo0 : dump] = qbase + tid * VEC + j + 1;
+            hd[(cn1[j] > lo1) ? lo1 : dump] = qbase + (PF_BLOCK + tid) * VEC + j + 1;
+        }
+        return covered;
+    };
+    int covered = scatter_window(c0, c1, 0, 0);  // positions of this round the window(s) account for
+    int windows = 1;
+    for (; windows < PF_MAX_WINDOWS && covered < RE; ++windows) {  // uniform: `covered` comes from LDS
+        __syncthreads();                                            // everyone has read sh_cl
+        T d0[VEC], d1[VEC];
+        if (!next_window(windows, d0, d1)) break;
+        covered = scatter_window(d0, d1, windows * WIN, covered);
     }
     __syncthreads();
     int h[VEC];
@@ -249,12 +267,13 @@ __device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (
     int carry = wave_prev(inc, 0);
 #pragma unroll
     for (int w = 0; w < PF_NWAVES - 1; ++w) carry = (w < wid) ? imax(carry, sh_wm[w]) : carry;
+    const int64_t beyond = (int64_t)ws + (int64_t)windows * WIN;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int64_t i = i0 + j;
         const int q = imax(carry, h[j]);
         int res = ws + q - 1;
-        if (i < N && (tid * VEC + j >= covered || q == 0)) res = fallback(i, (q == 0) ? 0 : (ws + WIN < N ? ws + WIN : N));
+        if (i < N && (tid * VEC + j >= covered || q == 0)) res = fallback(i, (q == 0) ? 0 : (int)(beyond < N ? beyond : N));
         idx[j] = (i < N && res < N) ? res : N - 1;
     }
 }
@@ -590,6 +609,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
                 }
                 int res[VEC];
                 inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                                           [&](int it, T (&d0)[VEC], T (&d1)[VEC]) -> bool {
+                                               const int w0 = ws + it * SearchWin<T, VEC>::WIN;
+                                               if (w0 >= N) return false;
+                                               const int wja = w0 + tid * VEC, wjb = w0 + (PF_BLOCK + tid) * VEC;
+#pragma unroll
+                                               for (int j = 0; j < VEC; ++j) d0[j] = d1[j] = Lim<T>::inf();
+                                               if (wja < N) { if (VEC == 1) d0[0] = col[wja]; else load_vec<T, VEC>(col + wja, d0); }
+                                               if (wjb < N) { if (VEC == 1) d1[0] = col[wjb]; else load_vec<T, VEC>(col + wjb, d1); }
+                                               return true;
+                                           },
                                            [&](int64_t i, int from) { return thread_lower_bound<T>(col, from, N, grid_position<T>(i, ub, nT)); },
                                            res);
                 if (i0 < g.N) {
@@ -1251,8 +1280,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             if constexpr (sizeof(T) == 4) {
                 const int sp = spec_of();
                 if (sp == 1) return go(mode_c, std::integral_constant<int, 1>{});
-                // (the SISR specialisation of the multinomial variant spills: measured slower than the generic kernel)
-                if constexpr (decltype(mode_c)::value == 0) {
+                // (the SISR specialisation spills in the multinomial variant and in the closed-form kernels: measured
+                // slower than the generic kernel there)
+                if constexpr (decltype(mode_c)::value == 0 && !FAST) {
                     if (sp == 2) return go(mode_c, std::integral_constant<int, 2>{});
                 }
             }
