@@ -715,27 +715,18 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     const int64_t first = (int64_t)kt * g.tile_elems;
     const int64_t last = (first + g.tile_elems < g.N ? first + g.tile_elems : g.N) - 1;
     const T* l_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;
-    // 64-ary search for the first i in [first, last] with cdf(i) >= p (cdf(last) >= p by the choice of kt)
-    int64_t slo = first, shi = last + 1;
-    while (shi - slo > PF_WAVE) {
-        const int64_t len = shi - slo;
-        const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
-        int64_t probe = slo + (lane + 1) * st - 1;
-        if (probe > shi - 1) probe = shi - 1;
-        const bool ge = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1) >= p;
-        const unsigned long long bal = __ballot(ge);
-        if (bal == 0ull) { slo = shi - 1; shi = slo + 1; break; }
-        const int f = __ffsll((long long)bal) - 1;
-        int64_t nhi = slo + (int64_t)(f + 1) * st;
-        if (nhi > shi) nhi = shi;
-        slo = slo + (int64_t)f * st;
-        shi = nhi;
-    }
-    const int64_t i = slo + lane;
-    const bool ge = (i < shi) ? (cdf_from_local<T>(l_col[i], Pk, fk, Pn, i == last, i == g.N - 1) >= p) : true;
+    // Window start inside tile kt: ONE 64-ary probe round.  The step kernel does not need the exact ancestor of the tile's
+    // first position, only an index at or before it whose predecessor lies below p (entries ahead of the ancestor own no
+    // position and cost nothing but window capacity) - so the bracket the first round yields (<= tile / 64 entries wide)
+    // is enough, and the second, dependent probe round (a further memory latency) is not spent.
+    const int64_t len = last + 1 - first;
+    const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
+    int64_t probe = first + (lane + 1) * st - 1;
+    if (probe > last) probe = last;
+    const bool ge = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1) >= p;
     const unsigned long long bal = __ballot(ge);
-    const int f = __ffsll((long long)bal) - 1;
-    int64_t res = slo + f;
+    const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
+    int64_t res = first + (int64_t)f * st;
     if (res > last) res = last;
     if (lane == 0) {
         a.j0[cb + t] = (int32_t)res;
