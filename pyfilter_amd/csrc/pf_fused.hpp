@@ -31,7 +31,13 @@ namespace pf {
             blockIdx.y == 0 && threadIdx.x == 0)                                                \
             (a).dbg[slot] = (unsigned long long)clock64();                                      \
     } while (0)
+#define PF_STAMP_PLAN(a, slot)                                                                  \
+    do {                                                                                        \
+        if ((a).debug_cut < 0 && !(a).finalize_only && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) \
+            (a).dbg[slot] = (unsigned long long)wall_clock64();                                  \
+    } while (0)
 #else
+#define PF_STAMP_PLAN(a, slot) do { } while (0)
 #define PF_CUT(a, n) false
 #ifdef PF_ISA_MARKS  // stage boundaries as comments in the ISA listing (static instruction counts; they pin the schedule)
 #define PF_STAMP(a, slot) asm volatile("; PF_MARK " #slot)
@@ -602,6 +608,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int nplan = (g.tiles + PF_NWAVES - 1) / PF_NWAVES;
+    PF_STAMP_PLAN(a, 0);
     const int step = a.step;
     const bool obs = !a.finalize_only && a.is_obs();
     const bool apf = a.filter == PF_FILTER_APF;
@@ -619,6 +626,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     // land on the other side of the threshold - they always prepare the table (this kernel is latency-bound either way).
     if (a.finalize_only || (apf && !obs)) return;
     const int slot_m = two ? PQ_M2 : PQ_M1, slot_s = two ? PQ_S2 : PQ_S1;
+    // issued first, used last: the Philox epoch / the step's systematic offset (dependent loads otherwise exposed between the
+    // table and the probe)
+    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    const T u_taped = (!multinomial && a.u_tape) ? a.u_tape[(int64_t)step * g.B + b] : T(0);
 
     // one load of the tiles' (max, sum) pairs - thread t owns the IT consecutive tiles [t * IT, (t + 1) * IT) - then two
     // workgroup exchanges: the column maximum, and the scan whose total is the column sum
@@ -633,6 +645,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
         mymax = mloc[q] > mymax ? mloc[q] : mymax;
     }
     const double MR = block_max<double>(mymax, redm);
+    PF_STAMP_PLAN(a, 1);
     double incl[PF_COMBINE_ITERS], run = 0.0, total;
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
@@ -641,6 +654,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     }
     const double excl = block_scan_excl(run, reds, total);
     const double SR = total;
+    PF_STAMP_PLAN(a, 2);
     if (threadIdx.x == 0) ptl[0] = 0.0;
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
@@ -660,8 +674,6 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     // multinomial: the resampling positions are the order statistics of N iid uniforms, built from normalised Exp(1)
     // spacings (Philox, regenerated wherever needed); their per-tile sums were reduced with the partials, so the first
     // position of every tile follows from a second prefix table
-    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
-    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     if (multinomial) {
         double inclE[PF_COMBINE_ITERS], runE = 0.0, totalE;
 #pragma unroll
@@ -700,16 +712,28 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
         draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + (int64_t)t * g.tile_elems), e0);
         p = (T)((pel[t] + (double)e0[0]) * (1.0 / pel[g.tiles + 1]));
     } else {
-        const T ub = a.u_tape ? a.u_tape[(int64_t)step * g.B + b] : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
+        const T ub = a.u_tape ? u_taped : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
         p = grid_position<T>((int64_t)t * g.tile_elems, ub, T(g.N));
     }
     // the tile holding the ancestor: first kt whose end value T(P_{kt+1}) (1 for the last tile) is >= p
+    // (64-ary over the LDS table: two probe rounds for 1024 tiles instead of ten dependent reads)
     int lo = 0, hi = g.tiles - 1;
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((T)ptl[mid + 1] < p) lo = mid + 1; else hi = mid;
+        const int len = hi - lo + 1;
+        const int st = (len + PF_WAVE - 1) / PF_WAVE;
+        int probe = lo + (lane + 1) * st - 1;
+        if (probe > hi) probe = hi;
+        const bool ge = (probe >= g.tiles - 1) || !((T)ptl[probe + 1] < p);
+        const unsigned long long bal = __ballot(ge);
+        const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;
+        int nhi = lo + (f + 1) * st - 1;
+        if (nhi > hi) nhi = hi;
+        lo = lo + f * st;
+        if (lo > nhi) lo = nhi;
+        hi = nhi;
     }
     const int kt = lo;
+    PF_STAMP_PLAN(a, 3);
     const double Pk = ptl[kt], Pn = ptl[kt + 1];
     const double fk = exp_diff_t<T>(a.part_r()[slot_m * stride + cb + kt], MR) / SR;
     const int64_t first = (int64_t)kt * g.tile_elems;
@@ -728,6 +752,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
     const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
     int64_t res = first + (int64_t)f * st;
     if (res > last) res = last;
+    PF_STAMP_PLAN(a, 4);
     if (lane == 0) {
         a.j0[cb + t] = (int32_t)res;
         a.k0[cb + t] = kt;

@@ -100,6 +100,7 @@ def main():
             sc = [st[i] - st[0] for i in range(0, 7)]
             sp = [st[i] - st[8] for i in range(8, 16)]
             print("   scan stamps (cycles from start: combine_done, finalize_done, pre-loop, pre-blockscan, post-blockscan, round_end):", sc[1:], " (PF_DEBUG_CUT=-(tile+1) selects the stamped tile)")
+            print("   plan stamps (10 ns ticks: start, max known, scan done, tile found, probe done):", [st[i] - st[0] for i in range(5)])
             t0w = min(st[16:24])
             print("   wall clock (10 ns ticks since the first of 8 sampled workgroups, tiles 0,128,..,896): start", [v - t0w for v in st[16:24]],
                   " end", [v - t0w for v in st[24:32]])
