@@ -14,6 +14,7 @@ class APF(ParticleFilter):
     _FILTER_KIND = L.FILTER_APF
 
     def predict(self, state: ParticleFilterCorrection) -> ParticleFilterPrediction:
+        self._refresh_parameters()  # parameter tensors are read live (in-place updates between moves)
         normalized = state.normalized_weights()
         old_indices = torch.arange(normalized.shape[0], device=normalized.device)
         if self.batch_shape:

@@ -126,6 +126,28 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             ctx.u_tape = self._u_tape.to(device=device, dtype=dtype).reshape(self._u_tape.shape[0], b).contiguous()
         return ctx
 
+    def _params_signature(self):
+        """(identity, in-place version) of every model parameter tensor: cheap host-side change detection."""
+        tensors = list(self._model.hidden.parameters) + list(self._model.parameters)
+        init = getattr(self._model.hidden, "initial_parameters", None)
+        if init is not None:
+            tensors += list(init)
+        return tuple((id(t), t._version) for t in tensors if isinstance(t, torch.Tensor))
+
+    def _refresh_parameters(self):
+        """The reference's model callables read the parameter tensors live, so in-place updates between calls (SMC^2 /
+        PMMH ``exchange`` / ``resample`` of parameters) take effect at once.  The kernels read a packed copy: re-pack it
+        (into the same buffer - captured graphs keep their pointer) whenever a parameter tensor was modified in place."""
+        ctx = self._ctx
+        if ctx is None:
+            return
+        sig = self._params_signature()
+        if getattr(ctx, "params_signature", None) != sig:
+            if getattr(ctx, "params_signature", None) is not None:
+                b = self.batch_shape[0] if self._batched else 1
+                ctx.params.copy_(pack_params(self._model, b, ctx.params.dtype, ctx.params.device))
+            ctx.params_signature = sig
+
     def initialize(self) -> ParticleFilterCorrection:
         assert self._model is not None, "Model has not been initialized!"
         self._proposal.set_model(self.ssm)
@@ -237,6 +259,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             self._proposal.set_model(self.ssm)
             self._ctx = self._build_context(*self._device_dtype())
             self._proposal._set_context(self._ctx)
+        self._refresh_parameters()
         ctx, kind = self._ctx, self._ctx.kind
         ts_in = state.timeseries_state
         x_in = ops.to_soa(ts_in.value, self._batched, self._has_event)   # views of library buffers: no copies
@@ -317,6 +340,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             self._proposal.set_model(self.ssm)
             self._ctx = self._build_context(*self._device_dtype())
             self._proposal._set_context(self._ctx)
+        self._refresh_parameters()
         ctx = self._ctx
         kind = ctx.kind
         x0 = state.timeseries_state.value

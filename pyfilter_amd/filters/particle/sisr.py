@@ -13,6 +13,7 @@ class SISR(ParticleFilter):
     _FILTER_KIND = L.FILTER_SISR
 
     def predict(self, state: ParticleFilterCorrection) -> ParticleFilterPrediction:
+        self._refresh_parameters()  # parameter tensors are read live (in-place updates between moves)
         ts_state = state.get_timeseries_state()
         weights = state.weights
         prev_inds = state.previous_indices

@@ -575,3 +575,49 @@ def test_multinomial_many_tiles_against_kalman(n, b):
     assert (res.loglikelihood.cpu().double().reshape(-1) - kll).abs().max().item() < 30.0 * tol
     idx = res.latest_state.previous_indices.reshape(n, -1)
     assert (idx[1:] >= idx[:-1]).all() and idx.min() >= 0 and idx.max() <= n - 1
+
+
+@pytest.mark.parametrize("route", ["batch", "online", "steps"])
+def test_parameters_are_read_live(route, monkeypatch):
+    """The reference's model callables read the parameter tensors on every call, so an in-place update between moves
+    (what SMC^2 / PMMH do when they exchange or resample parameters) takes effect immediately.  The kernels read a packed
+    copy of the parameters: it must follow in-place updates - the run after the update equals a run of a filter built
+    with the new values from scratch (identical draws)."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.timeseries import models
+
+    if route == "steps":
+        monkeypatch.setenv("PF_NO_FUSED_STEP", "1")
+    n, b, t_len = 4096, 3, 6
+    gen = torch.Generator().manual_seed(2)
+    z = torch.randn(t_len, n, b, generator=gen, dtype=torch.float64)
+    u = torch.rand(t_len, b, generator=gen, dtype=torch.float64)
+    z0 = torch.randn(n, b, generator=gen, dtype=torch.float64)
+    y = torch.linspace(-0.3, 0.4, t_len, dtype=torch.float64).cuda()
+
+    def build(beta):
+        tt = lambda v: torch.tensor(v, dtype=torch.float64, device="cuda")  # noqa: E731
+        ssm = ts.LinearStateSpaceModel(models.AR(tt(0.0), beta, tt(0.2)), (tt(1.0), tt(0.3)))
+        f = APF(ssm, n, proposal=proposals.LinearGaussianObservations())
+        f.set_batch_shape(torch.Size([b]))
+        f.set_tape(z=z, u=u, z0=z0)
+        return f
+
+    def run(f):
+        if route == "batch":
+            return f.batch_filter(y, bar=False).loglikelihood
+        state, tot = f.initialize(), 0.0
+        for t in range(t_len):
+            state = f.filter(y[t], state)
+            tot = tot + state.get_loglikelihood()
+        return tot
+
+    beta = torch.tensor([0.5, 0.7, 0.9], dtype=torch.float64, device="cuda")
+    filt = build(beta)
+    first = run(filt)
+    beta.mul_(0.0).add_(torch.tensor([0.95, 0.2, 0.6], dtype=torch.float64, device="cuda"))   # in place
+    second = run(filt)
+    fresh = run(build(torch.tensor([0.95, 0.2, 0.6], dtype=torch.float64, device="cuda")))
+    assert not torch.allclose(first, second)
+    torch.testing.assert_close(second, fresh, rtol=1e-12, atol=1e-12)
