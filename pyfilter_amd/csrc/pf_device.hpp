@@ -76,6 +76,14 @@ __device__ __forceinline__ float pf_rcp_c(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ double pf_rcp_c(double x) { return 1.0 / x; }
 __device__ __forceinline__ float pf_sqrt_c(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double pf_sqrt_c(double x) { return sqrt(x); }
+// a / b, sqrt, log in the generic per-particle arithmetic: float -> hardware reciprocal / sqrt / log (1 ulp class; the
+// compiler's exact division alone is ~10 instructions), double -> the exact forms (the parity path keeps its rounding)
+__device__ __forceinline__ float pf_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double pf_div(double a, double b) { return a / b; }
+__device__ __forceinline__ float pf_sqrt_g(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double pf_sqrt_g(double x) { return sqrt(x); }
+__device__ __forceinline__ float pf_log_g(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309417f; }
+__device__ __forceinline__ double pf_log_g(double x) { return log(x); }
 __device__ __forceinline__ float pf_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double pf_abs(double x) { return fabs(x); }
 

@@ -357,14 +357,14 @@ template <typename T, int K> __device__ __forceinline__ void chol_lower(const T 
         T s = a[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= l[j][k] * l[j][k];
-        const T ljj = pf_sqrt(s);
+        const T ljj = pf_sqrt_g(s);
         l[j][j] = ljj;
 #pragma unroll
         for (int i = j + 1; i < K; ++i) {
             T t = a[i][j];
 #pragma unroll
             for (int k = 0; k < j; ++k) t -= l[i][k] * l[j][k];
-            l[i][j] = t / ljj;
+            l[i][j] = pf_div(t, ljj);
         }
     }
 }
@@ -380,13 +380,13 @@ template <typename T, int K> __device__ __forceinline__ void spd_inverse(const T
         for (int j = 0; j < K; ++j) li[i][j] = T(0);
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        li[j][j] = T(1) / l[j][j];
+        li[j][j] = pf_div(T(1), l[j][j]);
 #pragma unroll
         for (int i = j + 1; i < K; ++i) {
             T t = T(0);
 #pragma unroll
             for (int k = j; k < i; ++k) t -= l[i][k] * li[k][j];
-            li[i][j] = t / l[i][i];
+            li[i][j] = pf_div(t, l[i][i]);
         }
     }
 #pragma unroll
@@ -434,7 +434,7 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
         }
     }
     if constexpr (MO == 1) {
-        return normal_logpdf(r[0], T(0), pf_sqrt(cov[0][0]));
+        return normal_logpdf(r[0], T(0), pf_sqrt_g(cov[0][0]));
     } else {
         T l[MO][MO];
         chol_lower<T, MO>(cov, l);
@@ -445,9 +445,9 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
             T t = r[i];
 #pragma unroll
             for (int k = 0; k < i; ++k) t -= l[i][k] * v[k];
-            v[i] = t / l[i][i];
+            v[i] = pf_div(t, l[i][i]);
             quad += v[i] * v[i];
-            logdet += pf_log(l[i][i]);
+            logdet += pf_log_g(l[i][i]);
         }
         return -T(0.5) * quad - logdet - T(cp.O) * T(PF_LOG_SQRT_2PI);
     }
@@ -486,7 +486,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
     T hvi[D], prec[D][D], rhs[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        hvi[d] = T(1) / (scale[d] * scale[d]);
+        hvi[d] = pf_div(T(1), scale[d] * scale[d]);
         rhs[d] = hvi[d] * loc[d];
     }
 #pragma unroll
@@ -496,7 +496,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
 #pragma unroll
     for (int o = 0; o < MO; ++o) {
         if (o < cp.O) {
-            const T ovi = T(1) / (cp.os[o] * cp.os[o]);
+            const T ovi = pf_div(T(1), cp.os[o] * cp.os[o]);
             const T ry = ovi * (cp.y[o] - cp.ob[o]);
 #pragma unroll
             for (int i = 0; i < D; ++i) {
@@ -508,7 +508,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
     }
     T cov[D][D], km[D], l[D][D];
     if constexpr (D == 1) {
-        cov[0][0] = T(1) / prec[0][0];
+        cov[0][0] = pf_div(T(1), prec[0][0]);
     } else {
         spd_inverse<T, D>(prec, cov);
     }
@@ -527,7 +527,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
 #pragma unroll
         for (int j = 0; j <= i; ++j) t += l[i][j] * z[j];
         xn[i] = t;
-        logq += -T(0.5) * z[i] * z[i] - pf_log(l[i][i]) - T(PF_LOG_SQRT_2PI);
+        logq += -T(0.5) * z[i] * z[i] - pf_log_g(l[i][i]) - T(PF_LOG_SQRT_2PI);
     }
     return obs_logpdf<T, D>(md, cp, xn) + transition_logpdf<T, D>(md, xn, loc, scale) - logq;
 }
