@@ -783,20 +783,37 @@ template <typename T, int D, int MODE, int PROP, bool FAST> struct StepWaves {
 // launch is issued - so their branches, registers and dead paths (propagate-only move, tape loads, the other filter's
 // weight update) leave the kernel: 0 generic (flags read at run time: NaN observations, the run's last step, tapes,
 // device-side flags), 1 APF on an observed step followed by an observed step, 2 SISR on an observed step.
-template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC>
-__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value)) void k_fused_step(FusedArgs<T> a) {
+// LDS of one step workgroup (declared by the kernel, shared by the two bodies below)
+template <typename T, int D, int VEC> struct StepShared {
+    static constexpr int WIN = SearchWin<T, VEC>::WIN;
+    static constexpr bool XWIN = (sizeof(T) * D <= 8);
+    T* win;
+    T* xwin;
+    int* sh_j0;
+    int* sh_cl;
+    int* sh_wm;
+    double* red;
+    double* reds;
+    T* redm;
+};
+// RS: whether this column resamples in this step - a run-time fact for SISR (the bookkeeper's ESS test), so the kernel
+// holds both bodies and branches once, uniformly, at its top: the resampling body carries no carried-weights path (old
+// log-weights, direct state loads), the other one no ancestor stage.
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, bool RS>
+__device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
-    constexpr int WIN = SearchWin<T, VEC>::WIN;
+    constexpr int WIN = StepShared<T, D, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
     // ancestor gather is an LDS read instead of a second dependent global round trip
-    constexpr bool XWIN = (sizeof(T) * D <= 8);
-    __shared__ __attribute__((aligned(32))) T win[WIN];
-    __shared__ __attribute__((aligned(32))) T xwin[XWIN ? D * WIN : VEC];
-    __shared__ int sh_j0;
-    __shared__ int sh_cl[2 * PF_NWAVES], sh_wm[PF_NWAVES];
-    __shared__ double red[(4 + 2 * D) * PF_NWAVES];
-    __shared__ double reds[PF_NWAVES];
-    __shared__ T redm[2 * PF_NWAVES];
+    constexpr bool XWIN = StepShared<T, D, VEC>::XWIN;
+    T* const win = sh.win;
+    T* const xwin = sh.xwin;
+    int& sh_j0 = *sh.sh_j0;
+    int* const sh_cl = sh.sh_cl;
+    int* const sh_wm = sh.sh_wm;
+    double* const red = sh.red;
+    double* const reds = sh.reds;
+    T* const redm = sh.redm;
     int* hd = reinterpret_cast<int*>(win);  // systematic route: heads of the offspring ranges (the cdf window is not staged)
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -805,7 +822,7 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
     const int slot = step & 1;
     const bool obs = SPEC ? true : a.is_obs();
     const bool apf = SPEC ? (SPEC == 1) : (a.filter == PF_FILTER_APF);
-    const bool resample = (SPEC == 1) ? true : (a.stat[b].resample != 0);
+    constexpr bool resample = RS;
     constexpr bool multinomial = MODE == 1;
     const bool windowed = resample;  // both resamplers search an LDS window of the cdf (their positions are sorted)
     const bool pre_next = SPEC ? (SPEC == 1) : (a.is_obs_next() && apf);
@@ -1174,6 +1191,25 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value
 #ifdef PF_DEVTOOLS
     if (a.debug_cut < 0 && tid == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[24 + k / 128] = wall_clock64();
 #endif
+}
+
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC>
+__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value)) void k_fused_step(FusedArgs<T> a) {
+    using SH = StepShared<T, D, VEC>;
+    __shared__ __attribute__((aligned(32))) T win[SH::WIN];
+    __shared__ __attribute__((aligned(32))) T xwin[SH::XWIN ? D * SH::WIN : VEC];
+    __shared__ int sh_j0;
+    __shared__ int sh_cl[2 * PF_NWAVES], sh_wm[PF_NWAVES];
+    __shared__ double red[(4 + 2 * D) * PF_NWAVES];
+    __shared__ double reds[PF_NWAVES];
+    __shared__ T redm[2 * PF_NWAVES];
+    const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm};
+    if constexpr (SPEC == 1) {
+        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, true>(a, sh);
+    } else {
+        if (a.stat[blockIdx.y].resample != 0) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, true>(a, sh);
+        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, false>(a, sh);
+    }
 }
 
 }  // namespace pf

@@ -1282,9 +1282,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                 if (sp == 1) return go(mode_c, std::integral_constant<int, 1>{});
                 // (the SISR specialisation spills in the multinomial variant and in the closed-form kernels: measured
                 // slower than the generic kernel there)
-                if constexpr (decltype(mode_c)::value == 0 && !FAST) {
-                    if (sp == 2) return go(mode_c, std::integral_constant<int, 2>{});
-                }
+                if (sp == 2) return go(mode_c, std::integral_constant<int, 2>{});
             }
             go(mode_c, std::integral_constant<int, 0>{});
         };
