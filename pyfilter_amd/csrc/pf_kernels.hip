@@ -921,11 +921,15 @@ static inline ModelDesc to_desc(const pf_model* m) {
     return d;
 }
 
-// The fused-run instantiation matrix compiles as two translation units (the build runs them in parallel):
-//   -DPF_TU_NO_F64   : everything except the float64 fused kernels   (the main unit: C ABI, primitives, float32 runs)
-//   -DPF_TU_F64_ONLY : only the float64 fused kernels + their entry  (pf_run_f64)
-// Without either macro the file is a single self-contained unit.
-#ifndef PF_TU_F64_ONLY
+// The fused-run instantiation matrix compiles as three translation units (the build runs them in parallel):
+//   -DPF_TU_NO_F64 -DPF_TU_NO_F32DN : the main unit - C ABI, primitives, float32 fused kernels of scalar states
+//   -DPF_TU_F32DN_ONLY              : only the float32 fused kernels of D > 1 states + their entry (pf_run_f32_dn)
+//   -DPF_TU_F64_ONLY                : only the float64 fused kernels + their entry               (pf_run_f64)
+// Without any of the macros the file is a single self-contained unit.
+#if defined(PF_TU_F64_ONLY) || defined(PF_TU_F32DN_ONLY)
+#define PF_TU_NO_API
+#endif
+#ifndef PF_TU_NO_API
 extern "C" const char* pf_version(void) { return "pfamd 0.1.0 (gfx950)"; }
 
 extern "C" const char* pf_error_string(int code) {
@@ -1182,7 +1186,7 @@ extern "C" int pf_initial_sample(const double* m0, const double* s0, const void*
 // ---------------------------------------------------------------------------------------------------------------
 // fused loop
 // ---------------------------------------------------------------------------------------------------------------
-#endif  // !PF_TU_F64_ONLY
+#endif  // !PF_TU_NO_API
 
 template <typename T, int D, int VEC>
 static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
@@ -1399,17 +1403,30 @@ int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64
                hipStream_t st, float* kernel_ms);
 int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
                hipStream_t st, float* kernel_ms);
+int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                  hipStream_t st, float* kernel_ms);
 #define RUN(T, DD, V) return filter_run_impl<T, DD, V>(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
 #define RUN_D(T, V)                                       \
     if (D == 1) { RUN(T, 1, V) } else if (D == 2) { RUN(T, 2, V) } else { RUN(T, 3, V) }
-#ifndef PF_TU_F64_ONLY
+#ifndef PF_TU_NO_API
 int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
                hipStream_t st, float* kernel_ms) {
-    const int D = A->model.dim;
-    if (g.vec == 4) { RUN_D(float, 4) } else { RUN_D(float, 1) }
+    if (A->model.dim != 1) return pf_run_f32_dn(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
+    if (g.vec == 4) { RUN(float, 1, 4) } else { RUN(float, 1, 1) }
 }
 #endif
-#ifndef PF_TU_NO_F64
+#if !defined(PF_TU_NO_F32DN) && !defined(PF_TU_F64_ONLY)
+int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                  hipStream_t st, float* kernel_ms) {
+    const int D = A->model.dim;
+    if (g.vec == 4) {
+        if (D == 2) { RUN(float, 2, 4) } else { RUN(float, 3, 4) }
+    } else {
+        if (D == 2) { RUN(float, 2, 1) } else { RUN(float, 3, 1) }
+    }
+}
+#endif
+#if !defined(PF_TU_NO_F64) && !defined(PF_TU_F32DN_ONLY)
 int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
                hipStream_t st, float* kernel_ms) {
     const int D = A->model.dim;
@@ -1419,7 +1436,7 @@ int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64
 #undef RUN_D
 #undef RUN
 
-#ifndef PF_TU_F64_ONLY
+#ifndef PF_TU_NO_API
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms);
 
@@ -1511,4 +1528,4 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (A->dtype == PF_F64) return pf_run_f64(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
     return PF_EINVAL;
 }
-#endif  // !PF_TU_F64_ONLY
+#endif  // !PF_TU_NO_API
