@@ -128,7 +128,8 @@ template <typename T, int D> struct ColConsts {
     // D-generic part: linear observation + state-independent transition scale -> Bootstrap needs no per-particle
     // division / log (`lin_fast`); the scalar closed forms below additionally cover LinearGaussianObservations
     static constexpr int MAXO = ObsDim<D>::MAXO;
-    bool lin_fast;
+    // (vector states always observe linearly - PF_OBS_SV is scalar-only - so this is a compile-time fact)
+    static constexpr bool lin_fast = D > 1;
     T oi2s[MAXO], oks;          // 1 / (2 s_o^2) per observation component, sum_o (log s_o + log sqrt(2 pi))
     bool fast;
     T g, inv_g, inc, yb, ybn, a;  // yb / ybn: y - b for this / the next observation
@@ -140,7 +141,6 @@ template <typename T, int D> struct ColConsts {
 
     __device__ __forceinline__ void prepare(const ModelDesc& md, const ColParams<T, D>& cp) {
         fast = false;
-        lin_fast = (D > 1) && md.obs_kind == PF_OBS_LINEAR && md.hid_kind != PF_HID_VERHULST_EM;  // D = 1: scalar forms below
         if (lin_fast) {
             oks = T(0);
 #pragma unroll
