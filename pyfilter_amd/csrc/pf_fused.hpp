@@ -773,11 +773,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
 #define PF_WAVES_D1_GENERIC 4
 #endif
 // resident waves per SIMD the register allocation is tuned for (float; measured per variant, tools/kbench.py)
-template <typename T, int D, int MODE, int PROP, bool FAST> struct StepWaves {
+template <typename T, int D, int MODE, int PROP, bool FAST, int SPEC> struct StepWaves {
     static constexpr int value = sizeof(T) != 4 ? 1
                                  : D == 1     ? (FAST ? 4 : PF_WAVES_D1_GENERIC)
                                  : PROP == PF_PROP_LGO ? 2
-                                 : (MODE == 1 ? 4 : 3);
+                                 : (MODE == 1 || SPEC == 2) ? 4   // (a handful of spills, more than repaid by the fourth wave)
+                                 : 3;
 };
 // SPEC: the per-launch flags as compile-time constants for the two steady states of a run - known on the host when the
 // launch is issued - so their branches, registers and dead paths (propagate-only move, tape loads, the other filter's
@@ -1194,7 +1195,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 }
 
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC>
-__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST>::value)) void k_fused_step(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>::value)) void k_fused_step(FusedArgs<T> a) {
     using SH = StepShared<T, D, VEC>;
     __shared__ __attribute__((aligned(32))) T win[SH::WIN];
     __shared__ __attribute__((aligned(32))) T xwin[SH::XWIN ? D * SH::WIN : VEC];
