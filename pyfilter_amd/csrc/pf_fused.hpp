@@ -800,9 +800,14 @@ template <typename T, int D, int VEC> struct StepShared {
 // RS: whether this column resamples in this step - a run-time fact for SISR (the bookkeeper's ESS test), so the kernel
 // holds both bodies and branches once, uniformly, at its top: the resampling body carries no carried-weights path (old
 // log-weights, direct state loads), the other one no ancestor stage.
-template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, bool RS>
+// MK: the model kinds as compile-time constants where the generic per-particle arithmetic switches on them - 0 run-time
+// kinds, 1 Verhulst diffusion + stochastic-volatility observation (D = 1): the switch statements fold, their scalar branch
+// instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on 64 x 65 536).
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS>
 __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
+    ModelDesc md = a.md;
+    if constexpr (MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
     constexpr int WIN = StepShared<T, D, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
     // ancestor gather is an LDS read instead of a second dependent global round trip
@@ -1080,10 +1085,10 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         } else if constexpr (D == 1) {
             load_col_params<T, D>(a, b, step, obs, cp, late);
             if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim + late);
-            cc.prepare(a.md, cp);
+            cc.prepare(md, cp);
             __builtin_assume(cc.fast == FAST);
         } else if (r == 0) {  // D > 1: the rows were loaded up front (register room, and no exposed latency here)
-            cc.prepare(a.md, cp);
+            cc.prepare(md, cp);
             __builtin_assume(cc.fast == FAST);
         }
         T xo[D][VEC];
@@ -1119,12 +1124,12 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                         if (apf) wi = fc.sample_and_weight_apf(proposal, xr[j][0], zt[j][0], xn[0], pre_anc);
                         else wi = fc.sample_and_weight(proposal, xr[j][0], zt[j][0], xn[0]);
                     } else {
-                        wi = sample_and_weight<T, D>(a.md, proposal, cp, cc, xr[j], zt[j], xn);
+                        wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], zt[j], xn);
                     }
                     if (apf) {
                         // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
                         if constexpr (FAST) w_new = wi - pre_anc;
-                        else w_new = wi - pre_weight<T, D>(a.md, proposal, cp, cc, xr[j]);
+                        else w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j]);
                         if (is_nan_or_posinf(w_new)) poison = true;
                     } else {
                         if (is_nan_or_posinf(wi)) poison = true;
@@ -1133,7 +1138,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 } else {
                     // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
                     if constexpr (FAST) fc.sample_and_weight(PF_PROP_BOOTSTRAP, xr[j][0], zt[j][0], xn[0]);
-                    else sample_and_weight<T, D>(a.md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
+                    else sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
                     w_new = resample ? T(0) : lw_old[j];
                 }
                 lwo[j] = sanitize_logw(w_new);
@@ -1141,7 +1146,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
                 // first-stage weight of the next step, while the new particle is still in registers
                 if constexpr (FAST) pre_n[j] = pre_next ? fc.pre_weight(proposal, xn[0], true) : T(0);
-                else pre_n[j] = pre_next ? pre_weight<T, D>(a.md, proposal, cp, cc, xn, true) : T(0);
+                else pre_n[j] = pre_next ? pre_weight<T, D>(md, proposal, cp, cc, xn, true) : T(0);
                 // keep the scheduler from interleaving all VEC particles' arithmetic: that is what pushes the kernel
                 // over its register budget (spills cost real HBM traffic: PMC WRITE_SIZE)
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);
@@ -1185,7 +1190,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, pre_next ? M2 : M1,
                                    [&](const T (&xj)[D]) {
                                        if constexpr (FAST) return fc.pre_weight(proposal, xj[0], true);
-                                       else return pre_weight<T, D>(a.md, proposal, cp, cc, xj, true);
+                                       else return pre_weight<T, D>(md, proposal, cp, cc, xj, true);
                                    },
                                    g.rounds_per_tile == 1, e_rw, pre_next ? F2 : F1, reds);
     PF_STAMP(a, 15);
@@ -1194,7 +1199,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #endif
 }
 
-template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC>
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK>
 __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>::value)) void k_fused_step(FusedArgs<T> a) {
     using SH = StepShared<T, D, VEC>;
     __shared__ __attribute__((aligned(32))) T win[SH::WIN];
@@ -1206,10 +1211,10 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
     __shared__ T redm[2 * PF_NWAVES];
     const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm};
     if constexpr (SPEC == 1) {
-        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, true>(a, sh);
+        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh);
     } else {
-        if (a.stat[blockIdx.y].resample != 0) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, true>(a, sh);
-        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, false>(a, sh);
+        if (a.stat[blockIdx.y].resample != 0) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh);
+        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh);
     }
 }
 

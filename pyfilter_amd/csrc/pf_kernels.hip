@@ -1278,7 +1278,15 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         auto go = [&](auto mode_c, auto spec_c) {
             constexpr int MODE = decltype(mode_c)::value;
             constexpr int SPEC = decltype(spec_c)::value;
-            hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC>), grid, block, 0, st, a);
+            // model kinds folded at compile time for the stochastic-volatility built-in (float runs; for Lorenz-63 the
+            // same specialisation measured no gain)
+            if constexpr (sizeof(T) == 4 && !FAST && D == 1) {
+                if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) {
+                    hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 1>), grid, block, 0, st, a);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 0>), grid, block, 0, st, a);
         };
         auto with_mode = [&](auto mode_c) {
             if constexpr (sizeof(T) == 4) {

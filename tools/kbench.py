@@ -28,6 +28,14 @@ def make(model, filt, prop, n, b, dtype=torch.float32, resampler="systematic"):
     elif model == "lg":
         ssm = ts.LinearStateSpaceModel(models.AR(t(0.0, dtype), t(0.99, dtype), t(0.05, dtype)), (t(1.0, dtype), t(0.15, dtype)))
         o = ()
+    elif model == "sv":
+        kappa = t([0.05 + 0.01 * (i % 7) for i in range(b)], dtype)
+        gamma = t([1.0 + 0.1 * (i % 5) for i in range(b)], dtype)
+        sigma = t([0.10 + 0.02 * (i % 3) for i in range(b)], dtype)
+        mu = t([0.0 + 0.05 * (i % 4) for i in range(b)], dtype)
+        hidden = models.Verhulst(kappa, gamma, sigma, dt=0.2, initial=(t(1.0, dtype), t(0.1, dtype)))
+        ssm = models.StochasticVolatilityModel(hidden, mu)
+        o = ()
     elif model == "lorenz":
         hidden = models.Lorenz63(t(10.0, dtype), t(28.0, dtype), t(8.0 / 3.0, dtype), t(1.0, dtype), dt=0.01)
         a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]], dtype)
@@ -50,6 +58,7 @@ CONFIGS = {
     "apf_lgo_4m": ("sine", "apf", "lgo", 1 << 22, 1),
     "apf_lgo_64x64k": ("sine", "apf", "lgo", 65536, 64),
     "apf_lgo_1024x8k": ("sine", "apf", "lgo", 8192, 1024),
+    "apf_sv_64x64k": ("sv", "apf", "bootstrap", 65536, 64),
     "apf_lgo_256k": ("sine", "apf", "lgo", 1 << 18, 1),
     "apf_lgo_512k": ("sine", "apf", "lgo", 1 << 19, 1),
     "apf_lgo_2m": ("sine", "apf", "lgo", 1 << 21, 1),
