@@ -800,14 +800,15 @@ template <typename T, int D, int VEC> struct StepShared {
 // RS: whether this column resamples in this step - a run-time fact for SISR (the bookkeeper's ESS test), so the kernel
 // holds both bodies and branches once, uniformly, at its top: the resampling body carries no carried-weights path (old
 // log-weights, direct state loads), the other one no ancestor stage.
-// MK: the model kinds as compile-time constants where the generic per-particle arithmetic switches on them - 0 run-time
-// kinds, 1 Verhulst diffusion + stochastic-volatility observation (D = 1): the switch statements fold, their scalar branch
-// instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on 64 x 65 536).
+// MK: the model kinds as compile-time constants where the per-particle arithmetic switches on them.  Generic kernels: 0
+// run-time kinds, 1 Verhulst diffusion + stochastic-volatility observation (D = 1) - the switch statements fold, their
+// scalar branch instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on
+// 64 x 65 536).  Closed-form kernels (FAST): the shape of the one-step mean, 0 run time, 1 affine, 2 sine.
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS>
 __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     ModelDesc md = a.md;
-    if constexpr (MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
+    if constexpr (!FAST && MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
     constexpr int WIN = StepShared<T, D, VEC>::WIN;
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
     // ancestor gather is an LDS read instead of a second dependent global round trip
@@ -1121,8 +1122,8 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 if (obs) {
                     T wi, pre_anc = T(0);
                     if constexpr (FAST) {
-                        if (apf) wi = fc.sample_and_weight_apf(proposal, xr[j][0], zt[j][0], xn[0], pre_anc);
-                        else wi = fc.sample_and_weight(proposal, xr[j][0], zt[j][0], xn[0]);
+                        if (apf) wi = fc.template sample_and_weight_apf<FAST ? MK : 0>(proposal, xr[j][0], zt[j][0], xn[0], pre_anc);
+                        else wi = fc.template sample_and_weight<FAST ? MK : 0>(proposal, xr[j][0], zt[j][0], xn[0]);
                     } else {
                         wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], zt[j], xn);
                     }
@@ -1137,7 +1138,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                     }
                 } else {
                     // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
-                    if constexpr (FAST) fc.sample_and_weight(PF_PROP_BOOTSTRAP, xr[j][0], zt[j][0], xn[0]);
+                    if constexpr (FAST) fc.template sample_and_weight<FAST ? MK : 0>(PF_PROP_BOOTSTRAP, xr[j][0], zt[j][0], xn[0]);
                     else sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
                     w_new = resample ? T(0) : lw_old[j];
                 }
@@ -1145,7 +1146,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #pragma unroll
                 for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
                 // first-stage weight of the next step, while the new particle is still in registers
-                if constexpr (FAST) pre_n[j] = pre_next ? fc.pre_weight(proposal, xn[0], true) : T(0);
+                if constexpr (FAST) pre_n[j] = pre_next ? fc.template pre_weight<FAST ? MK : 0>(proposal, xn[0], true) : T(0);
                 else pre_n[j] = pre_next ? pre_weight<T, D>(md, proposal, cp, cc, xn, true) : T(0);
                 // keep the scheduler from interleaving all VEC particles' arithmetic: that is what pushes the kernel
                 // over its register budget (spills cost real HBM traffic: PMC WRITE_SIZE)
@@ -1189,7 +1190,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     if (from_local && (!apf || pre_next))
         tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, pre_next ? M2 : M1,
                                    [&](const T (&xj)[D]) {
-                                       if constexpr (FAST) return fc.pre_weight(proposal, xj[0], true);
+                                       if constexpr (FAST) return fc.template pre_weight<FAST ? MK : 0>(proposal, xj[0], true);
                                        else return pre_weight<T, D>(md, proposal, cp, cc, xj, true);
                                    },
                                    g.rounds_per_tile == 1, e_rw, pre_next ? F2 : F1, reds);

@@ -1286,6 +1286,11 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                     return;
                 }
             }
+            if constexpr (sizeof(T) == 4 && FAST && D == 1) {  // shape of the one-step mean of the closed-form models
+                if (a.md.hid_kind == PF_HID_SINE_EM) hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 2>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 1>), grid, block, 0, st, a);
+                return;
+            }
             hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 0>), grid, block, 0, st, a);
         };
         auto with_mode = [&](auto mode_c) {

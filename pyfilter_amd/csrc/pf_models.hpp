@@ -251,7 +251,10 @@ template <typename T> struct FastCol {
         i2s = q[PK_I2S]; ks = q[PK_KS]; c_loc = q[PK_CLOC]; c_y = q[PK_CY]; kstd = q[PK_KSTD];
         inv_g = q[PK_INVG]; i2inc = q[PK_I2INC]; kt = q[PK_KT]; kq = q[PK_KQ]; i2c = q[PK_I2C]; kc = q[PK_KC];
     }
-    __device__ __forceinline__ T loc(T x) const {
+    // LK: the shape of the one-step mean as a compile-time constant (0 decided by A2 at run time, 1 affine, 2 sine)
+    template <int LK = 0> __device__ __forceinline__ T loc(T x) const {
+        if constexpr (LK == 1) return A0 + (x - A3) * A1;
+        if constexpr (LK == 2) return x + pf_sin(x - A3) * A2;
         if (A2 != T(0)) return x + pf_sin(x - A3) * A2;
         return A0 + (x - A3) * A1;
     }
@@ -259,15 +262,15 @@ template <typename T> struct FastCol {
         const T r = (next ? ybn : yb) - a * x;
         return -(r * r) * i2s - ks;
     }
-    __device__ __forceinline__ T pre_weight(int proposal, T x, bool next = false) const {
-        if (proposal == PF_PROP_BOOTSTRAP) return obs_lp(loc(x), next);
+    template <int LK = 0> __device__ __forceinline__ T pre_weight(int proposal, T x, bool next = false) const {
+        if (proposal == PF_PROP_BOOTSTRAP) return obs_lp(loc<LK>(x), next);
         const T r = (next ? ybn : yb) - a * x;
         return -(r * r) * i2c - kc;
     }
     // APF: the importance weight and the first-stage weight of the ancestor in one go - both need loc(x), and the
     // compiler does not merge two pf_sin evaluations across its large-argument branch
-    __device__ __forceinline__ T sample_and_weight_apf(int proposal, T x, T z, T& xn, T& pre) const {
-        const T l = loc(x);
+    template <int LK = 0> __device__ __forceinline__ T sample_and_weight_apf(int proposal, T x, T z, T& xn, T& pre) const {
+        const T l = loc<LK>(x);
         if (proposal == PF_PROP_BOOTSTRAP) {
             pre = obs_lp(l);
             xn = l + g * (z * inc);
@@ -280,8 +283,8 @@ template <typename T> struct FastCol {
         const T eps = (xn - l) * inv_g;
         return obs_lp(xn) + (-(eps * eps) * i2inc - kt) - (-T(0.5) * z * z - kq);
     }
-    __device__ __forceinline__ T sample_and_weight(int proposal, T x, T z, T& xn) const {
-        const T l = loc(x);
+    template <int LK = 0> __device__ __forceinline__ T sample_and_weight(int proposal, T x, T z, T& xn) const {
+        const T l = loc<LK>(x);
         if (proposal == PF_PROP_BOOTSTRAP) {
             xn = l + g * (z * inc);
             return obs_lp(xn);
