@@ -921,12 +921,13 @@ static inline ModelDesc to_desc(const pf_model* m) {
     return d;
 }
 
-// The fused-run instantiation matrix compiles as three translation units (the build runs them in parallel):
-//   -DPF_TU_NO_F64 -DPF_TU_NO_F32DN : the main unit - C ABI, primitives, float32 fused kernels of scalar states
+// The fused-run instantiation matrix compiles as four translation units (the build runs them in parallel):
+//   -DPF_TU_NO_F64 -DPF_TU_NO_F32DN -DPF_TU_NO_F32D1 : the main unit - C ABI and the stand-alone primitives
+//   -DPF_TU_F32D1_ONLY -DPF_TU_VEC=4|1 : only the float32 fused kernels of scalar states for one vector width + entry
 //   -DPF_TU_F32DN_ONLY              : only the float32 fused kernels of D > 1 states + their entry (pf_run_f32_dn)
 //   -DPF_TU_F64_ONLY                : only the float64 fused kernels + their entry               (pf_run_f64)
 // Without any of the macros the file is a single self-contained unit.
-#if defined(PF_TU_F64_ONLY) || defined(PF_TU_F32DN_ONLY)
+#if defined(PF_TU_F64_ONLY) || defined(PF_TU_F32DN_ONLY) || defined(PF_TU_F32D1_ONLY)
 #define PF_TU_NO_API
 #endif
 #ifndef PF_TU_NO_API
@@ -1421,14 +1422,41 @@ int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, in
 #define RUN(T, DD, V) return filter_run_impl<T, DD, V>(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
 #define RUN_D(T, V)                                       \
     if (D == 1) { RUN(T, 1, V) } else if (D == 2) { RUN(T, 2, V) } else { RUN(T, 3, V) }
+int pf_run_f32_d1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                  hipStream_t st, float* kernel_ms);
 #ifndef PF_TU_NO_API
 int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
                hipStream_t st, float* kernel_ms) {
     if (A->model.dim != 1) return pf_run_f32_dn(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
-    if (g.vec == 4) { RUN(float, 1, 4) } else { RUN(float, 1, 1) }
+    return pf_run_f32_d1(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
 }
 #endif
-#if !defined(PF_TU_NO_F32DN) && !defined(PF_TU_F64_ONLY)
+int pf_run_f32_d1_v4(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                     hipStream_t st, float* kernel_ms);
+int pf_run_f32_d1_v1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                     hipStream_t st, float* kernel_ms);
+#ifndef PF_TU_NO_API
+int pf_run_f32_d1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                  hipStream_t st, float* kernel_ms) {
+    return g.vec == 4 ? pf_run_f32_d1_v4(A, g, wl, t0, n_steps, finalize, st, kernel_ms)
+                      : pf_run_f32_d1_v1(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
+}
+#endif
+#if !defined(PF_TU_NO_F32D1) && !defined(PF_TU_F64_ONLY) && !defined(PF_TU_F32DN_ONLY)
+#if !defined(PF_TU_VEC) || PF_TU_VEC == 4
+int pf_run_f32_d1_v4(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                     hipStream_t st, float* kernel_ms) {
+    RUN(float, 1, 4)
+}
+#endif
+#if !defined(PF_TU_VEC) || PF_TU_VEC == 1
+int pf_run_f32_d1_v1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
+                     hipStream_t st, float* kernel_ms) {
+    RUN(float, 1, 1)
+}
+#endif
+#endif
+#if !defined(PF_TU_NO_F32DN) && !defined(PF_TU_F64_ONLY) && !defined(PF_TU_F32D1_ONLY)
 int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
                   hipStream_t st, float* kernel_ms) {
     const int D = A->model.dim;
@@ -1439,7 +1467,7 @@ int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, in
     }
 }
 #endif
-#if !defined(PF_TU_NO_F64) && !defined(PF_TU_F32DN_ONLY)
+#if !defined(PF_TU_NO_F64) && !defined(PF_TU_F32DN_ONLY) && !defined(PF_TU_F32D1_ONLY)
 int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
                hipStream_t st, float* kernel_ms) {
     const int D = A->model.dim;
