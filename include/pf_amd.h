@@ -215,6 +215,20 @@ int pf_filter_graph_destroy(void* handle);
 int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                         float* kernel_ms);
 
+/* ------------------------------------------------------------------------------------------------------------ *
+ * test support (no reference counterpart): lets a parity test feed the oracle the very draws a *production* run used
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* out (n_steps, D, B, N) <- the standard normals the fused step kernel draws from Philox(seed) at local steps
+ * step0 .. step0 + n_steps - 1 (seed = pf_filter_args.seed + *step_counter of the run to reproduce). */
+int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_steps, void* out, int64_t N, int64_t B, int64_t D,
+                          int dtype, void* stream);
+
+/* The step-kernel instantiations the calling thread's most recent pf_filter_run launches selected, oldest first:
+ * out[i] = { step, sizeof(T), D, VEC, MODE, PROP, FAST, SPEC, MK } (9 int32 per record, at most 64 are kept).
+ * Returns the number of records written (>= 0) or a negative PF_E* code. */
+int pf_debug_launch_trace(int32_t* out, int max_records);
+
 #ifdef __cplusplus
 }
 #endif

@@ -880,6 +880,24 @@ __global__ __launch_bounds__(PF_BLOCK) void k_initial_sample(double m0a, double 
     }
 }
 
+// Test support (pf_debug_draw_normals): the standard normals the fused step kernel draws for steps step0 .. - the same
+// draw_normals<T, D, VEC> call, addressed as the step kernel addresses it (thread = VEC consecutive particles).
+template <typename T, int D, int VEC>
+__global__ __launch_bounds__(PF_BLOCK) void k_debug_normals(uint64_t seed, uint32_t step0, T* __restrict__ out, int64_t N,
+                                                            int B) {
+    const int b = blockIdx.y;
+    const uint32_t s = blockIdx.z;
+    const int64_t i0 = ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x) * VEC;
+    if (i0 >= N) return;
+    T zt[VEC][D];
+    draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, step0 + s, (uint64_t)((int64_t)b * N + i0), zt);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+            if (i0 + j < N) out[(((int64_t)s * D + d) * B + b) * N + i0 + j] = zt[j][d];
+}
+
 }  // namespace pf
 
 #include "pf_fused.hpp"
@@ -1184,10 +1202,60 @@ extern "C" int pf_initial_sample(const double* m0, const double* s0, const void*
     return PF_OK;
 }
 
+
+// ---- test support ----------------------------------------------------------------------------------------------------
+extern "C" int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_steps, void* out, int64_t N, int64_t B,
+                                     int64_t D, int dtype, void* stream) {
+    if (!out || bad_shape(N, B) || D < 1 || D > PF_MAXD || n_steps < 1 || n_steps > 65535) return PF_EINVAL;
+    const Geom g = make_geom(N, B);
+    const dim3 grid((unsigned)((N + g.round_elems - 1) / g.round_elems), (unsigned)B, (unsigned)n_steps);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(T, DD, V) hipLaunchKernelGGL((k_debug_normals<T, DD, V>), grid, dim3(PF_BLOCK), 0, st, seed, step0, (T*)out, N, (int)B)
+#define CALL_D(T, V) do { if (D == 1) CALL(T, 1, V); else if (D == 2) CALL(T, 2, V); else CALL(T, 3, V); } while (0)
+    if (dtype == PF_F32) { if (g.vec == 4) CALL_D(float, 4); else CALL_D(float, 1); }
+    else if (dtype == PF_F64) { if (g.vec == 4) CALL_D(double, 4); else CALL_D(double, 1); }
+    else return PF_EINVAL;
+#undef CALL_D
+#undef CALL
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fused loop
 // ---------------------------------------------------------------------------------------------------------------
 #endif  // !PF_TU_NO_API
+
+// Test support: which step-kernel instantiation each launch of the calling thread's most recent fused runs selected
+// (pf_debug_launch_trace).  A per-thread ring, written on the host at launch time - nothing a kernel ever reads.
+#define PF_TRACE_LEN 64
+#define PF_TRACE_FIELDS 9
+struct LaunchTrace {
+    int32_t rec[PF_TRACE_LEN][PF_TRACE_FIELDS];
+    uint64_t count;
+};
+LaunchTrace& launch_trace();
+static inline void trace_launch(int step, int tbytes, int d, int vec, int mode, int prop, int fast, int spec, int mk) {
+    LaunchTrace& t = launch_trace();
+    int32_t* r = t.rec[t.count % PF_TRACE_LEN];
+    r[0] = step; r[1] = tbytes; r[2] = d; r[3] = vec; r[4] = mode; r[5] = prop; r[6] = fast; r[7] = spec; r[8] = mk;
+    ++t.count;
+}
+#ifndef PF_TU_NO_API
+LaunchTrace& launch_trace() {
+    static thread_local LaunchTrace t = {};
+    return t;
+}
+extern "C" int pf_debug_launch_trace(int32_t* out, int max_records) {
+    if (!out || max_records < 0) return PF_EINVAL;
+    const LaunchTrace& t = launch_trace();
+    const uint64_t have = t.count < PF_TRACE_LEN ? t.count : PF_TRACE_LEN;
+    const int n = (uint64_t)max_records < have ? max_records : (int)have;
+    for (int i = 0; i < n; ++i)  // oldest of the last n first
+        for (int f = 0; f < PF_TRACE_FIELDS; ++f) out[i * PF_TRACE_FIELDS + f] = t.rec[(t.count - n + i) % PF_TRACE_LEN][f];
+    return n;
+}
+#endif
 
 template <typename T, int D, int VEC>
 static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
@@ -1279,20 +1347,21 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         auto go = [&](auto mode_c, auto spec_c) {
             constexpr int MODE = decltype(mode_c)::value;
             constexpr int SPEC = decltype(spec_c)::value;
+            auto launch = [&](auto mk_c) {
+                constexpr int MK = decltype(mk_c)::value;
+                trace_launch((int)a.step, (int)sizeof(T), D, VEC, MODE, PROP, FAST ? 1 : 0, SPEC, MK);
+                hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, MK>), grid, block, 0, st, a);
+            };
             // model kinds folded at compile time for the stochastic-volatility built-in (float runs; for Lorenz-63 the
             // same specialisation measured no gain)
             if constexpr (sizeof(T) == 4 && !FAST && D == 1) {
-                if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) {
-                    hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 1>), grid, block, 0, st, a);
-                    return;
-                }
+                if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) return launch(std::integral_constant<int, 1>{});
             }
             if constexpr (sizeof(T) == 4 && FAST && D == 1) {  // shape of the one-step mean of the closed-form models
-                if (a.md.hid_kind == PF_HID_SINE_EM) hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 2>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 1>), grid, block, 0, st, a);
-                return;
+                if (a.md.hid_kind == PF_HID_SINE_EM) return launch(std::integral_constant<int, 2>{});
+                return launch(std::integral_constant<int, 1>{});
             }
-            hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, 0>), grid, block, 0, st, a);
+            launch(std::integral_constant<int, 0>{});
         };
         auto with_mode = [&](auto mode_c) {
             if constexpr (sizeof(T) == 4) {

@@ -291,3 +291,29 @@ def initial_sample_soa(m0, s0, n: int, b: int, d: int, dtype, device, seed: int,
         "pf_initial_sample",
     )
     return x
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# test support
+# ----------------------------------------------------------------------------------------------------------------
+TRACE_FIELDS = ("step", "tbytes", "D", "VEC", "MODE", "PROP", "FAST", "SPEC", "MK")
+
+
+def debug_draw_normals(seed: int, steps: int, n: int, b: int, d: int, dtype, device, step0: int = 0) -> torch.Tensor:
+    """``(steps, D, B, N)``: the standard normals a fused run with effective Philox seed ``seed`` (= the filter's seed
+    + the plan's epoch) draws at local steps ``step0 ..`` (pf_debug_draw_normals)."""
+    out = torch.empty((steps, d, b, n), dtype=dtype, device=device)
+    L.require_gpu(out)
+    L.check(L.load().pf_debug_draw_normals(seed & 0xFFFFFFFFFFFFFFFF, step0, steps, out.data_ptr(), n, b, d,
+                                           L.dtype_code(dtype), L.stream_ptr()), "pf_debug_draw_normals")
+    return out
+
+
+def debug_launch_trace(last: int = 64):
+    """The step-kernel instantiations of this thread's latest fused launches, oldest first, as dicts (pf_debug_launch_trace)."""
+    buf = (C.c_int32 * (len(TRACE_FIELDS) * last))()
+    n = L.load().pf_debug_launch_trace(buf, last)
+    if n < 0:
+        L.check(n, "pf_debug_launch_trace")
+    k = len(TRACE_FIELDS)
+    return [dict(zip(TRACE_FIELDS, buf[i * k:(i + 1) * k])) for i in range(n)]

@@ -1,0 +1,333 @@
+"""Identical-draw parity of the *production* float32 step-kernel instantiations - the ones ``bench.py`` times.
+
+The specialised kernels (``SPEC = 1``: APF observed -> observed, ``SPEC = 2``: SISR observed; closed-form ``MK`` foldings)
+are selected only for float32 runs that draw their normals from Philox, so the tape-driven parity tests never execute
+them.  Here the run keeps its Philox normals (only the resampling uniforms are injected, which the selection ignores),
+``pf_debug_draw_normals`` dumps exactly the normals the kernel consumed, and the oracle (``oracle/cpu_ref.py``,
+``pyfilter/filters/particle/apf.py:25-46``, ``sisr.py:14-56``) is teacher-forced with them from the same state:
+
+* APF: a 2-step ``batch_filter(y[t:t+2], init_state=...)`` - step 0 takes ``SPEC = 1`` (its output is the state left in
+  the run's other buffer), the last step the generic variant;
+* SISR: a 1-step run (``SPEC = 2``).
+
+``pf_debug_launch_trace`` asserts which instantiation really ran.  Bars (those of ``test_float32_teacher_forced_steps``):
+x within 1e-5 of the state's scale and w within 2e-5 rel + 2e-4 where the ancestors agree, ancestor flips <= 2e-4."""
+import math
+
+import pytest
+import torch
+
+from oracle import cpu_ref
+from oracle.cases import CASES, build_spec
+from pyfilter_amd import ops
+from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+
+
+def _teacher_state(es, t, x, w, ll, idx):
+    from pyfilter_amd.filters.particle.state import ParticleFilterCorrection
+    from pyfilter_amd.timeseries import TimeseriesState
+
+    return ParticleFilterCorrection(TimeseriesState(t, x, es), w, ll, idx)
+
+
+def _normals_ref_layout(filt, steps, n, b, d, has_event):
+    """The run's normals in the reference layout ``(steps, N, B, [D])`` (float32 values, exactly what the kernel drew)."""
+    plan = filt._last_run["plan"]
+    seed = filt._seed + int(plan.epoch.item())
+    z = ops.debug_draw_normals(seed, steps, n, b, d, F32, "cuda")  # (steps, D, B, N)
+    z = z.permute(0, 3, 2, 1)
+    return (z if has_event else z[..., 0]).cpu()
+
+
+def _oracle_step(spec, case, y_t, x, w, prev_idx, z, u, dtype):
+    """One teacher-forced oracle step from float32 inputs, evaluated in ``dtype``."""
+    x, w, z, u, y_t = x.to(dtype), w.clone().to(dtype), z.to(dtype), u.to(dtype), y_t.to(dtype)
+    if bool(y_t.isnan().all()):
+        idx = torch.arange(x.shape[0]).unsqueeze(-1).expand(w.shape)  # APF.predict hands out identity ancestors (apf.py:18-23)
+        if case["filter"] == "sisr":
+            x, w, _, idx, _ = cpu_ref.sisr_predict(spec, x, w, prev_idx, u, case["ess_threshold"] * x.shape[0])
+        xn, wn, ll = cpu_ref.propagate_only_step(spec, x, w, z)
+        return xn, wn, ll, idx
+    if case["filter"] == "apf":
+        return cpu_ref.apf_step(spec, case["proposal"], y_t, x, w, z, u)
+    xn, wn, ll, idx, _ = cpu_ref.sisr_step(spec, case["proposal"], y_t, x, w, prev_idx, z, u, case["ess_threshold"] * x.shape[0])
+    return xn, wn, ll, idx
+
+
+def _compare_step(tag, x_gpu, w_gpu, ll_gpu, idx_gpu, ref64, ref32, n_total):
+    """Returns the number of ancestor flips.  ``ref64`` / ``ref32``: oracle outputs (x, w, ll, idx) in fp64 / fp32."""
+    x64, w64, ll64, idx64 = ref64
+    idx32 = ref32[3]
+    if idx_gpu is not None:
+        same = (idx_gpu == idx64) | (idx_gpu == idx32)
+    else:  # ancestors of an intermediate step are not kept: a flipped ancestor shows as a different particle
+        sc = x64.abs().max().item()
+        dxa = (x_gpu.double() - x64).abs()
+        same = dxa <= 1e-5 * sc + 1e-6
+        if same.dim() > w64.dim():
+            same = same.all(dim=-1)
+    flips = int((~same).sum())
+    ok = same if x64.dim() == same.dim() else same.unsqueeze(-1)
+    scale = x64.abs().max().item()
+    dx = (x_gpu.double() - x64).abs()
+    assert (dx[ok.expand_as(dx)] <= 1e-5 * scale + 1e-6).all(), f"{tag}: x off by {dx[ok.expand_as(dx)].max():.3e}"
+    fin = same & torch.isfinite(w64)
+    dw = (w_gpu.double() - w64).abs()
+    assert (dw[fin] <= 2e-5 * w64[fin].abs() + 2e-4).all(), f"{tag}: w off by {dw[fin].max():.3e}"
+    if ll_gpu is not None:
+        torch.testing.assert_close(ll_gpu.double(), ll64, rtol=1e-4, atol=1e-4 + 10.0 * flips / max(1, n_total // max(1, ll64.numel())))
+    return flips
+
+
+def _expect_variant(case, steps_observed, first):
+    """(SPEC of the first launch)"""
+    if not steps_observed[0]:
+        return 0
+    if case["filter"] == "apf":
+        return 1 if (len(steps_observed) > 1 and steps_observed[1]) else 0
+    return 2
+
+
+@pytest.mark.parametrize("name", [c["name"] for c in CASES])
+def test_production_step_kernels_match_oracle_on_their_own_draws(name):
+    case = next(c for c in CASES if c["name"] == name)
+    dt = "f32" if "f32" in case["dtypes"] else "f64"  # the teacher states: the reference's own (cast to float32 if need be)
+    g = load_golden(name, dt)
+    spec64, spec32 = build_spec(case, torch.float64), build_spec(case, F32)
+    n, b = case["N"], case["B"]
+    y = g["y"].to(F32)
+    t_len = y.shape[0]
+    apf = case["filter"] == "apf"
+    run_len = 2 if apf else 1
+    d = max(1, spec64.dim)
+    has_event = spec64.dim > 0
+    flips, seen_spec, checked = 0, set(), 0
+    filt = build_filter_from_case(case, g, F32, "cuda", tape=False)
+    filt.set_tape(u=g["u_tape"].to(F32))  # uniforms injected, normals stay Philox: the production kernels are selected
+    es = filt._model.hidden.event_shape
+    for t in range(0, t_len - run_len + 1):
+        if t == 0:
+            x_prev, w_prev = g["x0"].to(F32), torch.zeros(g["x0"].shape[:2] if has_event else g["x0"].shape, dtype=F32)
+            idx_prev = torch.arange(n).unsqueeze(-1).expand(n, b).contiguous()
+            ll_prev = torch.zeros(b, dtype=F32)
+        else:
+            x_prev, w_prev = g["step_x"][t - 1].to(F32), g["step_w"][t - 1].to(F32)
+            idx_prev, ll_prev = g["step_idx"][t - 1], g["step_ll"][t - 1].to(F32)
+        w_prev = torch.nan_to_num(w_prev, nan=-math.inf, posinf=-math.inf)
+        prev = _teacher_state(es, t, x_prev.cuda(), w_prev.clone().cuda(), ll_prev.cuda(), idx_prev.cuda())
+        res = filt.batch_filter(y[t:t + run_len].cuda(), bar=False, init_state=prev)
+        torch.cuda.synchronize()
+        trace = ops.debug_launch_trace(run_len)
+        observed = [not bool(y[t + s].isnan().all()) for s in range(run_len)]
+        assert [r["step"] for r in trace] == list(range(run_len)) and all(r["tbytes"] == 4 for r in trace)
+        assert trace[0]["SPEC"] == _expect_variant(case, observed, True), (trace, observed)
+        seen_spec.add(trace[0]["SPEC"])
+        z = _normals_ref_layout(filt, run_len, n, b, d, has_event)
+        u = g["u_tape"].to(F32)
+        plan = filt._last_run["plan"]
+        last = res.latest_state
+        if apf:
+            # step 0 (SPEC = 1 when both steps are observed): its output state sits in the run's odd buffers
+            x1 = ops.from_soa(plan.x[1], True, has_event).cpu()
+            w1 = ops.from_cols(plan.logw[1], True).cpu()
+            r64 = _oracle_step(spec64, case, y[t], x_prev, w_prev, idx_prev, z[0], u[t], torch.float64)
+            r32 = _oracle_step(spec32, case, y[t], x_prev, w_prev, idx_prev, z[0], u[t], F32)
+            flips += _compare_step(f"{name} t={t} step0", x1, w1, plan.ll_steps[0].cpu(), None, r64, r32, n * b)
+            # step 1 (generic variant: the run's last step), teacher-forced from the kernel's own step-0 state
+            r64 = _oracle_step(spec64, case, y[t + 1], x1, w1, r64[3], z[1], u[t + 1], torch.float64)
+            r32 = _oracle_step(spec32, case, y[t + 1], x1, w1, r32[3], z[1], u[t + 1], F32)
+            flips += _compare_step(f"{name} t={t} step1", last.timeseries_state.value.cpu(), last.weights.cpu(),
+                                   last.get_loglikelihood().cpu(), last.previous_indices.cpu(), r64, r32, n * b)
+            checked += 2
+        else:
+            r64 = _oracle_step(spec64, case, y[t], x_prev, w_prev, idx_prev, z[0], u[t], torch.float64)
+            r32 = _oracle_step(spec32, case, y[t], x_prev, w_prev, idx_prev, z[0], u[t], F32)
+            flips += _compare_step(f"{name} t={t}", last.timeseries_state.value.cpu(), last.weights.cpu(),
+                                   last.get_loglikelihood().cpu(), last.previous_indices.cpu(), r64, r32, n * b)
+            checked += 1
+    assert (1 if apf else 2) in seen_spec, f"the specialised kernel never ran: {seen_spec}"
+    assert flips <= max(2, int(2e-4 * n * b * checked)), f"{flips} ancestor flips in {checked} steps"
+
+
+def _bench_shape_case(model, filt_name, prop, n, b, ess=0.9):
+    return dict(name=f"{model}_{filt_name}_{prop}", model=model, filter=filt_name, proposal=prop, N=n, B=b, T=4,
+                ess_threshold=ess, seed=4242, dtypes=("f32",))
+
+
+@pytest.mark.parametrize("model,filt_name,prop,n,b", [
+    ("sine", "apf", "lgo", 1 << 20, 1),          # BASELINE config 2: the headline instantiation (FAST, MK = 2, SPEC = 1)
+    ("sv_batched", "apf", "bootstrap", 65536, 8),  # config 3 (8 of the 64 series): generic MK = 1, SPEC = 1
+    ("lorenz", "sisr", "bootstrap", 1 << 20, 1),  # config 4's model: D = 3, SPEC = 2
+    ("ou_batched", "sisr", "lgo", 8192, 16),      # config 5's theta-shard shape (16 of 128 columns): SPEC = 2
+    ("lg1d", "apf", "bootstrap", 1 << 18, 2),     # affine closed form (MK = 1) with the bootstrap proposal
+])
+def test_production_step_kernels_at_benchmark_shapes(model, filt_name, prop, n, b):
+    """The same check on multi-tile shapes, from the filter's own Philox-initialised state and then from a state with
+    non-trivial weights (the second run starts where the first ended)."""
+    from oracle.cases import simulate
+
+    case = _bench_shape_case(model, filt_name, prop, n, b)
+    spec64, spec32 = build_spec(case, torch.float64), build_spec(case, F32)
+    y = simulate(case, spec64).to(F32)
+    apf = filt_name == "apf"
+    run_len = 2 if apf else 1
+    d, has_event = max(1, spec64.dim), spec64.dim > 0
+    gen = torch.Generator().manual_seed(77)
+    u = torch.rand((8, b), generator=gen, dtype=F32)
+    ssm = build_ssm_from_case(case, F32, "cuda")
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+
+    cls = APF if apf else SISR
+    filt = cls(ssm, n, proposal={"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop](),
+               ess_threshold=case["ess_threshold"], seed=99)
+    filt.set_batch_shape(torch.Size([b]))
+    filt.set_tape(u=u)
+    state = filt.initialize()
+    flips = checked = 0
+    t = 0
+    for _ in range(2):
+        xs = state.timeseries_state.value.cpu()
+        ws = state.weights.cpu().clone()
+        idx_prev = state.previous_indices.cpu()
+        res = filt.batch_filter(y[t:t + run_len].cuda(), bar=False, init_state=state)
+        torch.cuda.synchronize()
+        trace = ops.debug_launch_trace(run_len)
+        assert trace[0]["SPEC"] == (1 if apf else 2) and trace[0]["tbytes"] == 4 and trace[0]["D"] == d, trace
+        z = _normals_ref_layout(filt, run_len, n, b, d, has_event)
+        plan = filt._last_run["plan"]
+        last = res.latest_state
+        if apf:
+            x1 = ops.from_soa(plan.x[1], True, has_event).cpu()
+            w1 = ops.from_cols(plan.logw[1], True).cpu()
+            r64 = _oracle_step(spec64, case, y[t], xs, ws, idx_prev, z[0], u[t], torch.float64)
+            r32 = _oracle_step(spec32, case, y[t], xs, ws, idx_prev, z[0], u[t], F32)
+            flips += _compare_step(f"{case['name']} t={t} step0", x1, w1, plan.ll_steps[0].cpu(), None, r64, r32, n * b)
+            r64 = _oracle_step(spec64, case, y[t + 1], x1, w1, r64[3], z[1], u[t + 1], torch.float64)
+            r32 = _oracle_step(spec32, case, y[t + 1], x1, w1, r32[3], z[1], u[t + 1], F32)
+        else:
+            r64 = _oracle_step(spec64, case, y[t], xs, ws, idx_prev, z[0], u[t], torch.float64)
+            r32 = _oracle_step(spec32, case, y[t], xs, ws, idx_prev, z[0], u[t], F32)
+        flips += _compare_step(f"{case['name']} t={t} last", last.timeseries_state.value.cpu(), last.weights.cpu(),
+                               last.get_loglikelihood().cpu(), last.previous_indices.cpu(), r64, r32, n * b)
+        checked += run_len
+        state = last
+        t += run_len
+    assert flips <= max(2, int(2e-4 * n * b * checked)), f"{flips} ancestor flips in {checked} steps"
+
+
+# ---- BASELINE configs 3 and 4 as written -------------------------------------------------------------------------------
+def _lorenz_ssm(dtype):
+    case = dict(model="lorenz", B=1)
+    return build_ssm_from_case(case, dtype, "cuda")
+
+
+def test_config4_lorenz_sisr_multinomial_4m_particles():
+    """BASELINE configs[3] as written (short T): Lorenz-63 Euler-Maruyama, SISR + Bootstrap, **multinomial**, 2^22
+    particles, float32 - the ``D = 3, MODE = 1`` step kernel.  ``torch.multinomial`` is not injectable
+    (``pyfilter/resampling.py:55-65``), so: (i) the kernel's own step is teacher-forced through the oracle *given its
+    ancestors* and its own Philox normals (propagation + weights of every particle, identical draws); (ii) the
+    ancestors are a valid multinomial draw - sorted, in range, offspring counts consistent with N W (chi-square over
+    weight-deciles); (iii) means / log-likelihood agree with the float64 run of the same filter and with the systematic
+    run within Monte-Carlo error."""
+    from oracle.cases import simulate
+    from pyfilter_amd import resampling
+    from pyfilter_amd.filters.particle import SISR, proposals
+
+    n, t_len = 1 << 22, 6
+    case = dict(name="cfg4", model="lorenz", filter="sisr", proposal="bootstrap", N=n, B=1, T=t_len, ess_threshold=0.9, seed=404)
+    spec64 = build_spec(case, torch.float64)
+    y = simulate(case, spec64)
+
+    def run(dtype, resampler, seed=11, init_state=None, steps=slice(None)):
+        f = SISR(_lorenz_ssm(dtype), n, proposal=proposals.Bootstrap(), resampling=resampler, ess_threshold=0.9, seed=seed)
+        r = f.batch_filter(y[steps].to(dtype).cuda(), bar=False, init_state=init_state)
+        torch.cuda.synchronize()
+        return f, r
+
+    f32m, r32m = run(F32, resampling.multinomial)
+    tr = ops.debug_launch_trace(t_len)
+    assert all(r["MODE"] == 1 and r["D"] == 3 and r["tbytes"] == 4 and r["SPEC"] == 2 for r in tr), tr
+    _, r64m = run(torch.float64, resampling.multinomial)
+    _, r32s = run(F32, resampling.systematic)
+
+    for r in (r32m, r64m, r32s):
+        assert torch.isfinite(r.filter_means).all() and torch.isfinite(r.loglikelihood).all()
+    se = (r64m.filter_variance[1:].double() / n).sqrt().cpu()
+    m32, m64, ms = r32m.filter_means[1:].double().cpu(), r64m.filter_means[1:].double().cpu(), r32s.filter_means[1:].double().cpu()
+    # independent Monte-Carlo runs (different draws): the difference of two carries twice the variance
+    assert ((m32 - m64).abs() <= 10.0 * se + 1e-5 * m64.abs() + 2e-4).all(), ((m32 - m64).abs() / se).max()
+    assert ((m32 - ms).abs() <= 10.0 * se + 1e-5 * m64.abs() + 2e-4).all(), ((m32 - ms).abs() / se).max()
+    assert abs(r32m.loglikelihood.item() - r64m.loglikelihood.item()) < 0.02 * t_len
+    assert abs(r32m.loglikelihood.item() - r32s.loglikelihood.item()) < 0.02 * t_len
+
+    # (i) + (ii): one more multinomial step from the final state, teacher-forced given the kernel's ancestors
+    state = r32m.latest_state
+    xs, ws = state.timeseries_state.value.cpu(), state.weights.cpu().clone()
+    y_next = simulate(dict(case, T=t_len + 1), spec64)[t_len:t_len + 1].to(F32)
+    f2 = SISR(_lorenz_ssm(F32), n, proposal=proposals.Bootstrap(), resampling=resampling.multinomial, ess_threshold=1.1, seed=12)
+    r2 = f2.batch_filter(y_next.cuda(), bar=False, init_state=state)
+    torch.cuda.synchronize()
+    tr = ops.debug_launch_trace(1)
+    assert tr[0]["MODE"] == 1 and tr[0]["D"] == 3 and tr[0]["SPEC"] == 2, tr
+    last = r2.latest_state
+    anc = last.previous_indices.cpu()
+    assert (anc[1:] >= anc[:-1]).all() and anc.min() >= 0 and anc.max() <= n - 1
+    z = _normals_ref_layout(f2, 1, n, 1, 3, True)[0, :, 0]  # (N, 3): the filter is unbatched
+    x_r = xs.double()[anc]
+    x_new, wi = cpu_ref.bootstrap_sample_and_weight(spec64, y_next[0].double(), x_r, z.double())
+    scale = x_new.abs().max().item()
+    assert ((last.timeseries_state.value.cpu().double() - x_new).abs() <= 1e-5 * scale + 1e-6).all()
+    fin = torch.isfinite(wi)
+    assert ((last.weights.cpu().double() - wi).abs()[fin] <= 2e-5 * wi[fin].abs() + 2e-4).all()
+    # offspring counts vs N W, pooled over 16 weight-quantile groups: chi-square (groups expecting < 50 offspring dropped)
+    W = cpu_ref.normalize(ws.double())
+    counts = torch.bincount(anc, minlength=n).double()
+    groups = W.argsort().reshape(16, -1)
+    exp_g = (W[groups] * n).sum(dim=1)
+    obs_g = counts[groups].sum(dim=1)
+    keep = exp_g >= 50.0
+    dof = int(keep.sum()) - 1
+    chi2 = ((obs_g - exp_g)[keep] ** 2 / exp_g[keep]).sum().item()
+    assert dof >= 3 and chi2 < dof + 8.0 * math.sqrt(2.0 * dof), (chi2, dof)
+
+
+def test_config3_sv_64_series_full_size_invariants():
+    """BASELINE configs[2] at full size (64 independent series x 65 536 particles, APF + Bootstrap, float32, Philox):
+    the production instantiation ran (generic MK = 1, SPEC = 1), outputs finite, ancestors sorted / in range, every
+    series' mean inside its particle cloud, the same seed reproduces bit for bit, two seeds agree within Monte-Carlo
+    error, and the float64 run of the same filter agrees within Monte-Carlo error."""
+    from oracle.cases import simulate
+    from pyfilter_amd.filters.particle import APF, proposals
+
+    n, b, t_len = 65536, 64, 12
+    case = dict(name="cfg3", model="sv_batched", filter="apf", proposal="bootstrap", N=n, B=b, T=t_len, ess_threshold=0.9, seed=303)
+    y = simulate(case, build_spec(case, torch.float64))
+
+    def run(dtype, seed):
+        f = APF(build_ssm_from_case(case, dtype, "cuda"), n, proposal=proposals.Bootstrap(), seed=seed)
+        f.set_batch_shape(torch.Size([b]))
+        r = f.batch_filter(y.to(dtype).cuda(), bar=False)
+        torch.cuda.synchronize()
+        return r
+
+    r1 = run(F32, 1)
+    tr = ops.debug_launch_trace(t_len)
+    assert all(r["tbytes"] == 4 and r["D"] == 1 and r["FAST"] == 0 and r["MK"] == 1 for r in tr), tr
+    assert [r["SPEC"] for r in tr] == [1] * (t_len - 1) + [0], tr
+    r2, r1b, r64 = run(F32, 2), run(F32, 1), run(torch.float64, 3)
+    for r in (r1, r2, r64):
+        assert torch.isfinite(r.filter_means).all() and torch.isfinite(r.loglikelihood).all()
+        idx = r.latest_state.previous_indices
+        assert (idx[1:] >= idx[:-1]).all() and idx.min() >= 0 and idx.max() <= n - 1
+        xs = r.latest_state.timeseries_state.value
+        m = r.filter_means[-1, :, 0]
+        assert ((xs.min(dim=0)[0] <= m) & (m <= xs.max(dim=0)[0])).all()
+    assert torch.equal(r1.filter_means, r1b.filter_means) and torch.equal(r1.loglikelihood, r1b.loglikelihood)
+    se = (r64.filter_variance[1:].double() / n).sqrt()
+    for other in (r2, r64):
+        d = (r1.filter_means[1:].double() - other.filter_means[1:].double()).abs()
+        assert (d <= 8.0 * se + 1e-5).all(), (d / (se + 1e-12)).max()
+        assert ((r1.loglikelihood.double() - other.loglikelihood.double()).abs() < 0.05).all()
