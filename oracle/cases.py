@@ -55,10 +55,11 @@ def build_spec(case, dtype=torch.float64) -> M.ModelSpec:
     if m == "sine":  # README.md:44-67
         return M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
     if m == "sv_batched":  # stochastic-volatility.ipynb, B distinct parameter rows + B distinct series
-        kappa = t([0.05 + 0.01 * i for i in range(b)])
-        gamma = t([1.0 + 0.1 * i for i in range(b)])
-        sigma = t([0.10 + 0.02 * i for i in range(b)])
-        mu = t([0.0 + 0.05 * i for i in range(b)])
+        k = case.get("param_step_scale", 1.0)  # spacing of the B parameter rows (1: the golden fixtures)
+        kappa = t([0.05 + 0.01 * k * i for i in range(b)])
+        gamma = t([1.0 + 0.1 * k * i for i in range(b)])
+        sigma = t([0.10 + 0.02 * k * i for i in range(b)])
+        mu = t([0.0 + 0.05 * k * i for i in range(b)])
         return M.ModelSpec(M.HID_VERHULST_EM, (kappa, gamma, sigma), 0, 0.2, (1.0, 0.1), M.OBS_SV, (mu,), 0)
     if m == "lorenz":  # lorenz.ipynb
         return M.ModelSpec(

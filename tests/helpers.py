@@ -28,10 +28,11 @@ def build_ssm_from_case(case, dtype, device):
         hidden = models.SineDiffusion(t(0.0), t(1.0), dt=0.1)
         ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.1)))
     elif m == "sv_batched":
-        kappa = t([0.05 + 0.01 * i for i in range(b)])
-        gamma = t([1.0 + 0.1 * i for i in range(b)])
-        sigma = t([0.10 + 0.02 * i for i in range(b)])
-        mu = t([0.0 + 0.05 * i for i in range(b)])
+        k = case.get("param_step_scale", 1.0)  # spacing of the B parameter rows (1: the golden fixtures)
+        kappa = t([0.05 + 0.01 * k * i for i in range(b)])
+        gamma = t([1.0 + 0.1 * k * i for i in range(b)])
+        sigma = t([0.10 + 0.02 * k * i for i in range(b)])
+        mu = t([0.0 + 0.05 * k * i for i in range(b)])
         hidden = models.Verhulst(kappa, gamma, sigma, dt=0.2, initial=(t(1.0), t(0.1)))
         ssm = models.StochasticVolatilityModel(hidden, mu)
     elif m == "lorenz":
