@@ -1,22 +1,28 @@
-// pf_fused.hpp - the fused SISR / APF time step: two kernel launches per step, one of them light.
+// pf_fused.hpp - the fused SISR / APF time step: ONE kernel launch per step.
 //
-// Systematic resampling (the default):
-//   k_fused_plan  (grid ceil(tiles/4)+1 x B)  no per-particle pass.  Re-reduces the column's per-tile partials into the
-//                 tile-prefix table (P_t, f_t); each wave finds j0 for one position tile (tile via the table, element via
-//                 a 64-ary search over the tile-local scans); one extra workgroup per column does the bookkeeping
-//                 (moments row, log-likelihood increment of the previous step, resampling decision).
-//   k_fused_step  (grid tiles x B)  stages a window of local scans L_i, maps them to cdf values (P_k + f_k L_i, fp64,
-//                 rounded once), LDS searchsorted from j0, gathers x[anc] (from LDS when small), propagates
-//                 (Philox / tape), weighs, stores x', logw', anc - and, while the new state is in registers: the next
-//                 step's per-tile partials (max / sum exp / sum exp^2, pivoted weighted moments, the APF's first-stage
-//                 weights against y_{t+1}) and the tile-local inclusive scan L'_i of the next resampling weights.
-// Multinomial resampling runs the same two kernels: the sorted resampling positions (order statistics of N iid uniforms)
+//   k_fused_step  (grid (tiles + 1) x B)
+//     prologue    every workgroup re-reduces the column's per-tile partials (<= 1024 (max, sum) pairs, L2-hot) into the
+//                 tile-prefix table (P_t, f_t) in LDS, decides - SISR - whether the column resamples (ESS test on the
+//                 same sums: identical arithmetic in every workgroup, so they all agree), and its first wave finds the
+//                 window start j0 of the tile's first position (tile via the table, element via one 64-ary probe of the
+//                 tile-local scans).  There is no planning kernel: the former k_fused_plan cost 8.4 of the 24 us of a
+//                 step at 2^20 particles while moving no data.
+//     body        stages a window of local scans L_i, maps them to cdf values (P_k + f_k L_i, fp64, rounded once), takes
+//                 the ancestors from the inverted systematic grid (or an LDS search: multinomial / very large grids),
+//                 gathers x[anc] (from LDS when small), propagates (Philox / tape), weighs, stores x', logw', anc - and,
+//                 while the new state is in registers: the next step's per-tile partials (max / sum exp / sum exp^2,
+//                 pivoted weighted moments, the APF's first-stage weights against y_{t+1}) and the tile-local inclusive
+//                 scan L'_i of the next resampling weights.
+//     bookkeeper  workgroup `tiles` of every column: moments row of the incoming state, log-likelihood increment of
+//                 the previous step, the bases of the next one.  Nothing in the same launch depends on it.
+// Multinomial resampling runs the same kernel: the sorted resampling positions (order statistics of N iid uniforms)
 // are normalised prefix sums of Exp(1) spacings that the step kernel regenerates per round (Philox + workgroup scan);
-// the planning kernel adds a prefix table of the spacings' tile sums (reduced with the partials one step earlier).
+// the prologue adds a prefix table of the spacings' tile sums (reduced with the partials one step earlier).
 //
-// k_fused_reduce produces the partials / local scans of the very first state only.  A kernel boundary is the only
-// inter-workgroup synchronisation; the step index, "observed" flags and observation rows are kernel arguments set by
-// the host loop (or baked into a captured hipGraph), so a launch has no dependent flag-load prologue.
+// k_fused_reduce produces the partials / local scans of the very first state of a run (and the run's per-column
+// records: closed-form constants, the moments' pivot); k_fused_book is the bookkeeper alone, for the last state.  A kernel
+// boundary is the only inter-workgroup synchronisation; the step index, "observed" flags and observation rows are kernel
+// arguments set by the host loop (or baked into a captured hipGraph), so a launch has no dependent flag-load prologue.
 #pragma once
 
 namespace pf {
@@ -31,13 +37,7 @@ namespace pf {
             blockIdx.y == 0 && threadIdx.x == 0)                                                \
             (a).dbg[slot] = (unsigned long long)clock64();                                      \
     } while (0)
-#define PF_STAMP_PLAN(a, slot)                                                                  \
-    do {                                                                                        \
-        if ((a).debug_cut < 0 && !(a).finalize_only && blockIdx.x == 100 && blockIdx.y == 0 && threadIdx.x == 0) \
-            (a).dbg[slot] = (unsigned long long)wall_clock64();                                  \
-    } while (0)
 #else
-#define PF_STAMP_PLAN(a, slot) do { } while (0)
 #define PF_CUT(a, n) false
 #ifdef PF_ISA_MARKS  // stage boundaries as comments in the ISA listing (static instruction counts; they pin the schedule)
 #define PF_STAMP(a, slot) asm volatile("; PF_MARK " #slot)
@@ -71,18 +71,12 @@ template <typename T> struct FusedArgs {
     double* part;          // per-tile partials, two copies: state q's live in copy q & 1 (the step kernel reads the plan of
     int64_t part_stride;   // state `step` while it writes the partials of state `step + 1`; a replayed step stays exact)
     ColStat* stat;
-    int32_t* poison;  // [2][B]
-    int32_t* j0;      // [B][tiles]
-    int32_t* k0;      // [B][tiles] tile index of j0
-    double* ptab;     // [B][tiles + 1] normalised exclusive prefix of the tiles' resampling mass (P_0 = 0 ... P_tiles ~ 1)
-    double* ftab;     // [B][tiles]     exp(m_t - M) / S: scale of tile t's local (max-shifted) sums
-    double* etab;     // [B][tiles + 1] multinomial: exclusive prefix of the tiles' Exp(1) spacing sums; [tiles] = grand
-                      // total incl. the closing spacing (the sorted uniforms are prefix / total)
-    T* cpack;         // [B][PK_N] this step's closed-form constants of every column (scalar fast path; see FastCol)
-    T* ucol;          // [B] this step's systematic offset u of every column
-    int t0;           // first step of this run: the partials of state t0 are taken about pivot 0, later ones about the
-                      // previous state's mean (row q - 1 of `means`)
-    int from_local;   // systematic pipeline: `cdf` holds per-tile local scans L_i, the cdf is P_k + f_k * L_i
+    int32_t* poison;  // [4][B]: slot s & 3 poisons ll_s (written by the launches of steps s - 1 and s, consumed - and
+                      // cleared - by the bookkeeper of launch s + 1: three launches may touch three different slots)
+    T* cpack;         // [B][PK_N] the run's closed-form constants of every column (scalar fast path; see FastCol)
+    double* piv0;     // [B][PF_MAXD] pivot of the weighted moments of the run's first two states (a particle of the first)
+    int t0;           // first step of this run: the partials of states t0, t0 + 1 are taken about piv0, those of a later
+                      // state q about the mean of state q - 2 (row q - 2 of `means`: written two launches earlier)
     // per launch
     int step;       // local step index: slot = step & 1 is read, the other written
     int obs;        // this step weighs against y[step]                     (-1: read obs_dev[step])
@@ -94,7 +88,10 @@ template <typename T> struct FusedArgs {
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
     __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
-    int replay;     // measurement replays: the bookkeeper computes but does not publish (results stay untouched)
+    // pivot of the weighted-moment partials of state q (see t0), component d of column b
+    template <int D> __device__ __forceinline__ T pivot(int q, int b, int d) const {
+        return (q - 2 >= t0) ? means[((int64_t)(q - 2) * g.B + b) * D + d] : (T)piv0[(int64_t)b * PF_MAXD + d];
+    }
     int debug_cut;  // development knob (env PF_DEBUG_CUT): kernels return early after stage n; 0 = off
 };
 
@@ -382,6 +379,26 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 
     const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
     const T* x_base = a.x[slot];
+    // the run's per-column records.  Pivot of the weighted moments of the run's first two states: the column's first
+    // particle (any value inside the cloud keeps sum e (x - c)^2 - (sum e (x - c))^2 from cancelling); every workgroup
+    // loads it, workgroup 0 publishes it for the step kernels / bookkeepers of this run
+    T piv[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) piv[d] = x_base[((int64_t)d * g.B + b) * g.N];
+    if (k == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) a.piv0[(int64_t)b * PF_MAXD + d] = (double)piv[d];
+    }
+    if constexpr (D == 1) {
+        // closed-form constants (FastCol): functions of the parameters only - the step kernels add the observations
+        if (k == 0 && threadIdx.x == PF_BLOCK - 1 && a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM) {
+            ColParams<T, 1> cq;
+            ColConsts<T, 1> cd;
+            load_col_params<T, 1>(a, b, a.step, false, cq);
+            cd.prepare(a.md, cq);
+            write_col_pack<T>(a.md, cq, cd, a.cpack + (int64_t)b * PK_N);
+        }
+    }
     PartialAcc<T, D> acc;
     acc.init();
     const int64_t base = (int64_t)k * g.tile_elems;
@@ -403,11 +420,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
             for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
             pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) : T(0);
         }
-        T piv0[D];
-#pragma unroll
-        for (int d = 0; d < D; ++d) piv0[d] = T(0);
         T e_unused[VEC];
-        acc.template push_round<VEC>(lw, xv, pre_on, pre, piv0, e_unused);
+        acc.template push_round<VEC>(lw, xv, pre_on, pre, piv, e_unused);
         if (a.resampler == PF_RESAMPLE_MULTINOMIAL) {
             T ev[VEC];
             draw_exponentials<T, VEC>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_MULTINOMIAL, (uint32_t)a.step,
@@ -417,8 +431,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
         }
     }
     T M1, M2, F1, F2;
-    acc.template finish<true>(a.part_w(a.step), b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 1) * g.B + b], M1, M2, F1, F2);
-    if (a.from_local) {
+    acc.template finish<true>(a.part_w(a.step), b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 3) * g.B + b], M1, M2, F1, F2);
+    {
         __shared__ double reds[PF_NWAVES];
         T dummy[VEC];
 #pragma unroll
@@ -430,138 +444,130 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     }
 }
 
-// Combined column statistics from the per-tile partials.  The first PF_BLOCK tiles' values are passed in registers
-// (`early`, loaded at the very top of the kernel so their latency overlaps the tile's own work); further tiles are
-// read in the loops.  Two LDS exchanges: maxima, then every rescaled sum.
-struct ColCombine {
-    double m1, m2, S1, Q1, S2, prefK, prefK1;
-    double TE, prefE;  // multinomial: total / prefix (tiles below k) of the Exp(1) spacings
-};
+// Column-wide sums of one weight family from the per-tile partials: M = max_t m_t, S = sum_t s_t e_t and - WITH_Q -
+// Q = sum_t q_t e_t^2, e_t = exp(m_t - M); TABLE: also the tile-prefix table in LDS, ptl[t] = (sum_{t' < t} s_t' e_t') / S
+// (ptl[0] = 0 ... ptl[tiles] ~ 1) and ftl[t] = e_t / S, the scale of tile t's max-shifted local sums.  Thread t owns the
+// IT consecutive tiles [t * IT, (t + 1) * IT): one load of the (max, sum) pairs, then two workgroup exchanges (the column
+// maximum; the scan whose total is the column sum).  Every workgroup that needs these numbers - the step workgroups of
+// a column and its bookkeeper - runs THIS function on the same partials: the values (and the SISR resampling decision
+// taken from them) are bit-identical everywhere, which is what lets the step kernel do without a planning kernel.
+// redm: PF_NWAVES doubles, reds: 2 * PF_NWAVES doubles.  Ends with a barrier when TABLE (the table is readable).
 #define PF_COMBINE_ITERS (PF_MAX_TILES / PF_BLOCK)  // partial records per thread
-struct EarlyPartials {
-    double m1[PF_COMBINE_ITERS], s1[PF_COMBINE_ITERS], q1[PF_COMBINE_ITERS], m2[PF_COMBINE_ITERS], s2[PF_COMBINE_ITERS];
+struct ColSums {
+    double M, S, Q;
 };
-template <typename T>
-__device__ __forceinline__ void load_early_partials(const FusedArgs<T>& a, int64_t cb, int64_t stride, bool two,
-                                                    EarlyPartials& e) {
+template <typename T, bool WITH_Q, bool TABLE>
+__device__ __forceinline__ ColSums column_sums(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
+                                               int slot_s, double* ptl, double* ftl, double* redm, double* reds) {
+#pragma clang fp contract(off)  // the same operations in every instantiation / inlining context (see above)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
+    double mloc[PF_COMBINE_ITERS], sloc[PF_COMBINE_ITERS], qloc[PF_COMBINE_ITERS], mymax = -__builtin_huge_val();
 #pragma unroll
-    for (int it = 0; it < PF_COMBINE_ITERS; ++it) {
-        const int t = threadIdx.x + it * PF_BLOCK;
-        e.m1[it] = e.m2[it] = -__builtin_huge_val();
-        e.s1[it] = e.q1[it] = e.s2[it] = 0.0;
-        if (t < a.g.tiles) {
-            e.m1[it] = a.part_r()[PQ_M1 * stride + cb + t];
-            e.s1[it] = a.part_r()[PQ_S1 * stride + cb + t];
-            e.q1[it] = a.part_r()[PQ_Q1 * stride + cb + t];
-            if (two) {
-                e.m2[it] = a.part_r()[PQ_M2 * stride + cb + t];
-                e.s2[it] = a.part_r()[PQ_S2 * stride + cb + t];
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        const int t = threadIdx.x * IT + q;
+        const bool on = q < IT && t < tiles;
+        mloc[q] = on ? part[slot_m * stride + cb + t] : -__builtin_huge_val();
+        sloc[q] = on ? part[slot_s * stride + cb + t] : 0.0;
+        qloc[q] = (WITH_Q && on) ? part[PQ_Q1 * stride + cb + t] : 0.0;
+        mymax = mloc[q] > mymax ? mloc[q] : mymax;
+    }
+    const double MR = block_max<double>(mymax, redm);
+    double incl[PF_COMBINE_ITERS], ef[PF_COMBINE_ITERS], run = 0.0, qs = 0.0;
+#pragma unroll
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        ef[q] = exp_diff_t<T>(mloc[q], MR);
+        run += sloc[q] * ef[q];
+        incl[q] = run;
+        if (WITH_Q) qs += qloc[q] * ef[q] * ef[q];
+    }
+    const double incl_w = wave_scan_incl(run, lane);
+    const double qw = WITH_Q ? wave_sum(qs) : 0.0;
+    __syncthreads();
+    if (lane == 63) reds[wid] = incl_w;
+    if (WITH_Q && lane == 0) reds[PF_NWAVES + wid] = qw;
+    __syncthreads();
+    double wave_off = 0.0, tot = 0.0, qtot = 0.0;
+#pragma unroll
+    for (int w = 0; w < PF_NWAVES; ++w) {
+        const double sw = reds[w];
+        if (w < wid) wave_off += sw;
+        tot += sw;
+        if (WITH_Q) qtot += reds[PF_NWAVES + w];
+    }
+    if constexpr (TABLE) {
+        const double excl = wave_off + incl_w - run;
+        if (threadIdx.x == 0) ptl[0] = 0.0;
+#pragma unroll
+        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+            const int t = threadIdx.x * IT + q;
+            if (q < IT && t < tiles) {
+                ptl[t + 1] = (excl + incl[q]) / tot;
+                ftl[t] = ef[q] / tot;
             }
         }
+        __syncthreads();
     }
+    return ColSums{MR, tot, qtot};
 }
-template <typename T>
-__device__ __forceinline__ ColCombine combine_column(const FusedArgs<T>& a, const EarlyPartials& e, int64_t cb,
-                                                     int64_t stride, int k, bool two, double* red, double* redm) {
-    const Geom& g = a.g;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    double m1 = e.m1[0], m2 = e.m2[0];
+// multinomial: exclusive prefixes of the tiles' Exp(1) spacing sums in pel[0 .. tiles) and, one slot behind them
+// (pel[tiles + 1]), the grand total including the closing spacing `tail`.  Same thread-to-tile mapping as column_sums.
+__device__ __forceinline__ void spacing_table(const double* part, int64_t stride, int64_t cb, int tiles, double tail,
+                                              double* pel, double* reds) {
+    const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
+    double inclE[PF_COMBINE_ITERS], runE = 0.0, totalE;
 #pragma unroll
-    for (int it = 1; it < PF_COMBINE_ITERS; ++it) {
-        m1 = fmax(m1, e.m1[it]);
-        m2 = fmax(m2, e.m2[it]);
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        const int t = threadIdx.x * IT + q;
+        if (q < IT && t < tiles) runE += part[PQ_E * stride + cb + t];
+        inclE[q] = runE;
     }
-    m1 = wave_max(m1);
-    m2 = wave_max(m2);
-    if (lane == 0) {
-        redm[wid] = m1;
-        redm[PF_NWAVES + wid] = m2;
+    const double exclE = block_scan_excl(runE, reds, totalE);
+    if (threadIdx.x == 0) {
+        pel[0] = 0.0;
+        pel[tiles + 1] = totalE + tail;
+    }
+#pragma unroll
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
+        const int t = threadIdx.x * IT + q;
+        if (q < IT && t < tiles) pel[t + 1] = exclE + inclE[q];
     }
     __syncthreads();
-    m1 = redm[0];
-    m2 = redm[PF_NWAVES];
-#pragma unroll
-    for (int w = 1; w < PF_NWAVES; ++w) {
-        m1 = fmax(m1, redm[w]);
-        m2 = fmax(m2, redm[PF_NWAVES + w]);
-    }
-    // S1, Q1, S2 and the resampling-weight prefix below tile k / below tile k+1.  Both prefixes use the same masked
-    // loop + reduction tree, so tile k's "next" prefix is bit-identical to what tile k+1 computes as its own.
-    double v[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-    for (int it = 0; it < PF_COMBINE_ITERS; ++it) {
-        const int t = threadIdx.x + it * PF_BLOCK;
-        if (t < g.tiles) {
-            const double f = exp_diff_t<T>(e.m1[it], m1);
-            const double s = e.s1[it] * f;
-            v[0] += s;
-            v[1] += e.q1[it] * f * f;
-            double sr = s;
-            if (two) {
-                sr = e.s2[it] * exp_diff_t<T>(e.m2[it], m2);
-                v[2] += sr;
-            }
-            if (t < k) v[3] += sr;
-            if (t < k + 1) v[4] += sr;
-        }
-    }
-    block_sum<5>(v, red);
-    ColCombine c;
-    c.m1 = m1;
-    c.m2 = m2;
-    c.S1 = v[0];
-    c.Q1 = v[1];
-    c.S2 = v[2];
-    c.prefK = v[3];
-    c.prefK1 = v[4];
-    return c;
 }
 
 // The column's bookkeeping, run by one extra workgroup per column: moments of the current state (row `step` of
-// filter_means / filter_variance), the log-likelihood increment of the previous step, the resampling decision.
+// filter_means / filter_variance), the log-likelihood increment of the previous step, the bases of this one.
+// Reads the partials of state `step` only - nothing the step workgroups of the same launch write or wait for.
 template <typename T, int D>
-__device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const EarlyPartials& early, int b, int64_t cb,
-                                                    int64_t stride, bool obs, bool apf, bool two, double* red, double* redm,
-                                                    double* red2) {
+__device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, int b, double* red, double* redm, double* red2) {
     const Geom& g = a.g;
     const int step = a.step;
-    if (threadIdx.x == PF_BLOCK - 1 && !a.finalize_only) {
-        // this step's per-column records for the step kernel: the systematic offset and (scalar closed-form models) the
-        // constants of FastCol - evaluated once here instead of once per thread there
-        if (a.resampler == PF_RESAMPLE_SYSTEMATIC)
-            a.ucol[b] = a.u_tape ? a.u_tape[(int64_t)step * g.B + b]
-                                 : uniform_draw<T>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
-        if constexpr (D == 1) {
-            if (a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM) {
-                ColParams<T, 1> cp;
-                ColConsts<T, 1> cc;
-                load_col_params<T, 1>(a, b, step, obs, cp);
-                if (a.is_obs_next() && apf) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
-                cc.prepare(a.md, cp);
-                write_col_pack<T>(a.md, cp, cc, a.cpack + (int64_t)b * PK_N);
-            }
-        }
-    }
-    const ColCombine c = combine_column<T>(a, early, cb, stride, 0, two, red, redm);
-    const double lse_w = c.m1 + log(c.S1);
-    const double ess = c.S1 * c.S1 / c.Q1;
-    bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
+    const bool obs = !a.finalize_only && a.is_obs();
+    const bool apf = a.filter == PF_FILTER_APF;
+    const bool two = apf && obs;
+    const int64_t stride = (int64_t)g.B * g.tiles;
+    const int64_t cb = (int64_t)b * g.tiles;
+    const ColSums c1 = column_sums<T, true, false>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, nullptr, nullptr, redm, red);
+    ColSums c2{0.0, 1.0, 0.0};
+    if (two) c2 = column_sums<T, false, false>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, nullptr, nullptr, redm, red);
+    const double lse_w = c1.M + log(c1.S);
+    const double ess = c1.S * c1.S / c1.Q;
+    bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19 (the step workgroups: the same test)
     if (a.finalize_only) resample = false;
     double mv[2 * D];
 #pragma unroll
     for (int q = 0; q < 2 * D; ++q) {
         mv[q] = 0.0;
         for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-            mv[q] += a.part_r()[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part_r()[PQ_M1 * stride + cb + t], c.m1);
+            mv[q] += a.part_r()[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part_r()[PQ_M1 * stride + cb + t], c1.M);
     }
     block_sum<2 * D>(mv, red2);
-    if (threadIdx.x == 0 && !a.replay) {
+    if (threadIdx.x == 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {  // moments of the current state -> row `step` of filter_means / filter_variance
-            // the partials were taken about the pivot c = previous row's mean (0 for the run's first state)
-            const double piv = (step > a.t0) ? (double)a.means[((int64_t)(step - 1) * g.B + b) * D + d] : 0.0;
-            const double dm = mv[d] / c.S1;
-            double var = mv[D + d] / c.S1 - dm * dm;
+            const double piv = (double)a.template pivot<D>(step, b, d);  // the pivot the partials were taken about
+            const double dm = mv[d] / c1.S;
+            double var = mv[D + d] / c1.S - dm * dm;
             if (var < 0.0) var = 0.0;
             a.means[((int64_t)step * g.B + b) * D + d] = (T)(piv + dm);
             a.vars[((int64_t)step * g.B + b) * D + d] = (T)var;
@@ -570,7 +576,7 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
         // log-likelihood increment of the previous step: ll = lse(logw') - base_lse   (0 for unweighted steps)
         if (step > 0 && !st.ll_done) {
             double ll = 0.0;
-            const int pslot = (step - 1) & 1;
+            const int pslot = (step - 1) & 3;
             if (st.prev_observed) {
                 ll = lse_w - st.base_lse;
                 if (a.poison[pslot * g.B + b]) ll = __builtin_nan("");
@@ -586,177 +592,19 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, const 
             st.prev_observed = obs ? 1 : 0;
             // ll_t = [lse(w') - log N] + [lse(rw) - lse(w)] (apf.py:44) | lse(wi + log W), W = 1/N after resampling
             // else the carried weights (sisr.py:52-55)
-            st.base_lse = apf ? a.logN - ((c.m2 + log(c.S2)) - lse_w) : (resample ? a.logN : lse_w);
+            st.base_lse = apf ? a.logN - ((c2.M + log(c2.S)) - lse_w) : (resample ? a.logN : lse_w);
         }
         a.stat[b] = st;
     }
 }
 
-// Planning kernel of the systematic pipeline.  grid (ceil(tiles / 4) + 1, B): every workgroup re-reduces the column's
-// partials into the tile-prefix table (workgroup 0 publishes it: ptab / ftab), each of its 4 waves then finds j0 for one
-// position tile - the tile via the table, the element inside it with a 64-ary search over the local scans; the extra
-// workgroup does the column's bookkeeping.  No per-particle pass: the per-particle scan was done by the previous step
-// kernel (tile_local_scan) while the weights were in registers.
+// The bookkeeper alone (grid (1, B)): flushes the moments / log-likelihood of a run's last state (finalize_only).
 template <typename T, int D>
-__global__ __launch_bounds__(PF_BLOCK) void k_fused_plan(FusedArgs<T> a) {
-    __shared__ double red[6 * PF_NWAVES];
-    __shared__ double redm[2 * PF_NWAVES];
+__global__ __launch_bounds__(PF_BLOCK) void k_fused_book(FusedArgs<T> a) {
+    __shared__ double red[2 * PF_NWAVES];
+    __shared__ double redm[PF_NWAVES];
     __shared__ double red2[2 * D * PF_NWAVES];
-    __shared__ double reds[PF_NWAVES];
-    __shared__ double ptl[PF_MAX_TILES + 1];
-    __shared__ double pel[PF_MAX_TILES + 2];  // multinomial: prefixes of the spacing sums (+ the grand total)
-    const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
-    const int nplan = (g.tiles + PF_NWAVES - 1) / PF_NWAVES;
-    PF_STAMP_PLAN(a, 0);
-    const int step = a.step;
-    const bool obs = !a.finalize_only && a.is_obs();
-    const bool apf = a.filter == PF_FILTER_APF;
-    const bool two = apf && obs;
-    const int64_t stride = (int64_t)g.B * g.tiles;
-    const int64_t cb = (int64_t)b * g.tiles;
-    if (k == nplan) {
-        EarlyPartials early;
-        load_early_partials<T>(a, cb, stride, two, early);
-        column_bookkeeping<T, D>(a, early, b, cb, stride, obs, apf, two, red, redm, red2);
-        return;
-    }
-    // planners: nothing to do for a step that cannot resample.  A SISR step resamples when the bookkeeper's ESS test says
-    // so (stat.resample, read by the step kernel); the planners do not repeat that test - a differently ordered sum could
-    // land on the other side of the threshold - they always prepare the table (this kernel is latency-bound either way).
-    if (a.finalize_only || (apf && !obs)) return;
-    const int slot_m = two ? PQ_M2 : PQ_M1, slot_s = two ? PQ_S2 : PQ_S1;
-    // issued first, used last: the Philox epoch / the step's systematic offset (dependent loads otherwise exposed between the
-    // table and the probe)
-    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
-    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
-    const T u_taped = (!multinomial && a.u_tape) ? a.u_tape[(int64_t)step * g.B + b] : T(0);
-
-    // one load of the tiles' (max, sum) pairs - thread t owns the IT consecutive tiles [t * IT, (t + 1) * IT) - then two
-    // workgroup exchanges: the column maximum, and the scan whose total is the column sum
-    const int IT = (g.tiles + PF_BLOCK - 1) / PF_BLOCK;
-    double mloc[PF_COMBINE_ITERS], sloc[PF_COMBINE_ITERS], mymax = -__builtin_huge_val();
-#pragma unroll
-    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
-        const int t = threadIdx.x * IT + q;
-        const bool on = q < IT && t < g.tiles;
-        mloc[q] = on ? a.part_r()[slot_m * stride + cb + t] : -__builtin_huge_val();
-        sloc[q] = on ? a.part_r()[slot_s * stride + cb + t] : 0.0;
-        mymax = mloc[q] > mymax ? mloc[q] : mymax;
-    }
-    const double MR = block_max<double>(mymax, redm);
-    PF_STAMP_PLAN(a, 1);
-    double incl[PF_COMBINE_ITERS], run = 0.0, total;
-#pragma unroll
-    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
-        run += sloc[q] * exp_diff_t<T>(mloc[q], MR);
-        incl[q] = run;
-    }
-    const double excl = block_scan_excl(run, reds, total);
-    const double SR = total;
-    PF_STAMP_PLAN(a, 2);
-    if (threadIdx.x == 0) ptl[0] = 0.0;
-#pragma unroll
-    for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
-        const int t = threadIdx.x * IT + q;
-        if (q < IT && t < g.tiles) ptl[t + 1] = (excl + incl[q]) / SR;
-    }
-    __syncthreads();
-    if (k == 0) {
-        for (int t = threadIdx.x; t <= g.tiles; t += PF_BLOCK) a.ptab[(int64_t)b * (g.tiles + 1) + t] = ptl[t];
-#pragma unroll
-        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
-            const int t = threadIdx.x * IT + q;
-            if (q < IT && t < g.tiles) a.ftab[cb + t] = exp_diff_t<T>(mloc[q], MR) / SR;
-        }
-    }
-
-    // multinomial: the resampling positions are the order statistics of N iid uniforms, built from normalised Exp(1)
-    // spacings (Philox, regenerated wherever needed); their per-tile sums were reduced with the partials, so the first
-    // position of every tile follows from a second prefix table
-    if (multinomial) {
-        double inclE[PF_COMBINE_ITERS], runE = 0.0, totalE;
-#pragma unroll
-        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
-            const int t = threadIdx.x * IT + q;
-            if (q < IT && t < g.tiles) runE += a.part_r()[PQ_E * stride + cb + t];
-            inclE[q] = runE;
-        }
-        const double exclE = block_scan_excl(runE, reds, totalE);
-        T tail[1];
-        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)g.B * g.N + b), tail);
-        if (threadIdx.x == 0) {
-            pel[0] = 0.0;
-            pel[g.tiles + 1] = totalE + (double)tail[0];  // grand total (one slot behind the prefixes)
-        }
-#pragma unroll
-        for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
-            const int t = threadIdx.x * IT + q;
-            if (q < IT && t < g.tiles) pel[t + 1] = exclE + inclE[q];
-        }
-        __syncthreads();
-        if (k == 0) {
-            double* et = a.etab + (int64_t)b * (g.tiles + 1);
-            for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK) et[t] = pel[t];
-            if (threadIdx.x == 0) et[g.tiles] = pel[g.tiles + 1];
-        }
-    }
-
-    // j0 of position tile t: one wave each
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int t = k * PF_NWAVES + wid;
-    if (t >= g.tiles) return;
-    T p;
-    if (multinomial) {
-        T e0[1];
-        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + (int64_t)t * g.tile_elems), e0);
-        p = (T)((pel[t] + (double)e0[0]) * (1.0 / pel[g.tiles + 1]));
-    } else {
-        const T ub = a.u_tape ? u_taped : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
-        p = grid_position<T>((int64_t)t * g.tile_elems, ub, T(g.N));
-    }
-    // the tile holding the ancestor: first kt whose end value T(P_{kt+1}) (1 for the last tile) is >= p
-    // (64-ary over the LDS table: two probe rounds for 1024 tiles instead of ten dependent reads)
-    int lo = 0, hi = g.tiles - 1;
-    while (lo < hi) {
-        const int len = hi - lo + 1;
-        const int st = (len + PF_WAVE - 1) / PF_WAVE;
-        int probe = lo + (lane + 1) * st - 1;
-        if (probe > hi) probe = hi;
-        const bool ge = (probe >= g.tiles - 1) || !((T)ptl[probe + 1] < p);
-        const unsigned long long bal = __ballot(ge);
-        const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;
-        int nhi = lo + (f + 1) * st - 1;
-        if (nhi > hi) nhi = hi;
-        lo = lo + f * st;
-        if (lo > nhi) lo = nhi;
-        hi = nhi;
-    }
-    const int kt = lo;
-    PF_STAMP_PLAN(a, 3);
-    const double Pk = ptl[kt], Pn = ptl[kt + 1];
-    const double fk = exp_diff_t<T>(a.part_r()[slot_m * stride + cb + kt], MR) / SR;
-    const int64_t first = (int64_t)kt * g.tile_elems;
-    const int64_t last = (first + g.tile_elems < g.N ? first + g.tile_elems : g.N) - 1;
-    const T* l_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;
-    // Window start inside tile kt: ONE 64-ary probe round.  The step kernel does not need the exact ancestor of the tile's
-    // first position, only an index at or before it whose predecessor lies below p (entries ahead of the ancestor own no
-    // position and cost nothing but window capacity) - so the bracket the first round yields (<= tile / 64 entries wide)
-    // is enough, and the second, dependent probe round (a further memory latency) is not spent.
-    const int64_t len = last + 1 - first;
-    const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
-    int64_t probe = first + (lane + 1) * st - 1;
-    if (probe > last) probe = last;
-    const bool ge = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1) >= p;
-    const unsigned long long bal = __ballot(ge);
-    const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
-    int64_t res = first + (int64_t)f * st;
-    if (res > last) res = last;
-    PF_STAMP_PLAN(a, 4);
-    if (lane == 0) {
-        a.j0[cb + t] = (int32_t)res;
-        a.k0[cb + t] = kt;
-    }
+    column_bookkeeping<T, D>(a, blockIdx.y, red, redm, red2);
 }
 
 // MODE 0: systematic, ancestors from the inverted grid (grid_count);
@@ -793,10 +641,116 @@ template <typename T, int D, int VEC> struct StepShared {
     int* sh_j0;
     int* sh_cl;
     int* sh_wm;
-    double* red;
+    double* red;   // (4 + 2 D) * PF_NWAVES doubles
     double* reds;
     T* redm;
+    double* ptl;   // PF_MAX_TILES + 2: the column's tile-prefix table (column_sums); the multinomial prologue first builds
+                   // the prefixes of the Exp(1) spacing sums here (tiles + 2 entries) and takes what it needs from them
+    double* ftl;   // PF_MAX_TILES
+    int* sh_plan;  // 2: window start of the tile's first position, its tile
 };
+// What the prologue hands to the body.
+template <typename T> struct StepPlan {
+    int j0, kt0;       // window start of the tile's first position (an index at or before its ancestor) and its tile
+    T ub;              // systematic: the column's offset u
+    double offE, invE; // multinomial: this tile's offset into the running spacing sum, 1 / the column's total
+    bool resample;
+};
+// Prologue of a step workgroup: the column's table from the partials of the incoming state, the resampling decision,
+// the window start (wave 0; broadcast through LDS).  Everything here is L2-hot and tiny: <= 16 KB of partials, one
+// 64-lane probe of the tile-local scans.
+template <typename T, int D, int VEC, int MODE, int SPEC>
+__device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh) {
+    const Geom& g = a.g;
+    const int b = blockIdx.y, k = blockIdx.x;
+    const int step = a.step;
+    const bool obs = SPEC ? true : a.is_obs();
+    const bool apf = SPEC ? (SPEC == 1) : (a.filter == PF_FILTER_APF);
+    const bool two = apf && obs;
+    StepPlan<T> pl{0, 0, T(0), 0.0, 0.0, false};
+    if (apf && !obs) return pl;  // propagate-only move of the APF: identity ancestors, nothing to plan
+    constexpr bool multinomial = MODE == 1;
+    // issued first, used last: the Philox epoch / the step's systematic offset
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    const T u_taped = (!multinomial && a.u_tape) ? a.u_tape[(int64_t)step * g.B + b] : T(0);
+    const int64_t stride = (int64_t)g.B * g.tiles;
+    const int64_t cb = (int64_t)b * g.tiles;
+    double* const redm_d = sh.red + 2 * PF_NWAVES;
+    T e0[1] = {T(0)};
+    if constexpr (multinomial) {
+        // the resampling positions are the order statistics of N iid uniforms, built from normalised Exp(1) spacings
+        // (Philox, regenerated wherever needed); their per-tile sums were reduced with the partials, so the first position
+        // of every tile follows from a second prefix table - built in the LDS of the weights' table, before it
+        T tail[1];
+        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)g.B * g.N + b), tail);
+        spacing_table(a.part_r(), stride, cb, g.tiles, (double)tail[0], sh.ptl, sh.reds);
+        pl.offE = sh.ptl[k];
+        pl.invE = 1.0 / sh.ptl[g.tiles + 1];
+        draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + (int64_t)k * g.tile_elems), e0);
+    }
+    if (two) {
+        column_sums<T, false, true>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, sh.ptl, sh.ftl, redm_d, sh.red);
+        pl.resample = true;  // apf.py:29-31
+    } else {
+        const ColSums c = column_sums<T, true, true>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, sh.ptl, sh.ftl, redm_d, sh.red);
+        pl.resample = c.S * c.S / c.Q < a.thr_abs;  // sisr.py:18-19 (the bookkeeper: the same test)
+    }
+    if (!pl.resample) return pl;  // (uniform)
+    const double* ptl = sh.ptl;
+    T p;
+    if constexpr (multinomial) {
+        p = (T)((pl.offE + (double)e0[0]) * pl.invE);
+    } else {
+        pl.ub = a.u_tape ? u_taped : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
+        p = grid_position<T>((int64_t)k * g.tile_elems, pl.ub, T(g.N));
+    }
+    if (threadIdx.x < PF_WAVE) {
+        const int lane = threadIdx.x;
+        // the tile holding the ancestor: first kt whose end value T(P_{kt+1}) (1 for the last tile) is >= p
+        // (64-ary over the LDS table: two probe rounds for 1024 tiles instead of ten dependent reads)
+        int lo = 0, hi = g.tiles - 1;
+        while (lo < hi) {
+            const int len = hi - lo + 1;
+            const int st = (len + PF_WAVE - 1) / PF_WAVE;
+            int probe = lo + (lane + 1) * st - 1;
+            if (probe > hi) probe = hi;
+            const bool ge = (probe >= g.tiles - 1) || !((T)ptl[probe + 1] < p);
+            const unsigned long long bal = __ballot(ge);
+            const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;
+            int nhi = lo + (f + 1) * st - 1;
+            if (nhi > hi) nhi = hi;
+            lo = lo + f * st;
+            if (lo > nhi) lo = nhi;
+            hi = nhi;
+        }
+        const int kt = lo;
+        const double Pk = ptl[kt], Pn = ptl[kt + 1], fk = sh.ftl[kt];
+        const int64_t first = (int64_t)kt * g.tile_elems;
+        const int64_t last = (first + g.tile_elems < g.N ? first + g.tile_elems : g.N) - 1;
+        const T* l_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;
+        // Window start inside tile kt: ONE 64-ary probe round.  The body does not need the exact ancestor of the tile's
+        // first position, only an index at or before it whose predecessor lies below p (entries ahead of the ancestor own
+        // no position and cost nothing but window capacity) - so the bracket the first round yields (<= tile / 64 entries
+        // wide) is enough, and a second, dependent probe round (a further memory latency) is not spent.
+        const int64_t len = last + 1 - first;
+        const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
+        int64_t probe = first + (lane + 1) * st - 1;
+        if (probe > last) probe = last;
+        const bool ge = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1) >= p;
+        const unsigned long long bal = __ballot(ge);
+        const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
+        int64_t res = first + (int64_t)f * st;
+        if (res > last) res = last;
+        if (lane == 0) {
+            sh.sh_plan[0] = (int)res;
+            sh.sh_plan[1] = kt;
+        }
+    }
+    __syncthreads();
+    pl.j0 = sh.sh_plan[0];
+    pl.kt0 = sh.sh_plan[1];
+    return pl;
+}
 // RS: whether this column resamples in this step - a run-time fact for SISR (the bookkeeper's ESS test), so the kernel
 // holds both bodies and branches once, uniformly, at its top: the resampling body carries no carried-weights path (old
 // log-weights, direct state loads), the other one no ancestor stage.
@@ -805,7 +759,7 @@ template <typename T, int D, int VEC> struct StepShared {
 // scalar branch instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on
 // 64 x 65 536).  Closed-form kernels (FAST): the shape of the one-step mean, 0 run time, 1 affine, 2 sine.
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS>
-__device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh) {
+__device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, const StepPlan<T>& pl) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     ModelDesc md = a.md;
     if constexpr (!FAST && MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
@@ -840,16 +794,12 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     if (a.debug_cut < 0 && tid == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[16 + k / 128] = wall_clock64();
 #endif
 
-    // uniform loads first: the window start and the column's parameter rows
-    int j0 = windowed ? a.j0[(int64_t)b * g.tiles + k] : 0;
-    int kt0 = windowed ? a.k0[(int64_t)b * g.tiles + k] : 0;  // tile index of j0 (no integer division here)
+    // the window start of the tile's first position and its tile (prologue; no integer division here)
+    int j0 = pl.j0;
+    int kt0 = pl.kt0;
     // multinomial: this tile's offset into the running sum of the Exp(1) spacings and the reciprocal of their total
-    double offE = 0.0, invE = 0.0, carryE = 0.0;
-    if (MODE == 1 && windowed) {
-        const double* et = a.etab + (int64_t)b * (g.tiles + 1);
-        offE = et[k];
-        invE = 1.0 / et[g.tiles];
-    }
+    const double offE = pl.offE, invE = pl.invE;
+    double carryE = 0.0;
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const T* z_step = (!SPEC && a.z_tape) ? a.z_tape + (int64_t)step * D * g.B * g.N : nullptr;
 
@@ -862,7 +812,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         load_col_params<T, D>(a, b, step, obs, cp);
         if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim);
     }
-    const T ub = (!windowed || multinomial) ? T(0) : a.ucol[b];
+    const T ub = pl.ub;
 
     const T* x_in = a.x[slot];
     const T* lw_in = a.logw[slot] + (int64_t)b * g.N;
@@ -880,9 +830,8 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     PartialAcc<T, D> acc;
     acc.init();
     PF_STAMP(a, 9);
-    constexpr bool from_local = true;  // `cdf` / `pos` hold tile-local scans; the cdf is implied by the table
-    const double* ptab_col = a.ptab + (int64_t)b * (g.tiles + 1);
-    const double* ftab_col = a.ftab + (int64_t)b * g.tiles;
+    const double* ptab_col = sh.ptl;  // `cdf` / `pos` hold tile-local scans; the cdf is implied by the prologue's table (LDS)
+    const double* ftab_col = sh.ftl;
     CdfView<T> view;
     view.L = cdf_col;
     view.ptab = ptab_col;
@@ -1081,8 +1030,12 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         int32_t* const anc_col = la->anc + (int64_t)b * g.N;
 #endif
         if constexpr (FAST) {
-            // scalar loads of the record the bookkeeper wrote: 20 SGPRs
-            fc.load((const_ptr<T>)(uintptr_t)(a.cpack + (int64_t)b * PK_N) + late);
+            // scalar loads of the run's record (k_fused_reduce wrote it) and of this / the next step's observation
+            const_ptr<T> yq = (const_ptr<T>)(uintptr_t)a.y + late;
+            const int yc = a.y_rows == 1 ? 0 : b;
+            const T y_t = obs ? yq[(int64_t)step * a.y_rows + yc] : T(0);
+            const T y_n = pre_next ? yq[(int64_t)(step + 1) * a.y_rows + yc] : T(0);
+            fc.load((const_ptr<T>)(uintptr_t)(a.cpack + (int64_t)b * PK_N) + late, y_t, y_n);
         } else if constexpr (D == 1) {
             load_col_params<T, D>(a, b, step, obs, cp, late);
             if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim + late);
@@ -1166,9 +1119,10 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 if (pre_next) { if (VEC == 1) lw_out[i0] = pre_n[0]; else store_vec<T, VEC>(lw_out + i0, pre_n); }
                 return;
             }
-            T piv[D];
+            T piv[D];  // pivot of the moments of state step + 1: the mean of state step - 1, or the run's record (FusedArgs::pivot)
 #pragma unroll
-            for (int d = 0; d < D; ++d) piv[d] = la->means[((int64_t)step * g.B + b) * D + d];
+            for (int d = 0; d < D; ++d)
+                piv[d] = (step - 1 >= a.t0) ? la->means[((int64_t)(step - 1) * g.B + b) * D + d] : (T)la->piv0[(int64_t)b * PF_MAXD + d];
             acc.template push_round<VEC>(lwo, xo, pre_next, pre_n, piv, e_rw);
             if (multinomial) {
                 T ev[VEC];
@@ -1180,14 +1134,14 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         }
         if (windowed && r + 1 < g.rounds_per_tile) __syncthreads();  // the window is rewritten by the next round
     }
-    if (poison) atomicOr(&a.poison[(step & 1) * g.B + b], 1);
+    if (poison) atomicOr(&a.poison[(step & 3) * g.B + b], 1);
     if (PF_CUT(a, 3)) return;
     PF_STAMP(a, 14);
     T M1, M2, F1, F2;
-    acc.template finish<MODE == 1>(a.part_w(step + 1), b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 1) * g.B + b], M1, M2, F1, F2);
+    acc.template finish<MODE == 1>(a.part_w(step + 1), b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 3) * g.B + b], M1, M2, F1, F2);
     if (PF_CUT(a, 6)) return;
     // the next step's resampling weights, scanned per tile while they are at hand (their cdf = table + these local scans)
-    if (from_local && (!apf || pre_next))
+    if (!apf || pre_next)
         tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, pre_next ? M2 : M1,
                                    [&](const T (&xj)[D]) {
                                        if constexpr (FAST) return fc.template pre_weight<FAST ? MK : 0>(proposal, xj[0], true);
@@ -1210,12 +1164,19 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
     __shared__ double red[(4 + 2 * D) * PF_NWAVES];
     __shared__ double reds[PF_NWAVES];
     __shared__ T redm[2 * PF_NWAVES];
-    const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm};
+    __shared__ double ptl[PF_MAX_TILES + 2], ftl[PF_MAX_TILES];
+    __shared__ int sh_plan[2];
+    if (blockIdx.x == (unsigned)a.g.tiles) {  // the column's bookkeeper (scratch: 2 + 1 + 2 D rows of `red`)
+        column_bookkeeping<T, D>(a, blockIdx.y, red, red + 2 * PF_NWAVES, red + 3 * PF_NWAVES);
+        return;
+    }
+    const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan};
+    const StepPlan<T> pl = step_prologue<T, D, VEC, MODE, SPEC>(a, sh);
     if constexpr (SPEC == 1) {
-        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh);
+        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl);
     } else {
-        if (a.stat[blockIdx.y].resample != 0) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh);
-        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh);
+        if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl);
+        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh, pl);
     }
 }
 

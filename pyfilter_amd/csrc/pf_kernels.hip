@@ -75,15 +75,11 @@ struct WsLayout {
     size_t off_part;   // double partials[2][(6 + 2D)][B][tiles]
     size_t part_elems;
     size_t off_stat;   // ColStat[B]
-    size_t off_poison; // int32 [2][B]
+    size_t off_poison; // int32 [4][B]
     size_t off_ctr;    // int32 [4] (reserved)
-    size_t off_j0;     // int32 [2][B][tiles]: ancestor of the first grid position of every position tile + its tile index
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
-    size_t off_ptab;   // double [B][tiles + 1]
-    size_t off_ftab;   // double [B][tiles]
-    size_t off_etab;   // double [B][tiles + 1]
-    size_t off_cpack;  // T [B][PK_N] (sized for double)
-    size_t off_ucol;   // T [B]
+    size_t off_cpack;  // T [B][PK_N] (sized for double): the run's closed-form records
+    size_t off_piv0;   // double [B][PF_MAXD]: the run's moment pivots
     size_t total;
 };
 
@@ -98,23 +94,15 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.off_stat = o;
     o = align256(o + sizeof(ColStat) * (size_t)g.B);
     w.off_poison = o;
-    o = align256(o + sizeof(int32_t) * 2 * (size_t)g.B);
+    o = align256(o + sizeof(int32_t) * 4 * (size_t)g.B);
     w.off_ctr = o;
     o = align256(o + 64);
-    w.off_j0 = o;
-    o = align256(o + sizeof(int32_t) * 2 * (size_t)g.B * g.tiles);
     w.off_dbg = o;
     o = align256(o + 256);
-    w.off_ptab = o;
-    o = align256(o + sizeof(double) * (size_t)g.B * (g.tiles + 1));
-    w.off_ftab = o;
-    o = align256(o + sizeof(double) * (size_t)g.B * g.tiles);
-    w.off_etab = o;
-    o = align256(o + sizeof(double) * (size_t)g.B * (g.tiles + 1));
     w.off_cpack = o;
     o = align256(o + sizeof(double) * (size_t)g.B * 24);
-    w.off_ucol = o;
-    o = align256(o + sizeof(double) * (size_t)g.B);
+    w.off_piv0 = o;
+    o = align256(o + sizeof(double) * (size_t)g.B * PF_MAXD);
     w.total = o;
     return w;
 }
@@ -1290,20 +1278,11 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.part_stride = (int64_t)wl.part_elems;
     a.stat = (ColStat*)((char*)A->ws + wl.off_stat);
     a.poison = (int32_t*)((char*)A->ws + wl.off_poison);
-    a.j0 = (int32_t*)((char*)A->ws + wl.off_j0);
-    a.k0 = a.j0 + (size_t)g.B * g.tiles;
     a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
-    a.ptab = (double*)((char*)A->ws + wl.off_ptab);
-    a.ftab = (double*)((char*)A->ws + wl.off_ftab);
-    a.etab = (double*)((char*)A->ws + wl.off_etab);
     a.cpack = (T*)((char*)A->ws + wl.off_cpack);
-    a.ucol = (T*)((char*)A->ws + wl.off_ucol);
+    a.piv0 = (double*)((char*)A->ws + wl.off_piv0);
     static_assert(PK_N == 24, "workspace layout reserves 24 slots per column record");
-    {
-        a.from_local = 1;  // both resamplers run the planning pipeline (tile-local scans + prefix table)
-    }
     a.finalize_only = 0;
-    a.replay = 0;
     a.t0 = (int)t0;
     {
         const char* dc = getenv("PF_DEBUG_CUT");
@@ -1311,10 +1290,10 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     }
     const uint8_t* observed = A->observed;  // host array
 
-    const dim3 grid(g.tiles, g.B), block(PF_BLOCK);
-    const dim3 grid_plan((g.tiles + PF_NWAVES - 1) / PF_NWAVES + 1, g.B);
+    const dim3 grid_tiles(g.tiles, g.B), block(PF_BLOCK);
+    const dim3 grid(g.tiles + 1, g.B);  // the step kernel: one workgroup per tile + the column's bookkeeper
     if (t0 == 0) {
-        // fresh filter: no previous step to account for
+        // fresh filter: no previous step to account for (column records + poison flags)
         hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -1324,11 +1303,8 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.obs_dev = A->observed_dev;
     a.obs = n_steps > 0 ? (dev_flags ? -1 : (observed[t0] != 0)) : 0;
     a.obs_next = 0;
-    hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid_tiles, block, 0, st, a);
 
-    auto launch_plan = [&]() {
-        hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
-    };
     // ancestor stage of the step kernel: 0 inverted grid (systematic), 1 multinomial, 2 systematic by search - float
     // grids beyond 2^22 positions, where the closed form is not exact (PF_FORCE_SEARCH=1 selects it for testing)
     static const bool force_search = getenv("PF_FORCE_SEARCH") != nullptr;
@@ -1412,7 +1388,6 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         const int cut_all = a.debug_cut;
         if (cut_at_end && cut_all > 0 && s != n_steps - 2) a.debug_cut = 0;
 #endif
-        launch_plan();
         launch_step();
 #ifdef PF_DEVTOOLS
         a.debug_cut = cut_all;
@@ -1423,7 +1398,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.step = (int)(t0 + n_steps);
         a.obs = a.obs_next = 0;
         a.finalize_only = 1;
-        hipLaunchKernelGGL((k_fused_plan<T, D>), grid_plan, block, 0, st, a);
+        hipLaunchKernelGGL((k_fused_book<T, D>), dim3(1, g.B), block, 0, st, a);
     }
     if (kernel_ms) {
         hipError_t se = hipStreamSynchronize(st);
@@ -1431,51 +1406,11 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         float loop_ms = 0.f;
         (void)hipEventElapsedTime(&loop_ms, ev_loop[0], ev_loop[1]);
         for (auto& e : ev_loop) (void)hipEventDestroy(e);
+        // one kernel per step: the in-sequence time of a step IS the step kernel's launch-to-launch duration
         const float per_step = n_steps > 0 ? loop_ms / (float)n_steps : 0.f;
-        kernel_ms[0] = per_step;  // in-sequence time of one step (both kernels + their boundaries)
-        kernel_ms[1] = kernel_ms[2] = 0.f;
-        if (n_steps > 0) {
-            // How the step time splits between its two kernels: replay the last step - its launches are idempotent
-            // (same inputs, same outputs; the bookkeeper is muted) - back to back between events: `reps` x plan alone, then
-            // `reps` x step alone (after warming pairs).  The replays run L2-hotter than the real sequence (one direction
-            // of the double buffers only), so they only provide the RATIO; the durations reported are the in-sequence
-            // step time apportioned by it (against rocprofv3's per-kernel averages: sum within 1 %, the step kernel's
-            // share a few per cent high - the planning kernel gains more from hot caches than the step kernel does).
-            const int reps = 40;
-            hipEvent_t e0, e1, e2;
-            if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess) {
-                a.finalize_only = 0;
-                a.replay = 1;
-                a.step = (int)(t0 + n_steps - 1);
-                a.obs = dev_flags ? -1 : (observed[t0 + n_steps - 1] != 0);
-                a.obs_next = 0;
-                hipEvent_t e3;
-                (void)hipEventCreate(&e3);
-                for (int w = 0; w < 3; ++w) { launch_plan(); launch_step(); }
-                (void)hipEventRecord(e0, st);
-                for (int w = 0; w < reps; ++w) { launch_plan(); launch_step(); }
-                (void)hipEventRecord(e1, st);
-                for (int w = 0; w < reps; ++w) launch_plan();
-                (void)hipEventRecord(e2, st);
-                for (int w = 0; w < reps; ++w) launch_step();
-                (void)hipEventRecord(e3, st);
-                if (hipStreamSynchronize(st) == hipSuccess) {
-                    // both single-kernel chains run cache-hotter than the real sequence by a similar factor: their RATIO
-                    // splits the in-sequence step time
-                    float plan = 0.f, stepk = 0.f;
-                    (void)hipEventElapsedTime(&plan, e1, e2);
-                    (void)hipEventElapsedTime(&stepk, e2, e3);
-                    const float frac_plan = (plan + stepk) > 0.f ? plan / (plan + stepk) : 0.f;
-                    kernel_ms[1] = per_step * frac_plan;
-                    kernel_ms[2] = per_step * (1.f - frac_plan);
-                }
-                (void)hipEventDestroy(e0);
-                (void)hipEventDestroy(e1);
-                (void)hipEventDestroy(e2);
-                (void)hipEventDestroy(e3);
-                a.replay = 0;
-            }
-        }
+        kernel_ms[0] = per_step;
+        kernel_ms[1] = 0.f;  // (the planning kernel of earlier versions: folded into the step kernel's prologue)
+        kernel_ms[2] = per_step;
     }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PF_OK : (int)e;

@@ -138,6 +138,7 @@ template <typename T, int D> struct ColConsts {
     T c_loc, c_y, kstd, kq;  // LinearGaussianObservations kernel: mean = c_loc * loc + c_y, std, log std + log sqrt(2 pi)
     T i2c, kc;               // LGO pre-weight: 1 / (2 (s^2 + a^2 g^2)), log sqrt(s^2 + a^2 g^2) + log sqrt(2 pi)
     T ou_e;                  // exp(-kappa dt) for the OU kind
+    T ob, ovi, cov;          // observation offset b, 1 / s^2, posterior variance of the LGO kernel (c_y = cov a ovi (y - b))
 
     __device__ __forceinline__ void prepare(const ModelDesc& md, const ColParams<T, D>& cp) {
         fast = false;
@@ -171,12 +172,14 @@ template <typename T, int D> struct ColConsts {
             const T s = cp.os[0];
             yb = cp.y[0] - cp.ob[0];
             ybn = cp.yn[0] - cp.ob[0];
-            const T ovi = pf_rcp_c(s * s), hvi = inv_g * inv_g;
+            const T hvi = inv_g * inv_g;
+            ovi = pf_rcp_c(s * s);
+            ob = cp.ob[0];
             i2s = T(0.5) * ovi;
             ks = pf_log_c(s) + T(PF_LOG_SQRT_2PI);
             i2inc = T(0.5) * pf_rcp_c(inc * inc);
             kt = pf_log_c(inc * pf_abs(g)) + T(PF_LOG_SQRT_2PI);
-            const T cov = pf_rcp_c(hvi + a * ovi * a);
+            cov = pf_rcp_c(hvi + a * ovi * a);
             c_loc = cov * hvi;
             c_y = cov * (a * (ovi * yb));
             kstd = pf_sqrt_c(cov);
@@ -216,16 +219,18 @@ template <typename T, int D> struct ColConsts {
 };
 
 // ---------------------------------------------------------------------------------------------------------------
-// The scalar closed forms in canonical shape, one record per column and time step.  The column's bookkeeper (planning /
-// scan kernel) evaluates ColConsts::prepare once and stores the record; the step kernel reads it with scalar loads
-// (constant address space: the values sit in SGPRs, no per-thread recomputation, nothing uniform held in VGPRs).
+// The scalar closed forms in canonical shape, one record per column and RUN: they are functions of the parameters alone
+// except for the three entries that carry an observation (y_t - b, y_{t+1} - b, c_y), which the step kernel derives from
+// the record's (b, 1 / s^2, cov) and its two scalar observation loads.  k_fused_reduce evaluates ColConsts::prepare once
+// per run and stores the record; the step kernel reads it with scalar loads (constant address space: the values sit in
+// SGPRs, no per-thread recomputation).
 //   one-step mean:  A2 == 0:  loc = A0 + (x - A3) * A1      (linear AR: A3 = 0; OU: A0 = A3 = gamma, A1 = e^{-kappa dt})
 //                   A2 != 0:  loc = x + A2 * sin(x - A3)    (sine diffusion, A2 = dt)
 // The arithmetic is the one ColConsts::loc1 / sample_and_weight / pre_weight perform (same operations, same order).
 // ---------------------------------------------------------------------------------------------------------------
 enum {
     PK_A0 = 0, PK_A1, PK_A2, PK_A3, PK_G, PK_INC, PK_A, PK_YB, PK_YBN, PK_I2S, PK_KS, PK_CLOC, PK_CY, PK_KSTD, PK_INVG,
-    PK_I2INC, PK_KT, PK_KQ, PK_I2C, PK_KC, PK_USED, PK_N = 24
+    PK_I2INC, PK_KT, PK_KQ, PK_I2C, PK_KC, PK_OB, PK_OVI, PK_COV, PK_USED, PK_N = 24
 };
 template <typename T> using const_ptr = const __attribute__((address_space(4))) T*;
 
@@ -241,15 +246,21 @@ template <typename T> __device__ __forceinline__ void write_col_pack(const Model
     q[PK_G] = cc.g; q[PK_INC] = cc.inc; q[PK_A] = cc.a; q[PK_YB] = cc.yb; q[PK_YBN] = cc.ybn;
     q[PK_I2S] = cc.i2s; q[PK_KS] = cc.ks; q[PK_CLOC] = cc.c_loc; q[PK_CY] = cc.c_y; q[PK_KSTD] = cc.kstd;
     q[PK_INVG] = cc.inv_g; q[PK_I2INC] = cc.i2inc; q[PK_KT] = cc.kt; q[PK_KQ] = cc.kq; q[PK_I2C] = cc.i2c; q[PK_KC] = cc.kc;
+    q[PK_OB] = cc.ob; q[PK_OVI] = cc.ovi; q[PK_COV] = cc.cov;
 }
 
 template <typename T> struct FastCol {
     T A0, A1, A2, A3, g, inc, a, yb, ybn, i2s, ks, c_loc, c_y, kstd, inv_g, i2inc, kt, kq, i2c, kc;
-    __device__ __forceinline__ void load(const_ptr<T> q) {
+    // y_t / y_next: this step's and the next step's observation (0 when there is none: the terms are then unused)
+    __device__ __forceinline__ void load(const_ptr<T> q, T y_t, T y_next) {
         A0 = q[PK_A0]; A1 = q[PK_A1]; A2 = q[PK_A2]; A3 = q[PK_A3];
-        g = q[PK_G]; inc = q[PK_INC]; a = q[PK_A]; yb = q[PK_YB]; ybn = q[PK_YBN];
-        i2s = q[PK_I2S]; ks = q[PK_KS]; c_loc = q[PK_CLOC]; c_y = q[PK_CY]; kstd = q[PK_KSTD];
+        g = q[PK_G]; inc = q[PK_INC]; a = q[PK_A];
+        i2s = q[PK_I2S]; ks = q[PK_KS]; c_loc = q[PK_CLOC]; kstd = q[PK_KSTD];
         inv_g = q[PK_INVG]; i2inc = q[PK_I2INC]; kt = q[PK_KT]; kq = q[PK_KQ]; i2c = q[PK_I2C]; kc = q[PK_KC];
+        const T ob = q[PK_OB];
+        yb = y_t - ob;
+        ybn = y_next - ob;
+        c_y = q[PK_COV] * (a * (q[PK_OVI] * yb));  // (the operations of ColConsts::prepare, in its order)
     }
     // LK: the shape of the one-step mean as a compile-time constant (0 decided by A2 at run time, 1 affine, 2 sine)
     template <int LK = 0> __device__ __forceinline__ T loc(T x) const {
