@@ -112,56 +112,128 @@ def build_problem(name, dtype, device, world, rank, t_override=None):
     return filt, y.to(device), w
 
 
-def alg_bytes_per_particle(w, kernel, e=4):
-    """Algorithmic HBM bytes per particle per launch (e = bytes per state / weight element, ancestors
-    are int32).  The planning kernel touches no per-particle data (tile partials + a few probes); the step kernel reads
-    the local scans L (e) and x[anc] (e D), writes x' (e D), logw' (e), the next L (e), anc (4) - for both resamplers
-    (the multinomial positions are regenerated in registers)."""
+def byte_models(w, e=4):
+    """HBM bytes per particle per time step, two accountings (e = bytes per state / weight element):
+
+    * ``survey_8d`` - SURVEY.md section 8(d)'s contract figure: the compulsory traffic of the reference's dataflow (a reduce
+      pass, a scan pass and a fused search / gather / propagate / weight pass; int64 ancestors): 32 + 12 D for SISR,
+      32 + 16 D for APF (fp32);
+    * ``as_built`` - what the one kernel of a step has to move here: it reads the local scans L (e) and x[anc] (e D),
+      writes x' (e D), logw' (e), the next L (e), anc (int32) = 16 + 8 D (fp32) - the separate reduce and scan passes no
+      longer exist.  ``roofline.traffic`` (PMC) is to be read against this one."""
     d = w["D"]
-    return 0 if kernel == "plan" else e * (3 + 2 * d) + 4
+    k = e // 4
+    survey = k * (32 + (16 if w["filter"] == "apf" else 12) * d)
+    return {"survey_8d": survey, "as_built": e * (3 + 2 * d) + 4}
 
 
-def cpu_baseline(name, w, seconds_budget=15.0):
-    """The oracle (torch-CPU restatement of the reference's aten-op sequence) timed on this box's host cores on a
-    bounded sample of the same workload: same N, B, model, filter; as many time steps as fit the budget."""
-    from oracle import cpu_ref, models as M
+def host_info():
+    """CPU model, socket / core counts and a measured memory-copy ceiling of this box."""
+    import subprocess
 
-    if name not in ("apf_lgo_1m",):
-        return None
-    cores = os.cpu_count() or 1
-    spec = M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
-    n = w["N"]
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {ln.split(":", 1)[0].strip(): ln.split(":", 1)[1].strip() for ln in txt.splitlines() if ":" in ln}
+        info["model"] = kv.get("Model name")
+        sockets, cps = int(kv.get("Socket(s)", 1)), int(kv.get("Core(s) per socket", 0))
+        info["physical_cores"] = sockets * cps if cps else None
+        info["threads_per_core"] = int(kv.get("Thread(s) per core", 1))
+    except Exception:
+        pass
+    try:  # copy ceiling: out-of-place copy of 1 GiB of float32 with torch's intra-op threads (read + write bytes / time)
+        src = torch.empty(1 << 28, dtype=torch.float32).fill_(1.0)
+        dst = torch.empty_like(src)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            dst.copy_(src)
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        info["copy_GBs"] = 2 * src.numel() * 4 / best / 1e9
+        info["copy_threads"] = torch.get_num_threads()
+    except Exception:
+        pass
+    return info
+
+
+def oracle_problem(name, w):
+    """The oracle-side description of a workload: (ModelSpec, y, x0) with the parameters of ``build_problem``."""
+    from oracle import models as M
+
     g = torch.Generator().manual_seed(1)
-    y = torch.randn(4096, generator=g)
-    x0 = torch.randn(n)  # unbatched, the layout the reference is fastest in
+    n, b = w["N"], w["B"]
+    if name == "apf_lgo_1m":
+        spec = M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
+        return spec, torch.randn(4096, generator=g), torch.randn(n)  # unbatched, the layout the reference is fastest in
+    if name == "sv_batch":
+        kappa, gamma = 0.05 + 0.01 * torch.rand(b, generator=g), 1.0 + 0.2 * torch.rand(b, generator=g)
+        sigma, mu = 0.10 + 0.05 * torch.rand(b, generator=g), 0.05 * torch.randn(b, generator=g)
+        spec = M.ModelSpec(M.HID_VERHULST_EM, (kappa, gamma, sigma), 0, 0.2, (1.0, 0.1), M.OBS_SV, (mu,), 0)
+        return spec, 0.05 + torch.randn(4096, b, generator=g), 1.0 + 0.1 * torch.randn(n, b, generator=g)
+    if name == "lorenz_mn":
+        a = torch.tensor([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]])
+        m0, s0 = torch.tensor([-5.91652, -5.52332, 24.5723]), torch.full((3,), math.sqrt(10.0))
+        spec = M.ModelSpec(M.HID_LORENZ63_EM, (10.0, 28.0, 8.0 / 3.0, 1.0), 3, 0.01, (m0, s0), M.OBS_LINEAR,
+                           (a, torch.tensor([0.0]), torch.tensor([math.sqrt(0.1)])), 2)
+        y = torch.tensor([-4.7, 19.6]) + 0.3 * torch.randn(4096, 2, generator=g)
+        return spec, y, m0 + 0.3 * torch.randn(n, 3, generator=g)
+    if name == "smc2_shard":
+        kappa, gamma = 0.01 + 0.05 * torch.rand(b, generator=g), 0.2 * torch.randn(b, generator=g)
+        sigma = 0.03 + 0.04 * torch.rand(b, generator=g)
+        spec = M.ModelSpec(M.HID_OU, (kappa, gamma, sigma), 0, 1.0, (0.0, 0.1), M.OBS_LINEAR, (1.0, 0.0, 0.05), 0)
+        return spec, 0.1 * torch.randn(4096, generator=g), 0.1 * torch.randn(n, b, generator=g)
+    raise KeyError(name)
+
+
+def cpu_baseline(name, w, seconds_budget=12.0):
+    """The oracle (torch-CPU restatement of the reference's aten-op sequence, ``kind: "port"``) timed on this box's host
+    cores on a bounded sample of the same workload: same N, B, model, filter, proposal, resampler, fp32; as many time
+    steps as fit the budget (configs[3], ~2 s per step, is extrapolated from a handful of steps as BASELINE.md section 3
+    says).  Reported: the best thread count of a short sweep AND the single-thread figure, the CPU model, the physical
+    core count and a measured copy ceiling."""
+    from oracle import cpu_ref
+
+    spec, y, x0 = oracle_problem(name, w)
+    cores = os.cpu_count() or 1
+    n, b = w["N"], w["B"]
 
     def run(steps):
         t0 = time.perf_counter()
-        cpu_ref.batch_filter(spec, w["filter"], w["proposal"], y[:steps], x0, None, None)
+        cpu_ref.batch_filter(spec, w["filter"], w["proposal"], y[:steps], x0, None, None, resampler=w["resampler"])
         return time.perf_counter() - t0
 
+    host = host_info()
     # thread count: torch oversubscribes badly on many-core hosts (256 threads were 100x slower than 16 on the GPU
     # box), so give the CPU path its best case: a short sweep, keep the fastest
-    best = None
+    best, sweep = None, {}
     for th in sorted({c for c in (8, 16, 32, 64, 128) if c <= cores} | {min(cores, 8)}):
         torch.set_num_threads(th)
         run(1)
         dt_ = run(2) / 2
+        sweep[th] = n * b / dt_
         if best is None or dt_ < best[1]:
             best = (th, dt_)
         if dt_ > 3.0 * best[1]:
             break
-    cores = best[0]
-    torch.set_num_threads(cores)
-    per_step = run(3) / 3
-    steps = int(max(5, min(400, seconds_budget / per_step)))
+    torch.set_num_threads(1)
+    run(1)
+    k1 = int(max(2, min(8, 3.0 / max(1e-3, best[1] * best[0] / 2))))
+    dt1 = run(k1)
+    one_thread = n * b * k1 / dt1
+    cores_used = best[0]
+    torch.set_num_threads(cores_used)
+    steps = int(max(3, min(400, seconds_budget / best[1])))
     dt = run(steps)
     return {
-        "value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{name}: N={n}, B=1, {steps} time steps ({dt:.1f} s), fp32, torch {torch.__version__} CPU, "
-                  f"{cores} threads (fastest of a 8..128 sweep on {os.cpu_count()} logical CPUs); oracle/cpu_ref.py (same "
-                  f"aten-op sequence as the reference)",
+        "value": n * b * steps / dt, "unit": "particle-steps/s", "cores": cores_used, "kind": "port",
+        "sample": f"{name}: N={n}, B={b}, {steps} time steps ({dt:.1f} s) of T={w['T']}, fp32, torch {torch.__version__} CPU, "
+                  f"{cores_used} threads (fastest of a 8..128 sweep on {os.cpu_count()} logical CPUs); oracle/cpu_ref.py (same "
+                  f"aten-op sequence as the reference; within +-6 % of the imported reference where both ran)",
         "ms_per_filter_step": 1e3 * dt / steps,
+        "one_thread": {"value": one_thread, "steps": k1, "ms_per_filter_step": 1e3 * dt1 / k1},
+        "thread_sweep_particle_steps_per_s": sweep,
+        "host": host,
     }
 
 
@@ -275,27 +347,33 @@ def main():
     if args._inner:  # profiled child of pmc_traffic(): the timed passes above are all it needs
         return
 
-    # ---- per-kernel durations (HIP events on the launch stream) in a separate instrumented pass ------------------
+    # ---- the step kernel's duration: HIP events on the launch stream around the T launches of an instrumented pass ----
     filt._time_kernels = True
     filt.batch_filter(y, bar=False)
     torch.cuda.synchronize()
     filt._time_kernels = False
-    kms = dict(zip(("plan", "step"), filt.kernel_ms[1:3]))  # two kernels per time step
-    names = ("plan", "step")
-    kname = {"plan": "k_fused_plan", "step": "k_fused_step"}
-    dom = max(names, key=lambda k: kms[k])
+    step_ms = filt.kernel_ms[2]  # one kernel per time step: launch-to-launch duration inside the sequence
     esz = 8 if dtype == torch.float64 else 4
-    launch_bytes = {k: alg_bytes_per_particle(w, k, esz) * w["N"] * w["B"] for k in names}
-    achieved = launch_bytes[dom] / (kms[dom] * 1e-3) / 1e9
+    bm = byte_models(w, esz)
+    units = w["N"] * w["B"]  # particles one launch processes
+    gbs = {k: v * units / (step_ms * 1e-3) / 1e9 for k, v in bm.items()}
     roofline = {
-        "bound": "hbm", "kernel": kname[dom], "achieved": achieved,
-        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-        "bytes_per_launch": launch_bytes[dom],
-        "kernel_us": {kname[k]: 1e3 * kms[k] for k in names},
-        "all_kernels_GBs": {kname[k]: launch_bytes[k] / (kms[k] * 1e-3) / 1e9 for k in names},
-        "step_alg_bytes_per_particle": sum(alg_bytes_per_particle(w, k, esz) for k in names),
-        "whole_step_GBs": sum(alg_bytes_per_particle(w, k, esz) for k in names) * value / world / 1e9,
+        "bound": "hbm", "kernel": "k_fused_step", "achieved": gbs["survey_8d"],
+        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs["survey_8d"] / HBM_PEAK_GBS, "traffic": None,
+        "byte_model": "survey_8d: SURVEY.md 8(d) algorithmic bytes per particle-step (the reference dataflow's compulsory "
+                      "traffic) x particles per launch / the step kernel's in-sequence duration",
+        "bytes_per_particle": bm,
+        "bytes_per_launch": {k: v * units for k, v in bm.items()},
+        "kernel_us": {"k_fused_step": 1e3 * step_ms},
+        "duration_source": "HIP events on the launch stream around the T step launches (pf_filter_run_timed) / T; the "
+                           "rocprofv3 --kernel-trace --stats average of the same command is under profiles/",
+        "as_built": {"achieved": gbs["as_built"], "frac": gbs["as_built"] / HBM_PEAK_GBS,
+                     "note": "bytes the single kernel of a step must move as built (16 + 8 D in fp32); compare `traffic` with "
+                             "bytes_per_launch.as_built"},
+        "whole_job_GBs": {k: v * value / world / 1e9 for k, v in bm.items()},
     }
+    kname = {"step": "k_fused_step"}
+    dom = "step"
 
     if rank == 0 and world == 1 and not args.no_traffic:
         tr = pmc_traffic(kname[dom], args.workload, args.dtype)
@@ -320,6 +398,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            "world_size": world,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
             "config": {
                 "workload": f"{args.workload}: {w['filter'].upper()} + {w['proposal']} proposal, {w['resampler']} "
                             f"resampling, N={w['N']} particles x B={w['B']} filters per GPU, T={w['T']}, state dim {w['D']}",

@@ -85,6 +85,9 @@ template <typename T> struct FusedArgs {
     __device__ __forceinline__ bool is_obs() const { return obs >= 0 ? obs != 0 : obs_dev[step] != 0; }
     __device__ __forceinline__ bool is_obs_next() const { return obs_next >= 0 ? obs_next != 0 : obs_dev[step + 1] != 0; }
     int finalize_only;
+    int book_inline;  // the column's bookkeeping is done by its last step workgroup (after its own work) instead of an
+                      // extra workgroup per column: columns of few tiles, where the extra workgroups would be a large
+                      // share of the grid (1024 x 8192: every second one)
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
     __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
@@ -451,18 +454,22 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 // maximum; the scan whose total is the column sum).  Every workgroup that needs these numbers - the step workgroups of
 // a column and its bookkeeper - runs THIS function on the same partials: the values (and the SISR resampling decision
 // taken from them) are bit-identical everywhere, which is what lets the step kernel do without a planning kernel.
-// redm: PF_NWAVES doubles, reds: 2 * PF_NWAVES doubles.  Ends with a barrier when TABLE (the table is readable).
+// redm: PF_NWAVES doubles, reds: (2 + NX) * PF_NWAVES doubles.  Ends with a barrier when TABLE (the table is readable).
 #define PF_COMBINE_ITERS (PF_MAX_TILES / PF_BLOCK)  // partial records per thread
 struct ColSums {
     double M, S, Q;
 };
-template <typename T, bool WITH_Q, bool TABLE>
+// NX > 0 (the bookkeeper): additionally X[q] = sum_t x_{q,t} e_t for the NX partial rows `slot_x + q` - same load round,
+// same exchange (the moments' numerators).
+template <typename T, bool WITH_Q, bool TABLE, int NX = 0>
 __device__ __forceinline__ ColSums column_sums(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
-                                               int slot_s, double* ptl, double* ftl, double* redm, double* reds) {
+                                               int slot_s, double* ptl, double* ftl, double* redm, double* reds,
+                                               int slot_x = 0, double* X = nullptr) {
 #pragma clang fp contract(off)  // the same operations in every instantiation / inlining context (see above)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
     double mloc[PF_COMBINE_ITERS], sloc[PF_COMBINE_ITERS], qloc[PF_COMBINE_ITERS], mymax = -__builtin_huge_val();
+    double xloc[NX ? NX : 1][PF_COMBINE_ITERS];
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         const int t = threadIdx.x * IT + q;
@@ -470,22 +477,35 @@ __device__ __forceinline__ ColSums column_sums(const double* part, int64_t strid
         mloc[q] = on ? part[slot_m * stride + cb + t] : -__builtin_huge_val();
         sloc[q] = on ? part[slot_s * stride + cb + t] : 0.0;
         qloc[q] = (WITH_Q && on) ? part[PQ_Q1 * stride + cb + t] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xloc[i][q] = on ? part[(slot_x + i) * stride + cb + t] : 0.0;
         mymax = mloc[q] > mymax ? mloc[q] : mymax;
     }
     const double MR = block_max<double>(mymax, redm);
     double incl[PF_COMBINE_ITERS], ef[PF_COMBINE_ITERS], run = 0.0, qs = 0.0;
+    double xs[NX ? NX : 1];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = 0.0;
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         ef[q] = exp_diff_t<T>(mloc[q], MR);
         run += sloc[q] * ef[q];
         incl[q] = run;
         if (WITH_Q) qs += qloc[q] * ef[q] * ef[q];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[i] += xloc[i][q] * ef[q];
     }
     const double incl_w = wave_scan_incl(run, lane);
     const double qw = WITH_Q ? wave_sum(qs) : 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xs[i] = wave_sum(xs[i]);
     __syncthreads();
     if (lane == 63) reds[wid] = incl_w;
     if (WITH_Q && lane == 0) reds[PF_NWAVES + wid] = qw;
+    if (NX && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) reds[(2 + i) * PF_NWAVES + wid] = xs[i];
+    }
     __syncthreads();
     double wave_off = 0.0, tot = 0.0, qtot = 0.0;
 #pragma unroll
@@ -494,6 +514,13 @@ __device__ __forceinline__ ColSums column_sums(const double* part, int64_t strid
         if (w < wid) wave_off += sw;
         tot += sw;
         if (WITH_Q) qtot += reds[PF_NWAVES + w];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        double r = reds[(2 + i) * PF_NWAVES];
+#pragma unroll
+        for (int w = 1; w < PF_NWAVES; ++w) r += reds[(2 + i) * PF_NWAVES + w];
+        X[i] = r;
     }
     if constexpr (TABLE) {
         const double excl = wave_off + incl_w - run;
@@ -539,7 +566,7 @@ __device__ __forceinline__ void spacing_table(const double* part, int64_t stride
 // filter_means / filter_variance), the log-likelihood increment of the previous step, the bases of this one.
 // Reads the partials of state `step` only - nothing the step workgroups of the same launch write or wait for.
 template <typename T, int D>
-__device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, int b, double* red, double* redm, double* red2) {
+__device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, int b, double* red, double* redm) {
     const Geom& g = a.g;
     const int step = a.step;
     const bool obs = !a.finalize_only && a.is_obs();
@@ -547,43 +574,47 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, int b,
     const bool two = apf && obs;
     const int64_t stride = (int64_t)g.B * g.tiles;
     const int64_t cb = (int64_t)b * g.tiles;
-    const ColSums c1 = column_sums<T, true, false>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, nullptr, nullptr, redm, red);
+    // thread 0's scalar inputs are requested first: their latency overlaps the column sums
+    ColStat st{};
+    int poisoned = 0;
+    double ll_tot = 0.0, piv[D];
+    const int pslot = (step - 1) & 3;
+    if (threadIdx.x == 0) {
+        st = a.stat[b];
+        if (step > 0) {
+            poisoned = a.poison[pslot * g.B + b];
+            ll_tot = (double)a.ll_total[b];
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d) piv[d] = (double)a.template pivot<D>(step, b, d);  // the pivot the partials were taken about
+    }
+    double mv[2 * D];
+    const ColSums c1 = column_sums<T, true, false, 2 * D>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, nullptr, nullptr, redm, red, PQ_MX, mv);
     ColSums c2{0.0, 1.0, 0.0};
     if (two) c2 = column_sums<T, false, false>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, nullptr, nullptr, redm, red);
     const double lse_w = c1.M + log(c1.S);
     const double ess = c1.S * c1.S / c1.Q;
     bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19 (the step workgroups: the same test)
     if (a.finalize_only) resample = false;
-    double mv[2 * D];
-#pragma unroll
-    for (int q = 0; q < 2 * D; ++q) {
-        mv[q] = 0.0;
-        for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK)
-            mv[q] += a.part_r()[(PQ_MX + q) * stride + cb + t] * exp_diff_t<T>(a.part_r()[PQ_M1 * stride + cb + t], c1.M);
-    }
-    block_sum<2 * D>(mv, red2);
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {  // moments of the current state -> row `step` of filter_means / filter_variance
-            const double piv = (double)a.template pivot<D>(step, b, d);  // the pivot the partials were taken about
             const double dm = mv[d] / c1.S;
             double var = mv[D + d] / c1.S - dm * dm;
             if (var < 0.0) var = 0.0;
-            a.means[((int64_t)step * g.B + b) * D + d] = (T)(piv + dm);
+            a.means[((int64_t)step * g.B + b) * D + d] = (T)(piv[d] + dm);
             a.vars[((int64_t)step * g.B + b) * D + d] = (T)var;
         }
-        ColStat st = a.stat[b];
         // log-likelihood increment of the previous step: ll = lse(logw') - base_lse   (0 for unweighted steps)
         if (step > 0 && !st.ll_done) {
             double ll = 0.0;
-            const int pslot = (step - 1) & 3;
             if (st.prev_observed) {
                 ll = lse_w - st.base_lse;
-                if (a.poison[pslot * g.B + b]) ll = __builtin_nan("");
+                if (poisoned) ll = __builtin_nan("");
             }
             a.poison[pslot * g.B + b] = 0;
             a.ll_steps[(int64_t)(step - 1) * g.B + b] = (T)ll;
-            a.ll_total[b] = (T)((double)a.ll_total[b] + ll);
+            a.ll_total[b] = (T)(ll_tot + ll);
         }
         st.lse_w = lse_w;
         if (!a.finalize_only) st.resample = resample ? 1 : 0;
@@ -601,10 +632,9 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, int b,
 // The bookkeeper alone (grid (1, B)): flushes the moments / log-likelihood of a run's last state (finalize_only).
 template <typename T, int D>
 __global__ __launch_bounds__(PF_BLOCK) void k_fused_book(FusedArgs<T> a) {
-    __shared__ double red[2 * PF_NWAVES];
+    __shared__ double red[(2 + 2 * D) * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
-    __shared__ double red2[2 * D * PF_NWAVES];
-    column_bookkeeping<T, D>(a, blockIdx.y, red, redm, red2);
+    column_bookkeeping<T, D>(a, blockIdx.y, red, redm);
 }
 
 // MODE 0: systematic, ancestors from the inverted grid (grid_count);
@@ -1166,8 +1196,9 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
     __shared__ T redm[2 * PF_NWAVES];
     __shared__ double ptl[PF_MAX_TILES + 2], ftl[PF_MAX_TILES];
     __shared__ int sh_plan[2];
-    if (blockIdx.x == (unsigned)a.g.tiles) {  // the column's bookkeeper (scratch: 2 + 1 + 2 D rows of `red`)
-        column_bookkeeping<T, D>(a, blockIdx.y, red, red + 2 * PF_NWAVES, red + 3 * PF_NWAVES);
+    __shared__ double redb[PF_NWAVES];
+    if (!a.book_inline && blockIdx.x == (unsigned)a.g.tiles) {  // the column's bookkeeper (scratch: 2 + 2 D rows of `red`)
+        column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
         return;
     }
     const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan};
@@ -1178,6 +1209,8 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
         if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl);
         else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh, pl);
     }
+    if (a.book_inline && blockIdx.x == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
+        column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
 }
 
 }  // namespace pf

@@ -1291,7 +1291,11 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const uint8_t* observed = A->observed;  // host array
 
     const dim3 grid_tiles(g.tiles, g.B), block(PF_BLOCK);
-    const dim3 grid(g.tiles + 1, g.B);  // the step kernel: one workgroup per tile + the column's bookkeeper
+    // the step kernel: one workgroup per tile + the column's bookkeeper - an extra workgroup when the column has many
+    // tiles, else its last step workgroup (PF_BOOK_INLINE=0/1 overrides: development)
+    a.book_inline = g.tiles < 8 ? 1 : 0;
+    if (const char* bi = getenv("PF_BOOK_INLINE")) a.book_inline = atoi(bi) ? 1 : 0;
+    const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
         hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
