@@ -461,26 +461,40 @@ struct ColSums {
 };
 // NX > 0 (the bookkeeper): additionally X[q] = sum_t x_{q,t} e_t for the NX partial rows `slot_x + q` - same load round,
 // same exchange (the moments' numerators).
-template <typename T, bool WITH_Q, bool TABLE, int NX = 0>
-__device__ __forceinline__ ColSums column_sums(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
-                                               int slot_s, double* ptl, double* ftl, double* redm, double* reds,
-                                               int slot_x = 0, double* X = nullptr) {
-#pragma clang fp contract(off)  // the same operations in every instantiation / inlining context (see above)
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+// Two halves, so that a caller can put independent work (the step kernel: its Philox draws) between issuing the loads and
+// the first use of what they return.
+template <bool WITH_Q, int NX> struct ColPartials {
+    double m[PF_COMBINE_ITERS], s[PF_COMBINE_ITERS], q[PF_COMBINE_ITERS];
+    double x[NX ? NX : 1][PF_COMBINE_ITERS];
+};
+template <bool WITH_Q, int NX = 0>
+__device__ __forceinline__ void load_col_partials(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
+                                                  int slot_s, int slot_x, ColPartials<WITH_Q, NX>& r) {
     const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
-    double mloc[PF_COMBINE_ITERS], sloc[PF_COMBINE_ITERS], qloc[PF_COMBINE_ITERS], mymax = -__builtin_huge_val();
-    double xloc[NX ? NX : 1][PF_COMBINE_ITERS];
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         const int t = threadIdx.x * IT + q;
         const bool on = q < IT && t < tiles;
-        mloc[q] = on ? part[slot_m * stride + cb + t] : -__builtin_huge_val();
-        sloc[q] = on ? part[slot_s * stride + cb + t] : 0.0;
-        qloc[q] = (WITH_Q && on) ? part[PQ_Q1 * stride + cb + t] : 0.0;
+        r.m[q] = on ? part[slot_m * stride + cb + t] : -__builtin_huge_val();
+        r.s[q] = on ? part[slot_s * stride + cb + t] : 0.0;
+        r.q[q] = (WITH_Q && on) ? part[PQ_Q1 * stride + cb + t] : 0.0;
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xloc[i][q] = on ? part[(slot_x + i) * stride + cb + t] : 0.0;
-        mymax = mloc[q] > mymax ? mloc[q] : mymax;
+        for (int i = 0; i < NX; ++i) r.x[i][q] = on ? part[(slot_x + i) * stride + cb + t] : 0.0;
     }
+}
+template <typename T, bool WITH_Q, bool TABLE, int NX = 0>
+__device__ __forceinline__ ColSums column_sums(const ColPartials<WITH_Q, NX>& in, int tiles, double* ptl, double* ftl,
+                                               double* redm, double* reds, double* X = nullptr) {
+#pragma clang fp contract(off)  // the same operations in every instantiation / inlining context (see above)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
+    const double (&mloc)[PF_COMBINE_ITERS] = in.m;
+    const double (&sloc)[PF_COMBINE_ITERS] = in.s;
+    const double (&qloc)[PF_COMBINE_ITERS] = in.q;
+    const double (&xloc)[NX ? NX : 1][PF_COMBINE_ITERS] = in.x;
+    double mymax = -__builtin_huge_val();
+#pragma unroll
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) mymax = mloc[q] > mymax ? mloc[q] : mymax;
     const double MR = block_max<double>(mymax, redm);
     double incl[PF_COMBINE_ITERS], ef[PF_COMBINE_ITERS], run = 0.0, qs = 0.0;
     double xs[NX ? NX : 1];
@@ -589,9 +603,13 @@ __device__ __forceinline__ void column_bookkeeping(const FusedArgs<T>& a, int b,
         for (int d = 0; d < D; ++d) piv[d] = (double)a.template pivot<D>(step, b, d);  // the pivot the partials were taken about
     }
     double mv[2 * D];
-    const ColSums c1 = column_sums<T, true, false, 2 * D>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, nullptr, nullptr, redm, red, PQ_MX, mv);
+    ColPartials<true, 2 * D> p1;
+    ColPartials<false, 0> p2;
+    load_col_partials<true, 2 * D>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, PQ_MX, p1);
+    if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
+    const ColSums c1 = column_sums<T, true, false, 2 * D>(p1, g.tiles, nullptr, nullptr, redm, red, mv);
     ColSums c2{0.0, 1.0, 0.0};
-    if (two) c2 = column_sums<T, false, false>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, nullptr, nullptr, redm, red);
+    if (two) c2 = column_sums<T, false, false>(p2, g.tiles, nullptr, nullptr, redm, red);
     const double lse_w = c1.M + log(c1.S);
     const double ess = c1.S * c1.S / c1.Q;
     bool resample = apf ? obs : (ess < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19 (the step workgroups: the same test)
@@ -685,19 +703,24 @@ template <typename T> struct StepPlan {
     T ub;              // systematic: the column's offset u
     double offE, invE; // multinomial: this tile's offset into the running spacing sum, 1 / the column's total
     bool resample;
+    bool have_z0;      // the first round's standard normals were drawn in the prologue (under its load latency)
 };
 // Prologue of a step workgroup: the column's table from the partials of the incoming state, the resampling decision,
 // the window start (wave 0; broadcast through LDS).  Everything here is L2-hot and tiny: <= 16 KB of partials, one
 // 64-lane probe of the tile-local scans.
-template <typename T, int D, int VEC, int MODE, int SPEC>
-__device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh) {
+template <typename T, int D, int VEC, int MODE, int SPEC, bool EARLY_Z>
+__device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, T (&z0)[VEC][D]) {
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
     const int step = a.step;
     const bool obs = SPEC ? true : a.is_obs();
     const bool apf = SPEC ? (SPEC == 1) : (a.filter == PF_FILTER_APF);
     const bool two = apf && obs;
-    StepPlan<T> pl{0, 0, T(0), 0.0, 0.0, false};
+    StepPlan<T> pl{0, 0, T(0), 0.0, 0.0, false, false};
+    PF_STAMP(a, 0);
+#ifdef PF_DEVTOOLS
+    if (a.debug_cut < 0 && threadIdx.x == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[16 + k / 128] = wall_clock64();
+#endif
     if (apf && !obs) return pl;  // propagate-only move of the APF: identity ancestors, nothing to plan
     constexpr bool multinomial = MODE == 1;
     // issued first, used last: the Philox epoch / the step's systematic offset
@@ -718,13 +741,28 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
         pl.invE = 1.0 / sh.ptl[g.tiles + 1];
         draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + (int64_t)k * g.tile_elems), e0);
     }
+    // the column's partials are requested ...
+    ColPartials<true, 0> p1;
+    ColPartials<false, 0> p2;
+    if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
+    else load_col_partials<true, 0>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, 0, p1);
+    // ... and, while they travel (written by other CUs one launch ago: an Infinity-Cache round trip), the first round's
+    // standard normals are drawn: ~150 VALU instructions per thread that depend on nothing but the thread's index
+    // (EARLY_Z: only the kernels with registers to spare - holding the draws across the prologue costs the D = 3 and the
+    // generic scalar kernels more in spills than the overlap returns: measured)
+    if (EARLY_Z && (SPEC || !a.z_tape)) {
+        const int64_t i0 = (int64_t)k * g.tile_elems + threadIdx.x * VEC;
+        if (i0 < g.N) draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), z0);
+        pl.have_z0 = true;
+    }
     if (two) {
-        column_sums<T, false, true>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, sh.ptl, sh.ftl, redm_d, sh.red);
+        column_sums<T, false, true>(p2, g.tiles, sh.ptl, sh.ftl, redm_d, sh.red);
         pl.resample = true;  // apf.py:29-31
     } else {
-        const ColSums c = column_sums<T, true, true>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, sh.ptl, sh.ftl, redm_d, sh.red);
+        const ColSums c = column_sums<T, true, true>(p1, g.tiles, sh.ptl, sh.ftl, redm_d, sh.red);
         pl.resample = c.S * c.S / c.Q < a.thr_abs;  // sisr.py:18-19 (the bookkeeper: the same test)
     }
+    PF_STAMP(a, 1);
     if (!pl.resample) return pl;  // (uniform)
     const double* ptl = sh.ptl;
     T p;
@@ -779,6 +817,7 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
     __syncthreads();
     pl.j0 = sh.sh_plan[0];
     pl.kt0 = sh.sh_plan[1];
+    PF_STAMP(a, 2);
     return pl;
 }
 // RS: whether this column resamples in this step - a run-time fact for SISR (the bookkeeper's ESS test), so the kernel
@@ -789,7 +828,8 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
 // scalar branch instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on
 // 64 x 65 536).  Closed-form kernels (FAST): the shape of the one-step mean, 0 run time, 1 affine, 2 sine.
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS>
-__device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, const StepPlan<T>& pl) {
+__device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, const StepPlan<T>& pl,
+                                          const T (&z0)[VEC][D]) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     ModelDesc md = a.md;
     if constexpr (!FAST && MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
@@ -820,9 +860,6 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     const int N = (int)g.N;
     PF_STAMP(a, 8);
     if (PF_CUT(a, 1)) return;
-#ifdef PF_DEVTOOLS
-    if (a.debug_cut < 0 && tid == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[16 + k / 128] = wall_clock64();
-#endif
 
     // the window start of the tile's first position and its tile (prologue; no integer division here)
     int j0 = pl.j0;
@@ -944,6 +981,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) zt[j][d] = zr[j];
                 }
+            } else if (r == 0 && pl.have_z0) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (int d = 0; d < D; ++d) zt[j][d] = z0[j][d];
             } else {
                 draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), zt);
             }
@@ -1202,12 +1244,17 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
         return;
     }
     const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan};
-    const StepPlan<T> pl = step_prologue<T, D, VEC, MODE, SPEC>(a, sh);
+    T z0[VEC][D];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) z0[j][d] = T(0);
+    const StepPlan<T> pl = step_prologue<T, D, VEC, MODE, SPEC, (FAST && D == 1 && sizeof(T) == 4)>(a, sh, z0);
     if constexpr (SPEC == 1) {
-        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl);
+        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl, z0);
     } else {
-        if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl);
-        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh, pl);
+        if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl, z0);
+        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh, pl, z0);
     }
     if (a.book_inline && blockIdx.x == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
         column_bookkeeping<T, D>(a, blockIdx.y, red, redb);

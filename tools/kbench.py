@@ -106,14 +106,12 @@ def main():
             lib.pf_debug_offset(cfg[3], cfg[4], C.byref(off))
             ws = f._last_run["ws"]
             st = ws[off.value:off.value + 256].view(torch.int64).cpu().tolist()
-            sc = [st[i] - st[0] for i in range(0, 7)]
-            sp = [st[i] - st[8] for i in range(8, 16)]
-            print("   scan stamps (cycles from start: combine_done, finalize_done, pre-loop, pre-blockscan, post-blockscan, round_end):", sc[1:], " (PF_DEBUG_CUT=-(tile+1) selects the stamped tile)")
-            print("   plan stamps (10 ns ticks: start, max known, scan done, tile found, probe done):", [st[i] - st[0] for i in range(5)])
+            sp = [st[i] - st[0] for i in (1, 2, 8, 9, 10, 11, 12, 13, 14, 15)]
             t0w = min(st[16:24])
             print("   wall clock (10 ns ticks since the first of 8 sampled workgroups, tiles 0,128,..,896): start", [v - t0w for v in st[16:24]],
                   " end", [v - t0w for v in st[24:32]])
-            print("   step stamps (cycles from start: params, pre-loop, search_done, compute_done, push_done, pre-finish, end):", sp[1:])
+            print("   stamps of workgroup", -int(os.environ["PF_DEBUG_CUT"]) - 1, "(clock64 ticks from kernel entry: table built, window start known | body entry, "
+                  "pre-loop, loads issued + normals, ancestors, compute + stores, push, pre-finish, end):", sp)
         print(f"{name:22s} us/step {1e6 * wall / T:8.2f}  particle-steps/s {n * b * T / wall:10.3e}  kernels(us, event-bracketed) "
               f"scan {1e3 * k[1]:7.2f} step {1e3 * k[2]:7.2f}  ll {res.loglikelihood.reshape(-1)[0].item():.3f}", flush=True)
 

@@ -41,13 +41,19 @@ def collect(config, counters, cut, kernel="k_fused_step"):
 
 
 def build_dev():
-    """libpfamd_dev.so: the same sources with -DPF_DEVTOOLS (cycle stamps + stage cuts compiled in)."""
+    """libpfamd_dev.so: the float / scalar-state / VEC = 4 translation unit rebuilt with -DPF_DEVTOOLS (cycle stamps + stage
+    cuts compiled in), linked with the production objects of the other units (build/obj, from __graft_entry__.build())."""
     out = os.path.join(ROOT, "pyfilter_amd", "libpfamd_dev.so")
-    src = os.path.join(ROOT, "pyfilter_amd", "csrc", "pf_kernels.hip")
-    if not os.path.exists(out) or os.path.getmtime(out) < max(
-            os.path.getmtime(os.path.join(os.path.dirname(src), f)) for f in os.listdir(os.path.dirname(src))):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                               "-DPF_DEVTOOLS", src, "-o", out], cwd=os.path.dirname(src))
+    csrc = os.path.join(ROOT, "pyfilter_amd", "csrc")
+    src = os.path.join(csrc, "pf_kernels.hip")
+    objdir = os.path.join(ROOT, "build", "obj")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)):
+        hipcc = "/opt/rocm/bin/hipcc"
+        dev_obj = os.path.join(objdir, "pf_f32d1_v4_dev.o")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-DPF_DEVTOOLS",
+                               "-DPF_TU_F32D1_ONLY", "-DPF_TU_VEC=4", "-o", dev_obj], cwd=csrc)
+        others = [os.path.join(objdir, f) for f in ("pf_main.o", "pf_f32d1_v1.o", "pf_f32dn.o", "pf_f64.o")]
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", dev_obj] + others + ["-o", out], cwd=csrc)
     return out
 
 
