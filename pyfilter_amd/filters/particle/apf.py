@@ -35,7 +35,7 @@ class APF(ParticleFilter):
         elif kind == L.RESAMPLE_MULTINOMIAL:
             cols = ops.to_cols(resample_weights)
             W, _, _ = ops.normalize_cols(cols, want_w=True)
-            indices = ops.from_cols(ops.multinomial_cols(W, self._seed, step=int(ts_state.time_index)), batched).long()
+            indices = ops.from_cols(ops.multinomial_cols(W, self._run_seed, step=int(ts_state.time_index)), batched).long()
         else:
             indices = self._resampler(resample_weights)
 

@@ -1,7 +1,7 @@
 """
 ``ParticleFilter`` (``pyfilter/filters/particle/base.py:14-103,159-174``) with the MI355X fast path:
 
-``batch_filter`` runs the whole time loop inside ``libpfamd.so`` (``pf_filter_run``: three fused HIP kernels per step,
+``batch_filter`` runs the whole time loop inside ``libpfamd.so`` (``pf_filter_run``: ONE fused HIP kernel per step,
 no host synchronisation, ESS mask / NaN flags decided on the device) whenever the model is a built-in kind, the
 proposal is ``Bootstrap`` / ``LinearGaussianObservations`` and the resampler is this package's ``systematic`` /
 ``multinomial``.  Anything else (user callables, custom resamplers, ``record_states=True``) takes the step-by-step
@@ -21,11 +21,14 @@ from ...timeseries import StateSpaceModel, TimeseriesState
 from ...timeseries.models import pack_params
 from ..base import BaseFilter
 from ..result import FilterResult
+from ..schedule import expand
 from .proposals import Bootstrap, LinearGaussianObservations, Proposal
 from .proposals.base import KernelContext
 from .state import ParticleFilterCorrection, ParticleFilterPrediction
 
 _DEFAULT_SEED = 2024
+_GOLD = 0x9E3779B97F4A7C15  # odd 64-bit constant: consecutive draw epochs land on well-separated Philox keys
+_M64 = 0xFFFFFFFFFFFFFFFF
 
 
 class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPrediction]):
@@ -61,7 +64,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._z_tape = None
         self._u_tape = None
         self._z0 = None
-        self._plans = {}
+        self._fused_plans = {}   # (shape, schedule) -> _FusedPlan (captured hipGraphs; a handful, evicted oldest first)
+        self._single_plans = {}  # shape -> _SingleStepPlan (scratch of the online move; never evicted)
+        self._draws = 0          # draw epoch: every new stream of random numbers (initial sample, fused run, online
+                                 # move, step-by-step run) takes the next one - repeated calls are independent runs
+        self._copies = 0
+        self._obs_cache = None   # (identity of y, host copy of its observed flags): re-filtering the same data costs no sync
 
     # ------------------------------------------------------------------------------------------------------------
     @property
@@ -117,11 +125,11 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         b = self.batch_shape[0] if self._batched else 1
         params = pack_params(self._model, b, dtype, device)
         ctx = KernelContext(kind, params, self._seed, self._batched, self._has_event)
+        ctx.params_signature = self._params_signature()  # as packed: any later in-place update re-packs
+        ctx.init_host = None
         if self._z_tape is not None:
             z = self._z_tape.to(device=device, dtype=dtype)
-            t = z.shape[0]
-            z = z.reshape(t, n, b, kind.dim) if True else z
-            ctx.z_tape = z.permute(0, 3, 2, 1).contiguous()  # (T, D, B, N)
+            ctx.z_tape = z.reshape(z.shape[0], n, b, kind.dim).permute(0, 3, 2, 1).contiguous()  # (T, D, B, N)
         if self._u_tape is not None:
             ctx.u_tape = self._u_tape.to(device=device, dtype=dtype).reshape(self._u_tape.shape[0], b).contiguous()
         return ctx
@@ -142,35 +150,57 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if ctx is None:
             return
         sig = self._params_signature()
-        if getattr(ctx, "params_signature", None) != sig:
-            if getattr(ctx, "params_signature", None) is not None:
-                b = self.batch_shape[0] if self._batched else 1
-                ctx.params.copy_(pack_params(self._model, b, ctx.params.dtype, ctx.params.device))
+        if ctx.params_signature != sig:
+            b = self.batch_shape[0] if self._batched else 1
+            ctx.params.copy_(pack_params(self._model, b, ctx.params.dtype, ctx.params.device))
             ctx.params_signature = sig
+            ctx.init_host = None
+
+    def _ensure_context(self):
+        """The kernel context of the current model / tapes (built once, parameters re-packed when they change)."""
+        if self._ctx is None:
+            self._proposal.set_model(self.ssm)
+            self._ctx = self._build_context(*self._device_dtype())
+            self._proposal._set_context(self._ctx)
+        self._refresh_parameters()
+        return self._ctx
+
+    @property
+    def _run_seed(self) -> int:
+        """Seed of the current step-by-step run (set by ``initialize``)."""
+        return self._ctx.seed if self._ctx is not None else (self._seed + _GOLD * self._draws) & _M64
+
+    def _next_draw_seed(self) -> int:
+        """Seed of the next independent stream of Philox draws."""
+        self._draws += 1
+        seed = (self._seed + _GOLD * self._draws) & _M64
+        if self._ctx is not None:
+            self._ctx.seed = seed  # the step-by-step kernels of this run key their draws by (seed, time index)
+        return seed
 
     def initialize(self) -> ParticleFilterCorrection:
         assert self._model is not None, "Model has not been initialized!"
-        self._proposal.set_model(self.ssm)
         device, dtype = self._device_dtype()
-        self._ctx = self._build_context(device, dtype)
-        self._proposal._set_context(self._ctx)
+        ctx = self._ensure_context()
+        seed = self._next_draw_seed()
 
         n = self._base_particles[0]
         b = self.batch_shape[0] if self._batched else 1
         hidden = self._model.hidden
-        if self._ctx is not None and hasattr(hidden, "init_mean"):
-            d = self._ctx.kind.dim
+        if ctx is not None and hasattr(hidden, "init_mean"):
+            d = ctx.kind.dim
             z0 = None
             if self._z0 is not None:
                 z0 = ops.to_soa(self._z0.to(device=device, dtype=dtype), self._batched, self._has_event)
             im, isd = hidden.init_mean.to(device=device, dtype=dtype), hidden.init_scale.to(device=device, dtype=dtype)
             if im.numel() in (1, d) and isd.numel() in (1, d):
-                m0, s0 = im.reshape(-1).expand(d), isd.reshape(-1).expand(d)
-                soa = ops.initial_sample_soa(m0.tolist(), s0.tolist(), n, b, d, dtype, device, self._seed, z0)
+                if ctx.init_host is None:  # host copies of the initial mean / scale: one sync per parameter change
+                    ctx.init_host = (im.reshape(-1).expand(d).tolist(), isd.reshape(-1).expand(d).tolist())
+                soa = ops.initial_sample_soa(ctx.init_host[0], ctx.init_host[1], n, b, d, dtype, device, seed, z0)
             else:
                 # per-filter initial parameters (theta on the batch dim): standard draws from the kernel, then the
                 # column-wise affine map (once per run)
-                soa = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, device, self._seed, z0)
+                soa = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, device, seed, z0)
                 from ...timeseries.models import _expand
                 mb = _expand(im, b, (d,), dtype, device).t().unsqueeze(-1)  # (D, B, 1)
                 sb = _expand(isd, b, (d,), dtype, device).t().unsqueeze(-1)
@@ -192,6 +222,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
     def _propagate_only(self, prediction):
         return prediction.create_state_from_prediction(self._model, propagate=self._proposal._propagate)
 
+    def _copy_seed(self) -> int:
+        """A copy draws its own random numbers (the reference's copies share torch's global generator, i.e. never repeat
+        the original's draws); with tapes set the seed is irrelevant."""
+        self._copies += 1
+        return (self._seed ^ (_GOLD * (self._copies + 0x51ED27))) & _M64
+
     def copy(self):
         """NB: like the reference (``particle/base.py:165``) the *absolute* threshold is handed to the copy's
         ``ess_threshold`` - a copied SISR therefore effectively always resamples."""
@@ -201,7 +237,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             resampling=self._resampler,
             proposal=self._proposal.copy(),
             ess_threshold=self._resample_threshold,
-            seed=self._seed,
+            seed=self._copy_seed(),
             record_states=self.record_states,
             record_moments=self.record_moments,
             nan_strategy=self._nan_strategy,
@@ -255,12 +291,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         return new
 
     def _filter_fused_single(self, y: torch.Tensor, state: ParticleFilterCorrection) -> ParticleFilterCorrection:
-        if self._ctx is None:
-            self._proposal.set_model(self.ssm)
-            self._ctx = self._build_context(*self._device_dtype())
-            self._proposal._set_context(self._ctx)
-        self._refresh_parameters()
-        ctx, kind = self._ctx, self._ctx.kind
+        ctx = self._ensure_context()
+        kind = ctx.kind
         ts_in = state.timeseries_state
         x_in = ops.to_soa(ts_in.value, self._batched, self._has_event)   # views of library buffers: no copies
         lw_in = ops.to_cols(state.weights)
@@ -271,17 +303,15 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if y_dev.shape[1] not in (1, b):
             raise L.PfAmdError(f"observation of shape {tuple(y.shape)} does not broadcast against batch {b}")
         rows = y_dev.shape[1]
-        key = ("single", n, b, d, o, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
-               self._resampler_kind(), self._seed, float(self._resample_threshold))
-        plan = self._plans.get(key)
+        key = (n, b, d, o, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
+               self._resampler_kind(), float(self._resample_threshold))
+        plan = self._single_plans.get(key)
         if plan is None:
-            plan = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
-            self._plans[key] = plan
+            plan = self._single_plans[key] = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
         t_start = int(ts_in.time_index)
         # all-NaN observation -> propagate only (filters/base.py:212).  The reference branches on the host; here the flag
         # stays on the device (pf_filter_args.observed_dev), so consecutive filter() calls never wait for the GPU
         obs_flag = y_dev.isnan().all().logical_not().to(torch.uint8).reshape(1)
-        plan.calls += 1
 
         apf = self._FILTER_KIND == L.FILTER_APF
         x_out, lw_out = torch.empty_like(x_in), torch.empty_like(lw_in)
@@ -301,7 +331,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.model.params = ctx.params.data_ptr()
         a.y = y_dev.data_ptr()
         a.observed_dev = obs_flag.data_ptr()
-        a.seed = (self._seed + 0x9E3779B97F4A7C15 * plan.calls) & 0xFFFFFFFFFFFFFFFF  # fresh Philox draws per call
+        a.seed = self._next_draw_seed()  # fresh Philox draws per move
         a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
         a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
         a.anc = anc.data_ptr()
@@ -313,9 +343,10 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             assert z_tape.shape[0] == 1, "z tape shorter than the number of steps"
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + 1].contiguous()
-        a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: the column bookkeeper draws u (Philox)
+        a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: every workgroup draws its column's u (Philox)
         L.check(L.load().pf_filter_run(C.byref(a), 0, 1, 1, L.stream_ptr()), "pf_filter_run")
-        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, keep=(x_in, lw_in, y_dev, ctx.params, obs_flag))
+        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
+                              keep=(x_in, lw_in, y_dev, ctx.params, obs_flag))
 
         final_x = TimeseriesState(t_start + 1, ops.from_soa(x_out, self._batched, self._has_event),
                                   self._model.hidden.event_shape)
@@ -334,14 +365,21 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             return super().batch_filter(y, bar=bar, init_state=init_state)
         return self._batch_filter_fused(y, init_state)
 
+    def _observed_flags(self, y: torch.Tensor, y_dev: torch.Tensor) -> torch.Tensor:
+        """Host copy of "observation k carries information" (not all-NaN), one byte per observation.  The launch loop
+        reads the flags on the host (they select the kernel variant of every step), which costs one device round trip
+        per *new* data set: PMMH / SMC^2 re-filter the same ``y`` over and over, and for that the flags are remembered
+        by the tensor's identity and in-place version."""
+        ident = (y.data_ptr(), y._version, tuple(y.shape), y.dtype, y.device)
+        if self._obs_cache is not None and self._obs_cache[0] == ident:
+            return self._obs_cache[1]
+        flags = (~y_dev.isnan().reshape(y_dev.shape[0], -1).all(dim=1)).to(torch.uint8).cpu().contiguous()
+        self._obs_cache = (ident, flags)
+        return flags
+
     def _batch_filter_fused(self, y: torch.Tensor, init_state=None) -> FilterResult:
-        state = init_state or self.initialize()
-        if self._ctx is None:  # init_state supplied before any initialize()
-            self._proposal.set_model(self.ssm)
-            self._ctx = self._build_context(*self._device_dtype())
-            self._proposal._set_context(self._ctx)
-        self._refresh_parameters()
-        ctx = self._ctx
+        state = init_state if init_state is not None else self.initialize()
+        ctx = self._ensure_context()
         kind = ctx.kind
         x0 = state.timeseries_state.value
         device, dtype = x0.device, x0.dtype
@@ -349,53 +387,43 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         b = self.batch_shape[0] if self._batched else 1
         d, o = kind.dim, kind.obs_dim
 
-        result = self.initialize_with_result(state)
+        # row 0 of the moment series comes from the kernels too (the bookkeeper of the first launch reduces the incoming
+        # state), so the initial state's moments are not reduced a second time on the way in
+        result = FilterResult(state, self.record_states, self.record_moments, _defer_moments=True)
         t_obs = y.shape[0]
         if t_obs == 0:
+            result._moments.append(state.get_mean(), state.get_variance(), self._batched)
             return result
 
-        # ---- step schedule: observe_every_step > 1 inserts propagate-only sub-steps (filters/base.py:204-210) ----
-        oes = int(self._model.observe_every_step)
+        # ---- the run's moves (filters/schedule.py): observe_every_step > 1 inserts propagate-only sub-steps ----------
         t_start = int(state.timeseries_state.time_index)
+        sched = expand(t_start, t_obs, int(self._model.observe_every_step))
+        steps = sched.moves
         y_dev = y.to(device=device, dtype=dtype).reshape(t_obs, -1, o)
         if y_dev.shape[1] not in (1, b):
             raise L.PfAmdError(f"observations of shape {tuple(y.shape)} do not broadcast against batch {b}")
         rows = y_dev.shape[1]
-        y_nan = y_dev.isnan().reshape(t_obs, -1).all(dim=1)
-        if oes == 1:
-            steps = t_obs
-            y_steps = y_dev
-            observed = (~y_nan).to(torch.uint8)
-            obs_rows = None
+        informative = self._observed_flags(y, y_dev)  # host (T_obs,) uint8
+        if steps == t_obs:
+            y_steps, observed_host = y_dev, informative
         else:
-            sched, t = [], t_start
-            for k in range(t_obs):
-                while t % oes != 0:
-                    sched.append(-1)
-                    t += 1
-                sched.append(k)
-                t += 1
-            steps = len(sched)
-            sched_t = torch.tensor(sched, device=device)
+            at = torch.tensor(sched.rows)
+            observed_host = torch.zeros(steps, dtype=torch.uint8)
+            observed_host[at] = informative
             y_steps = torch.full((steps, rows, o), float("nan"), device=device, dtype=dtype)
-            is_obs = sched_t >= 0
-            y_steps[is_obs] = y_dev
-            observed = torch.zeros(steps, dtype=torch.uint8, device=device)
-            observed[is_obs] = (~y_nan).to(torch.uint8)
-            obs_rows = torch.nonzero(is_obs).reshape(-1) + 1
-        observed_host = observed.cpu().contiguous()  # the launch loop reads the flags on the host (one sync per call)
+            y_steps[at.to(device)] = y_dev
 
         taped = ctx.z_tape is not None or ctx.u_tape is not None
         use_graph = (not taped) and not getattr(self, "_time_kernels", False) and os.environ.get("PF_NO_GRAPH", "0") != "1"
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
-               self._resampler_kind(), self._seed, float(self._resample_threshold), bytes(observed_host.numpy().tobytes()))
-        plan = self._plans.get(key) if use_graph else None
+               self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes())
+        plan = self._fused_plans.get(key) if use_graph else None
         if plan is None:
             plan = _FusedPlan(self, kind, n, b, d, o, steps, rows, dtype, device, observed_host)
             if use_graph:
-                if len(self._plans) >= 4:  # a handful of (shape, schedule) combinations at most
-                    self._plans.pop(next(iter(self._plans))).destroy()
-                self._plans[key] = plan
+                if len(self._fused_plans) >= 4:  # a handful of (shape, schedule) combinations at most
+                    self._fused_plans.pop(next(iter(self._fused_plans))).destroy()
+                self._fused_plans[key] = plan
 
         # ---- load the inputs into the plan's (persistent) buffers -------------------------------------------------------
         plan.params.copy_(ctx.params)
@@ -404,7 +432,11 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         plan.anc.copy_(ops.to_cols(state.previous_indices.to(torch.int32)))
         plan.y.copy_(y_steps)
         plan.ll_total.zero_()
-        plan.epoch.add_(1)  # fresh Philox draws for every call (the base seed is baked into the launch arguments)
+        # fresh Philox draws for every call: the base seed is baked into the (captured) launch arguments, the kernels add
+        # the device word `epoch` to it - set here so that base + epoch = this run's draw seed (mod 2^64)
+        seed_eff = self._next_draw_seed()
+        word = (seed_eff - self._seed) & _M64
+        plan.epoch.fill_(word - (1 << 64) if word >= (1 << 63) else word)
         a = plan.args
         z_tape = u_tape = None
         if ctx.z_tape is not None:
@@ -413,12 +445,11 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + steps].contiguous()
         elif self._resampler_kind() == L.RESAMPLE_SYSTEMATIC:
-            # one uniform per (step, filter): T x B numbers drawn up front (a device generator seeded by (seed, call)),
+            # one uniform per (step, filter): T x B numbers drawn up front (a device generator seeded by the run's seed),
             # so no kernel spends a Philox chain on a per-column scalar
-            plan.u_gen.manual_seed((self._seed * 1000003 + int(plan.calls)) & 0x7FFFFFFFFFFFFFFF)
+            plan.u_gen.manual_seed(seed_eff & 0x7FFFFFFFFFFFFFFF)
             plan.u.uniform_(generator=plan.u_gen)
             u_tape = plan.u
-        plan.calls += 1
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)
 
         # NB the kernels index tapes / observations by the *local* step 0..steps-1 and draw Philox numbers by it too
@@ -435,24 +466,27 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             L.check(lib.pf_filter_graph_launch(plan.graph, L.stream_ptr()), "pf_filter_graph_launch")
         else:
             L.check(lib.pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
-        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws)  # keep device buffers alive
+        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=seed_eff)  # keep device buffers alive
 
         # ---- hand the results over in the reference's shapes (copies: a cached plan's buffers are reused) ------------
         slot = steps % 2
         x_fin, lw_fin = plan.x[slot].clone(), plan.logw[slot].clone()
-        means, variances, ll_steps = plan.means.clone(), plan.vars.clone(), plan.ll_steps.clone()
-        ll_total, anc = plan.ll_total.clone(), plan.anc.clone()
+        ll_steps, ll_total, anc = plan.ll_steps.clone(), plan.ll_total.clone(), plan.anc.clone()
         final_x = TimeseriesState(t_start + steps, ops.from_soa(x_fin, self._batched, self._has_event),
                                   self._model.hidden.event_shape)
         shape_md = (lambda t: t if self._batched else t[:, 0])
-        means_v, vars_v = shape_md(means), shape_md(variances)
+        means_v, vars_v = shape_md(plan.means), shape_md(plan.vars)  # (steps + 1, [B], D): copied by the moment log
         ll_last = ll_steps[-1] if self._batched else ll_steps[-1, 0]
         last = ParticleFilterCorrection(
             final_x, ops.from_cols(lw_fin, self._batched), ll_last, ops.from_cols(anc, self._batched).long(),
-            _moments=(means_v[-1], vars_v[-1]),
+            _moments=(means_v[-1].clone(), vars_v[-1].clone()),
         )
-        sel = slice(1, None) if obs_rows is None else obs_rows
-        result._extend_fused(means_v[sel], vars_v[sel], ll_total if self._batched else ll_total[0], last)
+        if steps == t_obs:
+            sel_m, sel_v = means_v, vars_v
+        else:  # the initial state's row, then the row of the move that consumed each observation
+            keep = torch.tensor([0] + [r + 1 for r in sched.rows], device=device)
+            sel_m, sel_v = means_v[keep], vars_v[keep]
+        result._extend_fused(sel_m, sel_v, ll_total if self._batched else ll_total[0], last)
         return result
 
 
@@ -467,7 +501,6 @@ class _SingleStepPlan:
         self.ws = L.new_workspace(n, b, device)
         self.observed = torch.ones(1, dtype=torch.uint8)  # host
         self.rows = rows
-        self.calls = 0
         a = L.PfFilterArgs()
         a.model = ops.make_model_struct(kind, filt._ctx.params)
         a.filter, a.proposal, a.resampler = filt._FILTER_KIND, filt._proposal._KERNEL_PROPOSAL, filt._resampler_kind()
@@ -501,7 +534,6 @@ class _FusedPlan:
         self.epoch = torch.zeros(1, device=device, dtype=torch.int64)
         self.u = torch.empty((steps, b), device=device, dtype=dtype)
         self.u_gen = torch.Generator(device=device)
-        self.calls = 0
         self.params = torch.empty_like(filt._ctx.params)
         self.ws = L.new_workspace(n, b, device)
         self.observed_host = observed_host

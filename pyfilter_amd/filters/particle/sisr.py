@@ -39,7 +39,7 @@ class SISR(ParticleFilter):
                 u = self._uniforms(int(ts_state.time_index), b, w_cols)
                 ops.systematic_cols(W_cols, u, normalized=True, colmask=colmask, idx=anc)
             else:
-                ops.multinomial_cols(W_cols, self._seed, step=int(ts_state.time_index), colmask=colmask, idx=anc)
+                ops.multinomial_cols(W_cols, self._run_seed, step=int(ts_state.time_index), colmask=colmask, idx=anc)
             x_soa = ops.gather_soa(ops.to_soa(ts_state.value, batched, has_event), anc, colmask)
             resampled_x = ops.from_soa(x_soa, batched, has_event)
             resampled_indices = ops.from_cols(anc, batched).long()

@@ -40,9 +40,13 @@ class ParticleFilterCorrection(Correction):
         self["_w"] = w
         self["_ll"] = ll
         self["_prev_inds"] = prev_indices
-        if _moments is None:  # the fused path hands over the moments its kernels already reduced
-            _moments = get_filter_mean_and_variance(x, self.normalized_weights())
-        self["_mean"], self["_var"] = _moments
+        # the fused path hands over the moments its kernels already reduced; otherwise they are reduced on first use
+        if _moments is not None:
+            self["_mean"], self["_var"] = _moments
+
+    def _ensure_moments(self):
+        if "_mean" not in self:
+            self["_mean"], self["_var"] = get_filter_mean_and_variance(self["_x"], self.normalized_weights())
 
     @property
     def timeseries_state(self) -> TimeseriesState:
@@ -60,9 +64,11 @@ class ParticleFilterCorrection(Correction):
         return self["_ll"]
 
     def get_mean(self) -> Tensor:
+        self._ensure_moments()
         return self["_mean"]
 
     def get_variance(self) -> Tensor:
+        self._ensure_moments()
         return self["_var"]
 
     def get_covariance(self) -> Tensor:
@@ -86,6 +92,7 @@ class ParticleFilterCorrection(Correction):
         and ancestors move with ``pf_columns_gather`` (whole contiguous columns in the library layout)."""
         from ... import ops
 
+        self._ensure_moments()
         ts = self.timeseries_state
         self["_x"] = ts.copy(values=ops.gather_filters(ts.value, indices))
         self["_w"] = ops.gather_filters(self.weights, indices)
@@ -98,6 +105,8 @@ class ParticleFilterCorrection(Correction):
         """Overwrite the filters selected by ``mask`` with those of ``other`` (``:160-168``), ``pf_columns_exchange``."""
         from ... import ops
 
+        self._ensure_moments()
+        other._ensure_moments()
         ts = self.timeseries_state
         new_x = ops.exchange_filters(ts.value, other.timeseries_state.value, mask)
         if new_x.data_ptr() != ts.value.data_ptr():
@@ -109,6 +118,7 @@ class ParticleFilterCorrection(Correction):
         self["_var"][mask] = other["_var"][mask]
 
     def state_dict(self) -> Dict[str, Any]:
+        self._ensure_moments()
         result = OrderedDict((k, v) for k, v in self.items() if isinstance(v, torch.Tensor))
         result["_x"] = {"time_index": self.timeseries_state.time_index, "value": self.timeseries_state.value}
         return result

@@ -73,11 +73,17 @@ class AR(_BuiltinProcess):
 
 
 class RandomWalk(_BuiltinProcess):
-    """Random walk ``x' = x + sigma e``; ``sigma`` of shape ``(D,)`` gives a D-dimensional diagonal walk."""
+    """Random walk ``x' = x + sigma e``.  ``dim`` = 2 or 3 gives a D-dimensional diagonal walk with ``sigma`` of shape
+    ``(D,)`` / ``(B, D)``; ``dim = 0`` a scalar walk (``sigma`` scalar or ``(B,)``).  ``dim=None`` infers it from an
+    UNBATCHED sigma (last dimension 2 or 3): pass it explicitly when sigma carries a batch dimension - a ``(B,)`` sigma
+    with B in {2, 3} is otherwise indistinguishable from a vector walk."""
 
-    def __init__(self, sigma, initial_mean=0.0, initial_scale=None):
+    def __init__(self, sigma, initial_mean=0.0, initial_scale=None, dim: Optional[int] = None):
         sigma = _as_tensor(sigma)
-        dim = sigma.shape[-1] if sigma.dim() > 0 and sigma.shape[-1] in (2, 3) else 0
+        if dim is None:
+            dim = sigma.shape[-1] if sigma.dim() == 1 and sigma.shape[-1] in (2, 3) else 0
+            if sigma.dim() > 1:
+                raise L.PfAmdError("RandomWalk: pass `dim` explicitly when sigma has a batch dimension")
         zeros, ones = torch.zeros_like(sigma), torch.ones_like(sigma)
         init_scale = sigma if initial_scale is None else initial_scale
         super().__init__(
@@ -162,10 +168,21 @@ def _expand(p: torch.Tensor, b: int, inner: Sequence[int], dtype, device) -> tor
         return p.reshape(()).expand(full)
     if tuple(p.shape) == full:
         return p
-    if tuple(p.shape) == inner:
+    per_filter, per_component = tuple(p.shape) == (b,), tuple(p.shape) == inner
+    if per_filter and per_component and b > 1:
+        # B == D: a (B,) vector could be one value per filter or one per state component.  The reference resolves this by
+        # torch broadcasting against (N, B, D) tensors - trailing dimensions align, i.e. per component - so that is kept,
+        # loudly: a per-filter parameter must be given as (B, 1) / (B, D)
+        import warnings
+
+        warnings.warn(f"parameter of shape {tuple(p.shape)} with batch = state dim = {b}: read as one value per state "
+                      "component (torch broadcasting); pass shape (B, 1) for one value per filter", stacklevel=3)
+    if per_component:
         return p.unsqueeze(0).expand(full)
-    if tuple(p.shape) == (b,):
+    if per_filter:
         return p.reshape((b,) + (1,) * len(inner)).expand(full)
+    if p.dim() == len(full) and p.shape[0] == b and all(ps in (1, fs) for ps, fs in zip(p.shape[1:], inner)):
+        return p.expand(full)  # (B, 1, ...): explicitly one value per filter
     raise L.PfAmdError(f"cannot broadcast a parameter of shape {tuple(p.shape)} to (batch={b}, {inner})")
 
 

@@ -201,3 +201,173 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
         assert int(out[st]) == C.sizeof(cls), (st, out[st], C.sizeof(cls))
         for n in fields[st]:
             assert int(out[f"{st}.{n}"]) == getattr(cls, n).offset, (st, n, out[f"{st}.{n}"], getattr(cls, n).offset)
+
+
+# ---- result containers / drivers (pure host logic, CPU tensors) ----------------------------------------------------
+class _ToyState(dict):
+    """A Correction-shaped object for the host-logic tests: mean / variance / ll tensors over a batch of B filters."""
+
+    def __init__(self, t, mean, var, ll):
+        super().__init__()
+        self.t, self.mean, self.var, self.ll = t, mean, var, ll
+
+    def get_mean(self):
+        return self.mean
+
+    def get_variance(self):
+        return self.var
+
+    def get_loglikelihood(self):
+        return self.ll
+
+    def resample(self, indices):
+        self.mean, self.var = self.mean[indices], self.var[indices]
+
+    def exchange(self, other, mask):
+        self.mean[mask], self.var[mask] = other.mean[mask], other.var[mask]
+
+    def state_dict(self):
+        return {"mean": self.mean}
+
+    def load_state_dict(self, sd):
+        self.mean = sd["mean"]
+
+
+def _toy_states(n, b=3, d=2, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [_ToyState(t, torch.randn(b, d, generator=g), torch.rand(b, d, generator=g), torch.full((b,), 0.5 * t)) for t in range(n)]
+
+
+@pytest.mark.parametrize("record_moments,expect", [(True, 9), (False, 1), (4, 4), (1, 1)])
+def test_filter_result_moment_log_window(record_moments, expect):
+    """The moment series behaves like the reference's deque(maxlen) of per-step tensors: rows, order, bound."""
+    from pyfilter_amd.filters import FilterResult
+
+    states = _toy_states(9)
+    res = FilterResult(states[0], False, record_moments)
+    for s in states[1:]:
+        res.append(s)
+    want_m = torch.stack([s.mean for s in states[-expect:]])
+    want_v = torch.stack([s.var for s in states[-expect:]])
+    assert res.filter_means.shape == (expect, 3, 2)
+    assert torch.equal(res.filter_means, want_m) and torch.equal(res.filter_variance, want_v)
+    # bulk rows (the fused kernels' hand-over) join the same window
+    more_m, more_v = torch.randn(6, 3, 2), torch.rand(6, 3, 2)
+    res._extend_fused(more_m, more_v, torch.zeros(3), states[-1])
+    full_m = torch.cat([torch.stack([s.mean for s in states]), more_m])
+    keep = full_m.shape[0] if record_moments is True else expect
+    assert torch.equal(res.filter_means, full_m[-keep:])
+    assert res.latest_state is states[-1] and len(res.states) == 1
+    # log-likelihood: running total on the (aliased) tensor of the initial state (result.py:34)
+    assert res.loglikelihood is states[0].ll
+
+
+def test_filter_result_resample_exchange_and_wire_format():
+    from pyfilter_amd.filters import FilterResult
+
+    sa, sb = _toy_states(6, seed=1), _toy_states(6, seed=2)
+    ra, rb = FilterResult(sa[0], True, True), FilterResult(sb[0], True, True)
+    for x, y in zip(sa[1:], sb[1:]):
+        ra.append(x)
+        rb.append(y)
+    ma, mb = ra.filter_means.clone(), rb.filter_means.clone()
+    mask = torch.tensor([True, False, True])
+    ra.exchange(rb, mask)
+    want = ma.clone()
+    want[:, mask] = mb[:, mask]
+    assert torch.equal(ra.filter_means, want) and torch.equal(rb.filter_means, mb)
+    idx = torch.tensor([2, 2, 0])
+    ll_before = ra.loglikelihood.clone()
+    ra.resample(idx)
+    assert torch.equal(ra.filter_means, want[:, idx]) and torch.equal(ra.loglikelihood, ll_before[idx])
+    ra.resample(torch.tensor([1, 0, 0]), entire_history=False)  # states + ll only
+    assert torch.equal(ra.filter_means, want[:, idx])
+    # wire format: the reference's keys (container.py:113-139, result.py:135-154)
+    sd = ra.state_dict()
+    assert list(sd) == ["tensor_tuples", "state", "log_likelihood"]
+    assert list(sd["tensor_tuples"]) == ["tensor_deque_None__filter_means", "tensor_deque_None__filter_variances"]
+    assert sd["tensor_tuples"]["tensor_deque_None__filter_means"].shape == (6, 3, 2)
+    fresh = FilterResult(_toy_states(1)[0], False, True)
+    fresh.load_state_dict(sd)
+    assert torch.equal(fresh.filter_means, ra.filter_means) and torch.equal(fresh.filter_variance, ra.filter_variance)
+    assert fresh.loglikelihood is sd["log_likelihood"]
+    tt = ra.tensor_tuples  # the reference's container view
+    assert set(tt.keys()) == {"filter_means", "filter_variances"} and len(tt["filter_means"]) == 6
+    bounded = FilterResult(_toy_states(1)[0], False, 5)
+    assert "tensor_deque_5__filter_means" in bounded.state_dict()["tensor_tuples"]
+
+
+def test_unbatched_scalar_moment_rows_keep_their_shape():
+    from pyfilter_amd.filters import FilterResult
+
+    st = [_ToyState(t, torch.tensor(float(t)), torch.tensor(0.1 * t), torch.tensor(0.0)) for t in range(4)]
+    res = FilterResult(st[0], False, True)
+    for s in st[1:]:
+        res.append(s)
+    assert res.filter_means.shape == (4,) and res.filter_means.tolist() == [0.0, 1.0, 2.0, 3.0]
+    st = [_ToyState(t, torch.full((1,), float(t)), torch.zeros(1), torch.tensor(0.0)) for t in range(3)]
+    res = FilterResult(st[0], False, True)
+    res._extend_fused(torch.tensor([[1.0], [2.0]]), torch.zeros(2, 1), torch.tensor(0.0), st[-1])
+    assert res.filter_means.shape == (3, 1)
+
+
+def test_move_schedule():
+    from pyfilter_amd.filters.schedule import expand, unobserved_moves_before
+
+    assert [unobserved_moves_before(t, 3) for t in range(7)] == [0, 2, 1, 0, 2, 1, 0]
+    assert expand(0, 3, 1) == ([0, 1, 2], [0, 1, 2])
+    s = expand(1, 2, 3)
+    assert s.source == [-1, -1, 0, -1, -1, 1] and s.rows == [2, 5] and s.moves == 6
+    assert expand(0, 0, 2).moves == 0
+
+
+def test_generic_driver_walks_the_schedule():
+    """``BaseFilter.filter`` / ``batch_filter``: unobserved sub-steps before every observation, a propagate-only move for
+    an all-NaN observation, intermediary states recorded only on request (filters/base.py:188-221)."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.base import BaseFilter
+    from pyfilter_amd.timeseries import models
+
+    class Pred:
+        def __init__(self, state):
+            self.state = state
+
+        def get_timeseries_state(self):
+            return self.state.tsx
+
+        def create_state_from_prediction(self, model):
+            return Toy(self.state.tsx.propagate_from(values=self.state.tsx.value), "propagated")
+
+    class Toy(_ToyState):
+        def __init__(self, tsx, kind):
+            super().__init__(int(tsx.time_index), tsx.value.clone(), torch.zeros(()), torch.zeros(()))
+            self.tsx, self.kind = tsx, kind
+
+        def get_timeseries_state(self):
+            return self.tsx
+
+    class F(BaseFilter):
+        def initialize(self):
+            return Toy(ts.TimeseriesState(0, torch.tensor(0.0), torch.Size([])), "init")
+
+        def predict(self, state):
+            return Pred(state)
+
+        def correct(self, y, prediction):
+            x = prediction.state.tsx
+            return Toy(x.propagate_from(values=torch.as_tensor(y, dtype=torch.float32)), "corrected")
+
+    hidden = models.AR(torch.tensor(0.0), torch.tensor(0.9), torch.tensor(0.1))
+    ssm = ts.LinearStateSpaceModel(hidden, (torch.tensor(1.0), torch.tensor(0.1)), observe_every_step=3)
+    y = torch.tensor([1.0, float("nan"), 3.0])
+    for inter, kinds in ((False, ["init", "corrected", "propagated", "corrected"]),
+                         (True, ["init", "corrected", "propagated", "propagated", "propagated", "propagated", "propagated", "corrected"])):
+        f = F(ssm, record_states=True, record_intermediary_states=inter)
+        res = f.batch_filter(y, bar=False)
+        assert [s.kind for s in res.states] == kinds
+        assert int(res.latest_state.tsx.time_index) == 7  # 0 -> 1, then 2 sub-steps + 1 move per further observation
+        assert res.filter_means.shape[0] == len(kinds)
+    with pytest.raises(NotImplementedError):
+        F(ssm, nan_strategy="drop")
+    with pytest.raises(ValueError):
+        F(42)

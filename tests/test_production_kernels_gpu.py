@@ -35,8 +35,7 @@ def _teacher_state(es, t, x, w, ll, idx):
 
 def _normals_ref_layout(filt, steps, n, b, d, has_event):
     """The run's normals in the reference layout ``(steps, N, B, [D])`` (float32 values, exactly what the kernel drew)."""
-    plan = filt._last_run["plan"]
-    seed = filt._seed + int(plan.epoch.item())
+    seed = filt._last_run["seed_eff"]  # base seed + the run's epoch word: what the kernels keyed Philox with
     z = ops.debug_draw_normals(seed, steps, n, b, d, F32, "cuda")  # (steps, D, B, N)
     z = z.permute(0, 3, 2, 1)
     return (z if has_event else z[..., 0]).cpu()
