@@ -257,9 +257,17 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         return None
 
     def _uniforms(self, step: int, b: int, like: torch.Tensor) -> torch.Tensor:
+        """The step's systematic offsets on the step-by-step route: the tape, or a device generator keyed by the run's
+        draw seed (so a rebuilt filter with the same seed repeats them and a second run does not)."""
         if self._ctx is not None and self._ctx.u_tape is not None:
             return self._ctx.u_tape[step]
-        return torch.empty(b, device=like.device, dtype=like.dtype).uniform_()
+        key = (self._run_seed, like.device)
+        gen = getattr(self, "_u_gen", None)
+        if gen is None or gen[0] != key:
+            g = torch.Generator(device=like.device)
+            g.manual_seed(self._run_seed & 0x7FFFFFFFFFFFFFFF)
+            gen = self._u_gen = (key, g)
+        return torch.empty(b, device=like.device, dtype=like.dtype).uniform_(generator=gen[1])
 
     # ------------------------------------------------------------------------------------------------------------
     # the fused loop
@@ -369,12 +377,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         """Host copy of "observation k carries information" (not all-NaN), one byte per observation.  The launch loop
         reads the flags on the host (they select the kernel variant of every step), which costs one device round trip
         per *new* data set: PMMH / SMC^2 re-filter the same ``y`` over and over, and for that the flags are remembered
-        by the tensor's identity and in-place version."""
-        ident = (y.data_ptr(), y._version, tuple(y.shape), y.dtype, y.device)
-        if self._obs_cache is not None and self._obs_cache[0] == ident:
-            return self._obs_cache[1]
+        by the tensor object and its in-place version."""
+        cached = self._obs_cache  # (the tensor object itself - an address alone could be a recycled allocation -, version, flags)
+        if cached is not None and cached[0] is y and cached[1] == y._version:
+            return cached[2]
         flags = (~y_dev.isnan().reshape(y_dev.shape[0], -1).all(dim=1)).to(torch.uint8).cpu().contiguous()
-        self._obs_cache = (ident, flags)
+        self._obs_cache = (y, y._version, flags)
         return flags
 
     def _batch_filter_fused(self, y: torch.Tensor, init_state=None) -> FilterResult:

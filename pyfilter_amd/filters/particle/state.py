@@ -101,6 +101,11 @@ class ParticleFilterCorrection(Correction):
         self["_mean"] = self["_mean"][indices]
         self["_var"] = self["_var"][indices]
 
+    def _gather_moments(self, indices: Tensor):
+        """The part of ``FilterResult.resample(entire_history=True)`` that reaches into a recorded state (see there)."""
+        self._ensure_moments()
+        self["_mean"], self["_var"] = self["_mean"][indices], self["_var"][indices]
+
     def exchange(self, other: "ParticleFilterCorrection", mask: Tensor):
         """Overwrite the filters selected by ``mask`` with those of ``other`` (``:160-168``), ``pf_columns_exchange``."""
         from ... import ops

@@ -254,6 +254,13 @@ class FilterResult(dict, Generic[TCorrection]):
         self._loglikelihood.copy_(self._loglikelihood[indices])
         if entire_history:
             self._moments.gather_filters(indices)
+            # Reference quirk, kept: there a recorded state's mean / variance tensors ARE entries of the series (append
+            # stores the same tensor objects, result.py:129-130), so gathering the series in place (result.py:111-114)
+            # already gathers them - and the state's own resample below gathers them a second time.
+            for s in list(self._states)[-self._moments.rows:]:
+                hook = getattr(s, "_gather_moments", None)
+                if hook is not None:
+                    hook(indices)
         for s in self._states:
             s.resample(indices)
         return self
