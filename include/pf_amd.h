@@ -191,6 +191,13 @@ typedef struct pf_filter_args {
     const uint8_t* observed_dev; /* optional DEVICE array (T) with the meaning of `observed`; when non-NULL it is used
                                   * instead (every kernel reads its step's flag with one scalar load), so the caller
                                   * needs no host-side knowledge of NaN observations - `filter()` runs without a sync */
+    int64_t ring; /* state history (FilterResult's recorded states, particle/base.py:105-157 smoothing): 0 or 2 = none - x[0] /
+                   * x[1], logw[0] / logw[1] are two buffers used alternately and `anc` holds the latest ancestors.
+                   * ring >= 3: x[0] is the base of a (ring, D, B, N) array, logw[0] of a (ring, B, N) array, anc of a
+                   * (ring, B, N) array (x[1] / logw[1] ignored); the state after step s - and the ancestors that lead to
+                   * it - live in slot (s + 1) % ring, the incoming state of step t0 in slot t0 % ring.  ring = n_steps + 1
+                   * keeps every state of a run.  A SISR step that does not resample copies its ancestors forward, as the
+                   * reference carries prev_inds (sisr.py:25-26). */
 } pf_filter_args;
 
 /* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; two kernel launches per
@@ -214,6 +221,24 @@ int pf_filter_graph_destroy(void* handle);
  * step's launches are idempotent).  Same results as pf_filter_run; not for throughput numbers. */
 int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                         float* kernel_ms);
+
+/* ------------------------------------------------------------------------------------------------------------ *
+ * smoothing over recorded states: ParticleFilter.smooth (particle/base.py:105-157).  S states, time-major histories:
+ * x_hist (S, D, B, N), logw_hist (S, B, N), anc_hist (S, B, N) with anc_hist[t] = ParticleFilterCorrection.previous_indices
+ * of state t (row 0 is never read); out (S, D, B, N).
+ * ------------------------------------------------------------------------------------------------------------ */
+
+/* method "fl" (_do_sample_fl, :136-152): out[S-1] = x[S-1]; walking back, out[t][i] = x[t][a_t(i)] with
+ * a_{S-1}(i) = i, a_t(i) = anc[t+1][a_{t+1}(i)]. */
+int pf_smooth_fixed_lag(const void* x_hist, const int32_t* anc_hist, void* out, int64_t S, int64_t N, int64_t B,
+                        int64_t D, int dtype, void* stream);
+
+/* method "ffbs" (_do_sample_ffbs, :105-134) for a built-in model: out[S-1] = x_last (D, B, N) - the last state resampled
+ * by the filter's resampler, done by the caller -, then for t = S-2 .. 0 trajectory j draws i from
+ * Categorical(logits_i = logw[t][i] + log p(out[t+1][j] | x[t][i])) and out[t][j] = x[t][i].
+ * u (S-1, B, N) uniforms in [0, 1) for the inverse-CDF draws (row t serves step t), or NULL -> Philox(seed). */
+int pf_smooth_ffbs(const pf_model* model, const void* x_hist, const void* logw_hist, const void* x_last, const void* u,
+                   uint64_t seed, void* out, int64_t S, int64_t N, int64_t B, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------ *
  * test support (no reference counterpart): lets a parity test feed the oracle the very draws a *production* run used

@@ -342,6 +342,55 @@ def batch_filter(
 
 
 # --------------------------------------------------------------------------------------------------------------
+# smoothing over recorded states (pyfilter/filters/particle/base.py:105-157)
+# --------------------------------------------------------------------------------------------------------------
+def smooth_fl(xs, prev_inds):
+    """``_do_sample_fl`` (particle/base.py:136-152).  ``xs``: list of S state tensors ``(N,[B],[D])``; ``prev_inds``: list
+    of S ``previous_indices`` tensors ``(N,[B])`` (entry 0 unused).  Returns ``(S, N, [B], [D])``."""
+    n = xs[-1].shape[0]
+    result = (xs[-1],)
+    idx = torch.arange(n)
+    if prev_inds[-1].dim() > 1:
+        idx = idx.unsqueeze(-1).expand(prev_inds[-1].shape)
+    latest = len(xs) - 1
+    for s in range(len(xs) - 2, -1, -1):
+        idx = batched_gather(prev_inds[latest], idx, 0)
+        result += (batched_gather(xs[s], idx, 0),)
+        latest = s
+    return torch.stack(result[::-1], dim=0)
+
+
+def ffbs_logits(spec, x_t, w_t, x_next):
+    """The logits of one backward step, ``weights = state.weights.unsqueeze(0) + density.log_prob(res[-1].unsqueeze(1))``
+    (particle/base.py:112-117): ``(N_j, N_i, [B])`` for trajectories j at ``x_next`` and candidates i of state t."""
+    loc, scale = M.mean_scale(spec, x_t)  # (N_i, [B], [D]) each
+    lp = M.transition_log_prob(spec, x_next.unsqueeze(1), loc.unsqueeze(0), scale.unsqueeze(0))
+    return w_t.unsqueeze(0) + lp
+
+
+def smooth_ffbs(spec, xs, ws, start, u):
+    """``_do_sample_ffbs`` (particle/base.py:105-134) with the ``Categorical(logits).sample()`` draws (not injectable in
+    the reference) realised by inverse CDF from the SAME logits: trajectory j takes the first candidate whose running
+    probability exceeds ``u[t, j]``.  ``start``: the resampled last state ``(N,[B],[D])``; ``u (S-1, N, [B])``."""
+    res = [start]
+    for t in range(len(xs) - 2, -1, -1):
+        logits = ffbs_logits(spec, xs[t], ws[t], res[-1])  # (N_j, N_i, [B])
+        if logits.dim() == 3:
+            logits = logits.moveaxis(1, 2)  # (N_j, B, N_i)
+        m = logits.max(dim=-1, keepdim=True)[0]
+        e = (logits - m).exp().double()
+        cdf = e.cumsum(dim=-1)
+        target = u[t].double().unsqueeze(-1) * cdf[..., -1:]
+        idx = (cdf > target).to(torch.int64).argmax(dim=-1)  # first candidate beyond the target
+        x_t = xs[t]
+        if spec.dim > 0:
+            res.append(x_t.gather(0, idx.unsqueeze(-1).expand(idx.shape + (spec.dim,))))
+        else:
+            res.append(x_t.gather(0, idx))
+    return torch.stack(res[::-1], dim=0)
+
+
+# --------------------------------------------------------------------------------------------------------------
 # exact Kalman filter for the linear-Gaussian kinds (replaces pykalman in the reference's statistical tests,
 # tests/filters/test_particle.py:63-111)
 # --------------------------------------------------------------------------------------------------------------

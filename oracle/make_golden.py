@@ -5,7 +5,11 @@ TEST INFRASTRUCTURE — generates ``tests/golden/*.npz`` by running the **unmodi
     python oracle/make_golden.py            # regenerates every fixture (fp64 and fp32 runs, one subprocess each)
 
 What is recorded per case: inputs ``y, x0, z tape (T,N,B,[D]) , u tape (T,B)``, model spec, and the
-reference's outputs: per-step ``x, w, ll, idx``, and ``filter_means, filter_variance, loglikelihood``.
+reference's outputs: per-step ``x, w, ll, idx``, and ``filter_means, filter_variance, loglikelihood``; the reference's
+``smooth(states, "fl")`` over all T + 1 states (deterministic given the states); for the cases in ``FFBS_CASES`` the
+mean / variance over trajectories of ``smooth(states, "ffbs")`` (its ``Categorical`` draws are not injectable:
+statistical fixture); for the cases in ``STATE_DICT_CASES`` the reference's ``FilterResult.state_dict()`` after
+``STATE_DICT_AT`` observations, flattened to ``sd::<path>`` keys (checkpoint interoperability, SURVEY.md 8(f)3).
 
 Tape injection (the reference's arithmetic is untouched):
 * ``torch.normal(mean, std)`` is wrapped to draw ``z = randn(shape)`` (float32, upcast), record it and return
@@ -24,6 +28,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+FFBS_CASES = ("lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot")
+STATE_DICT_CASES = ("lg1d_apf_lgo", "lorenz_sisr_boot", "sv_sisr_boot")
+STATE_DICT_AT = 12  # observations consumed when the checkpoint is taken
 
 
 def _main_child(dtype_name: str):
@@ -131,6 +138,17 @@ def _main_child(dtype_name: str):
             return ts.StateSpaceModel(hidden, lambda x, mu: Normal(mu, x.value), op)
         raise NotImplementedError(spec.obs)
 
+    def flatten_state_dict(sd, prefix="sd"):
+        """Nested dict of tensors -> ``{"sd::a::b": ndarray}`` (copies: the checkpoint is a snapshot)."""
+        flat = {}
+        for k, v in sd.items():
+            key = f"{prefix}::{k}"
+            if isinstance(v, dict):
+                flat.update(flatten_state_dict(v, key))
+            else:
+                flat[key] = torch.as_tensor(v).detach().clone().numpy()
+        return flat
+
     # ---------------------------------------------------------------------------------------------------------
     os.makedirs(GOLDEN, exist_ok=True)
 
@@ -173,7 +191,10 @@ def _main_child(dtype_name: str):
 
         steps = {k: [] for k in ("x", "w", "ll", "idx")}
         u_tape, z_tape = [], []
+        all_states, checkpoint = [state], None
         for t in range(t_len):
+            if t == STATE_DICT_AT and case["name"] in STATE_DICT_CASES:
+                checkpoint = flatten_state_dict(result.state_dict())
             tape.cur_u = torch.rand(b, dtype=torch.float32)
             u_tape.append(tape.cur_u)
             state = filt.filter(y[t], state, result=result)
@@ -184,6 +205,7 @@ def _main_child(dtype_name: str):
             steps["w"].append(state.weights.clone())
             steps["ll"].append(state.get_loglikelihood().clone())
             steps["idx"].append(state.previous_indices.clone())
+            all_states.append(state)
 
         out = {
             "y": y.numpy(),
@@ -197,6 +219,19 @@ def _main_child(dtype_name: str):
         }
         for k, v in steps.items():
             out[f"step_{k}"] = torch.stack(v).numpy()
+        # smoothing over the recorded states (particle/base.py:105-157); everything the filtering part of the fixture
+        # holds was produced above - the calls below only consume further random numbers
+        out["smooth_fl"] = filt.smooth(all_states, "fl").numpy()
+        if case["name"] in FFBS_CASES and dtype_name == "f64":
+            tape.mask = torch.ones(b, dtype=torch.bool)
+            tape.cur_u = torch.rand(b, dtype=torch.float32)
+            draws = [filt.smooth(all_states, "ffbs") for _ in range(4)]  # 4 independent backward passes
+            traj = torch.stack(draws)  # (4, T + 1, N, B, [D])
+            out["ffbs_u_last"] = tape.cur_u.numpy()
+            out["ffbs_mean"] = traj.mean(dim=(0, 2)).numpy()
+            out["ffbs_var"] = traj.var(dim=(0, 2)).numpy()
+        if checkpoint is not None:
+            out.update(checkpoint)
         path = os.path.join(GOLDEN, f"{case['name']}_{dtype_name}.npz")
         np.savez_compressed(path, **out)
         print(f"wrote {path}: ll={result.loglikelihood.tolist()}")

@@ -28,6 +28,7 @@ EXPORTS = (
     "pf_multinomial", "pf_gather", "pf_loglik", "pf_moments", "pf_pre_weight", "pf_sample_and_weight",
     "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed", "pf_filter_graph_create", "pf_filter_graph_launch",
     "pf_filter_graph_destroy", "pf_columns_gather", "pf_columns_exchange", "pf_debug_draw_normals", "pf_debug_launch_trace",
+    "pf_smooth_fixed_lag", "pf_smooth_ffbs",
 )
 
 
@@ -53,6 +54,7 @@ class PfFilterArgs(C.Structure):
         ("step_counter", C.c_void_p),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("observed_dev", C.c_void_p),
+        ("ring", C.c_int64),
     ]
 
 
@@ -97,6 +99,8 @@ def load() -> C.CDLL:
     lib.pf_filter_graph_create.argtypes = [C.POINTER(PfFilterArgs), i64, i64, i32, vp, C.POINTER(vp)]
     lib.pf_filter_graph_launch.argtypes = [vp, vp]
     lib.pf_filter_graph_destroy.argtypes = [vp]
+    lib.pf_smooth_fixed_lag.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, vp]
+    lib.pf_smooth_ffbs.argtypes = [C.POINTER(PfModel), vp, vp, vp, vp, u64, vp, i64, i64, i64, i32, vp]
     lib.pf_debug_draw_normals.argtypes = [u64, u32, i64, vp, i64, i64, i64, i32, vp]
     lib.pf_debug_launch_trace.argtypes = [C.POINTER(C.c_int32), i32]
     for name in EXPORTS:

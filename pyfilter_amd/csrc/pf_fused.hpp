@@ -58,6 +58,8 @@ template <typename T> struct FusedArgs {
     T* x[2];
     T* logw[2];
     int32_t* anc;
+    const int32_t* anc_prev;  // state history only: the ancestors of the incoming state (a SISR step that keeps its
+                              // weights carries them forward into its own slot), else nullptr
     T* cdf;
     T* pos;      // (B, N) sorted resampling positions (multinomial)
     const T* y;  // (T, y_rows, O)
@@ -1186,6 +1188,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             if (VEC == 1) lw_out[i0] = lwo[0]; else store_vec<T, VEC>(lw_out + i0, lwo);
             if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
                 if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
+            } else if (la->anc_prev) {  // ... which, with a state history, means copying them into this state's slot
+                const int32_t* ap = la->anc_prev + (int64_t)b * g.N + i0;
+                int prev[VEC];
+                if (VEC == 1) prev[0] = ap[0]; else load_vec<int, VEC>(ap, prev);
+                if (VEC == 1) anc_col[i0] = prev[0]; else store_vec<int, VEC>(anc_col + i0, prev);
             }
             if (PF_CUT(a, 5)) {
                 if (pre_next) { if (VEC == 1) lw_out[i0] = pre_n[0]; else store_vec<T, VEC>(lw_out + i0, pre_n); }

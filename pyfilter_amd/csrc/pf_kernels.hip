@@ -886,6 +886,138 @@ __global__ __launch_bounds__(PF_BLOCK) void k_debug_normals(uint64_t seed, uint3
             if (i0 + j < N) out[(((int64_t)s * D + d) * B + b) * N + i0 + j] = zt[j][d];
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// smoothing over a recorded state history (pyfilter/filters/particle/base.py:105-157), S states, time-major:
+//   x_hist (S, D, B, N), logw_hist / anc_hist (S, B, N); anc_hist[t] = the ancestors in state t - 1 of state t's particles.
+// ---------------------------------------------------------------------------------------------------------------
+
+// "fl" (_do_sample_fl, :136-152): every particle of the last state walks its ancestral line backwards.  One thread per
+// trajectory; the walk is a chain of dependent gathers (latency-bound, N B chains in flight hide it).
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_trace_ancestors(const T* __restrict__ x_hist,
+                                                              const int32_t* __restrict__ anc_hist, T* __restrict__ out,
+                                                              int64_t S, int64_t N, int B, int D) {
+    const int b = blockIdx.y;
+    const int64_t plane = (int64_t)B * N;
+    for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * PF_BLOCK) {
+        int64_t idx = i;
+        for (int64_t t = S - 1; t >= 0; --t) {
+            for (int d = 0; d < D; ++d)
+                out[(t * D + d) * plane + (int64_t)b * N + i] = x_hist[(t * D + d) * plane + (int64_t)b * N + idx];
+            if (t > 0) idx = anc_hist[t * plane + (int64_t)b * N + idx];
+        }
+    }
+}
+
+// "ffbs" (_do_sample_ffbs, :105-134): backward simulation.  Trajectory j holds x_{t+1}^{(j)} and draws its state-t particle
+// from Categorical(logits_i = logw_t^{(i)} + log p(x_{t+1}^{(j)} | x_t^{(i)})) - an N x N evaluation per step that the
+// reference materialises as an (N, N, [B]) tensor.  Here: one thread per trajectory for the WHOLE backward pass
+// (trajectories are independent given the recorded states); the workgroup stages 256 candidates (one-step mean, scale and
+// weight of particle i) in LDS and every thread scans them twice - (max, sum exp) of its logits, then the inverse-CDF walk
+// with ONE uniform per (trajectory, step) (tape `u` (S - 1, B, N) or Philox).  O(N^2 S) flops, O(N S) memory.
+#define PF_STREAM_SMOOTH 5
+template <typename T, int D>
+__global__ __launch_bounds__(PF_BLOCK) void k_ffbs(ModelDesc md, const T* __restrict__ params, const T* __restrict__ x_hist,
+                                                    const T* __restrict__ logw_hist, const T* __restrict__ x_last,
+                                                    const T* __restrict__ u, uint64_t seed, T* __restrict__ out, int64_t S,
+                                                    int64_t N, int B) {
+    __shared__ T s_loc[D][PF_BLOCK], s_i2[D][PF_BLOCK], s_c[PF_BLOCK];
+    const int b = blockIdx.y;
+    const int O = md.obs_dim;
+    const int NP = 4 * D + O * D + 2 * O;
+    ColParams<T, D> cp;
+    cp.load(params + (int64_t)b * NP, O, nullptr);
+    const int64_t plane = (int64_t)B * N;
+    const int64_t j = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const bool on = j < N;
+    const T inc = (T)md.inc_scale;
+    T xj[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        xj[d] = on ? x_last[((int64_t)d * B + b) * N + j] : T(0);
+        if (on) out[((S - 1) * D + d) * plane + (int64_t)b * N + j] = xj[d];
+    }
+    const int64_t tiles = (N + PF_BLOCK - 1) / PF_BLOCK;
+    for (int64_t t = S - 2; t >= 0; --t) {
+        const T* xt = x_hist + t * D * plane;
+        const T* wt = logw_hist + t * plane + (int64_t)b * N;
+        // candidate i of a tile: its one-step mean / scale (model.hidden.build_density(state), :112) and its log-weight
+        auto stage = [&](int64_t tile) {
+            const int64_t i = tile * PF_BLOCK + threadIdx.x;
+            T xi[D], loc[D], sc[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) xi[d] = i < N ? xt[((int64_t)d * B + b) * N + i] : T(0);
+            mean_scale<T, D>(md, cp, xi, loc, sc);
+            T c = i < N ? sanitize_logw(wt[i]) : -Lim<T>::inf();
+            if (c == Lim<T>::lowest()) c = -Lim<T>::inf();  // a -inf weight stays out of the draw
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const T sd = sc[d] * inc;
+                s_loc[d][threadIdx.x] = loc[d];
+                s_i2[d][threadIdx.x] = T(0.5) / (sd * sd);
+                c -= pf_log(pf_abs(sd)) + T(PF_LOG_SQRT_2PI);
+            }
+            s_c[threadIdx.x] = c;
+        };
+        auto logit = [&](int q) {
+            T l = s_c[q];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const T r = xj[d] - s_loc[d][q];
+                l -= r * r * s_i2[d][q];
+            }
+            return l;
+        };
+        // pass 1: running (max, sum exp) over all candidates
+        T m = -Lim<T>::inf();
+        double ssum = 0.0;
+        for (int64_t tile = 0; tile < tiles; ++tile) {
+            __syncthreads();
+            stage(tile);
+            __syncthreads();
+            const int cnt = (int)((tile + 1) * PF_BLOCK <= N ? PF_BLOCK : N - tile * PF_BLOCK);
+            for (int q = 0; q < cnt; ++q) {
+                const T l = logit(q);
+                if (l > m) {
+                    ssum = (m == -Lim<T>::inf()) ? 0.0 : ssum * (double)pf_exp(m - l);
+                    m = l;
+                }
+                if (l != -Lim<T>::inf()) ssum += (double)pf_exp(l - m);
+            }
+        }
+        // pass 2: inverse CDF - the first candidate whose running sum reaches u * total
+        T uj;
+        if (u) uj = on ? u[t * plane + (int64_t)b * N + j] : T(0);
+        else uj = uniform_draw<T>(seed, PF_STREAM_SMOOTH, (uint32_t)t, (uint64_t)((int64_t)b * N + (on ? j : 0)));
+        const double target = (double)uj * ssum;
+        double run = 0.0;
+        int64_t pick = -1, last_pos = 0;
+        for (int64_t tile = 0; tile < tiles; ++tile) {
+            __syncthreads();
+            stage(tile);
+            __syncthreads();
+            const int cnt = (int)((tile + 1) * PF_BLOCK <= N ? PF_BLOCK : N - tile * PF_BLOCK);
+            for (int q = 0; q < cnt; ++q) {
+                const T l = logit(q);
+                if (l != -Lim<T>::inf()) {
+                    const double e = (double)pf_exp(l - m);
+                    if (e > 0.0) last_pos = tile * PF_BLOCK + q;
+                    run += e;
+                    if (pick < 0 && run > target) pick = tile * PF_BLOCK + q;
+                }
+            }
+        }
+        if (pick < 0) pick = last_pos;  // u = 1 - eps against a rounded-down total
+        if (on) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                xj[d] = xt[((int64_t)d * B + b) * N + pick];
+                out[(t * D + d) * plane + (int64_t)b * N + j] = xj[d];
+            }
+        }
+    }
+}
+
 }  // namespace pf
 
 #include "pf_fused.hpp"
@@ -1191,6 +1323,40 @@ extern "C" int pf_initial_sample(const double* m0, const double* s0, const void*
 }
 
 
+
+// ---- smoothing ---------------------------------------------------------------------------------------------------------
+extern "C" int pf_smooth_fixed_lag(const void* x_hist, const int32_t* anc_hist, void* out, int64_t S, int64_t N, int64_t B,
+                                   int64_t D, int dtype, void* stream) {
+    if (!x_hist || !anc_hist || !out || S < 1 || bad_shape(N, B) || D < 1 || D > PF_MAXD) return PF_EINVAL;
+    const dim3 grid(ew_blocks(N), (int)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_trace_ancestors<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)x_hist, anc_hist, (float*)out, S, N, (int)B, (int)D);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_trace_ancestors<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)x_hist, anc_hist, (double*)out, S, N, (int)B, (int)D);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_smooth_ffbs(const pf_model* model, const void* x_hist, const void* logw_hist, const void* x_last,
+                              const void* u, uint64_t seed, void* out, int64_t S, int64_t N, int64_t B, int dtype,
+                              void* stream) {
+    if (!model || !x_hist || !logw_hist || !x_last || !out || S < 1 || bad_shape(N, B)) return PF_EINVAL;
+    int rc = check_model(model);
+    if (rc) return rc;
+    const ModelDesc md = to_desc(model);
+    const dim3 grid((unsigned)((N + PF_BLOCK - 1) / PF_BLOCK), (int)B);
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(T, DD)                                                                                                         \
+    hipLaunchKernelGGL((k_ffbs<T, DD>), grid, dim3(PF_BLOCK), 0, st, md, (const T*)model->params, (const T*)x_hist,          \
+                       (const T*)logw_hist, (const T*)x_last, (const T*)u, seed, (T*)out, S, N, (int)B);
+    PF_DISPATCH_T_D(dtype, model->dim, CALL)
+#undef CALL
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
 // ---- test support ----------------------------------------------------------------------------------------------------
 extern "C" int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_steps, void* out, int64_t N, int64_t B,
                                      int64_t D, int dtype, void* stream) {
@@ -1264,6 +1430,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.logw[0] = (T*)A->logw[0];
     a.logw[1] = (T*)A->logw[1];
     a.anc = A->anc;
+    a.anc_prev = nullptr;
     a.cdf = (T*)A->cdf;
     a.pos = (T*)A->pos;
     a.y = (const T*)A->y;
@@ -1301,6 +1468,19 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
         if (e != hipSuccess) return (int)e;
     }
+    // state history: slot pointers per launch (the kernels keep addressing "buffer step & 1 is read, the other written")
+    const int64_t ring = A->ring >= 3 ? A->ring : 0;
+    auto place = [&](int64_t t) {  // launch of step t: reads state t, writes state t + 1
+        if (!ring) return;
+        const int64_t rs = t % ring, wsl = (t + 1) % ring, bn = (int64_t)g.B * g.N;
+        a.x[t & 1] = (T*)A->x[0] + rs * D * bn;
+        a.x[(t + 1) & 1] = (T*)A->x[0] + wsl * D * bn;
+        a.logw[t & 1] = (T*)A->logw[0] + rs * bn;
+        a.logw[(t + 1) & 1] = (T*)A->logw[0] + wsl * bn;
+        a.anc = A->anc + wsl * bn;
+        a.anc_prev = A->anc + rs * bn;
+    };
+    place(t0);
     // partials of the incoming state (afterwards every step kernel leaves the partials of the state it wrote)
     a.step = (int)t0;
     const bool dev_flags = A->observed_dev != nullptr;  // the kernels read the flags themselves
@@ -1383,6 +1563,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     for (int64_t s = 0; s < n_steps; ++s) {
         const int64_t t = t0 + s;
         a.step = (int)t;
+        place(t);
         a.obs = dev_flags ? -1 : (observed[t] != 0);
         a.obs_next = (s + 1 < n_steps) ? (dev_flags ? -1 : (observed[t + 1] != 0)) : 0;
 #ifdef PF_DEVTOOLS
@@ -1561,7 +1742,8 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     int rc = check_model(&A->model);
     if (rc) return rc;
     if (bad_shape(A->N, A->B) || t0 < 0 || n_steps < 0) return PF_EINVAL;
-    if (!A->x[0] || !A->x[1] || !A->logw[0] || !A->logw[1] || !A->anc || !A->cdf || !A->means || !A->vars ||
+    if (A->ring < 0 || A->ring == 1) return PF_EINVAL;
+    if (!A->x[0] || !A->logw[0] || (A->ring < 3 && (!A->x[1] || !A->logw[1])) || !A->anc || !A->cdf || !A->means || !A->vars ||
         !A->ll_steps || !A->ll_total || !A->ws)
         return PF_EINVAL;
     if (n_steps > 0 && (!A->y || (!A->observed && !A->observed_dev))) return PF_EINVAL;

@@ -280,8 +280,6 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             and type(self._proposal) in (Bootstrap, LinearGaussianObservations)
             and not self._proposal._custom_pre_weight
             and self._resampler_kind() is not None
-            and self.record_states is False
-            and not self._record_intermediary
             and hasattr(self._model.hidden, "init_mean")
         )
 
@@ -291,7 +289,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         reference's predict / correct sequence over the stand-alone kernels."""
         x = correction.timeseries_state.value
         if (not isinstance(y, torch.Tensor) or not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1
-                or os.environ.get("PF_NO_FUSED_STEP", "0") == "1"):
+                or self._record_intermediary or os.environ.get("PF_NO_FUSED_STEP", "0") == "1"):
             return super().filter(y, correction, result=result)
         new = self._filter_fused_single(y, correction)
         if result is not None:
@@ -369,7 +367,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
     def batch_filter(self, y, bar=True, init_state=None) -> FilterResult:
         assert self._model is not None, "Model has not been initialized!"
         device, _ = self._device_dtype()
-        if not self._fused_capable(device) or not isinstance(y, torch.Tensor):
+        if (not self._fused_capable(device) or not isinstance(y, torch.Tensor)
+                or os.environ.get("PF_NO_FUSED_BATCH", "0") == "1"):
             return super().batch_filter(y, bar=bar, init_state=init_state)
         return self._batch_filter_fused(y, init_state)
 
@@ -421,13 +420,25 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             y_steps = torch.full((steps, rows, o), float("nan"), device=device, dtype=dtype)
             y_steps[at.to(device)] = y_dev
 
+        # recorded states (FilterResult.states; smoothing): the kernels keep a history of `ring` state slots.  The slots
+        # become the recorded states themselves (views, no copies), so such a run gets buffers of its own
+        keep_states = FilterResult.states_kept(self.record_states)  # None = all
+        # the moves whose states / moment rows are reported: those that consumed an observation - and the unobserved
+        # sub-steps too when intermediary states are recorded (filters/base.py:207-208); q = move index + 1
+        reported = list(range(1, steps + 1)) if (steps == t_obs or self._record_intermediary) else [r + 1 for r in sched.rows]
+        if keep_states == 1:
+            ring, wanted = 0, reported[-1:]
+        else:
+            wanted = reported if keep_states is None else reported[-keep_states:]
+            ring = max(3, steps - wanted[0] + 1)  # slots for the states wanted[0] .. steps
         taped = ctx.z_tape is not None or ctx.u_tape is not None
-        use_graph = (not taped) and not getattr(self, "_time_kernels", False) and os.environ.get("PF_NO_GRAPH", "0") != "1"
+        use_graph = ((not taped) and not ring and not getattr(self, "_time_kernels", False)
+                     and os.environ.get("PF_NO_GRAPH", "0") != "1")
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
                self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes())
         plan = self._fused_plans.get(key) if use_graph else None
         if plan is None:
-            plan = _FusedPlan(self, kind, n, b, d, o, steps, rows, dtype, device, observed_host)
+            plan = _FusedPlan(self, kind, n, b, d, o, steps, rows, dtype, device, observed_host, ring=ring)
             if use_graph:
                 if len(self._fused_plans) >= 4:  # a handful of (shape, schedule) combinations at most
                     self._fused_plans.pop(next(iter(self._fused_plans))).destroy()
@@ -437,7 +448,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         plan.params.copy_(ctx.params)
         plan.x[0].copy_(ops.to_soa(x0, self._batched, self._has_event))
         plan.logw[0].copy_(ops.to_cols(state.weights))
-        plan.anc.copy_(ops.to_cols(state.previous_indices.to(torch.int32)))
+        (plan.anc_hist[0] if ring else plan.anc).copy_(ops.to_cols(state.previous_indices.to(torch.int32)))
         plan.y.copy_(y_steps)
         plan.ll_total.zero_()
         # fresh Philox draws for every call: the base seed is baked into the (captured) launch arguments, the kernels add
@@ -477,25 +488,115 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=seed_eff)  # keep device buffers alive
 
         # ---- hand the results over in the reference's shapes (copies: a cached plan's buffers are reused) ------------
-        slot = steps % 2
-        x_fin, lw_fin = plan.x[slot].clone(), plan.logw[slot].clone()
-        ll_steps, ll_total, anc = plan.ll_steps.clone(), plan.ll_total.clone(), plan.anc.clone()
-        final_x = TimeseriesState(t_start + steps, ops.from_soa(x_fin, self._batched, self._has_event),
-                                  self._model.hidden.event_shape)
         shape_md = (lambda t: t if self._batched else t[:, 0])
         means_v, vars_v = shape_md(plan.means), shape_md(plan.vars)  # (steps + 1, [B], D): copied by the moment log
-        ll_last = ll_steps[-1] if self._batched else ll_steps[-1, 0]
-        last = ParticleFilterCorrection(
-            final_x, ops.from_cols(lw_fin, self._batched), ll_last, ops.from_cols(anc, self._batched).long(),
-            _moments=(means_v[-1].clone(), vars_v[-1].clone()),
-        )
-        if steps == t_obs:
+        ll_steps, ll_total = plan.ll_steps.clone(), plan.ll_total.clone()
+        es = self._model.hidden.event_shape
+
+        def state_of(q, x_soa, lw, anc32):
+            """The state after move q - 1 (q >= 1) as the reference's object."""
+            ll_q = ll_steps[q - 1] if self._batched else ll_steps[q - 1, 0]
+            st = ParticleFilterCorrection(
+                TimeseriesState(t_start + q, ops.from_soa(x_soa, self._batched, self._has_event), es),
+                ops.from_cols(lw, self._batched), ll_q, ops.from_cols(anc32, self._batched).long(),
+                _moments=(means_v[q].clone(), vars_v[q].clone()),
+            )
+            st._anc32 = (anc32, st["_prev_inds"])
+            return st
+
+        if ring:
+            recorded = [state_of(q, plan.x_hist[q % ring], plan.logw_hist[q % ring], plan.anc_hist[q % ring]) for q in wanted]
+            last = recorded[-1]
+        else:
+            slot = steps % 2
+            last = state_of(steps, plan.x[slot].clone(), plan.logw[slot].clone(), plan.anc.clone())
+            recorded = None
+        if len(reported) == steps:
             sel_m, sel_v = means_v, vars_v
-        else:  # the initial state's row, then the row of the move that consumed each observation
-            keep = torch.tensor([0] + [r + 1 for r in sched.rows], device=device)
+        else:  # the initial state's row, then the row of every reported move
+            keep = torch.tensor([0] + reported, device=device)
             sel_m, sel_v = means_v[keep], vars_v[keep]
-        result._extend_fused(sel_m, sel_v, ll_total if self._batched else ll_total[0], last)
+        result._extend_fused(sel_m, sel_v, ll_total if self._batched else ll_total[0], last, states=recorded)
         return result
+
+    # ------------------------------------------------------------------------------------------------------------
+    # smoothing over recorded states (particle/base.py:105-157)
+    # ------------------------------------------------------------------------------------------------------------
+    def _history(self, states):
+        """``(x_hist (S, D, B, N), logw_hist (S, B, N), anc_hist (S, B, N) int32)`` of consecutive recorded states - views
+        of the kernels' history ring when the states came from a fused run, else stacked copies."""
+        xs = [ops.to_soa(s.timeseries_state.value, self._batched, self._has_event) for s in states]
+        ws = [ops.to_cols(s.weights) for s in states]
+        an = []
+        for s in states:
+            c = getattr(s, "_anc32", None)  # (int32 (B, N) buffer, the int64 tensor it was widened into)
+            an.append(c[0] if c is not None and c[1] is s["_prev_inds"] else ops.to_cols(s.previous_indices.to(torch.int32)))
+
+        def stacked(ts):
+            step = ts[0].numel() * ts[0].element_size()
+            if all(t.is_contiguous() for t in ts) and all(ts[k].data_ptr() == ts[0].data_ptr() + k * step for k in range(len(ts))):
+                return torch.as_strided(ts[0], (len(ts),) + tuple(ts[0].shape), (ts[0].numel(),) + tuple(ts[0].stride()))
+            return torch.stack(ts, 0).contiguous()
+
+        return stacked(xs), stacked(ws), stacked(an)
+
+    def set_smoothing_tape(self, u: Optional[torch.Tensor]):
+        """Parity mode for ``smooth(..., "ffbs")``: the uniforms of the backward draws, ``(S - 1, N, [B])`` (row t serves
+        the draw of state t given state t + 1) - ``None`` restores Philox."""
+        self._ffbs_u = u
+
+    def smooth(self, states, method: str = "ffbs") -> torch.Tensor:
+        """Smoothed trajectories ``(S, N, [B], [D])`` from recorded states: ``"fl"`` - every particle of the last state
+        traced back along its ancestors (:136-152); ``"ffbs"`` - forward filtering, backward simulation (:105-134).  Both are
+        one kernel launch over the state history for built-in models on the GPU; ``"ffbs"`` with user callables evaluates
+        the reference's (N, N) logits with torch ops."""
+        states = list(states)
+        low = method.lower()
+        if low not in ("ffbs", "fl"):
+            raise NotImplementedError(f"Currently do not support '{method}'!")
+        x_last = states[-1].timeseries_state.value
+        on_gpu = x_last.is_cuda
+        if low == "fl":
+            if not on_gpu:
+                raise L.PfAmdError("pyfilter_amd runs on MI355X only: smoothing needs states on the GPU")
+            x_hist, _, anc_hist = self._history(states)
+            out = ops.smooth_fixed_lag(x_hist, anc_hist)
+            return torch.stack([ops.from_soa(o, self._batched, self._has_event) for o in out.unbind(0)], 0)
+        # ffbs: the last state resampled by the filter's resampler, then the backward draws
+        w_last = states[-1].weights
+        idx = self._resampler(w_last)
+        from ..utils import batched_gather
+
+        start = batched_gather(x_last, idx, 0)
+        ctx = self._ensure_context()
+        if ctx is not None and on_gpu:
+            x_hist, w_hist, _ = self._history(states)
+            u = getattr(self, "_ffbs_u", None)
+            if u is not None:
+                s1 = len(states) - 1
+                u = u.to(device=x_hist.device, dtype=x_hist.dtype).reshape(s1, x_hist.shape[3], x_hist.shape[2]).permute(0, 2, 1).contiguous()
+            out = ops.smooth_ffbs(ctx.kind, ctx.params, x_hist, w_hist, ops.to_soa(start, self._batched, self._has_event),
+                                  u, self._next_draw_seed())
+            return torch.stack([ops.from_soa(o, self._batched, self._has_event) for o in out.unbind(0)], 0)
+        return self._ffbs_with_callables(states, start)
+
+    def _ffbs_with_callables(self, states, start):
+        """User-defined models: the reference's own evaluation (an (N, N, [B]) logits tensor per step) with torch ops."""
+        from torch.distributions import Categorical
+
+        res = [start]
+        has_event = self._has_event
+        for state in reversed(states[:-1]):
+            density = self._model.hidden.build_density(state.timeseries_state)
+            w_state = density.log_prob(res[-1].unsqueeze(1))
+            weights = state.weights.unsqueeze(0) + w_state
+            if self._batched:
+                weights = weights.moveaxis(1, 2)
+            indices = Categorical(logits=weights).sample()
+            if has_event:
+                indices = indices.unsqueeze(-1).expand(self.particles + self._model.hidden.event_shape)
+            res.append(state.timeseries_state.value.gather(0, indices))
+        return torch.stack(res[::-1], dim=0)
 
 
 class _SingleStepPlan:
@@ -528,10 +629,17 @@ class _FusedPlan:
     them across ``batch_filter`` calls means repeated runs (PMMH / SMC^2 re-filter the same data many times,
     ``inference/batch/mcmc/utils.py:55``) replay one graph instead of issuing 2 T kernel launches from the host."""
 
-    def __init__(self, filt, kind, n, b, d, o, steps, rows, dtype, device, observed_host):
-        self.x = (torch.empty((d, b, n), device=device, dtype=dtype), torch.empty((d, b, n), device=device, dtype=dtype))
-        self.logw = (torch.empty((b, n), device=device, dtype=dtype), torch.empty((b, n), device=device, dtype=dtype))
-        self.anc = torch.empty((b, n), device=device, dtype=torch.int32)
+    def __init__(self, filt, kind, n, b, d, o, steps, rows, dtype, device, observed_host, ring=0):
+        self.ring = ring
+        if ring:  # state history (pf_filter_args.ring): slot q % ring holds the state after move q - 1
+            self.x_hist = torch.empty((ring, d, b, n), device=device, dtype=dtype)
+            self.logw_hist = torch.empty((ring, b, n), device=device, dtype=dtype)
+            self.anc_hist = torch.empty((ring, b, n), device=device, dtype=torch.int32)
+            self.x, self.logw, self.anc = (self.x_hist[0], self.x_hist[1]), (self.logw_hist[0], self.logw_hist[1]), self.anc_hist
+        else:
+            self.x = (torch.empty((d, b, n), device=device, dtype=dtype), torch.empty((d, b, n), device=device, dtype=dtype))
+            self.logw = (torch.empty((b, n), device=device, dtype=dtype), torch.empty((b, n), device=device, dtype=dtype))
+            self.anc = torch.empty((b, n), device=device, dtype=torch.int32)
         self.cdf = torch.empty((b, n), device=device, dtype=dtype)
         self.pos = torch.empty((b, n), device=device, dtype=dtype)
         self.y = torch.empty((steps, rows, o), device=device, dtype=dtype)
@@ -563,6 +671,7 @@ class _FusedPlan:
         a.ll_steps, a.ll_total = self.ll_steps.data_ptr(), self.ll_total.data_ptr()
         a.step_counter = self.epoch.data_ptr()
         a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        a.ring = ring
         self.args = a
 
     def destroy(self):

@@ -132,7 +132,7 @@ class ParticleFilterCorrection(Correction):
         values = state_dict["_x"]["value"]
         mine = self.timeseries_state
         assert mine.value.shape == values.shape, f"shape mismatch: {mine.value.shape} != {values.shape}"
-        self["_x"] = mine.propagate_from(values=values, time_increment=-mine.time_index + state_dict["_x"]["time_index"])
+        self["_x"] = mine.propagate_from(values=values, time_increment=int(state_dict["_x"]["time_index"]) - int(mine.time_index))
         for k in ("_w", "_ll", "_prev_inds", "_mean", "_var"):
             self[k] = state_dict[k]
 

@@ -187,6 +187,11 @@ class FilterResult(dict, Generic[TCorrection]):
         else:
             self.append(init_state)
 
+    @staticmethod
+    def states_kept(record_states: BoolOrInt) -> Optional[int]:
+        """How many states a result keeps (``None`` = all): the reference's deque rule (container.py:10-18)."""
+        return _deque_maxlen(record_states)
+
     # ---- the reference's read interface -------------------------------------------------------------------------
     @property
     def loglikelihood(self) -> torch.Tensor:

@@ -317,3 +317,37 @@ def debug_launch_trace(last: int = 64):
         L.check(n, "pf_debug_launch_trace")
     k = len(TRACE_FIELDS)
     return [dict(zip(TRACE_FIELDS, buf[i * k:(i + 1) * k])) for i in range(n)]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# smoothing over a recorded state history
+# ----------------------------------------------------------------------------------------------------------------
+def smooth_fixed_lag(x_hist: torch.Tensor, anc_hist: torch.Tensor) -> torch.Tensor:
+    """``x_hist (S, D, B, N)``, ``anc_hist (S, B, N)`` int32 -> the ancestral lines of the last state's particles
+    ``(S, D, B, N)`` (pf_smooth_fixed_lag; ``_do_sample_fl``, particle/base.py:136-152)."""
+    L.require_gpu(x_hist, anc_hist)
+    s, d, b, n = x_hist.shape
+    assert anc_hist.shape == (s, b, n) and anc_hist.dtype == torch.int32 and anc_hist.is_contiguous() and x_hist.is_contiguous()
+    out = torch.empty_like(x_hist)
+    L.check(L.load().pf_smooth_fixed_lag(x_hist.data_ptr(), anc_hist.data_ptr(), out.data_ptr(), s, n, b, d,
+                                         L.dtype_code(x_hist.dtype), L.stream_ptr()), "pf_smooth_fixed_lag")
+    return out
+
+
+def smooth_ffbs(kind, params: torch.Tensor, x_hist: torch.Tensor, logw_hist: torch.Tensor, x_last: torch.Tensor,
+                u: Optional[torch.Tensor], seed: int) -> torch.Tensor:
+    """Backward simulation over ``x_hist (S, D, B, N)`` / ``logw_hist (S, B, N)`` starting from ``x_last (D, B, N)``
+    (pf_smooth_ffbs; ``_do_sample_ffbs``, particle/base.py:105-134).  ``u (S - 1, B, N)`` or None (Philox)."""
+    L.require_gpu(x_hist, logw_hist, x_last, u, params)
+    s, d, b, n = x_hist.shape
+    assert logw_hist.shape == (s, b, n) and x_last.shape == (d, b, n)
+    assert x_hist.is_contiguous() and logw_hist.is_contiguous() and x_last.is_contiguous()
+    if u is not None:
+        u = u.to(x_hist.dtype).contiguous()
+        assert u.shape == (s - 1, b, n)
+    out = torch.empty_like(x_hist)
+    m = make_model_struct(kind, params)
+    L.check(L.load().pf_smooth_ffbs(C.byref(m), x_hist.data_ptr(), logw_hist.data_ptr(), x_last.data_ptr(), L.ptr(u),
+                                    seed & 0xFFFFFFFFFFFFFFFF, out.data_ptr(), s, n, b, L.dtype_code(x_hist.dtype),
+                                    L.stream_ptr()), "pf_smooth_ffbs")
+    return out

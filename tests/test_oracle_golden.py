@@ -1,5 +1,6 @@
 """Pins the oracle (``oracle/cpu_ref.py``) against golden vectors produced by the unmodified reference
 (``oracle/make_golden.py``): per-step states, ancestors, log-likelihoods and the final FilterResult moments."""
+import math
 import os
 
 import numpy as np
@@ -57,3 +58,46 @@ def test_primitives_match_reference(golden_dir, dt):
         v = g[f"norm_{nm}_v"]
         torch.testing.assert_close(cpu_ref.log_likelihood(v, W), g[f"norm_{nm}_ll_w"], rtol=0, atol=0, equal_nan=True)
         torch.testing.assert_close(cpu_ref.log_likelihood(v), g[f"norm_{nm}_ll"], rtol=0, atol=0)
+
+
+def _recorded(g, case, dtype):
+    """The reference's T + 1 recorded states from a fixture: (xs, ws, prev_inds) lists."""
+    n, b = case["N"], case["B"]
+    xs = [g["x0"]] + list(g["step_x"].unbind(0))
+    ws = [torch.zeros(n, b, dtype=dtype)] + list(g["step_w"].unbind(0))
+    idx0 = torch.arange(n).unsqueeze(-1).expand(n, b)
+    return xs, ws, [idx0] + list(g["step_idx"].unbind(0))
+
+
+@pytest.mark.parametrize("name,dt", PARAMS)
+def test_fixed_lag_smoothing_matches_reference(golden_dir, name, dt):
+    """``smooth(states, "fl")`` of the reference (particle/base.py:136-152) is pure index chasing: exact."""
+    case = next(c for c in CASES if c["name"] == name)
+    g = load(golden_dir, name, dt)
+    xs, _, inds = _recorded(g, case, DT[dt])
+    assert torch.equal(cpu_ref.smooth_fl(xs, inds), g["smooth_fl"])
+
+
+@pytest.mark.parametrize("name", ["lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot"])
+def test_ffbs_oracle_against_reference_statistics(golden_dir, name):
+    """``smooth(states, "ffbs")``: the reference's ``Categorical`` draws cannot be injected, so the oracle (inverse CDF on
+    the same logits) is pinned statistically - the per-time mean over trajectories of 4 independent backward passes of
+    the reference (fixture) against the oracle's, within Monte-Carlo error."""
+    case = next(c for c in CASES if c["name"] == name)
+    g = load(golden_dir, name, "f64")
+    spec = build_spec(case, torch.float64)
+    xs, ws, _ = _recorded(g, case, torch.float64)
+    n, b = case["N"], case["B"]
+    gen = torch.Generator().manual_seed(11)
+    W = cpu_ref.normalize(ws[-1].clone())
+    start_idx = cpu_ref.systematic(W, normalized=True, u=g["ffbs_u_last"].double().reshape(-1, 1))
+    start = cpu_ref.batched_gather(xs[-1], start_idx, 0)
+    draws = [cpu_ref.smooth_ffbs(spec, xs, ws, start, torch.rand((len(xs) - 1, n, b), generator=gen, dtype=torch.float64))
+             for _ in range(4)]
+    traj = torch.stack(draws)
+    mean = traj.mean(dim=(0, 2))
+    # both sides average 4 N trajectories that share ancestors heavily: allow 6 standard errors of N effective draws
+    se = (g["ffbs_var"] / n).sqrt() * math.sqrt(2.0)
+    assert ((mean - g["ffbs_mean"]).abs() <= 6.0 * se + 1e-9).all(), ((mean - g["ffbs_mean"]).abs() / (se + 1e-12)).max()
+    # the last state is the resampled one on both sides, given the same uniform: exact
+    torch.testing.assert_close(traj[0, -1].mean(dim=0), traj[1, -1].mean(dim=0), rtol=0, atol=0)
