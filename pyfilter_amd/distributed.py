@@ -5,12 +5,21 @@ ROCm; ``"gloo"`` in the CPU tests).
 What shards: the **batch dimension** - a set of fully independent filters (``filters/base.py:93-119``: every
 reduction / scan / search runs over the particle axis only).  SMC^2 puts its theta-particles there
 (``inference/sequential/base.py:31-34``), so theta-columns are block-sharded across ranks and each rank runs the
-single-GPU fused loop on its ``(N, B / world)`` slice with its slice of the parameters.  The only exchange the path
-needs is the **all-gather of the per-filter log-likelihood increments** (``B`` floats = a few KiB: latency-bound, not
-link-bound) so that every rank can update the theta-weights / theta-ESS identically (``sequential/state.py:35-44``,
-``smc2.py:59-62``).  A single filter (B = 1) does *not* shard - that would need a cross-GPU scan - replicas only.
+single-GPU fused loop on its ``(N, B / world)`` slice with its slice of the parameters.  A single filter (B = 1) does
+*not* shard - that would need a cross-GPU scan - replicas only.
+
+Exchanges (``Shard``), all along the filter (batch) dimension:
+
+* every observation: **all-gather of the per-filter log-likelihood increments** - ``B`` floats, a few KiB,
+  latency-bound - so that every rank updates the theta-weights and takes the ESS decision identically
+  (``sequential/state.py:35-44``, ``smc2.py:59-62``);
+* on a rejuvenation (``kernels/mh.py:52-108``): all-gather of the stacked theta ``(B, P)`` (the MVN proposal is built
+  from all of them, identically everywhere), the identical systematic theta-resample on every rank, and the
+  **redistribution of the surviving filters' states** to the ranks that own their new positions
+  (``Shard.take_filters``: all-gather of the columns + local gather - <= N (4 D + 12) bytes per column, ~100 MB in
+  total at 1024 x 8192, once per rejuvenation).
 """
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -44,20 +53,57 @@ def shard_columns(t: torch.Tensor, total: int, dim: int = -1) -> torch.Tensor:
 def all_gather_columns(local: torch.Tensor, total: int) -> torch.Tensor:
     """All-gather along the last dim of per-column values (log-likelihoods ``(B_local,)`` or ``(T, B_local)``) into the
     full ``(..., total)`` tensor, in global column order, on every rank.  Uneven shards are padded to the largest one."""
-    rank, w = world()
-    if w == 1:
-        return local
-    sizes = [shard_bounds(total, r, w)[1] - shard_bounds(total, r, w)[0] for r in range(w)]
-    width = max(sizes)
-    lead = local.shape[:-1]
-    buf = local.new_zeros(lead + (width,))
-    buf[..., : local.shape[-1]] = local
-    out = [local.new_empty(lead + (width,)) for _ in range(w)]
-    dist.all_gather(out, buf.contiguous())
-    return torch.cat([out[r][..., : sizes[r]] for r in range(w)], dim=-1)
+    return Shard(total).all_gather(local, dim=-1)
 
 
 def theta_ess(log_weights: torch.Tensor) -> torch.Tensor:
     """ESS of the (gathered) theta-weights - identical on every rank since every rank holds all ``B`` values."""
     w = torch.softmax(log_weights - log_weights.max(), dim=0)
     return 1.0 / (w * w).sum()
+
+
+class Shard:
+    """This rank's block of ``total`` filters and the collectives over the filter dimension.  With one process (no
+    process group) every method is the identity / a local operation, so single-GPU code runs through the same calls."""
+
+    def __init__(self, total: int, group=None):
+        self.total = int(total)
+        self.group = group
+        self.rank, self.world = world()
+        self.spans: List[Tuple[int, int]] = [shard_bounds(self.total, r, self.world) for r in range(self.world)]
+        self.lo, self.hi = self.spans[self.rank]
+
+    @property
+    def local(self) -> int:
+        return self.hi - self.lo
+
+    def slice(self, t: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        """This rank's block of a globally indexed tensor."""
+        return t.narrow(dim, self.lo, self.local)
+
+    def all_gather(self, local: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        """Concatenation of every rank's block along ``dim``, in global order, identical on every rank."""
+        if self.world == 1:
+            return local
+        dim = dim % local.dim()
+        moved = local.movedim(dim, 0).contiguous()
+        sizes = [hi - lo for lo, hi in self.spans]
+        width = max(sizes)
+        buf = moved.new_zeros((width,) + tuple(moved.shape[1:]))
+        buf[: moved.shape[0]] = moved
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        dist.all_gather(out, buf, group=self.group)
+        return torch.cat([out[r][: sizes[r]] for r in range(self.world)], dim=0).movedim(0, dim)
+
+    def all_mean(self, local_sum: torch.Tensor, local_count: int) -> torch.Tensor:
+        """Mean over all filters of a quantity summed locally (e.g. an acceptance rate)."""
+        if self.world == 1:
+            return local_sum / max(1, local_count)
+        v = torch.stack([local_sum.to(torch.float64).reshape(()), torch.tensor(float(local_count), device=local_sum.device, dtype=torch.float64)])
+        dist.all_reduce(v, group=self.group)
+        return (v[0] / v[1]).to(local_sum.dtype)
+
+    def take(self, local: torch.Tensor, global_index: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        """``concat(all blocks)[global_index]`` along ``dim`` - this rank's new block after a global gather (resampling of
+        theta-particles: ``global_index`` = the ancestors of this rank's positions)."""
+        return self.all_gather(local, dim).index_select(dim % local.dim(), global_index.to(local.device))

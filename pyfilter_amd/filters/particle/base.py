@@ -84,10 +84,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
     def increase_particles(self, factor: int):
         self._base_particles = torch.Size([int(factor * self._base_particles[0])])
         self._resample_threshold *= factor
+        self._ctx = None  # (tapes / scratch are sized by the particle count)
 
     def initialize_model(self, context):
         super().initialize_model(context)
         self._proposal.set_model(self._model)
+        self._ctx = None  # the kernel context (kind, packed parameter rows) belongs to the model just replaced
 
     def set_tape(self, z: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, z0: Optional[torch.Tensor] = None):
         """Parity mode: inject the random draws instead of generating them with Philox.

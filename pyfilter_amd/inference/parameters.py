@@ -1,0 +1,146 @@
+"""theta-particles: the parameters of B parallel filters with their priors - the slice of the reference's
+``InferenceContext`` / ``PriorBoundParameter`` (``pyfilter/inference/context.py:193-270``, ``parameter.py:79-107``,
+``prior.py:47-123``) that SMC^2 and PMMH use.
+
+Every parameter is ONE tensor of shape ``(B, *event)`` that the model holds by reference: the filters of this library
+read parameter tensors live (in-place updates re-pack the kernels' parameter rows), so ``unstack_parameters`` /
+``exchange`` / ``resample`` write in place and the next filter move sees the new values - nothing is rebuilt."""
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+from torch.distributions import Distribution, TransformedDistribution
+from torch.distributions.constraint_registry import biject_to
+
+
+def _on_device(d: Distribution, device, dtype) -> Distribution:
+    """The same distribution with its parameter tensors on ``device`` (rebuilt from ``arg_constraints``, which names the
+    constructor arguments of every standard torch distribution)."""
+    args = {}
+    for name in d.arg_constraints:
+        v = d.__dict__.get(name)
+        if v is None:  # lazily derived alternatives (e.g. MultivariateNormal's precision / covariance forms)
+            continue
+        args[name] = v.to(device=device, dtype=dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v
+    try:
+        return type(d)(**args)
+    except TypeError:
+        return d
+
+
+class Prior:
+    """A prior with its bijection to unconstrained space (``prior.py:47-123``)."""
+
+    def __init__(self, distribution: Distribution, device=None, dtype=None):
+        if device is not None:
+            distribution = _on_device(distribution, device, dtype)
+        self.distribution = distribution
+        self.bijection = biject_to(distribution.support)
+        self.unconstrained = TransformedDistribution(distribution, self.bijection.inv)
+
+    @property
+    def numel(self) -> int:
+        return max(1, self.distribution.event_shape.numel())
+
+    def get_unconstrained(self, x: torch.Tensor) -> torch.Tensor:
+        return self.bijection.inv(x)
+
+    def get_constrained(self, u: torch.Tensor) -> torch.Tensor:
+        return self.bijection(u)
+
+    def eval_prior(self, x: torch.Tensor, constrained: bool = True) -> torch.Tensor:
+        if constrained:
+            return self.distribution.log_prob(x)
+        return self.unconstrained.log_prob(self.get_unconstrained(x))
+
+
+class ThetaParticles:
+    """Named parameters of ``batch`` parallel filters.  ``self[name]`` is the tensor to hand to the model."""
+
+    def __init__(self, priors: Dict[str, Distribution], batch: int, device="cuda", dtype=torch.float32, shard=None):
+        self.device, self.dtype = torch.device(device), dtype
+        self.priors = OrderedDict((k, v if isinstance(v, Prior) else Prior(v, self.device, dtype)) for k, v in priors.items())
+        self.batch_shape = torch.Size([batch])
+        self.shard = shard  # pyfilter_amd.distributed.Shard or None: `batch` is this rank's block of the theta-particles
+        self._values: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    # ---- values ---------------------------------------------------------------------------------------------------
+    def initialize_parameters(self, generator: Optional[torch.Generator] = None):
+        """Draws every parameter from its prior (``context.initialize_parameters``): ``(B, *event)`` per name.  With a (CPU)
+        ``generator`` the draws are reproducible - inverse CDF of its uniforms where the prior has one - and, sharded, every
+        rank draws the same global set and keeps its block."""
+        total = self.shard.total if self.shard is not None else self.batch_shape[0]
+        for name, prior in self.priors.items():
+            d = prior.distribution
+            shape = torch.Size([total])
+            v = None
+            if generator is not None:
+                try:
+                    u = torch.rand(shape + d.event_shape, generator=generator, dtype=torch.float64).clamp(1e-12, 1 - 1e-12)
+                    v = d.icdf(u.to(device=self.device, dtype=self.dtype))
+                except NotImplementedError:
+                    v = None
+            if v is None:
+                v = d.sample(shape)
+            if self.shard is not None:
+                v = self.shard.slice(v)
+            v = v.to(device=self.device, dtype=self.dtype).clone()
+            if name in self._values:
+                self._values[name].copy_(v)
+            else:
+                self._values[name] = v.contiguous()
+        return self
+
+    def __getitem__(self, name: str) -> torch.Tensor:
+        return self._values[name]
+
+    def names(self):
+        return list(self.priors)
+
+    def like(self) -> "ThetaParticles":
+        """An independent set with the same priors / shape (the proposal's parameters: ``context.make_new``)."""
+        other = ThetaParticles(self.priors, self.batch_shape[0], self.device, self.dtype, self.shard)
+        for k, v in self._values.items():
+            other._values[k] = v.clone()
+        return other
+
+    # ---- stacked views (context.py:193-243) -----------------------------------------------------------------------
+    def stack_parameters(self, constrained: bool = True) -> torch.Tensor:
+        """``(B, P)``: the parameters side by side, flattened per filter."""
+        cols = []
+        for name, prior in self.priors.items():
+            v = self._values[name]
+            cols.append((v if constrained else prior.get_unconstrained(v)).reshape(self.batch_shape[0], -1))
+        return torch.cat(cols, dim=-1)
+
+    def unstack_parameters(self, x: torch.Tensor, constrained: bool = True):
+        """Writes ``x (B, P)`` back into the parameter tensors - in place."""
+        at = 0
+        for name, prior in self.priors.items():
+            v = self._values[name]
+            k = max(1, v[0].numel())
+            part = x[..., at:at + k].reshape(v.shape)
+            v.copy_(part if constrained else prior.get_constrained(part))
+            at += k
+
+    def eval_priors(self, constrained: bool = True) -> torch.Tensor:
+        """``(B,)`` sum of the log priors (``context.py:245-253``)."""
+        return sum(p.eval_prior(self._values[n], constrained) for n, p in self.priors.items())
+
+    # ---- whole-filter moves ---------------------------------------------------------------------------------------
+    def exchange(self, other: "ThetaParticles", mask: torch.Tensor):
+        for name, v in self._values.items():
+            m = mask.reshape(mask.shape + (1,) * (v.dim() - 1))
+            v.copy_(torch.where(m, other._values[name], v))
+
+    def resample(self, indices: torch.Tensor):
+        """``theta <- theta[indices]`` in place.  Sharded: ``indices`` are GLOBAL ancestors of this rank's positions."""
+        for name, v in self._values.items():
+            v.copy_(v[indices] if self.shard is None or self.shard.world == 1 else self.shard.take(v, indices))
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._values.items())
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            self._values[k].copy_(v)

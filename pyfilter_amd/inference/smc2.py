@@ -1,0 +1,229 @@
+"""SMC^2 (Chopin, Jacob & Papaspiliopoulos) on the hot path: theta-particles on the filters' batch dimension, one fused
+``filter()`` move per observation, an ESS-triggered rejuvenation that resamples whole filters and moves them with PMMH.
+
+Mirrors ``pyfilter/inference/sequential/smc2.py:53-65`` (``SMC2._step``), ``sequential/state.py:35-44`` (weights / ESS
+bookkeeping), ``sequential/kernels/mh.py:52-140`` (``ParticleMetropolisHastings.update`` incl. the particle doubling of
+``_increase_states``) - with the reference's ``InferenceContext`` replaced by ``ThetaParticles``.
+
+More than one GPU (``Shard``; one process per GPU): every rank owns a block of the theta-particles and runs the same code
+on it.  Per observation the per-theta log-likelihood increments are all-gathered (B floats) so that all ranks hold the
+same theta-weights and take the same ESS decision; a rejuvenation performs the same systematic resampling of the
+theta-particles on every rank (same weights, same uniform), takes the surviving filters' states from their owners
+(``FilterResult`` blocks via ``Shard.take``), fits the proposal to all theta-particles and averages the acceptance rate
+over all of them."""
+from typing import Callable, Optional
+
+import torch
+
+from ..distributed import Shard
+from ..filters.result import FilterResult
+from .parameters import ThetaParticles
+from .pmmh import SymmetricMH, run_pmmh
+from .utils import theta_ess, theta_normalize, theta_systematic
+
+
+class TooManyIncreases(Exception):
+    pass
+
+
+class SMC2State:
+    """Algorithm state (``sequential/state.py:8-95``): theta log-weights ``w`` (this rank's block), the filters' result,
+    the ESS history and the observations parsed so far (PMMH re-filters them)."""
+
+    def __init__(self, weights: torch.Tensor, filter_state: FilterResult, shard: Optional[Shard] = None):
+        self.w = weights
+        self.filter_state = filter_state
+        self.shard = shard
+        self.ess = [self._ess()]
+        self.parsed = []
+        self.current_iteration = 0
+
+    def global_weights(self) -> torch.Tensor:
+        return self.w if self.shard is None or self.shard.world == 1 else self.shard.all_gather(self.w)
+
+    def _ess(self) -> torch.Tensor:
+        return theta_ess(self.global_weights())
+
+    def append(self, filter_state):
+        """``w += ll_t`` and the new ESS (state.py:35-44).  Sharded: the all-gather of the increments happens here."""
+        self.w += filter_state.get_loglikelihood()
+        self.ess.append(self._ess())
+
+    def append_data(self, y: torch.Tensor):
+        self.parsed.append(y)
+
+    @property
+    def parsed_data(self) -> torch.Tensor:
+        return torch.stack(self.parsed, dim=0)
+
+    def normalized_weights(self) -> torch.Tensor:
+        return theta_normalize(self.global_weights())
+
+    def replicate(self, filter_state) -> "SMC2State":
+        other = SMC2State.__new__(SMC2State)
+        other.w, other.filter_state, other.shard = torch.zeros_like(self.w), filter_state, self.shard
+        other.ess, other.parsed, other.current_iteration = [], self.parsed, self.current_iteration
+        return other
+
+    def state_dict(self):
+        return {"filter_state": self.filter_state.state_dict(), "w": self.w, "current_iteration": self.current_iteration,
+                "ess": torch.stack(self.ess), "parsed_data": self.parsed_data if self.parsed else torch.tensor([])}
+
+
+def _take_filters(result: FilterResult, shard: Optional[Shard], indices: torch.Tensor, local_indices: torch.Tensor):
+    """``FilterResult.resample`` for a sharded set of filters: ``indices`` = the GLOBAL ancestors of this rank's
+    positions.  Single process: the reference's in-place gather (one ``pf_columns_gather`` per buffer)."""
+    if shard is None or shard.world == 1:
+        result.resample(local_indices)
+        return
+    # every per-filter quantity of the result travels as its block along the batch dimension
+    result._loglikelihood.copy_(shard.take(result._loglikelihood, indices))
+    log = result._moments
+    if log._buf is not None:
+        cols = log._live_columns()  # (1, B_local, rows * 2 dim)
+        log._buf = shard.take(cols[0], indices).reshape(log._buf.shape)
+    from .. import ops
+
+    for s in result._states:
+        s._ensure_moments()
+        ts = s.timeseries_state
+        x = ops.to_soa(ts.value, True, ts.value.dim() > 2)              # (D, B_local, N)
+        s["_x"] = ts.copy(values=ops.from_soa(shard.take(x, indices, dim=1).contiguous(), True, ts.value.dim() > 2))
+        s["_w"] = ops.from_cols(shard.take(ops.to_cols(s["_w"]), indices).contiguous(), True)
+        s["_prev_inds"] = ops.from_cols(shard.take(ops.to_cols(s["_prev_inds"]), indices).contiguous(), True)
+        for k in ("_ll", "_mean", "_var"):
+            s[k] = shard.take(s[k], indices)
+
+
+class ParticleMetropolisHastings:
+    """The rejuvenation kernel (``kernels/mh.py:15-140``)."""
+
+    def __init__(self, num_steps: int = 1, proposal=None, distance_threshold: Optional[float] = None,
+                 acceptance_threshold: float = 0.2, max_increases: int = 5, resampler: Callable = theta_systematic):
+        self._n_steps = num_steps
+        self._proposal = proposal or SymmetricMH()
+        self._dist_thresh = distance_threshold
+        self._is_adaptive = distance_threshold is not None
+        self._acceptance_threshold = acceptance_threshold
+        self._max_increases = max_increases
+        self._increases = 0
+        self._resampler = resampler
+        self.acceptance_history = []
+
+    def update(self, theta: ThetaParticles, filter_, state: SMC2State, generator=None) -> SMC2State:
+        shard = state.shard
+        sharded = shard is not None and shard.world > 1
+        # the same resampling on every rank: same (gathered) weights, same uniform (the generator is a CPU stream seeded
+        # identically everywhere and advanced in lock step - no broadcast needed)
+        W = state.normalized_weights()
+        u = torch.rand((), generator=generator)
+        indices = self._resampler(W, u)
+        mine = shard.slice(indices) if sharded else indices
+        dist = self._proposal.build(theta, state, filter_, state.parsed_data)
+
+        theta.resample(mine)
+        _take_filters(state.filter_state, shard, mine, indices)
+        shape = torch.Size([]) if any(dist.batch_shape) else filter_.batch_shape
+
+        old = theta.stack_parameters(constrained=False)
+        proposal_theta = theta.like()
+        proposal_filter = filter_.copy()
+        proposal_filter.initialize_model(proposal_theta)
+
+        previous_distance, acceptance_rate = 0.0, 0.0
+        for i in range(self._n_steps):
+            accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, state.parsed_data,
+                                shape, mutate_kernel=False, generator=generator)
+            rate = accepted.float().sum()
+            rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
+            acceptance_rate = (float(rate) + i * acceptance_rate) / (i + 1)  # the kernel's one host decision per move
+            self.acceptance_history.append(acceptance_rate)
+            if acceptance_rate < self._acceptance_threshold:  # abort early: more state particles are needed
+                return self._increase_states(filter_, state, theta)
+            if not self._is_adaptive:
+                continue
+            new = theta.stack_parameters(constrained=False)
+            distance = (new - old).abs().amax(dim=0).mean()
+            if sharded:
+                distance = shard.all_mean(distance * new.shape[0], new.shape[0])
+            distance = float(distance)
+            if abs(distance - previous_distance) <= self._dist_thresh * previous_distance:
+                break
+            previous_distance = distance
+
+        filter_.initialize_model(theta)
+        state.w.fill_(0.0)
+        return state
+
+    def _increase_states(self, filter_, state: SMC2State, theta: ThetaParticles) -> SMC2State:
+        """Doubles the number of state particles and re-filters the parsed data (``kernels/mh.py:110-140``)."""
+        self._increases += 1
+        if self._increases > self._max_increases:
+            raise TooManyIncreases(f"Configuration only allows {self._max_increases}!")
+        filter_.initialize_model(theta)
+        filter_.increase_particles(2.0)
+        filter_.set_batch_shape(filter_.batch_shape)
+        new_filter_state = filter_.batch_filter(state.parsed_data, bar=False)
+        weight = new_filter_state.loglikelihood - state.filter_state.loglikelihood
+        res = SMC2State(weight, new_filter_state, state.shard)
+        res.ess, res.parsed, res.current_iteration = state.ess, state.parsed, state.current_iteration
+        return res
+
+
+class SMC2:
+    """``SMC2(filter_, particles, threshold, kernel)`` (``smc2.py:11-65``).  ``filter_`` is built with a model *builder*
+    ``theta -> StateSpaceModel`` (the reference's ``context -> model``); ``priors`` maps parameter names to distributions.
+    ``particles`` is the TOTAL number of theta-particles; under a process group each rank holds its block."""
+
+    def __init__(self, filter_, particles: int, priors, threshold: float = 0.2, kernel=None, max_increases: int = 5,
+                 device="cuda", dtype=torch.float32, seed: int = 0, group=None, **kwargs):
+        self.filter = filter_
+        self.shard = Shard(particles, group)
+        self.particles = torch.Size([particles])
+        self.theta = ThetaParticles(priors, self.shard.local, device, dtype, self.shard)
+        self.filter.set_batch_shape(torch.Size([self.shard.local]))
+        self._threshold = threshold
+        self._kernel = ParticleMetropolisHastings(proposal=kernel, max_increases=max_increases, **kwargs)
+        self._gen = torch.Generator().manual_seed(seed)  # CPU: the same stream on every rank (theta-level draws)
+        self._seed = seed
+        if self.shard.world > 1 and hasattr(self.filter, "_seed"):
+            # the kernels key their Philox streams by the LOCAL column index: decorrelate the ranks' blocks
+            self.filter._seed = (self.filter._seed + 0xD1B54A32D192ED03 * self.shard.rank) & 0xFFFFFFFFFFFFFFFF
+
+    def initialize(self) -> SMC2State:
+        g = torch.Generator().manual_seed(self._seed * 7919 + 13)  # every rank draws all B and keeps its block
+        self.theta.initialize_parameters(g)
+        self.filter.initialize_model(self.theta)
+        init_state = self.filter.initialize()
+        w = torch.zeros(self.shard.local, device=init_state.get_loglikelihood().device, dtype=init_state.get_loglikelihood().dtype)
+        return SMC2State(w, self.filter.initialize_with_result(init_state), self.shard)
+
+    def step(self, y: torch.Tensor, state: SMC2State) -> SMC2State:
+        state = self._step(y, state)
+        state.current_iteration += 1
+        return state
+
+    def _step(self, y: torch.Tensor, state: SMC2State) -> SMC2State:
+        """One observation (``smc2.py:53-65``)."""
+        state.append_data(y)
+        filter_state = self.filter.filter(y, state.filter_state.latest_state, result=state.filter_state)
+        state.append(filter_state)
+        gw = state.global_weights()
+        # the reference's host branch (smc2.py:59-62): one small device -> host copy per observation
+        rejuvenate = bool((state.ess[-1] < self._threshold * self.particles[0]) | ~gw.isfinite().all())
+        if rejuvenate:
+            state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
+        return state
+
+    def fit(self, y: torch.Tensor) -> SMC2State:
+        state = self.initialize()
+        for yt in y:
+            state = self.step(yt, state)
+        return state
+
+    def posterior_mean(self, state: SMC2State) -> torch.Tensor:
+        """Weighted mean of the stacked (constrained) parameters over ALL theta-particles."""
+        vals, w = self.theta.stack_parameters(True), state.w
+        if self.shard.world > 1:
+            vals, w = self.shard.all_gather(vals), self.shard.all_gather(w)
+        return theta_normalize(w) @ vals

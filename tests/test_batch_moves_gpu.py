@@ -128,3 +128,65 @@ def test_smc2_example_recovers_the_parameters():
     b, s = out["mean"].tolist()
     assert abs(b - 0.8) < 0.15 and abs(s - 0.4) < 0.12, (b, s)
     assert torch.isfinite(out["loglikelihood"]).all()
+
+
+def _lg_data(t_len, seed=1, beta=0.8, sigma=0.4):
+    g = torch.Generator().manual_seed(seed)
+    x, ys = 0.0, []
+    for _ in range(t_len):
+        x = beta * x + sigma * torch.randn((), generator=g).item()
+        ys.append(x + 0.3 * torch.randn((), generator=g).item())
+    return torch.tensor(ys, device="cuda")
+
+
+def test_smc2_doubles_the_state_particles_when_acceptance_is_low():
+    """``ParticleMetropolisHastings._increase_states`` on the GPU filters (kernels/mh.py:110-140; the reference's
+    ``tests/inference/test_sequential.py:48-50``): 5 state particles give likelihood estimates too noisy to accept, the
+    kernel doubles them (``increase_particles``), re-filters the parsed data in one fused call and carries on."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "smc2_linear_gaussian.py")
+    spec = importlib.util.spec_from_file_location("smc2_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.smc2(_lg_data(40), n_theta=128, n_state=5, ess_frac=0.7, seed=5, acceptance_threshold=0.6, max_increases=12)
+    assert out["increases"] >= 1 and out["state_particles"] == 5 * 2 ** out["increases"]
+    assert torch.isfinite(out["mean"]).all() and torch.isfinite(out["loglikelihood"]).all()
+
+
+def test_run_pmmh_moves_chains_towards_the_posterior():
+    """``run_pmmh`` (mcmc/utils.py:14-77) as the step of B parallel PMMH chains on the GPU filters: all device-resident
+    (no host branch per move); after a few dozen moves the chains sit around the data-generating parameters."""
+    from torch.distributions import Uniform
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2State, SymmetricMH, ThetaParticles, run_pmmh
+    from pyfilter_amd.timeseries import models
+
+    y = _lg_data(120, seed=2)
+    b = 96
+
+    def build(theta):
+        t = lambda v: torch.tensor(v, device="cuda")  # noqa: E731
+        return ts.LinearStateSpaceModel(models.AR(t(0.0), theta["beta"], theta["sigma"]), (t(1.0), t(0.3)))
+
+    priors = {"beta": Uniform(0.0, 1.0), "sigma": Uniform(0.05, 1.0)}
+    theta = ThetaParticles(priors, b).initialize_parameters(torch.Generator().manual_seed(0))
+    prop_theta = theta.like()
+    filt = APF(build, 1024, proposal=proposals.LinearGaussianObservations(), seed=1)
+    filt.set_batch_shape(torch.Size([b]))
+    filt.initialize_model(theta)
+    prop_filt = filt.copy()
+    prop_filt.initialize_model(prop_theta)
+    state = SMC2State(torch.zeros(b, device="cuda"), filt.batch_filter(y, bar=False))
+    proposal = SymmetricMH()
+    rates = []
+    for _ in range(40):
+        kernel = proposal.build(theta, state, filt, y)
+        rates.append(run_pmmh(theta, state, proposal, kernel, prop_filt, prop_theta, y, filt.batch_shape).float().mean())
+    rate = torch.stack(rates).mean().item()
+    mean = theta.stack_parameters(True).mean(0).tolist()
+    assert 0.02 < rate < 0.9, rate
+    assert abs(mean[0] - 0.8) < 0.15 and abs(mean[1] - 0.4) < 0.12, mean
