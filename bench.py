@@ -11,7 +11,13 @@ inputs already resident in HBM.  Workloads (``--workload``):
                  1 048 576 particles, T = 250, systematic resampling
     sv_batch     configs[2]: Verhulst SV, APF + Bootstrap, 64 series x 65 536 particles
     lorenz_mn    configs[3]: Lorenz-63, SISR + Bootstrap, 4 194 304 particles, multinomial resampling
-    smc2_shard   configs[4]: one theta-shard of SMC^2 (1 024 / n_gpus filters x 8 192 particles, T = 500)
+    smc2_shard   configs[4]: one theta-shard of SMC^2 (1 024 / n_gpus filters x 8 192 particles, T = 500), the filtering
+                 pass alone (one batch_filter call per step of the bench, log-likelihoods all-gathered at its end)
+    smc2         configs[4] as the algorithm: ``pyfilter_amd.inference.SMC2`` on the OU model / priors of the reference's
+                 tests/inference/models.py - 1 024 theta-particles block-sharded over the ranks, one fused filter() move
+                 per observation, the theta-weights all-gathered EVERY observation (RCCL), ESS-triggered PMMH
+                 rejuvenations with filter-state redistribution.  Counts the T filtering moves of all theta-particles;
+                 rejuvenation work is overhead inside the timed region.
 
 Multi-GPU (``torchrun --nproc-per-node N bench.py --gpus N``): one process per GPU; the path does not shard a single
 filter (that would need a cross-GPU scan), so every rank runs its own independent filters (weak scaling) and the
@@ -40,7 +46,58 @@ WORKLOADS = {
     "sv_batch": dict(filter="apf", proposal="bootstrap", resampler="systematic", N=65536, B=64, D=1, T=1000),
     "lorenz_mn": dict(filter="sisr", proposal="bootstrap", resampler="multinomial", N=1 << 22, B=1, D=3, T=2000),
     "smc2_shard": dict(filter="apf", proposal="bootstrap", resampler="systematic", N=8192, B=1024, D=1, T=500),
+    "smc2": dict(filter="apf", proposal="lgo", resampler="systematic", N=8192, B=1024, D=1, T=500),
 }
+
+
+def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None):
+    """BASELINE configs[4] as the algorithm; returns (elapsed seconds for `steps` full fits, info)."""
+    import torch.distributed as dist
+    from torch.distributions import Exponential, LogNormal, Normal
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    t_len = t_override or w["T"]
+    g = torch.Generator().manual_seed(123)  # tests/inference/models.py:13-19: OU(0.025, 0, 0.05), y = x + 0.05 v
+    x, ys = 0.0, []
+    for _ in range(t_len):
+        x = x * math.exp(-0.025) + 0.05 * math.sqrt((1 - math.exp(-0.05)) / 0.05) * torch.randn((), generator=g).item()
+        ys.append(x + 0.05 * torch.randn((), generator=g).item())
+    y = torch.tensor(ys, dtype=dtype, device=device)
+    priors = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}  # models.py:29-31
+
+    def build(theta):
+        t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
+
+    def fit(seed):
+        filt = APF(build, w["N"], proposal=proposals.LinearGaussianObservations(), seed=2024 + seed)
+        alg = SMC2(filt, w["B"], priors, threshold=0.2, device=device, dtype=dtype, seed=seed)
+        state = alg.fit(y)
+        return alg, state
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(warmup):
+        fit(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        alg, state = fit(100 + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    info = {"rejuvenations": len(alg._kernel.acceptance_history), "particle_increases": alg._kernel._increases,
+            "state_particles_at_end": int(alg.filter.particles[0]), "posterior_mean": alg.posterior_mean(state).tolist(),
+            "theta_per_rank": alg.shard.local, "T": t_len}
+    return elapsed, info, state.global_weights()
+
 
 
 def build_problem(name, dtype, device, world, rank, t_override=None):
@@ -310,6 +367,29 @@ def main():
         ge.build()
     if world > 1:
         dist.barrier()
+
+    if args.workload == "smc2":
+        w = dict(WORKLOADS["smc2"])
+        elapsed, info, ll_all = run_smc2(w, dtype, device, world, rank, args.steps, args.warmup, args.T)
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = tmax.item()
+        if rank == 0:
+            value = w["N"] * w["B"] * info["T"] * args.steps / elapsed
+            print(json.dumps({
+                "metric": "particle-steps/sec (batch x particles x T), SMC^2 1024 theta x 8192 particles", "value": value,
+                "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": args.dtype, "data": "synthetic", "world_size": world,
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                "config": {"workload": f"smc2: SMC^2, APF + lgo, {w['B']} theta-particles (sharded {info['theta_per_rank']} per GPU) x "
+                                       f"{w['N']} state particles, T={info['T']}, per-observation all-gather of the theta-weights",
+                           "parallelism": f"theta-particles block-sharded over {world} GPU(s)", **info},
+                "roofline": None, "cpu_baseline": None}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     filt, y, w = build_problem(args.workload, dtype, device, world, rank, args.T)
 
