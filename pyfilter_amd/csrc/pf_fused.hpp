@@ -836,6 +836,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     ModelDesc md = a.md;
     if constexpr (!FAST && MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
     constexpr int WIN = StepShared<T, D, VEC>::WIN;
+    // the window of cdf entries a round stages: 256 * (VEC + V1).  The inverted-grid variant reads 256 entries beyond one
+    // per position (its window starts within tile / 64 of the first ancestor; a stretch of negligible weights walks on
+    // window by window); the searching variants stage two per position and binary-search them in LDS
+    constexpr int V1 = (MODE == 0) ? 1 : VEC;
+    constexpr int STAGED = PF_BLOCK * (VEC + V1);
     // the particles behind the cdf window are staged in LDS too when they are small (<= 8 B per particle), so the
     // ancestor gather is an LDS read instead of a second dependent global round trip
     constexpr bool XWIN = StepShared<T, D, VEC>::XWIN;
@@ -942,9 +947,10 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         }
 
         // ---- 1. issue the window loads (cdf, and the particles behind it) ------------------------------------------
+        // thread t stages entries ws + t * VEC + j (c0) and ws + 256 * VEC + t * V1 + j (c1): see inverse_grid_round
         const int ws = j0 - (j0 % VEC);
-        T c0[VEC], c1[VEC], xa[D][VEC], xb[D][VEC];
-        const int ja = ws + tid * VEC, jb = ws + (PF_BLOCK + tid) * VEC;
+        T c0[VEC], c1[V1], xa[D][VEC], xb[D][V1];
+        const int ja = ws + tid * VEC, jb = ws + PF_BLOCK * VEC + tid * V1;
         const bool ina = windowed && ja < N, inb = windowed && jb < N;
         if (ina) {
             if (VEC == 1) c0[0] = cdf_col[ja]; else load_vec<T, VEC>(cdf_col + ja, c0);
@@ -957,12 +963,12 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             }
         }
         if (inb) {
-            if (VEC == 1) c1[0] = cdf_col[jb]; else load_vec<T, VEC>(cdf_col + jb, c1);
+            if (V1 == 1) c1[0] = cdf_col[jb]; else load_vec<T, V1>(cdf_col + jb, c1);
             if (XWIN) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     const T* xc = x_in + ((int64_t)d * g.B + b) * g.N + jb;
-                    if (VEC == 1) xb[d][0] = xc[0]; else load_vec<T, VEC>(xc, xb[d]);
+                    if (V1 == 1) xb[d][0] = xc[0]; else load_vec<T, V1>(xc, xb[d]);
                 }
             }
         }
@@ -1007,7 +1013,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             // tile % VEC == 0).  kt0 is the tile of the window start (from the planning kernel, advanced as windows move
             // on); a window spans at most a few tiles, so compares replace the integer divisions.  Indices inside a column
             // fit 32 bits (N <= 2^30).
-            auto map_window = [&](int w0, int wja, int wjb, bool wina, bool winb, T (&m0)[VEC], T (&m1)[VEC]) {
+            auto map_window = [&](int w0, int wja, int wjb, bool wina, bool winb, T (&m0)[VEC], T (&m1)[V1]) {
                 const int te = g.tile_elems;
                 while ((unsigned)((kt0 + 1) * te) <= (unsigned)w0) ++kt0;  // uniform; only ever advances
                 int kta = kt0, ktb = kt0;
@@ -1024,17 +1030,18 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 const int la = (int)(ea < (unsigned)N ? ea : (unsigned)N) - 1;
                 const int lb = (int)(eb < (unsigned)N ? eb : (unsigned)N) - 1;
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
+                for (int j = 0; j < VEC; ++j)
                     m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
+#pragma unroll
+                for (int j = 0; j < V1; ++j)
                     m1[j] = winb ? cdf_from_local<T>(m1[j], tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
-                }
             };
             map_window(ws, ja, jb, ina, inb, c0, c1);
             if (XWIN) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     if (ina) { if (VEC == 1) xwin[d * WIN + tid] = xa[d][0]; else store_vec<T, VEC>(xwin + d * WIN + tid * VEC, xa[d]); }
-                    if (inb) { if (VEC == 1) xwin[d * WIN + PF_BLOCK + tid] = xb[d][0]; else store_vec<T, VEC>(xwin + d * WIN + (PF_BLOCK + tid) * VEC, xb[d]); }
+                    if (inb) { if (V1 == 1) xwin[d * WIN + PF_BLOCK * VEC + tid] = xb[d][0]; else store_vec<T, V1>(xwin + d * WIN + PF_BLOCK * VEC + tid * V1, xb[d]); }
                 }
             }
             if constexpr (MODE != 0) {
@@ -1059,14 +1066,14 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             } else {
                 // Systematic grid, inverted: no search (inverse_grid_round); positions the window does not reach take a
                 // binary search in the implied cdf
-                inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
-                                           [&](int it, T (&d0)[VEC], T (&d1)[VEC]) -> bool {  // the window after the staged one(s)
-                                               const int w0 = ws + it * WIN;
+                inverse_grid_round<T, VEC, V1>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                                           [&](int it, T (&d0)[VEC], T (&d1)[V1]) -> bool {  // the window after the staged one(s)
+                                               const int w0 = ws + it * STAGED;
                                                if (w0 >= N) return false;
-                                               const int wja = w0 + tid * VEC, wjb = w0 + (PF_BLOCK + tid) * VEC;
+                                               const int wja = w0 + tid * VEC, wjb = w0 + PF_BLOCK * VEC + tid * V1;
                                                const bool wina = wja < N, winb = wjb < N;
                                                if (wina) { if (VEC == 1) d0[0] = cdf_col[wja]; else load_vec<T, VEC>(cdf_col + wja, d0); }
-                                               if (winb) { if (VEC == 1) d1[0] = cdf_col[wjb]; else load_vec<T, VEC>(cdf_col + wjb, d1); }
+                                               if (winb) { if (V1 == 1) d1[0] = cdf_col[wjb]; else load_vec<T, V1>(cdf_col + wjb, d1); }
                                                map_window(w0, wja, wjb, wina, winb, d0, d1);
                                                return true;
                                            },
@@ -1136,7 +1143,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int q = idx[j] - ws;
-                    const bool in_lds = XWIN && windowed && q >= 0 && q < WIN;
+                    const bool in_lds = XWIN && windowed && q >= 0 && q < STAGED;
 #pragma unroll
                     for (int d = 0; d < D; ++d)
                         xr[j][d] = in_lds ? xwin[d * WIN + q] : x_in[((int64_t)d * g.B + b) * g.N + idx[j]];

@@ -191,48 +191,56 @@ __device__ __forceinline__ void grid_counts_local(const T (&c)[VEC], T u, T nT, 
 // the call (the first barrier inside orders that against the scatter); `fallback(i, from)` resolves positions the
 // window does not reach (from = first index not staged, or 0 when - defensively - no head precedes the position).
 // sh_cl: 2 * PF_NWAVES ints, sh_wm: PF_NWAVES ints.  Three barriers.
-#define PF_MAX_WINDOWS 8
-// `next_window(it, d0, d1)` stages the cdf entries [ws + it * WIN, ws + (it + 1) * WIN) the same way (returns false when
+#define PF_MAX_WINDOWS 12
+// `next_window(it, d0, d1)` stages the cdf entries [ws + it * S, ws + (it + 1) * S) the same way (returns false when
 // the column ends before them).  It is only called when the windows so far do not account for all RE positions - a
 // stretch of negligible weights - and lets the workgroup walk on window by window (up to PF_MAX_WINDOWS) before the
 // remaining positions fall back to per-position binary searches, whose ~20 dependent loads would set the duration of
 // the whole kernel.
-template <typename T, int VEC, typename NextWindow, typename Fallback>
-__device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (&c1)[VEC], int ws, int r0i, int RE, int N,
+// V1: entries per thread of the window's second part.  A window is S = 256 * (VEC + V1) entries: thread t holds entries
+// t * VEC + j (c0) and 256 * VEC + t * V1 + j (c1).  V1 = VEC is the 2 x 256 x VEC window of the stand-alone resampler;
+// the fused step kernel uses V1 = 1 - 256 * VEC positions rarely need more than 256 * (VEC + 1) entries when the window
+// starts within tile / 64 of the first ancestor, and every entry staged is an entry read, mapped and counted.
+template <typename T, int VEC, int V1, typename NextWindow, typename Fallback>
+__device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (&c1)[V1], int ws, int r0i, int RE, int N,
                                                    T ub, T nT, T rcN, bool pow2, int64_t i0, int* hd, int* sh_cl, int* sh_wm,
                                                    NextWindow&& next_window, Fallback&& fallback, int (&idx)[VEC]) {
-    constexpr int WIN = 2 * PF_BLOCK * VEC;
+    constexpr int S = PF_BLOCK * (VEC + V1);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int dump = RE + lane;
     // counts of one staged window -> heads; returns the number of positions accounted for so far
-    auto scatter_window = [&](const T (&w0)[VEC], const T (&w1)[VEC], int qbase, int covered_before) -> int {
-        int cn0[VEC], cn1[VEC];
+    auto scatter_window = [&](const T (&w0)[VEC], const T (&w1)[V1], int qbase, int covered_before) -> int {
+        int cn0[VEC], cn1[V1];
         if (pow2) {
             grid_counts_local<T, VEC, true>(w0, ub, nT, rcN, N, r0i, RE, cn0);
-            grid_counts_local<T, VEC, true>(w1, ub, nT, rcN, N, r0i, RE, cn1);
+            grid_counts_local<T, V1, true>(w1, ub, nT, rcN, N, r0i, RE, cn1);
         } else {
             grid_counts_local<T, VEC, false>(w0, ub, nT, rcN, N, r0i, RE, cn0);
-            grid_counts_local<T, VEC, false>(w1, ub, nT, rcN, N, r0i, RE, cn1);
+            grid_counts_local<T, V1, false>(w1, ub, nT, rcN, N, r0i, RE, cn1);
         }
         if (lane == 63) {
             sh_cl[wid] = cn0[VEC - 1];
-            sh_cl[PF_NWAVES + wid] = cn1[VEC - 1];
+            sh_cl[PF_NWAVES + wid] = cn1[V1 - 1];
         }
         __syncthreads();  // the wave-boundary counts are visible; `hd` is zeroed
-        int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[VEC - 1], 0);
+        int pv0 = wave_prev(cn0[VEC - 1], 0), pv1 = wave_prev(cn1[V1 - 1], 0);
         if (lane == 0) {
             pv0 = wid ? sh_cl[wid - 1] : covered_before;  // entries before the first window own no position of this round
-            pv1 = sh_cl[PF_NWAVES + wid - 1];              // wave 0: the first half's last entry
+            pv1 = sh_cl[PF_NWAVES + wid - 1];              // wave 0: the first part's last entry
         }
         const int covered = sh_cl[2 * PF_NWAVES - 1];
         // branch-free scatter: entries without offspring in this round write to a per-lane dump slot behind the RE heads
         // (exec-mask juggling per conditional store costs ~5 scalar instructions, a v_cndmask one vector instruction)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const int lo0 = j ? cn0[j - 1] : pv0, lo1 = j ? cn1[j - 1] : pv1;
+            const int lo0 = j ? cn0[j - 1] : pv0;
             hd[(cn0[j] > lo0) ? lo0 : dump] = qbase + tid * VEC + j + 1;
-            hd[(cn1[j] > lo1) ? lo1 : dump] = qbase + (PF_BLOCK + tid) * VEC + j + 1;
+        }
+#pragma unroll
+        for (int j = 0; j < V1; ++j) {
+            const int lo1 = j ? cn1[j - 1] : pv1;
+            hd[(cn1[j] > lo1) ? lo1 : dump] = qbase + PF_BLOCK * VEC + tid * V1 + j + 1;
         }
         return covered;
     };
@@ -240,9 +248,9 @@ __device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (
     int windows = 1;
     for (; windows < PF_MAX_WINDOWS && covered < RE; ++windows) {  // uniform: `covered` comes from LDS
         __syncthreads();                                            // everyone has read sh_cl
-        T d0[VEC], d1[VEC];
+        T d0[VEC], d1[V1];
         if (!next_window(windows, d0, d1)) break;
-        covered = scatter_window(d0, d1, windows * WIN, covered);
+        covered = scatter_window(d0, d1, windows * S, covered);
     }
     __syncthreads();
     int h[VEC];
@@ -255,7 +263,7 @@ __device__ __forceinline__ void inverse_grid_round(const T (&c0)[VEC], const T (
     int carry = wave_prev(inc, 0);
 #pragma unroll
     for (int w = 0; w < PF_NWAVES - 1; ++w) carry = (w < wid) ? imax(carry, sh_wm[w]) : carry;
-    const int64_t beyond = (int64_t)ws + (int64_t)windows * WIN;
+    const int64_t beyond = (int64_t)ws + (int64_t)windows * S;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int64_t i = i0 + j;
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
                     if (!(jb < N)) c1[j] = Lim<T>::inf();
                 }
                 int res[VEC];
-                inverse_grid_round<T, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                inverse_grid_round<T, VEC, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
                                            [&](int it, T (&d0)[VEC], T (&d1)[VEC]) -> bool {
                                                const int w0 = ws + it * SearchWin<T, VEC>::WIN;
                                                if (w0 >= N) return false;
