@@ -670,12 +670,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_book(FusedArgs<T> a) {
 #ifndef PF_WAVES_D1_GENERIC
 #define PF_WAVES_D1_GENERIC 4
 #endif
+#ifndef PF_WAVES_DN_A
+#define PF_WAVES_DN_A 3  // (4 waves = 128 VGPRs spill 128 B / lane once the prologue lives in this kernel: measured slower)
+#endif
 // resident waves per SIMD the register allocation is tuned for (float; measured per variant, tools/kbench.py)
 template <typename T, int D, int MODE, int PROP, bool FAST, int SPEC> struct StepWaves {
     static constexpr int value = sizeof(T) != 4 ? 1
                                  : D == 1     ? (FAST ? 4 : PF_WAVES_D1_GENERIC)
                                  : PROP == PF_PROP_LGO ? 2
-                                 : (MODE == 1 || SPEC == 2) ? 4   // (a handful of spills, more than repaid by the fourth wave)
+                                 : (MODE == 1 || SPEC == 2) ? PF_WAVES_DN_A
                                  : 3;
 };
 // SPEC: the per-launch flags as compile-time constants for the two steady states of a run - known on the host when the

@@ -101,6 +101,10 @@ class ParticleFilterCorrection(Correction):
         self["_mean"] = self["_mean"][indices]
         self["_var"] = self["_var"][indices]
 
+    def predict_path(self, model: StateSpaceModel, num_steps: int):
+        """Forecast ``num_steps`` ahead from this state's particles (``particle/state.py:173-174``)."""
+        return model.sample_states(num_steps, x_0=self.timeseries_state)
+
     def _gather_moments(self, indices: Tensor):
         """The part of ``FilterResult.resample(entire_history=True)`` that reaches into a recorded state (see there)."""
         self._ensure_moments()

@@ -165,6 +165,17 @@ class AffineEulerMaruyama(AffineProcess):
         super().__init__(_ms, parameters, increment_distribution, initial_kernel, initial_parameters)
 
 
+class StateSpacePath:
+    """Sampled hidden states and observations (the slice of ``stochproc.timeseries.result.StateSpacePath`` that
+    ``ParticleFilterCorrection.predict_path`` exposes): ``get_paths() -> (x (steps, *shape), y (steps, *shape))``."""
+
+    def __init__(self, xs, ys):
+        self._x, self._y = torch.stack(xs, 0), torch.stack(ys, 0)
+
+    def get_paths(self):
+        return self._x, self._y
+
+
 class StateSpaceModel:
     """Hidden process + observation density builder ``f(x, *parameters) -> Distribution``."""
 
@@ -188,6 +199,18 @@ class StateSpaceModel:
     @property
     def n_dim(self) -> int:
         return len(self.event_shape)
+
+    def sample_states(self, steps: int, samples=torch.Size([]), x_0: Optional[TimeseriesState] = None) -> StateSpacePath:
+        """``steps`` moves of the hidden process from ``x_0`` (default: an initial sample) with an observation drawn at
+        every one of them - forecasting from a filter state (``particle/state.py:173-174``).  Off the hot path: plain
+        torch draws on the model's device."""
+        x = x_0 if x_0 is not None else self.hidden.initial_sample(samples)
+        xs, ys = [], []
+        for _ in range(steps):
+            x = self.hidden.propagate(x)
+            xs.append(x.value)
+            ys.append(self.build_density(x).sample())
+        return StateSpacePath(xs, ys)
 
     def to(self, device):
         self.hidden.to(device)

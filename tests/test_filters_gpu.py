@@ -726,3 +726,23 @@ def test_repeated_runs_and_copies_draw_fresh_numbers(route, monkeypatch):
         assert (a - other).abs().max().item() < 0.5
     x1, x2 = f.initialize().timeseries_state.value, f.initialize().timeseries_state.value
     assert not torch.equal(x1, x2)
+
+
+@pytest.mark.parametrize("name", ["sine_apf_lgo", "lorenz_sisr_boot"])
+def test_predict_path_from_the_latest_state(name):
+    """``latest_state.predict_path(model, steps)`` (the reference's tests/filters/test_particle.py:117-134): paths of the
+    hidden state and the observations, ``(steps, N, [B], [D])`` / ``(steps, N, [B], [O])``, starting at the filter's
+    particles."""
+    case = next(c for c in CASES if c["name"] == name)
+    g = load_golden(name, "f64")
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    res = filt.batch_filter(g["y"].cuda(), bar=False)
+    path = res.latest_state.predict_path(filt.ssm, 6)
+    x, y = path.get_paths()
+    assert x.shape == torch.Size([6, *filt.particles, *filt.ssm.hidden.event_shape])
+    assert y.shape[:3] == x.shape[:3] and torch.isfinite(x).all() and torch.isfinite(y).all()
+    # one move from the particles: the one-step mean of the model, up to its noise
+    spec = build_spec(case, torch.float64)
+    loc, scale = cpu_ref.M.mean_scale(spec, res.latest_state.timeseries_state.value.cpu())
+    zscore = (x[0].cpu() - loc) / (scale * spec.inc_scale)
+    assert abs(zscore.mean().item()) < 0.2 and abs(zscore.std().item() - 1.0) < 0.2
