@@ -200,9 +200,9 @@ def host_info():
         pass
     try:  # copy ceiling: out-of-place copy of 1 GiB of float32 with torch's intra-op threads (read + write bytes / time)
         src = torch.empty(1 << 28, dtype=torch.float32).fill_(1.0)
-        dst = torch.empty_like(src)
+        dst = torch.empty_like(src).fill_(0.0)  # (pages touched before the timed copies)
         best = None
-        for _ in range(3):
+        for _ in range(6):
             t0 = time.perf_counter()
             dst.copy_(src)
             dt = time.perf_counter() - t0
