@@ -153,7 +153,7 @@ int pf_initial_sample(const double* m0, const double* s0, const void* z, uint64_
 
 /* ------------------------------------------------------------------------------------------------------------ *
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and
- * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; two kernels per step.
+ * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; one kernel per step.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct pf_filter_args {
     pf_model model;
@@ -200,25 +200,25 @@ typedef struct pf_filter_args {
                    * reference carries prev_inds (sisr.py:25-26). */
 } pf_filter_args;
 
-/* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; two kernel launches per
- * step (plan: tile-prefix table + window starts + per-column bookkeeping; step: ancestors + gather + propagate + weight
- * + the next state's partials and tile-local scans) plus one reduce launch for the incoming state.
+/* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; ONE kernel launch per step
+ * (prologue: the column's tile-prefix table + window start from the previous launch's per-tile partials; body: ancestors
+ * + gather + propagate + weight + the next state's partials and tile-local scans; one workgroup per column keeps the
+ * books: moments row, log-likelihood increment) plus one reduce launch for the incoming state.
  * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps). */
 int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
 
 /* hipGraph variant: captures the launch sequence pf_filter_run would issue (every pointer, the step flags and the
  * observation offsets are baked into the kernel nodes) and returns an opaque handle OWNED BY THE CALLER; replaying it
- * costs one host call instead of 2 T launches (an eager launch costs the host ~5 us, a graph kernel node ~1.5 us).
+ * costs one host call instead of T launches (an eager launch costs the host ~5 us, a graph kernel node ~1.5 us).
  * The buffers named in `args` must stay alive and in place for the handle's lifetime; `y`'s contents may change. */
 int pf_filter_graph_create(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                            void** handle);
 int pf_filter_graph_launch(void* handle, void* stream);
 int pf_filter_graph_destroy(void* handle);
 
-/* Measurement variant of pf_filter_run (synchronises the stream).  kernel_ms[0] = in-sequence duration of one step
- * (HIP events on `stream` around the whole step loop / n_steps); kernel_ms[1], kernel_ms[2] = that time apportioned to
- * the planning kernel and the step kernel by the ratio of their single-kernel replay chains (the last
- * step's launches are idempotent).  Same results as pf_filter_run; not for throughput numbers. */
+/* Measurement variant of pf_filter_run (synchronises the stream).  kernel_ms[0] = kernel_ms[2] = in-sequence duration of
+ * one step = of its one kernel (HIP events on `stream` around the whole step loop / n_steps); kernel_ms[1] = 0 (the
+ * planning kernel of earlier versions).  Same results as pf_filter_run; not for throughput numbers. */
 int pf_filter_run_timed(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream,
                         float* kernel_ms);
 

@@ -263,7 +263,7 @@ template <typename T, int D> struct PartialAcc {
 
 // cdf value of particle i from its tile-local scan L_i: P_k + f_k * L_i in fp64, clamped to the next tile's prefix,
 // rounded once to T; a tile's last element is pinned to T(P_{k+1}) and the column's last one to 1 (resampling.py:49).
-// The planning kernel (j0 search) and the step kernel (window staging) both go through this one function.
+// The prologue's probe (j0 search) and the body (window staging) both go through this one function.
 template <typename T>
 __device__ __forceinline__ T cdf_from_local(T L, double Pk, double fk, double Pnext, bool tile_last, bool col_last) {
     double c = Pk + fk * (double)L;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_book(FusedArgs<T> a) {
 //         ancestors by searching the staged window;
 // MODE 2: systematic with the searching ancestor stage - float grids beyond 2^22 positions, where the closed form of
 //         MODE 0 is not exact.  Compile-time so that no variant carries another's registers.  All three read the cdf as
-//         tile-local scans + the planning kernel's table.
+//         tile-local scans + the prologue's table.
 // PROP: the proposal as a compile-time constant (0 Bootstrap, 1 LinearGaussianObservations) or -1 = run-time switch.
 // For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
 // FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         int idx[VEC];
         if (windowed) {
             // local scans -> cdf values of one staged window [w0, w0 + WIN) (a staged vector never straddles a tile:
-            // tile % VEC == 0).  kt0 is the tile of the window start (from the planning kernel, advanced as windows move
+            // tile % VEC == 0).  kt0 is the tile of the window start (from the prologue, advanced as windows move
             // on); a window spans at most a few tiles, so compares replace the integer divisions.  Indices inside a column
             // fit 32 bits (N <= 2^30).
             auto map_window = [&](int w0, int wja, int wjb, bool wina, bool winb, T (&m0)[VEC], T (&m1)[V1]) {

@@ -3,7 +3,7 @@
 A proposal evaluates the model in one of two ways:
 
 * the model has a built-in kernel kind (``ssm.kernel_kind``): one HIP elementwise kernel
-  (``pf_sample_and_weight`` / ``pf_pre_weight``) - and, inside ``batch_filter``, the fused three-kernel step;
+  (``pf_sample_and_weight`` / ``pf_pre_weight``) - and, inside ``batch_filter``, the fused one-kernel step;
 * otherwise the reference's own route: the user's callables evaluated with PyTorch-ROCm ops.
 """
 from abc import ABC

@@ -9,7 +9,7 @@ event_shape / parameters / observe_every_step``.
 Two ways to define a model:
 
 * **built-in kinds** (``pyfilter_amd.timeseries.models``): closed-form processes whose arithmetic lives in the HIP
-  kernels (``csrc/pf_models.hpp``) - these run the fused three-kernel step;
+  kernels (``csrc/pf_models.hpp``) - these run the fused step (one HIP kernel per time step);
 * **user callables** (exactly the reference's way, README.md:44-67): ``mean_scale`` / observation builders are python
   callables evaluated with PyTorch-ROCm ops on the device; normalise / scan / search / gather / moments still run in
   the HIP kernels.

@@ -1,6 +1,6 @@
 """
 Built-in model kinds: processes whose per-particle arithmetic is implemented in ``csrc/pf_models.hpp`` so the whole
-SISR/APF step runs in three fused HIP kernels.  Each class is *also* a regular :class:`AffineProcess` (its
+SISR/APF step runs in one fused HIP kernel.  Each class is *also* a regular :class:`AffineProcess` (its
 ``mean_scale`` is available as PyTorch ops), so a built-in process can be combined with a user-defined observation
 density on the generic path.
 

@@ -553,7 +553,7 @@ def test_tiny_particle_counts(n, b, filt_name, prop):
 @pytest.mark.parametrize("n,b", [(1 << 22, 1), (65536 + 4, 3)])
 def test_multinomial_many_tiles_against_kalman(n, b):
     """Multinomial resampling across many tiles / several rounds per tile (the sorted positions are rebuilt per round
-    from Exp(1) spacings whose tile sums travel through the planning kernel's second prefix table): with this many
+    from Exp(1) spacings whose tile sums travel through the prologue's second prefix table): with this many
     particles the filter must sit on the exact Kalman filter - a misplaced tile offset would show as a bias far above
     the Monte-Carlo error - and the ancestors must come out sorted."""
     from pyfilter_amd import resampling, timeseries as ts
