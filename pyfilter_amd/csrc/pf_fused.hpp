@@ -494,10 +494,11 @@ __device__ __forceinline__ ColSums column_sums(const ColPartials<WITH_Q, NX>& in
     const double (&sloc)[PF_COMBINE_ITERS] = in.s;
     const double (&qloc)[PF_COMBINE_ITERS] = in.q;
     const double (&xloc)[NX ? NX : 1][PF_COMBINE_ITERS] = in.x;
-    double mymax = -__builtin_huge_val();
+    // (the maxima are values of T carried as doubles: reduced in T - half the cross-lane traffic for float filters)
+    T mymax_t = -Lim<T>::inf();
 #pragma unroll
-    for (int q = 0; q < PF_COMBINE_ITERS; ++q) mymax = mloc[q] > mymax ? mloc[q] : mymax;
-    const double MR = block_max<double>(mymax, redm);
+    for (int q = 0; q < PF_COMBINE_ITERS; ++q) mymax_t = (T)mloc[q] > mymax_t ? (T)mloc[q] : mymax_t;
+    const double MR = (double)block_max<T>(mymax_t, reinterpret_cast<T*>(redm));
     double incl[PF_COMBINE_ITERS], ef[PF_COMBINE_ITERS], run = 0.0, qs = 0.0;
     double xs[NX ? NX : 1];
 #pragma unroll
@@ -540,13 +541,14 @@ __device__ __forceinline__ ColSums column_sums(const ColPartials<WITH_Q, NX>& in
     }
     if constexpr (TABLE) {
         const double excl = wave_off + incl_w - run;
+        const double inv_tot = 1.0 / tot;  // one division per thread, not 2 IT (an fp64 division is ~30 instructions)
         if (threadIdx.x == 0) ptl[0] = 0.0;
 #pragma unroll
         for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
             const int t = threadIdx.x * IT + q;
             if (q < IT && t < tiles) {
-                ptl[t + 1] = (excl + incl[q]) / tot;
-                ftl[t] = ef[q] / tot;
+                ptl[t + 1] = (excl + incl[q]) * inv_tot;
+                ftl[t] = ef[q] * inv_tot;
             }
         }
         __syncthreads();
