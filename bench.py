@@ -100,7 +100,7 @@ def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None):
 
 
 
-def build_problem(name, dtype, device, world, rank, t_override=None):
+def build_problem(name, dtype, device, world, rank, t_override=None, n_override=None):
     from pyfilter_amd import resampling, timeseries as ts
     from pyfilter_amd.filters.particle import APF, SISR, proposals
     from pyfilter_amd.timeseries import models
@@ -108,6 +108,8 @@ def build_problem(name, dtype, device, world, rank, t_override=None):
     w = dict(WORKLOADS[name])
     if t_override:
         w["T"] = t_override
+    if n_override:
+        w["N"] = n_override
     t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
     gen = torch.Generator().manual_seed(123 + rank)
     b = w["B"]
@@ -294,7 +296,7 @@ def cpu_baseline(name, w, seconds_budget=12.0):
     }
 
 
-def pmc_traffic(kernel_substr, workload, dtype_name, t_len=20):
+def pmc_traffic(kernel_substr, workload, dtype_name, t_len=20, n_override=None):
     """HBM bytes per launch of one kernel from rocprofv3 PMC counters, collected as MI355X_MICROARCH.md (HBM section)
     prescribes: FETCH_SIZE and WRITE_SIZE in *separate* --pmc passes (TCC slots), kernel-trace only; both are in KiB;
     on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so it is doubled
@@ -312,7 +314,7 @@ def pmc_traffic(kernel_substr, workload, dtype_name, t_len=20):
         out = tempfile.mkdtemp(prefix="pf_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--_inner", "--workload", workload, "--dtype", dtype_name,
-               "--T", str(t_len), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+               "--T", str(t_len), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"] + (["--N", str(n_override)] if n_override else [])
         env = dict(os.environ, TMPDIR="/tmp", PF_NO_GRAPH="1")
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -344,6 +346,7 @@ def main():
     ap.add_argument("--workload", default="apf_lgo_1m", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--T", type=int, default=None, help="override the number of observations")
+    ap.add_argument("--N", type=int, default=None, help="override the number of particles (development: shape studies)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--_inner", action="store_true", help=argparse.SUPPRESS)
@@ -391,7 +394,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    filt, y, w = build_problem(args.workload, dtype, device, world, rank, args.T)
+    filt, y, w = build_problem(args.workload, dtype, device, world, rank, args.T, args.N)
 
     def barrier():
         torch.cuda.synchronize()
@@ -456,7 +459,7 @@ def main():
     dom = "step"
 
     if rank == 0 and world == 1 and not args.no_traffic:
-        tr = pmc_traffic(kname[dom], args.workload, args.dtype)
+        tr = pmc_traffic(kname[dom], args.workload, args.dtype, n_override=args.N)
         if tr is not None:
             roofline["traffic"] = tr["bytes_per_launch"]
             roofline["traffic_detail"] = tr
