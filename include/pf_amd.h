@@ -250,7 +250,7 @@ int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_steps, void* 
                           int dtype, void* stream);
 
 /* The step-kernel instantiations the calling thread's most recent pf_filter_run launches selected, oldest first:
- * out[i] = { step, sizeof(T), D, VEC, MODE, PROP, FAST, SPEC, MK } (9 int32 per record, at most 64 are kept).
+ * out[i] = { step, sizeof(T), D, VEC, MODE, PROP, FAST, SPEC, MK, MULTI } (10 int32 per record, at most 64 are kept).
  * Returns the number of records written (>= 0) or a negative PF_E* code. */
 int pf_debug_launch_trace(int32_t* out, int max_records);
 

@@ -77,6 +77,8 @@ template <typename T> struct FusedArgs {
                       // cleared - by the bookkeeper of launch s + 1: three launches may touch three different slots)
     T* cpack;         // [B][PK_N] the run's closed-form constants of every column (scalar fast path; see FastCol)
     double* piv0;     // [B][PF_MAXD] pivot of the weighted moments of the run's first two states (a particle of the first)
+    double* ctab;     // [2][B][tiles * R * 4][2] per-chunk (C, g) of the chunk-local scans (see ChunkScan); double buffered by
+    int64_t ctab_stride;  // state parity like the scans themselves
     int t0;           // first step of this run: the partials of states t0, t0 + 1 are taken about piv0, those of a later
                       // state q about the mean of state q - 2 (row q - 2 of `means`: written two launches earlier)
     // per launch
@@ -93,6 +95,12 @@ template <typename T> struct FusedArgs {
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
     __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
+    __device__ __forceinline__ const double* ctab_r(int b) const {
+        return ctab + (int64_t)(step & 1) * ctab_stride + (int64_t)b * g.tiles * g.rounds_per_tile * PF_NWAVES * 2;
+    }
+    __device__ __forceinline__ double* ctab_w(int state, int b) const {
+        return ctab + (int64_t)(state & 1) * ctab_stride + (int64_t)b * g.tiles * g.rounds_per_tile * PF_NWAVES * 2;
+    }
     // pivot of the weighted-moment partials of state q (see t0), component d of column b
     template <int D> __device__ __forceinline__ T pivot(int q, int b, int d) const {
         return (q - 2 >= t0) ? means[((int64_t)(q - 2) * g.B + b) * D + d] : (T)piv0[(int64_t)b * PF_MAXD + d];
@@ -261,12 +269,31 @@ template <typename T, int D> struct PartialAcc {
     }
 };
 
-// cdf value of particle i from its tile-local scan L_i: P_k + f_k * L_i in fp64, clamped to the next tile's prefix,
-// rounded once to T; a tile's last element is pinned to T(P_{k+1}) and the column's last one to 1 (resampling.py:49).
-// The prologue's probe (j0 search) and the body (window staging) both go through this one function.
+// The scan of a tile's resampling weights is stored CHUNK by chunk (a chunk = the 64 * VEC consecutive particles one wave
+// owns in a round): L_i = inclusive scan inside the chunk of exp(rw_i - m_c), m_c the chunk's own maximum - produced by
+// wave-level operations alone (no workgroup barrier, no second pass over the tile once its maximum is known; for
+// multi-round tiles that second pass used to re-read the whole state).  A chunk's values become tile-level through
+// (C_c, g_c) = (sum_{c' < c} t_c' g_c', exp(m_c - M)), written once per tile after its last round (finalize_chunk_table):
+//   cdf_i = T(min(P_k + f_k (C_c + g_c L_i), P_{k+1})),
+// fp64, rounded once to T; a tile's last element is pinned to T(P_{k+1}) and the column's last one to 1
+// (resampling.py:49).  The prologue's probe, the body's window staging and the fallback search all go through this one
+// function.  Chunk-local sums are <= 64 VEC, so the stored T values carry their full precision.
+#define PF_LDS_CHUNKS PF_WAVE  // tiles of up to this many chunks (16 rounds) keep their raw chunk records in LDS
+// Single-round tiles know their maximum before anything is stored: their scans are tile-level (one workgroup scan of
+// the exponentials the partial accumulator holds anyway), i.e. (C, g) = (0, 1) everywhere - the kernels of that geometry
+// (MULTI = false) neither write nor read a chunk table.
 template <typename T>
 __device__ __forceinline__ T cdf_from_local(T L, double Pk, double fk, double Pnext, bool tile_last, bool col_last) {
     double c = Pk + fk * (double)L;
+    if (c > Pnext) c = Pnext;
+    T r = (T)c;
+    if (tile_last) r = col_last ? T(1) : (T)Pnext;
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ T cdf_from_local(T L, double C, double gq, double Pk, double fk, double Pnext, bool tile_last,
+                                            bool col_last) {
+    double c = Pk + fk * (C + gq * (double)L);
     if (c > Pnext) c = Pnext;
     T r = (T)c;
     if (tile_last) r = col_last ? T(1) : (T)Pnext;
@@ -276,6 +303,8 @@ template <typename T> struct CdfView {  // searches in the implied cdf of one co
     const T* L;
     const double* ptab;  // this column's (tiles + 1) prefixes
     const double* ftab;
+    const double* ct;    // this column's per-chunk (C, g) pairs; nullptr for single-round tiles
+    int chunk_elems;
     int N;
     int tile_elems;
     int tiles;
@@ -297,7 +326,14 @@ template <typename T> struct CdfView {  // searches in the implied cdf of one co
             const double Pk = ptab[kt], fk = ftab[kt], Pn = ptab[kt + 1];
             while (a < b) {
                 const int mid = (a + b) >> 1;
-                if (cdf_from_local<T>(L[mid], Pk, fk, Pn, mid == end - 1, mid == N - 1) < p) a = mid + 1; else b = mid;
+                T cv;
+                if (ct) {
+                    const double* cg = ct + 2 * (mid / chunk_elems);
+                    cv = cdf_from_local<T>(L[mid], cg[0], cg[1], Pk, fk, Pn, mid == end - 1, mid == N - 1);
+                } else {
+                    cv = cdf_from_local<T>(L[mid], Pk, fk, Pn, mid == end - 1, mid == N - 1);
+                }
+                if (cv < p) a = mid + 1; else b = mid;
             }
             if (a < end) return a;
         }
@@ -305,67 +341,80 @@ template <typename T> struct CdfView {  // searches in the implied cdf of one co
     }
 };
 
-// Tile-local inclusive scan of the resampling weights of the state in slot `slot`, relative to the tile maximum MR:
-// L_i = sum_{j <= i, j in tile} exp(rw_j - MR), fp64 accumulation, stored as T in `a.cdf`.  rw = logw (SISR) or
-// sanitize(pre_weight(x, y) + logw) (APF, `two`; `next` selects the observation the pre-weight is taken against).
-// Single-round tiles pass exp(rw - thread max) and the thread's factor exp(thread max - MR) in registers (have_regs:
-// PartialAcc::push_round / finish computed them already), otherwise the state is re-read (L2-hot).
-// `prew(xj)`: the first-stage weight of one particle (only evaluated on the re-read path of APF steps).
-template <typename T, int D, int VEC, typename PreW>
-__device__ __forceinline__ void tile_local_scan(const FusedArgs<T>& a, int b, int k, int slot, T* l_out, bool two, T MR,
-                                                PreW&& prew, bool have_regs, const T (&e_reg)[VEC], T f_reg, double* reds) {
-    const Geom& g = a.g;
-    const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
-    const T* x_base = a.x[slot];
-    T* l_col = l_out + (int64_t)b * g.N;
-    const int64_t base = (int64_t)k * g.tile_elems;
+// One round of the chunk-local scan (see cdf_from_local): rw[j] the thread's VEC resampling log-weights (-inf beyond the
+// column), executed by every lane of every wave (wave-level reductions).  Stores L_i and leaves the chunk's raw record
+// (m_c, t_c) in LDS (`lds_rec`, tiles of <= PF_LDS_CHUNKS chunks) or in the tile's slice of the chunk table (`raw`).
+template <typename T, int VEC>
+__device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T* __restrict__ l_dst, int chunk,
+                                                 double* lds_rec, double* raw) {
+    const int lane = threadIdx.x & 63;
+    T mt = rw[0];
+#pragma unroll
+    for (int j = 1; j < VEC; ++j) mt = rw[j] > mt ? rw[j] : mt;
+    const T mc = wave_max<T>(mt);
+    double incl[VEC], local = 0.0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        local += (rw[j] == -Lim<T>::inf()) ? 0.0 : (double)pf_exp_w(rw[j] - mc);
+        incl[j] = local;
+    }
+    const double iw = wave_scan_incl(local, lane);
+    if (on) {
+        const double excl = iw - local;
+        T outv[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + incl[j]);
+        if (VEC == 1) l_dst[0] = outv[0]; else store_vec<T, VEC>(l_dst, outv);
+    }
+    if (lane == 63) {
+        double* rec = lds_rec ? lds_rec + 2 * chunk : raw + 2 * chunk;
+        rec[0] = (double)mc;
+        rec[1] = iw;
+    }
+}
+// After a tile's last round: raw chunk records (m_c, t_c) -> (C_c, g_c) in the chunk table, and the tile's (max, sum)
+// of the resampling weights.  Tiles of <= 64 chunks: one barrier (the records), then wave-level arithmetic (every wave
+// redundantly, wave 0 writes).  `ct_tile`: the tile's slice of the chunk table (also holds the raw records of larger tiles).
+template <typename T>
+__device__ __forceinline__ void finalize_chunk_table(double* ct_tile, const double* lds_rec, int nchunks, double* reds,
+                                                     T* redm, double& M_out, double& S_out) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();  // the last round's records are in place
+    if (lds_rec) {
+        const bool valid = lane < nchunks;
+        const double mq = valid ? lds_rec[2 * lane] : -__builtin_huge_val();
+        const double tq = valid ? lds_rec[2 * lane + 1] : 0.0;
+        const double M = (double)wave_max<T>((T)mq);
+        const double gq = exp_diff_t<T>(mq, M);
+        const double v = tq * gq;
+        const double iw = wave_scan_incl(v, lane);
+        if (wid == 0 && valid) {
+            ct_tile[2 * lane] = iw - v;
+            ct_tile[2 * lane + 1] = gq;
+        }
+        M_out = M;
+        S_out = lane_get(iw, 63);
+        return;
+    }
+    T mx = -Lim<T>::inf();
+    for (int q = threadIdx.x; q < nchunks; q += PF_BLOCK) mx = (T)ct_tile[2 * q] > mx ? (T)ct_tile[2 * q] : mx;
+    const double M = (double)block_max<T>(mx, redm);
     double carry = 0.0;
-    for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t r0 = base + (int64_t)r * g.round_elems;
-        if (r0 >= g.N) break;
-        const int64_t i0 = r0 + threadIdx.x * VEC;
-        const bool on = i0 < g.N;
-        T rw[VEC];
-        if (on) {
-            if (!have_regs) {
-                T lw[VEC];
-                if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
-                if (two) {
-                    T xv[D][VEC];
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
-                        if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        T xj[D];
-#pragma unroll
-                        for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-                        rw[j] = sanitize_logw(prew(xj) + lw[j]);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) rw[j] = lw[j];
-                }
-            }
-        }
-        double e[VEC], local = 0.0, total;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            if (have_regs) local += on ? (double)(e_reg[j] * f_reg) : 0.0;
-            else local += (on && rw[j] != -Lim<T>::inf()) ? (double)pf_exp_w(rw[j] - MR) : 0.0;
-            e[j] = local;
-        }
-        const double excl = block_scan_excl(local, reds, total);
-        if (on) {
-            T outv[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) outv[j] = (T)(carry + excl + e[j]);
-            if (VEC == 1) l_col[i0] = outv[0]; else store_vec<T, VEC>(l_col + i0, outv);
+    for (int q0 = 0; q0 < nchunks; q0 += PF_BLOCK) {
+        const int q = q0 + threadIdx.x;
+        const bool valid = q < nchunks;
+        const double gq = exp_diff_t<T>(valid ? ct_tile[2 * q] : -__builtin_huge_val(), M);
+        const double v = valid ? ct_tile[2 * q + 1] * gq : 0.0;
+        double total;
+        const double excl = block_scan_excl(v, reds, total);
+        if (valid) {
+            ct_tile[2 * q] = carry + excl;
+            ct_tile[2 * q + 1] = gq;
         }
         carry += total;
     }
+    M_out = M;
+    S_out = carry;
 }
 
 // partials of the state in slot (step & 1) - only needed for the first state of a run
@@ -406,46 +455,78 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     }
     PartialAcc<T, D> acc;
     acc.init();
+    __shared__ double reds[PF_NWAVES];
+    __shared__ double crec[2 * PF_LDS_CHUNKS];
+    const bool use_lds = g.rounds_per_tile * PF_NWAVES <= PF_LDS_CHUNKS;
+    double* const ct_tile = a.ctab_w(a.step, b) + 2 * (int64_t)k * g.rounds_per_tile * PF_NWAVES;
+    T* const l_col = ((a.step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;  // double buffered like the state (step parity)
     const int64_t base = (int64_t)k * g.tile_elems;
+    int rk = 0;
     for (int r = 0; r < g.rounds_per_tile; ++r) {
-        const int64_t i0 = base + (int64_t)r * g.round_elems + threadIdx.x * VEC;
-        if (i0 >= g.N) break;
-        T lw[VEC], xv[D][VEC];
-        if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
+        const int64_t r0 = base + (int64_t)r * g.round_elems;
+        if (r0 >= g.N) break;
+        ++rk;
+        const int64_t i0 = r0 + threadIdx.x * VEC;
+        const bool on = i0 < g.N;
+        T rw[VEC];
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
-            if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
+        for (int j = 0; j < VEC; ++j) rw[j] = -Lim<T>::inf();
+        if (on) {
+            T lw[VEC], xv[D][VEC];
+            if (VEC == 1) lw[0] = lw_col[i0]; else load_vec<T, VEC>(lw_col + i0, lw);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const T* xc = x_base + ((int64_t)d * g.B + b) * g.N + i0;
+                if (VEC == 1) xv[d][0] = xc[0]; else load_vec<T, VEC>(xc, xv[d]);
+            }
+            T pre[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                T xj[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
+                pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) : T(0);
+                if (pre_on && is_nan_or_posinf(pre[j])) acc.poison = true;
+                rw[j] = pre_on ? sanitize_logw(pre[j] + lw[j]) : lw[j];
+            }
+            T e_unused[VEC];
+            acc.template push_round<VEC>(lw, xv, false, pre, piv, e_unused);  // (the resampling family: the chunk scan below)
+            if (a.resampler == PF_RESAMPLE_MULTINOMIAL) {
+                T ev[VEC];
+                draw_exponentials<T, VEC>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_MULTINOMIAL, (uint32_t)a.step,
+                                          (uint64_t)((int64_t)b * g.N + i0), ev);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
+            }
         }
-        T pre[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            T xj[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-            pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) : T(0);
-        }
-        T e_unused[VEC];
-        acc.template push_round<VEC>(lw, xv, pre_on, pre, piv, e_unused);
-        if (a.resampler == PF_RESAMPLE_MULTINOMIAL) {
-            T ev[VEC];
-            draw_exponentials<T, VEC>(a.seed + (a.seed_dev ? *a.seed_dev : 0ull), PF_STREAM_MULTINOMIAL, (uint32_t)a.step,
-                                      (uint64_t)((int64_t)b * g.N + i0), ev);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
-        }
+        chunk_scan_round<T, VEC>(rw, on, l_col + i0, r * PF_NWAVES + (threadIdx.x >> 6), use_lds ? crec : nullptr, ct_tile);
     }
     T M1, M2, F1, F2;
-    acc.template finish<true>(a.part_w(a.step), b, k, g.B, g.tiles, pre_on, red, redm, &a.poison[(a.step & 3) * g.B + b], M1, M2, F1, F2);
-    {
-        __shared__ double reds[PF_NWAVES];
-        T dummy[VEC];
+    acc.template finish<true>(a.part_w(a.step), b, k, g.B, g.tiles, false, red, redm, &a.poison[(a.step & 3) * g.B + b], M1, M2, F1, F2);
+    double Mc, Sc;
+    finalize_chunk_table<T>(ct_tile, use_lds ? crec : nullptr, rk * PF_NWAVES, reds, redm, Mc, Sc);
+    if (threadIdx.x == 0) {  // the resampling family's (max, sum) come from the scan
+        const int64_t stride = (int64_t)g.B * g.tiles, o = (int64_t)b * g.tiles + k;
+        if (pre_on) {
+            a.part_w(a.step)[PQ_M2 * stride + o] = Mc;
+            a.part_w(a.step)[PQ_S2 * stride + o] = Sc;
+        } else {
+            a.part_w(a.step)[PQ_S1 * stride + o] = Sc;
+        }
+    }
+    if (g.rounds_per_tile == 1) {
+        // the step kernels of single-round tiles read tile-level scans and no chunk table (cdf_from_local): fold (C, g) in
+        __syncthreads();  // the chunk table of this tile is written (wave 0)
+        const int64_t i0 = base + threadIdx.x * VEC;
+        if (i0 < g.N) {
+            const double* cg = ct_tile + 2 * (threadIdx.x >> 6);
+            const double C = cg[0], gq = cg[1];
+            T v[VEC];
+            if (VEC == 1) v[0] = l_col[i0]; else load_vec<T, VEC>(l_col + i0, v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) dummy[j] = T(0);
-        // local scans are double buffered like the state: step s reads buffer s & 1 while it writes the next one
-        tile_local_scan<T, D, VEC>(a, b, k, slot, (a.step & 1) ? a.pos : a.cdf, pre_on, pre_on ? M2 : M1,
-                                   [&](const T (&xj)[D]) { return pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, false); }, false,
-                                   dummy, T(0), reds);
+            for (int j = 0; j < VEC; ++j) v[j] = (T)(C + gq * (double)v[j]);
+            if (VEC == 1) l_col[i0] = v[0]; else store_vec<T, VEC>(l_col + i0, v);
+        }
     }
 }
 
@@ -703,6 +784,7 @@ template <typename T, int D, int VEC> struct StepShared {
                    // the prefixes of the Exp(1) spacing sums here (tiles + 2 entries) and takes what it needs from them
     double* ftl;   // PF_MAX_TILES
     int* sh_plan;  // 2: window start of the tile's first position, its tile
+    double* crec;  // 2 * PF_LDS_CHUNKS: raw chunk records (m_c, t_c) of the scan this launch writes
 };
 // What the prologue hands to the body.
 template <typename T> struct StepPlan {
@@ -715,7 +797,7 @@ template <typename T> struct StepPlan {
 // Prologue of a step workgroup: the column's table from the partials of the incoming state, the resampling decision,
 // the window start (wave 0; broadcast through LDS).  Everything here is L2-hot and tiny: <= 16 KB of partials, one
 // 64-lane probe of the tile-local scans.
-template <typename T, int D, int VEC, int MODE, int SPEC, bool EARLY_Z>
+template <typename T, int D, int VEC, int MODE, int SPEC, bool EARLY_Z, bool MULTI>
 __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, T (&z0)[VEC][D]) {
     const Geom& g = a.g;
     const int b = blockIdx.y, k = blockIdx.x;
@@ -811,7 +893,14 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
         const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
         int64_t probe = first + (lane + 1) * st - 1;
         if (probe > last) probe = last;
-        const bool ge = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1) >= p;
+        T cprobe;
+        if constexpr (MULTI) {
+            const double* cg = a.ctab_r(b) + 2 * (probe / (PF_WAVE * VEC));
+            cprobe = cdf_from_local<T>(l_col[probe], cg[0], cg[1], Pk, fk, Pn, probe == last, probe == g.N - 1);
+        } else {
+            cprobe = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1);
+        }
+        const bool ge = cprobe >= p;
         const unsigned long long bal = __ballot(ge);
         const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
         int64_t res = first + (int64_t)f * st;
@@ -834,7 +923,7 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
 // run-time kinds, 1 Verhulst diffusion + stochastic-volatility observation (D = 1) - the switch statements fold, their
 // scalar branch instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on
 // 64 x 65 536).  Closed-form kernels (FAST): the shape of the one-step mean, 0 run time, 1 affine, 2 sine.
-template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS>
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS, bool MULTI>
 __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, const StepPlan<T>& pl,
                                           const T (&z0)[VEC][D]) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
@@ -915,13 +1004,29 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     view.L = cdf_col;
     view.ptab = ptab_col;
     view.ftab = ftab_col;
+    const double* const ct_col = MULTI ? a.ctab_r(b) : nullptr;  // per-chunk (C, g) of the scans this step reads
+    view.ct = ct_col;
+    view.chunk_elems = PF_WAVE * VEC;
     view.N = N;
     view.tile_elems = g.tile_elems;
     view.tiles = g.tiles;
 
-    T e_rw[VEC];  // the last round's exp(rw - thread max) of the next resampling weights (reused by the local scan)
+    T e_rw[VEC];
+    T rwn[VEC];   // this round's next resampling weights (-inf beyond the column)
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) e_rw[j] = T(0);
+    for (int j = 0; j < VEC; ++j) {
+        e_rw[j] = T(0);
+        rwn[j] = -Lim<T>::inf();
+    }
+    const bool scan_next = !apf || pre_next;  // a next resampling exists: its weights are scanned by this kernel
+    // single-round tiles: the tile maximum is known before anything is stored, so the scan is tile-level (one workgroup scan
+    // of the exponentials the partial accumulator already holds) and every chunk's (C, g) is (0, 1); multi-round tiles
+    // scan chunk by chunk inside the loop (re-reading the tile once its maximum is known would double the kernel's reads)
+    constexpr bool single = !MULTI;
+    const bool use_lds = g.rounds_per_tile * PF_NWAVES <= PF_LDS_CHUNKS;
+    double* const ct_tile = a.ctab_w(step + 1, b) + 2 * (int64_t)k * g.rounds_per_tile * PF_NWAVES;
+    T* const l_next = ((step & 1) ? a.cdf : a.pos) + (int64_t)b * g.N;  // the scans of state step + 1
+    int rk = 0;
     for (int r = 0; r < g.rounds_per_tile; ++r) {
         const int64_t r0 = base + (int64_t)r * g.round_elems;
         if (r0 >= g.N) break;
@@ -1034,12 +1139,24 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 const unsigned ea = (unsigned)(kta + 1) * te, eb = (unsigned)(ktb + 1) * te;
                 const int la = (int)(ea < (unsigned)N ? ea : (unsigned)N) - 1;
                 const int lb = (int)(eb < (unsigned)N ? eb : (unsigned)N) - 1;
+                if constexpr (MULTI) {  // (a staged vector lies inside one chunk: chunk boundaries are multiples of 64 VEC)
+                    const double* cga = ct_col + 2 * ((wina ? wja : 0) / (PF_WAVE * VEC));
+                    const double* cgb = ct_col + 2 * ((winb ? wjb : 0) / (PF_WAVE * VEC));
+                    const double Ca = cga[0], ga = cga[1], Cb = cgb[0], gb = cgb[1];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
+                    for (int j = 0; j < VEC; ++j)
+                        m0[j] = wina ? cdf_from_local<T>(m0[j], Ca, ga, tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
 #pragma unroll
-                for (int j = 0; j < V1; ++j)
-                    m1[j] = winb ? cdf_from_local<T>(m1[j], tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
+                    for (int j = 0; j < V1; ++j)
+                        m1[j] = winb ? cdf_from_local<T>(m1[j], Cb, gb, tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j)
+                        m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
+#pragma unroll
+                    for (int j = 0; j < V1; ++j)
+                        m1[j] = winb ? cdf_from_local<T>(m1[j], tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
+                }
             };
             map_window(ws, ja, jb, ina, inb, c0, c1);
             if (XWIN) {
@@ -1214,7 +1331,16 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #pragma unroll
             for (int d = 0; d < D; ++d)
                 piv[d] = (step - 1 >= a.t0) ? la->means[((int64_t)(step - 1) * g.B + b) * D + d] : (T)la->piv0[(int64_t)b * PF_MAXD + d];
-            acc.template push_round<VEC>(lwo, xo, pre_next, pre_n, piv, e_rw);
+            // the next resampling weights (scanned chunk by chunk below); the partial accumulator keeps the weights' own
+            // family (moments, ll, ESS)
+            if constexpr (MULTI) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    if (pre_next && is_nan_or_posinf(pre_n[j])) acc.poison = true;
+                    rwn[j] = pre_next ? sanitize_logw(pre_n[j] + lwo[j]) : lwo[j];
+                }
+            }
+            acc.template push_round<VEC>(lwo, xo, single && pre_next, pre_n, piv, e_rw);
             if (multinomial) {
                 T ev[VEC];
                 draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)(step + 1), (uint64_t)((int64_t)b * g.N + i0), ev);
@@ -1223,29 +1349,59 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             }
             PF_STAMP(a, 13);
         }
+        if (scan_next && !single) {  // (uniform) every lane of every wave: the chunk-local scan is wave-level
+            chunk_scan_round<T, VEC>(rwn, on, l_next + i0, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) rwn[j] = -Lim<T>::inf();
+            ++rk;
+        }
         if (windowed && r + 1 < g.rounds_per_tile) __syncthreads();  // the window is rewritten by the next round
     }
     if (poison) atomicOr(&a.poison[(step & 3) * g.B + b], 1);
     if (PF_CUT(a, 3)) return;
     PF_STAMP(a, 14);
     T M1, M2, F1, F2;
-    acc.template finish<MODE == 1>(a.part_w(step + 1), b, k, g.B, g.tiles, pre_next, red, redm, &a.poison[((step + 1) & 3) * g.B + b], M1, M2, F1, F2);
+    acc.template finish<MODE == 1>(a.part_w(step + 1), b, k, g.B, g.tiles, single && pre_next, red, redm, &a.poison[((step + 1) & 3) * g.B + b], M1, M2, F1, F2);
     if (PF_CUT(a, 6)) return;
-    // the next step's resampling weights, scanned per tile while they are at hand (their cdf = table + these local scans)
-    if (!apf || pre_next)
-        tile_local_scan<T, D, VEC>(a, b, k, slot ^ 1, (step & 1) ? a.cdf : a.pos, pre_next, pre_next ? M2 : M1,
-                                   [&](const T (&xj)[D]) {
-                                       if constexpr (FAST) return fc.template pre_weight<FAST ? MK : 0>(proposal, xj[0], true);
-                                       else return pre_weight<T, D>(md, proposal, cp, cc, xj, true);
-                                   },
-                                   g.rounds_per_tile == 1, e_rw, pre_next ? F2 : F1, reds);
+    if (scan_next && single) {
+        // exp(rw - thread max) and the thread's factor exp(thread max - tile max) are in registers (push_round / finish)
+        const int64_t i0 = base + tid * VEC;
+        const bool on = i0 < g.N;
+        const T f = pre_next ? F2 : F1;
+        double e[VEC], local = 0.0, total;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            local += on ? (double)(e_rw[j] * f) : 0.0;
+            e[j] = local;
+        }
+        const double excl = block_scan_excl(local, reds, total);
+        if (on) {
+            T outv[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + e[j]);
+            if (VEC == 1) l_next[i0] = outv[0]; else store_vec<T, VEC>(l_next + i0, outv);
+        }
+    } else if (scan_next) {
+        // the chunk table of the next step's resampling weights, and the tile's (max, sum) of that family from the same sums
+        double Mc, Sc;
+        finalize_chunk_table<T>(ct_tile, use_lds ? sh.crec : nullptr, rk * PF_NWAVES, reds, redm, Mc, Sc);
+        if (tid == 0) {
+            const int64_t stride = (int64_t)g.B * g.tiles, o = (int64_t)b * g.tiles + k;
+            if (pre_next) {  // APF: rw = first-stage weight + log-weight
+                a.part_w(step + 1)[PQ_M2 * stride + o] = Mc;
+                a.part_w(step + 1)[PQ_S2 * stride + o] = Sc;
+            } else {         // SISR resamples on the weights themselves
+                a.part_w(step + 1)[PQ_S1 * stride + o] = Sc;
+            }
+        }
+    }
     PF_STAMP(a, 15);
 #ifdef PF_DEVTOOLS
     if (a.debug_cut < 0 && tid == 0 && b == 0 && (k % 128) == 0 && k / 128 < 8) a.dbg[24 + k / 128] = wall_clock64();
 #endif
 }
 
-template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK>
+template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool MULTI>
 __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>::value)) void k_fused_step(FusedArgs<T> a) {
     using SH = StepShared<T, D, VEC>;
     __shared__ __attribute__((aligned(32))) T win[SH::WIN];
@@ -1257,23 +1413,24 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
     __shared__ T redm[2 * PF_NWAVES];
     __shared__ double ptl[PF_MAX_TILES + 2], ftl[PF_MAX_TILES];
     __shared__ int sh_plan[2];
+    __shared__ double crec[MULTI ? 2 * PF_LDS_CHUNKS : 2];
     __shared__ double redb[PF_NWAVES];
     if (!a.book_inline && blockIdx.x == (unsigned)a.g.tiles) {  // the column's bookkeeper (scratch: 2 + 2 D rows of `red`)
         column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
         return;
     }
-    const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan};
+    const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan, crec};
     T z0[VEC][D];
 #pragma unroll
     for (int j = 0; j < VEC; ++j)
 #pragma unroll
         for (int d = 0; d < D; ++d) z0[j][d] = T(0);
-    const StepPlan<T> pl = step_prologue<T, D, VEC, MODE, SPEC, (FAST && D == 1 && sizeof(T) == 4)>(a, sh, z0);
+    const StepPlan<T> pl = step_prologue<T, D, VEC, MODE, SPEC, (FAST && D == 1 && sizeof(T) == 4), MULTI>(a, sh, z0);
     if constexpr (SPEC == 1) {
-        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl, z0);
+        step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true, MULTI>(a, sh, pl, z0);
     } else {
-        if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true>(a, sh, pl, z0);
-        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false>(a, sh, pl, z0);
+        if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true, MULTI>(a, sh, pl, z0);
+        else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false, MULTI>(a, sh, pl, z0);
     }
     if (a.book_inline && blockIdx.x == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
         column_bookkeeping<T, D>(a, blockIdx.y, red, redb);

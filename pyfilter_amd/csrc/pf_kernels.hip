@@ -80,6 +80,8 @@ struct WsLayout {
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
     size_t off_cpack;  // T [B][PK_N] (sized for double): the run's closed-form records
     size_t off_piv0;   // double [B][PF_MAXD]: the run's moment pivots
+    size_t off_ctab;   // double [2][B][tiles * rounds_per_tile * 4][2]: per-chunk (offset, factor) of the chunk-local scans
+    size_t ctab_elems;
     size_t total;
 };
 
@@ -103,6 +105,9 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     o = align256(o + sizeof(double) * (size_t)g.B * 24);
     w.off_piv0 = o;
     o = align256(o + sizeof(double) * (size_t)g.B * PF_MAXD);
+    w.off_ctab = o;
+    w.ctab_elems = (size_t)g.B * g.tiles * g.rounds_per_tile * PF_NWAVES * 2;
+    o = align256(o + 2 * sizeof(double) * w.ctab_elems);
     w.total = o;
     return w;
 }
@@ -1067,11 +1072,13 @@ static inline ModelDesc to_desc(const pf_model* m) {
     return d;
 }
 
-// The fused-run instantiation matrix compiles as four translation units (the build runs them in parallel):
+// The fused-run instantiation matrix compiles as several translation units (the build runs them in parallel):
 //   -DPF_TU_NO_F64 -DPF_TU_NO_F32DN -DPF_TU_NO_F32D1 : the main unit - C ABI and the stand-alone primitives
 //   -DPF_TU_F32D1_ONLY -DPF_TU_VEC=4|1 : only the float32 fused kernels of scalar states for one vector width + entry
 //   -DPF_TU_F32DN_ONLY              : only the float32 fused kernels of D > 1 states + their entry (pf_run_f32_dn)
 //   -DPF_TU_F64_ONLY                : only the float64 fused kernels + their entry               (pf_run_f64)
+//   ... each of the kernel units additionally with -DPF_TU_MULTI=0|1: only the kernels of single-round / multi-round
+//   tiles (the MULTI template argument of k_fused_step; entries carry the suffix _m0 / _m1)
 // Without any of the macros the file is a single self-contained unit.
 #if defined(PF_TU_F64_ONLY) || defined(PF_TU_F32DN_ONLY) || defined(PF_TU_F32D1_ONLY)
 #define PF_TU_NO_API
@@ -1391,16 +1398,16 @@ extern "C" int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_st
 // Test support: which step-kernel instantiation each launch of the calling thread's most recent fused runs selected
 // (pf_debug_launch_trace).  A per-thread ring, written on the host at launch time - nothing a kernel ever reads.
 #define PF_TRACE_LEN 64
-#define PF_TRACE_FIELDS 9
+#define PF_TRACE_FIELDS 10
 struct LaunchTrace {
     int32_t rec[PF_TRACE_LEN][PF_TRACE_FIELDS];
     uint64_t count;
 };
 LaunchTrace& launch_trace();
-static inline void trace_launch(int step, int tbytes, int d, int vec, int mode, int prop, int fast, int spec, int mk) {
+static inline void trace_launch(int step, int tbytes, int d, int vec, int mode, int prop, int fast, int spec, int mk, int multi) {
     LaunchTrace& t = launch_trace();
     int32_t* r = t.rec[t.count % PF_TRACE_LEN];
-    r[0] = step; r[1] = tbytes; r[2] = d; r[3] = vec; r[4] = mode; r[5] = prop; r[6] = fast; r[7] = spec; r[8] = mk;
+    r[0] = step; r[1] = tbytes; r[2] = d; r[3] = vec; r[4] = mode; r[5] = prop; r[6] = fast; r[7] = spec; r[8] = mk; r[9] = multi;
     ++t.count;
 }
 #ifndef PF_TU_NO_API
@@ -1419,7 +1426,7 @@ extern "C" int pf_debug_launch_trace(int32_t* out, int max_records) {
 }
 #endif
 
-template <typename T, int D, int VEC>
+template <typename T, int D, int VEC, bool MULTI>
 static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
                            int finalize, hipStream_t st, float* kernel_ms) {
     FusedArgs<T> a;
@@ -1456,6 +1463,8 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.dbg = (unsigned long long*)((char*)A->ws + wl.off_dbg);
     a.cpack = (T*)((char*)A->ws + wl.off_cpack);
     a.piv0 = (double*)((char*)A->ws + wl.off_piv0);
+    a.ctab = (double*)((char*)A->ws + wl.off_ctab);
+    a.ctab_stride = (int64_t)wl.ctab_elems;
     static_assert(PK_N == 24, "workspace layout reserves 24 slots per column record");
     a.finalize_only = 0;
     a.t0 = (int)t0;
@@ -1517,8 +1526,8 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             constexpr int SPEC = decltype(spec_c)::value;
             auto launch = [&](auto mk_c) {
                 constexpr int MK = decltype(mk_c)::value;
-                trace_launch((int)a.step, (int)sizeof(T), D, VEC, MODE, PROP, FAST ? 1 : 0, SPEC, MK);
-                hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, MK>), grid, block, 0, st, a);
+                trace_launch((int)a.step, (int)sizeof(T), D, VEC, MODE, PROP, FAST ? 1 : 0, SPEC, MK, MULTI ? 1 : 0);
+                hipLaunchKernelGGL((k_fused_step<T, D, VEC, MODE, PROP, FAST, SPEC, MK, MULTI>), grid, block, 0, st, a);
             };
             // model kinds folded at compile time for the stochastic-volatility built-in (float runs; for Lorenz-63 the
             // same specialisation measured no gain)
@@ -1609,67 +1618,76 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     return e == hipSuccess ? PF_OK : (int)e;
 }
 
-// one entry per arithmetic type (see the translation-unit note above)
-int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-               hipStream_t st, float* kernel_ms);
-int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-               hipStream_t st, float* kernel_ms);
-int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                  hipStream_t st, float* kernel_ms);
-#define RUN(T, DD, V) return filter_run_impl<T, DD, V>(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
-#define RUN_D(T, V)                                       \
-    if (D == 1) { RUN(T, 1, V) } else if (D == 2) { RUN(T, 2, V) } else { RUN(T, 3, V) }
-int pf_run_f32_d1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                  hipStream_t st, float* kernel_ms);
+// one entry per arithmetic type / state dimension / vector width / tile geometry (see the translation-unit note above)
+#define PF_RUN_ARGS const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize, \
+                    hipStream_t st, float* kernel_ms
+#define PF_RUN_PASS A, g, wl, t0, n_steps, finalize, st, kernel_ms
+int pf_run_f32(PF_RUN_ARGS);
+int pf_run_f64(PF_RUN_ARGS);
+#define PF_DECLARE_LEAVES(SFX)            \
+    int pf_run_f32_d1_v4##SFX(PF_RUN_ARGS); \
+    int pf_run_f32_d1_v1##SFX(PF_RUN_ARGS); \
+    int pf_run_f32_dn##SFX(PF_RUN_ARGS);    \
+    int pf_run_f64##SFX(PF_RUN_ARGS);
+PF_DECLARE_LEAVES(_m0)
+PF_DECLARE_LEAVES(_m1)
 #ifndef PF_TU_NO_API
-int pf_run_f32(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-               hipStream_t st, float* kernel_ms) {
-    if (A->model.dim != 1) return pf_run_f32_dn(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
-    return pf_run_f32_d1(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
+int pf_run_f32(PF_RUN_ARGS) {
+    const bool multi = g.rounds_per_tile > 1;
+    if (A->model.dim != 1) return multi ? pf_run_f32_dn_m1(PF_RUN_PASS) : pf_run_f32_dn_m0(PF_RUN_PASS);
+    if (g.vec == 4) return multi ? pf_run_f32_d1_v4_m1(PF_RUN_PASS) : pf_run_f32_d1_v4_m0(PF_RUN_PASS);
+    return multi ? pf_run_f32_d1_v1_m1(PF_RUN_PASS) : pf_run_f32_d1_v1_m0(PF_RUN_PASS);
+}
+int pf_run_f64(PF_RUN_ARGS) {
+    return g.rounds_per_tile > 1 ? pf_run_f64_m1(PF_RUN_PASS) : pf_run_f64_m0(PF_RUN_PASS);
 }
 #endif
-int pf_run_f32_d1_v4(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                     hipStream_t st, float* kernel_ms);
-int pf_run_f32_d1_v1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                     hipStream_t st, float* kernel_ms);
-#ifndef PF_TU_NO_API
-int pf_run_f32_d1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                  hipStream_t st, float* kernel_ms) {
-    return g.vec == 4 ? pf_run_f32_d1_v4(A, g, wl, t0, n_steps, finalize, st, kernel_ms)
-                      : pf_run_f32_d1_v1(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
-}
+#define RUN(T, DD, V, MULTI) return filter_run_impl<T, DD, V, MULTI>(PF_RUN_PASS);
+#define RUN_D(T, V, MULTI) \
+    if (D == 1) { RUN(T, 1, V, MULTI) } else if (D == 2) { RUN(T, 2, V, MULTI) } else { RUN(T, 3, V, MULTI) }
+#define PF_DEFINE_D1_V4(SFX, MULTI) int pf_run_f32_d1_v4##SFX(PF_RUN_ARGS) { RUN(float, 1, 4, MULTI) }
+#define PF_DEFINE_D1_V1(SFX, MULTI) int pf_run_f32_d1_v1##SFX(PF_RUN_ARGS) { RUN(float, 1, 1, MULTI) }
+#define PF_DEFINE_DN(SFX, MULTI)                                              \
+    int pf_run_f32_dn##SFX(PF_RUN_ARGS) {                                     \
+        const int D = A->model.dim;                                           \
+        if (g.vec == 4) {                                                     \
+            if (D == 2) { RUN(float, 2, 4, MULTI) } else { RUN(float, 3, 4, MULTI) } \
+        } else {                                                              \
+            if (D == 2) { RUN(float, 2, 1, MULTI) } else { RUN(float, 3, 1, MULTI) } \
+        }                                                                     \
+    }
+#define PF_DEFINE_F64(SFX, MULTI)                                    \
+    int pf_run_f64##SFX(PF_RUN_ARGS) {                               \
+        const int D = A->model.dim;                                  \
+        if (g.vec == 4) { RUN_D(double, 4, MULTI) } else { RUN_D(double, 1, MULTI) } \
+    }
+#if !defined(PF_TU_MULTI) || PF_TU_MULTI == 0
+#define PF_FOR_M0(X) X(_m0, false)
+#else
+#define PF_FOR_M0(X)
+#endif
+#if !defined(PF_TU_MULTI) || PF_TU_MULTI == 1
+#define PF_FOR_M1(X) X(_m1, true)
+#else
+#define PF_FOR_M1(X)
 #endif
 #if !defined(PF_TU_NO_F32D1) && !defined(PF_TU_F64_ONLY) && !defined(PF_TU_F32DN_ONLY)
 #if !defined(PF_TU_VEC) || PF_TU_VEC == 4
-int pf_run_f32_d1_v4(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                     hipStream_t st, float* kernel_ms) {
-    RUN(float, 1, 4)
-}
+PF_FOR_M0(PF_DEFINE_D1_V4)
+PF_FOR_M1(PF_DEFINE_D1_V4)
 #endif
 #if !defined(PF_TU_VEC) || PF_TU_VEC == 1
-int pf_run_f32_d1_v1(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                     hipStream_t st, float* kernel_ms) {
-    RUN(float, 1, 1)
-}
+PF_FOR_M0(PF_DEFINE_D1_V1)
+PF_FOR_M1(PF_DEFINE_D1_V1)
 #endif
 #endif
 #if !defined(PF_TU_NO_F32DN) && !defined(PF_TU_F64_ONLY) && !defined(PF_TU_F32D1_ONLY)
-int pf_run_f32_dn(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-                  hipStream_t st, float* kernel_ms) {
-    const int D = A->model.dim;
-    if (g.vec == 4) {
-        if (D == 2) { RUN(float, 2, 4) } else { RUN(float, 3, 4) }
-    } else {
-        if (D == 2) { RUN(float, 2, 1) } else { RUN(float, 3, 1) }
-    }
-}
+PF_FOR_M0(PF_DEFINE_DN)
+PF_FOR_M1(PF_DEFINE_DN)
 #endif
 #if !defined(PF_TU_NO_F64) && !defined(PF_TU_F32DN_ONLY) && !defined(PF_TU_F32D1_ONLY)
-int pf_run_f64(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize,
-               hipStream_t st, float* kernel_ms) {
-    const int D = A->model.dim;
-    if (g.vec == 4) { RUN_D(double, 4) } else { RUN_D(double, 1) }
-}
+PF_FOR_M0(PF_DEFINE_F64)
+PF_FOR_M1(PF_DEFINE_F64)
 #endif
 #undef RUN_D
 #undef RUN

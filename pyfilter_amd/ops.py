@@ -296,7 +296,7 @@ def initial_sample_soa(m0, s0, n: int, b: int, d: int, dtype, device, seed: int,
 # ----------------------------------------------------------------------------------------------------------------
 # test support
 # ----------------------------------------------------------------------------------------------------------------
-TRACE_FIELDS = ("step", "tbytes", "D", "VEC", "MODE", "PROP", "FAST", "SPEC", "MK")
+TRACE_FIELDS = ("step", "tbytes", "D", "VEC", "MODE", "PROP", "FAST", "SPEC", "MK", "MULTI")
 
 
 def debug_draw_normals(seed: int, steps: int, n: int, b: int, d: int, dtype, device, step0: int = 0) -> torch.Tensor:
