@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
         if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true, MULTI>(a, sh, pl, z0);
         else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false, MULTI>(a, sh, pl, z0);
     }
-    if (a.book_inline && blockIdx.x == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
+    if (a.book_inline == 1 && blockIdx.x == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
         column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
 }
 

@@ -1478,7 +1478,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     // the step kernel: one workgroup per tile + the column's bookkeeper - an extra workgroup when the column has many
     // tiles, else its last step workgroup (PF_BOOK_INLINE=0/1 overrides: development)
     a.book_inline = g.tiles < 8 ? 1 : 0;
-    if (const char* bi = getenv("PF_BOOK_INLINE")) a.book_inline = atoi(bi) ? 1 : 0;
+    if (const char* bi = getenv("PF_BOOK_INLINE")) a.book_inline = atoi(bi);  // (2: nobody keeps the books - timing experiments)
     const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
