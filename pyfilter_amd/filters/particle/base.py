@@ -194,12 +194,16 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             z0 = None
             if self._z0 is not None:
                 z0 = ops.to_soa(self._z0.to(device=device, dtype=dtype), self._batched, self._has_event)
-            im, isd = hidden.init_mean.to(device=device, dtype=dtype), hidden.init_scale.to(device=device, dtype=dtype)
+            im, isd = hidden.init_mean, hidden.init_scale
             if im.numel() in (1, d) and isd.numel() in (1, d):
-                if ctx.init_host is None:  # host copies of the initial mean / scale: one sync per parameter change
-                    ctx.init_host = (im.reshape(-1).expand(d).tolist(), isd.reshape(-1).expand(d).tolist())
+                # host copies of the initial mean / scale, taken once per parameter change: any per-call transfer of these
+                # few numbers (host -> device for CPU-resident constants, device -> host for device ones) would make the
+                # host wait for the whole queue of the previous run
+                if ctx.init_host is None:
+                    ctx.init_host = (im.reshape(-1).expand(d).to(torch.float64).tolist(), isd.reshape(-1).expand(d).to(torch.float64).tolist())
                 soa = ops.initial_sample_soa(ctx.init_host[0], ctx.init_host[1], n, b, d, dtype, device, seed, z0)
             else:
+                im, isd = im.to(device=device, dtype=dtype), isd.to(device=device, dtype=dtype)
                 # per-filter initial parameters (theta on the batch dim): standard draws from the kernel, then the
                 # column-wise affine map (once per run)
                 soa = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, device, seed, z0)
