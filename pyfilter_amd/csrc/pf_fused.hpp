@@ -122,7 +122,8 @@ __device__ __forceinline__ void load_col_params(const FusedArgs<T>& a, int b, in
 // Accumulates the per-tile partials of a state from registers.  Per-thread accumulators are of the filter's type T: a
 // thread sums at most 4 R terms, the workgroup / column sums above it are fp64.  The weighted moments are taken about a
 // per-column pivot c (the previous state's mean) - sum e (x - c), sum e (x - c)^2 - so the variance never cancels.
-template <typename T, int D> struct PartialAcc {
+// WQ: also sum e^2 (the ESS of the weights - SISR's resampling test; an APF never looks at it)
+template <typename T, int D, bool WQ = true> struct PartialAcc {
     T m1, m2;          // running maxima of logw / rw
     T s1, s2, q1;      // sum e, sum e_rw, sum e^2
     T mx[D], mxx[D];   // sum e (x - c), sum e (x - c)^2
@@ -149,7 +150,7 @@ template <typename T, int D> struct PartialAcc {
         if (m > m1) {
             const T rs = (m1 == -Lim<T>::inf()) ? T(0) : pf_exp_w(m1 - m);
             s1 *= rs;
-            q1 *= rs * rs;
+            if constexpr (WQ) q1 *= rs * rs;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 mx[d] *= rs;
@@ -163,7 +164,7 @@ template <typename T, int D> struct PartialAcc {
             if (lw[j] != lw[j]) e = lw[j];
             e_out[j] = e;
             s1 += e;
-            q1 += e * e;
+            if constexpr (WQ) q1 += e * e;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const T xd = x[d][j] - piv[d];
@@ -222,7 +223,7 @@ template <typename T, int D> struct PartialAcc {
         constexpr int NS = 3 + 2 * D;
         T sums[NS];
         sums[0] = s1 * f1;
-        sums[1] = q1 * f1 * f1;
+        sums[1] = WQ ? q1 * f1 * f1 : T(0);
         sums[2] = pre_on ? s2 * f2 : T(0);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -231,7 +232,7 @@ template <typename T, int D> struct PartialAcc {
         }
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
-            const T ws = wave_sum(sums[q]);
+            const T ws = (WQ || q != 1) ? wave_sum(sums[q]) : T(0);
             if (lane == 0) red[q * PF_NWAVES + wid] = (double)ws;
         }
         if constexpr (WITH_ES) {
@@ -995,7 +996,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     const bool pow2 = (N & (N - 1)) == 0;                  // then the grid division is an exact multiplication
 
     bool poison = false;
-    PartialAcc<T, D> acc;
+    PartialAcc<T, D, SPEC != 1> acc;  // (SPEC = 1: APF steady state - the weights' ESS is never looked at)
     acc.init();
     PF_STAMP(a, 9);
     const double* ptab_col = sh.ptl;  // `cdf` / `pos` hold tile-local scans; the cdf is implied by the prologue's table (LDS)
