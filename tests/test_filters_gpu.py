@@ -520,9 +520,10 @@ def test_residual_resampler_in_a_filter(filt_name):
 
 
 def test_multi_round_tiles_pass_the_parity_suite():
-    """Tiles of several rounds (the geometry of the multi-million-particle configurations: a workgroup walks R rounds of
-    1024 particles, re-reads the state for the tile-local scan, chains the window start from round to round) are reached
-    at test sizes by lowering the workgroup target: PF_TARGET_WGS=2 gives R up to 16 for the float64 parity cases."""
+    """Tiles of several rounds (the geometry of the multi-million-particle configurations - the MULTI kernels: a workgroup
+    walks R rounds of 1024 particles, scans the next resampling weights chunk by chunk, chains the window start from round
+    to round) are reached at test sizes by lowering the workgroup target: PF_TARGET_WGS=2 gives R = 512 at 2^20 particles
+    (chunk records in global memory, the block-level finalisation), 16 gives R <= 64 (records in LDS)."""
     import subprocess
     import sys
 
@@ -533,6 +534,13 @@ def test_multi_round_tiles_pass_the_parity_suite():
                             "-k", "benchmark_sizes or ragged or weight_collapse or matches_reference"],
                            env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, f"PF_TARGET_WGS={wgs}\n" + r.stdout[-3000:] + r.stderr[-2000:]
+    # the float32 production instantiations of the multi-round geometry against the oracle on their own draws
+    for wgs in ("64", "4"):
+        env = dict(os.environ, PF_TARGET_WGS=wgs)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_production_kernels_gpu.py"), "-m", "gpu", "-q",
+                            "-x", "-k", "production_step_kernels"], env=env, cwd=os.path.dirname(here), capture_output=True,
+                           text=True, timeout=1500)
+        assert r.returncode == 0, f"PF_TARGET_WGS={wgs} (production kernels)\n" + r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("n,b", [(1, 1), (2, 3), (7, 2), (64, 1), (257, 2)])
