@@ -16,7 +16,7 @@ Exchanges (``Shard``), all along the filter (batch) dimension:
 * on a rejuvenation (``kernels/mh.py:52-108``): all-gather of the stacked theta ``(B, P)`` (the MVN proposal is built
   from all of them, identically everywhere), the identical systematic theta-resample on every rank, and the
   **redistribution of the surviving filters' states** to the ranks that own their new positions
-  (``Shard.take_filters``: all-gather of the columns + local gather - <= N (4 D + 12) bytes per column, ~100 MB in
+  (``Shard.take`` per buffer, driven by ``inference/smc2.py:_take_filters``: all-gather of the columns + local gather - <= N (4 D + 12) bytes per column, ~100 MB in
   total at 1024 x 8192, once per rejuvenation).
 """
 from typing import List, Optional, Tuple
@@ -89,6 +89,12 @@ class Shard:
         moved = local.movedim(dim, 0).contiguous()
         sizes = [hi - lo for lo, hi in self.spans]
         width = max(sizes)
+        if min(sizes) == width and dist.get_backend(self.group) == "nccl":
+            # even blocks on RCCL: one collective straight into the concatenated tensor (no padding, no second copy - this
+            # is the path that moves whole filter states, ~100 MB per rejuvenation at 1024 x 8192)
+            out = moved.new_empty((self.world * width,) + tuple(moved.shape[1:]))
+            dist.all_gather_into_tensor(out, moved, group=self.group)
+            return out.movedim(0, dim)
         buf = moved.new_zeros((width,) + tuple(moved.shape[1:]))
         buf[: moved.shape[0]] = moved
         out = [torch.empty_like(buf) for _ in range(self.world)]

@@ -80,6 +80,14 @@ class ThetaParticles:
                     v = d.icdf(u.to(device=self.device, dtype=self.dtype))
                 except NotImplementedError:
                     v = None
+            if v is None and generator is not None:
+                # no inverse CDF (Beta, Gamma, event-shaped priors ...): the distribution's own sampler under a forked
+                # global stream seeded from the generator - still the same draws on every rank
+                word = int(torch.randint(0, 2 ** 62, (), generator=generator))
+                devs = [self.device] if self.device.type == "cuda" else []
+                with torch.random.fork_rng(devices=devs):
+                    torch.manual_seed(word)
+                    v = d.sample(shape)
             if v is None:
                 v = d.sample(shape)
             if self.shard is not None:

@@ -70,12 +70,13 @@ class SMC2State:
                 "ess": torch.stack(self.ess), "parsed_data": self.parsed_data if self.parsed else torch.tensor([])}
 
 
-def _take_filters(result: FilterResult, shard: Optional[Shard], indices: torch.Tensor, local_indices: torch.Tensor):
-    """``FilterResult.resample`` for a sharded set of filters: ``indices`` = the GLOBAL ancestors of this rank's
-    positions.  Single process: the reference's in-place gather (one ``pf_columns_gather`` per buffer)."""
+def _take_filters(result: FilterResult, shard: Optional[Shard], mine: torch.Tensor):
+    """``FilterResult.resample`` for a sharded set of filters: ``mine`` = the GLOBAL ancestors of this rank's positions
+    (single process: all of them, and the reference's in-place gather - one ``pf_columns_gather`` per buffer)."""
     if shard is None or shard.world == 1:
-        result.resample(local_indices)
+        result.resample(mine)
         return
+    indices = mine
     # every per-filter quantity of the result travels as its block along the batch dimension
     result._loglikelihood.copy_(shard.take(result._loglikelihood, indices))
     log = result._moments
@@ -122,7 +123,7 @@ class ParticleMetropolisHastings:
         dist = self._proposal.build(theta, state, filter_, state.parsed_data)
 
         theta.resample(mine)
-        _take_filters(state.filter_state, shard, mine, indices)
+        _take_filters(state.filter_state, shard, mine)
         shape = torch.Size([]) if any(dist.batch_shape) else filter_.batch_shape
 
         old = theta.stack_parameters(constrained=False)
