@@ -151,6 +151,17 @@ int pf_sample_and_weight(const pf_model* model, int proposal, int weigh, const v
 int pf_initial_sample(const double* m0, const double* s0, const void* z, uint64_t seed, void* x, int64_t N,
                       int64_t B, int64_t D, int dtype, void* stream);
 
+/* "Observation k carries information": out[k] = 1 unless every element of y[k] ((steps, row_elems), row_elems =
+ * y_rows * O) is NaN - the reference's host test `y.isnan().all()` that turns a move into propagate-only
+ * (filters/base.py:212), for all steps of a series in one launch.  `out`: device bytes (steps). */
+int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems, int dtype, uint8_t* out, void* stream);
+
+/* theta-level bookkeeping of SMC^2 (inference/sequential/state.py:35-44 `get_ess(normalize(w))`, smc2.py:59-62
+ * `(~isfinite(w)).any()`) in one launch: out[0] = effective sample size of the B log-weights under
+ * pyfilter.utils.normalize (utils.py:49-64: NaN / +inf count as -inf, all -inf -> uniform), out[1] = 1 if every
+ * weight is finite else 0.  `out`: two device values of `dtype`. */
+int pf_theta_ess(const void* logw, int64_t B, int dtype, void* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------ *
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and
  * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; one kernel per step.
@@ -175,7 +186,9 @@ typedef struct pf_filter_args {
     int64_t y_rows;           /* 1 or B */
     const uint8_t* observed;  /* HOST array (T): 0 = all-NaN observation or unobserved sub-step: propagate only,
                                * ll = 0.  The only host-resident argument: the launch loop reads it to set each
-                               * kernel's flags, so no kernel needs a dependent flag load before its first data load. */
+                               * kernel's flags, so no kernel needs a dependent flag load before its first data load.
+                               * NULL together with `observed_dev` (runs of <= 128 steps): the library derives the
+                               * flags from y itself, on the device (pf_observed_flags into the workspace). */
     /* optional tapes (parity mode); NULL -> Philox */
     const void* z_tape; /* (T, D, B, N) */
     const void* u_tape; /* (T, B) */

@@ -28,7 +28,7 @@ EXPORTS = (
     "pf_multinomial", "pf_gather", "pf_loglik", "pf_moments", "pf_pre_weight", "pf_sample_and_weight",
     "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed", "pf_filter_graph_create", "pf_filter_graph_launch",
     "pf_filter_graph_destroy", "pf_columns_gather", "pf_columns_exchange", "pf_debug_draw_normals", "pf_debug_launch_trace",
-    "pf_smooth_fixed_lag", "pf_smooth_ffbs",
+    "pf_smooth_fixed_lag", "pf_smooth_ffbs", "pf_observed_flags", "pf_theta_ess",
 )
 
 
@@ -101,6 +101,8 @@ def load() -> C.CDLL:
     lib.pf_filter_graph_destroy.argtypes = [vp]
     lib.pf_smooth_fixed_lag.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, vp]
     lib.pf_smooth_ffbs.argtypes = [C.POINTER(PfModel), vp, vp, vp, vp, u64, vp, i64, i64, i64, i32, vp]
+    lib.pf_observed_flags.argtypes = [vp, i64, i64, i32, vp, vp]
+    lib.pf_theta_ess.argtypes = [vp, i64, i32, vp, vp]
     lib.pf_debug_draw_normals.argtypes = [u64, u32, i64, vp, i64, i64, i64, i32, vp]
     lib.pf_debug_launch_trace.argtypes = [C.POINTER(C.c_int32), i32]
     for name in EXPORTS:
@@ -138,7 +140,9 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """The caller's current HIP stream (raw handle) - the fast accessor: ``torch.cuda.current_stream()`` builds a Python
+    object per call (~15 us), which the online filter move pays once per observation."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 _ws_cache = {}

@@ -1437,4 +1437,48 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
         column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
 }
 
+// "Observation k carries information" (filters/base.py:212: an all-NaN observation is a propagate-only move): one wave per
+// step, flag[k] = any element of y[k] is not NaN.  Launched by pf_filter_run itself when the caller passes neither flag
+// array, and exported as pf_observed_flags.
+template <typename T>
+__global__ __launch_bounds__(PF_WAVE) void k_observed_flags(const T* __restrict__ y, int64_t row_elems, uint8_t* __restrict__ out) {
+    const T* row = y + (int64_t)blockIdx.x * row_elems;
+    bool any = false;
+    for (int64_t i = threadIdx.x; i < row_elems; i += PF_WAVE) any |= !(row[i] != row[i]);
+    const unsigned long long bal = __ballot(any);
+    if (threadIdx.x == 0) out[blockIdx.x] = bal ? 1 : 0;
+}
+
+// theta-level bookkeeping of SMC^2 in one launch (sequential/state.py:35-44, smc2.py:59-62): effective sample size of B
+// log-weights under pyfilter.utils.normalize (NaN / +inf count as -inf; all -inf -> uniform) and whether every weight is
+// finite.  One workgroup; B is the number of theta-particles (10^2 .. 10^5).  out[0] = ESS, out[1] = 1 if all finite.
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_ess(const T* __restrict__ w, int64_t B, T* __restrict__ out) {
+    __shared__ T redm[PF_NWAVES];
+    __shared__ double red[3 * PF_NWAVES];
+    T m = -Lim<T>::inf();
+    bool finite = true;
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        const T v = w[i];
+        finite &= !(is_nan_or_posinf(v) || v == -Lim<T>::inf());
+        const T s = is_nan_or_posinf(v) ? -Lim<T>::inf() : v;
+        m = s > m ? s : m;
+    }
+    m = block_max<T>(m, redm);
+    double acc[3] = {0.0, 0.0, finite ? 0.0 : 1.0};
+    if (m > -Lim<T>::inf()) {
+        for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+            const T v = w[i];
+            const double e = is_nan_or_posinf(v) ? 0.0 : exp((double)v - (double)m);
+            acc[0] += e;
+            acc[1] += e * e;
+        }
+    }
+    block_sum<3>(acc, red);
+    if (threadIdx.x == 0) {
+        out[0] = (T)(acc[1] > 0.0 ? acc[0] * acc[0] / acc[1] : (double)B);
+        out[1] = acc[2] == 0.0 ? T(1) : T(0);
+    }
+}
+
 }  // namespace pf

@@ -26,6 +26,7 @@ namespace pf {
 // ---------------------------------------------------------------------------------------------------------------
 #define PF_MAX_TILES 1024
 #define PF_TARGET_WGS 1024
+#define PF_AUTO_FLAGS 128  // steps whose observed flags pf_filter_run derives itself (workspace slot)
 
 struct Geom {
     int64_t N;
@@ -76,7 +77,7 @@ struct WsLayout {
     size_t part_elems;
     size_t off_stat;   // ColStat[B]
     size_t off_poison; // int32 [4][B]
-    size_t off_ctr;    // int32 [4] (reserved)
+    size_t off_ctr;    // int32 [4] (reserved) | at +64: uint8 [PF_AUTO_FLAGS] observed flags derived on the device
     size_t off_dbg;    // uint64 [32]: development timestamps (clock64) of workgroup (0, 0)
     size_t off_cpack;  // T [B][PK_N] (sized for double): the run's closed-form records
     size_t off_piv0;   // double [B][PF_MAXD]: the run's moment pivots
@@ -98,7 +99,7 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.off_poison = o;
     o = align256(o + sizeof(int32_t) * 4 * (size_t)g.B);
     w.off_ctr = o;
-    o = align256(o + 64);
+    o = align256(o + 64 + PF_AUTO_FLAGS);
     w.off_dbg = o;
     o = align256(o + 256);
     w.off_cpack = o;
@@ -1338,6 +1339,28 @@ extern "C" int pf_initial_sample(const double* m0, const double* s0, const void*
 }
 
 
+extern "C" int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems, int dtype, uint8_t* out, void* stream) {
+    if (!y || !out || steps < 0 || row_elems < 1 || steps > 0x7fffffff) return PF_EINVAL;
+    if (steps == 0) return PF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32) hipLaunchKernelGGL((k_observed_flags<float>), dim3((unsigned)steps), dim3(PF_WAVE), 0, st, (const float*)y, row_elems, out);
+    else if (dtype == PF_F64) hipLaunchKernelGGL((k_observed_flags<double>), dim3((unsigned)steps), dim3(PF_WAVE), 0, st, (const double*)y, row_elems, out);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_theta_ess(const void* logw, int64_t B, int dtype, void* out, void* stream) {
+    if (!logw || !out || B < 1) return PF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32) hipLaunchKernelGGL((k_theta_ess<float>), dim3(1), dim3(PF_BLOCK), 0, st, (const float*)logw, B, (float*)out);
+    else if (dtype == PF_F64) hipLaunchKernelGGL((k_theta_ess<double>), dim3(1), dim3(PF_BLOCK), 0, st, (const double*)logw, B, (double*)out);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+
 
 // ---- smoothing ---------------------------------------------------------------------------------------------------------
 extern "C" int pf_smooth_fixed_lag(const void* x_hist, const int32_t* anc_hist, void* out, int64_t S, int64_t N, int64_t B,
@@ -1500,8 +1523,16 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     place(t0);
     // partials of the incoming state (afterwards every step kernel leaves the partials of the state it wrote)
     a.step = (int)t0;
-    const bool dev_flags = A->observed_dev != nullptr;  // the kernels read the flags themselves
+    // neither flag array given: the flags are derived from y on the device, into the workspace (runs of <= PF_AUTO_FLAGS steps)
+    const bool auto_flags = !A->observed && !A->observed_dev && n_steps > 0;
+    const bool dev_flags = A->observed_dev != nullptr || auto_flags;  // the kernels read the flags themselves
     a.obs_dev = A->observed_dev;
+    if (auto_flags) {
+        uint8_t* fl = (uint8_t*)A->ws + wl.off_ctr + 64;
+        const int64_t row = A->y_rows * (int64_t)A->model.obs_dim;
+        hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * row, row, fl);
+        a.obs_dev = fl - t0;  // (indexed by the absolute step)
+    }
     a.obs = n_steps > 0 ? (dev_flags ? -1 : (observed[t0] != 0)) : 0;
     a.obs_next = 0;
     hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid_tiles, block, 0, st, a);
@@ -1772,7 +1803,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (!A->x[0] || !A->logw[0] || (A->ring < 3 && (!A->x[1] || !A->logw[1])) || !A->anc || !A->cdf || !A->means || !A->vars ||
         !A->ll_steps || !A->ll_total || !A->ws)
         return PF_EINVAL;
-    if (n_steps > 0 && (!A->y || (!A->observed && !A->observed_dev))) return PF_EINVAL;
+    if (n_steps > 0 && (!A->y || (!A->observed && !A->observed_dev && n_steps > PF_AUTO_FLAGS))) return PF_EINVAL;
     if (A->y_rows != 1 && A->y_rows != A->B) return PF_EINVAL;
     if (A->proposal == PF_PROP_LGO && A->model.obs_kind != PF_OBS_LINEAR) return PF_EUNSUPPORTED;
     if (A->filter != PF_FILTER_SISR && A->filter != PF_FILTER_APF) return PF_EUNSUPPORTED;

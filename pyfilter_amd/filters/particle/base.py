@@ -322,19 +322,16 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             plan = self._single_plans[key] = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
         t_start = int(ts_in.time_index)
         # all-NaN observation -> propagate only (filters/base.py:212).  The reference branches on the host; here the flag
-        # stays on the device (pf_filter_args.observed_dev), so consecutive filter() calls never wait for the GPU
-        obs_flag = y_dev.isnan().all().logical_not().to(torch.uint8).reshape(1)
+        # is derived on the device by the run itself (neither flag array passed), so consecutive filter() calls never
+        # wait for the GPU
 
         apf = self._FILTER_KIND == L.FILTER_APF
         x_out, lw_out = torch.empty_like(x_in), torch.empty_like(lw_in)
         if apf:
             anc = torch.empty((b, n), device=device, dtype=torch.int32)  # every APF step writes its ancestors
         else:  # SISR keeps the previous ancestors when it does not resample (sisr.py:25-26)
-            cached = getattr(state, "_anc32", None)  # (int32 (B, N) buffer, the int64 tensor it was widened into)
-            if cached is not None and cached[1] is state["_prev_inds"] and cached[0].shape == (b, n):
-                anc = cached[0].clone()
-            else:
-                anc = ops.to_cols(state.previous_indices.to(torch.int32))
+            own = state._anc32 is not None  # the kernels' buffer of the incoming state: copied, it stays that state's
+            anc = state.ancestors32().clone() if own else state.ancestors32().reshape(b, n).contiguous()
         stats = torch.zeros((4 * d + 2, b), device=device, dtype=dtype)  # means (2, B, D) | variances (2, B, D) | ll | total
         means, variances = stats[:2 * d].reshape(2, b, d), stats[2 * d:4 * d].reshape(2, b, d)
         ll_steps, ll_total = stats[4 * d].reshape(1, b), stats[4 * d + 1]
@@ -342,7 +339,6 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a = plan.args
         a.model.params = ctx.params.data_ptr()
         a.y = y_dev.data_ptr()
-        a.observed_dev = obs_flag.data_ptr()
         a.seed = self._next_draw_seed()  # fresh Philox draws per move
         a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
         a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
@@ -358,16 +354,15 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: every workgroup draws its column's u (Philox)
         L.check(L.load().pf_filter_run(C.byref(a), 0, 1, 1, L.stream_ptr()), "pf_filter_run")
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
-                              keep=(x_in, lw_in, y_dev, ctx.params, obs_flag))
+                              keep=(x_in, lw_in, y_dev, ctx.params))
 
         final_x = TimeseriesState(t_start + 1, ops.from_soa(x_out, self._batched, self._has_event),
                                   self._model.hidden.event_shape)
         shape_md = (lambda t: t if self._batched else t[0])
         new = ParticleFilterCorrection(
             final_x, ops.from_cols(lw_out, self._batched), shape_md(ll_steps[0]) if self._batched else ll_steps[0, 0],
-            ops.from_cols(anc, self._batched).long(), _moments=(shape_md(means[1]), shape_md(variances[1])),
+            None, _moments=(shape_md(means[1]), shape_md(variances[1])), _anc32=(anc, self._batched),
         )
-        new._anc32 = (anc, new["_prev_inds"])
         return new
 
     def batch_filter(self, y, bar=True, init_state=None) -> FilterResult:
@@ -386,7 +381,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         cached = self._obs_cache  # (the tensor object itself - an address alone could be a recycled allocation -, version, flags)
         if cached is not None and cached[0] is y and cached[1] == y._version:
             return cached[2]
-        flags = (~y_dev.isnan().reshape(y_dev.shape[0], -1).all(dim=1)).to(torch.uint8).cpu().contiguous()
+        flags = ops.observed_flags(y_dev).cpu()
         self._obs_cache = (y, y._version, flags)
         return flags
 
@@ -454,7 +449,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         plan.params.copy_(ctx.params)
         plan.x[0].copy_(ops.to_soa(x0, self._batched, self._has_event))
         plan.logw[0].copy_(ops.to_cols(state.weights))
-        (plan.anc_hist[0] if ring else plan.anc).copy_(ops.to_cols(state.previous_indices.to(torch.int32)))
+        (plan.anc_hist[0] if ring else plan.anc).copy_(state.ancestors32().reshape(b, n))
         plan.y.copy_(y_steps)
         plan.ll_total.zero_()
         # fresh Philox draws for every call: the base seed is baked into the (captured) launch arguments, the kernels add
@@ -504,10 +499,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             ll_q = ll_steps[q - 1] if self._batched else ll_steps[q - 1, 0]
             st = ParticleFilterCorrection(
                 TimeseriesState(t_start + q, ops.from_soa(x_soa, self._batched, self._has_event), es),
-                ops.from_cols(lw, self._batched), ll_q, ops.from_cols(anc32, self._batched).long(),
-                _moments=(means_v[q].clone(), vars_v[q].clone()),
+                ops.from_cols(lw, self._batched), ll_q, None,
+                _moments=(means_v[q].clone(), vars_v[q].clone()), _anc32=(anc32, self._batched),
             )
-            st._anc32 = (anc32, st["_prev_inds"])
             return st
 
         if ring:
@@ -535,8 +529,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ws = [ops.to_cols(s.weights) for s in states]
         an = []
         for s in states:
-            c = getattr(s, "_anc32", None)  # (int32 (B, N) buffer, the int64 tensor it was widened into)
-            an.append(c[0] if c is not None and c[1] is s["_prev_inds"] else ops.to_cols(s.previous_indices.to(torch.int32)))
+            an.append(s.ancestors32())  # (the kernels' own buffer - a slot of their history ring - while it is current)
 
         def stacked(ts):
             step = ts[0].numel() * ts[0].element_size()
@@ -608,13 +601,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
 class _SingleStepPlan:
     """Scratch + launch arguments of the fused *single-step* move behind ``filter()`` (the online / SMC^2 entry point):
     the kernels read the incoming state's own buffers and write freshly allocated ones that become the new state -
-    no staging copies, four launches (reduce, plan | scan, step, finalise) instead of the ~10 of the step-by-step route."""
+    no staging copies, four launches (observed flag, reduce, step, bookkeeping) instead of the ~10 of the step-by-step route."""
 
     def __init__(self, filt, kind, n, b, d, o, rows, dtype, device):
         self.cdf = torch.empty((b, n), device=device, dtype=dtype)
         self.pos = torch.empty((b, n), device=device, dtype=dtype)
         self.ws = L.new_workspace(n, b, device)
-        self.observed = torch.ones(1, dtype=torch.uint8)  # host
         self.rows = rows
         a = L.PfFilterArgs()
         a.model = ops.make_model_struct(kind, filt._ctx.params)
@@ -624,7 +616,7 @@ class _SingleStepPlan:
         a.ess_threshold = float(filt._resample_threshold) / float(n)
         a.seed = filt._seed
         a.cdf, a.pos = self.cdf.data_ptr(), self.pos.data_ptr()
-        a.y, a.y_rows, a.observed = None, rows, self.observed.data_ptr()
+        a.y, a.y_rows, a.observed, a.observed_dev = None, rows, None, None  # (flags: derived from y by the run)
         a.step_counter = None
         a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         self.args = a

@@ -34,15 +34,50 @@ class ParticleFilterPrediction(Prediction):
 
 
 class ParticleFilterCorrection(Correction):
-    def __init__(self, x: TimeseriesState, w: Tensor, ll: Tensor, prev_indices: Tensor, _moments=None):
+    _KEYS = ("_x", "_w", "_ll", "_prev_inds", "_mean", "_var")
+
+    def __init__(self, x: TimeseriesState, w: Tensor, ll: Tensor, prev_indices: Optional[Tensor], _moments=None,
+                 _anc32=None):
         super().__init__()
+        # the fused paths hand over the kernels' own int32 ``(B, N)`` ancestor buffer (``_anc32 = (buffer, batched)``)
+        # instead of ``prev_indices``: the reference's int64 tensor is widened from it on first access - an online filter
+        # move does not pay 8 B per particle for ancestors nobody looks at
+        self._anc32 = None
         self["_x"] = x
         self["_w"] = w
         self["_ll"] = ll
-        self["_prev_inds"] = prev_indices
-        # the fused path hands over the moments its kernels already reduced; otherwise they are reduced on first use
+        if prev_indices is not None:
+            self["_prev_inds"] = prev_indices
+        else:
+            assert _anc32 is not None
+            self._anc32 = _anc32
+        # ... and the moments their kernels already reduced; otherwise they are reduced on first use
         if _moments is not None:
             self["_mean"], self["_var"] = _moments
+
+    def __missing__(self, key):
+        if key == "_prev_inds" and self._anc32 is not None:
+            wide = self._view32().long()
+            dict.__setitem__(self, key, wide)  # (keeps the int32 buffer valid: both show the same ancestors)
+            return wide
+        raise KeyError(key)
+
+    def __setitem__(self, key, value):
+        if key == "_prev_inds":
+            self._anc32 = None  # set from outside: the kernels' buffer no longer is what the state shows
+        super().__setitem__(key, value)
+
+    def _view32(self) -> Tensor:
+        buf, batched = self._anc32
+        return buf.t() if batched else buf[0]
+
+    def ancestors32(self) -> Tensor:
+        """The ancestors as the kernels take them: int32 ``(B, N)`` - their own buffer while it is current."""
+        from ... import ops
+
+        if self._anc32 is not None:
+            return self._anc32[0]
+        return ops.to_cols(self["_prev_inds"].to(torch.int32))
 
     def _ensure_moments(self):
         if "_mean" not in self:
@@ -97,7 +132,11 @@ class ParticleFilterCorrection(Correction):
         self["_x"] = ts.copy(values=ops.gather_filters(ts.value, indices))
         self["_w"] = ops.gather_filters(self.weights, indices)
         self["_ll"][indices] = self["_ll"][indices]
-        self["_prev_inds"] = ops.gather_filters(self["_prev_inds"], indices)
+        if self._anc32 is not None and self._anc32[1]:  # the int32 buffer moves; the int64 view is rebuilt on demand
+            self._anc32 = (ops.to_cols(ops.gather_filters(self._view32(), indices)), True)
+            dict.pop(self, "_prev_inds", None)
+        else:
+            self["_prev_inds"] = ops.gather_filters(self["_prev_inds"], indices)
         self["_mean"] = self["_mean"][indices]
         self["_var"] = self["_var"][indices]
 
@@ -122,13 +161,21 @@ class ParticleFilterCorrection(Correction):
             self["_x"] = ts.copy(values=new_x)
         self["_w"] = ops.exchange_filters(self["_w"], other.weights, mask)
         self["_ll"][mask] = other.get_loglikelihood()[mask]
-        self["_prev_inds"] = ops.exchange_filters(self["_prev_inds"], other.previous_indices, mask)
+        if self._anc32 is not None and self._anc32[1] and getattr(other, "_anc32", None) is not None and other._anc32[1] \
+                and mask.dtype == torch.bool:
+            self._anc32 = (ops.to_cols(ops.exchange_filters(self._view32(), other._view32(), mask)), True)
+            dict.pop(self, "_prev_inds", None)
+        else:
+            self["_prev_inds"] = ops.exchange_filters(self["_prev_inds"], other.previous_indices, mask)
         self["_mean"][mask] = other["_mean"][mask]
         self["_var"][mask] = other["_var"][mask]
 
     def state_dict(self) -> Dict[str, Any]:
         self._ensure_moments()
-        result = OrderedDict((k, v) for k, v in self.items() if isinstance(v, torch.Tensor))
+        result = OrderedDict((k, self[k]) for k in self._KEYS[1:])
+        for k, v in self.items():  # (anything a caller attached)
+            if k not in result and isinstance(v, torch.Tensor):
+                result[k] = v
         result["_x"] = {"time_index": self.timeseries_state.time_index, "value": self.timeseries_state.value}
         return result
 

@@ -42,7 +42,16 @@ class SMC2State:
         return self.w if self.shard is None or self.shard.world == 1 else self.shard.all_gather(self.w)
 
     def _ess(self) -> torch.Tensor:
-        return theta_ess(self.global_weights())
+        """ESS of ALL theta-weights; ``self.stats`` keeps it together with the "every weight finite" flag - on the GPU both
+        come out of one launch (``pf_theta_ess``), so an observation costs one small device -> host copy."""
+        gw = self.global_weights()
+        if gw.is_cuda:
+            from .. import ops
+
+            self.stats = ops.theta_ess(gw)
+        else:  # (the multi-process CPU tests)
+            self.stats = torch.stack([theta_ess(gw), gw.isfinite().all().to(gw.dtype)])
+        return self.stats[0]
 
     def append(self, filter_state):
         """``w += ll_t`` and the new ESS (state.py:35-44).  Sharded: the all-gather of the increments happens here."""
@@ -62,7 +71,7 @@ class SMC2State:
     def replicate(self, filter_state) -> "SMC2State":
         other = SMC2State.__new__(SMC2State)
         other.w, other.filter_state, other.shard = torch.zeros_like(self.w), filter_state, self.shard
-        other.ess, other.parsed, other.current_iteration = [], self.parsed, self.current_iteration
+        other.ess, other.parsed, other.current_iteration, other.stats = [], self.parsed, self.current_iteration, None
         return other
 
     def state_dict(self):
@@ -209,10 +218,9 @@ class SMC2:
         state.append_data(y)
         filter_state = self.filter.filter(y, state.filter_state.latest_state, result=state.filter_state)
         state.append(filter_state)
-        gw = state.global_weights()
         # the reference's host branch (smc2.py:59-62): one small device -> host copy per observation
-        rejuvenate = bool((state.ess[-1] < self._threshold * self.particles[0]) | ~gw.isfinite().all())
-        if rejuvenate:
+        ess, finite = state.stats.tolist()
+        if ess < self._threshold * self.particles[0] or not finite:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
         return state
 

@@ -319,6 +319,30 @@ def debug_launch_trace(last: int = 64):
     return [dict(zip(TRACE_FIELDS, buf[i * k:(i + 1) * k])) for i in range(n)]
 
 
+def observed_flags(y: torch.Tensor) -> torch.Tensor:
+    """``y (T, ...)`` -> ``(T,)`` uint8 on the device: 1 unless the whole observation is NaN (pf_observed_flags;
+    ``filters/base.py:212``)."""
+    L.require_gpu(y)
+    y = y.contiguous()
+    steps = y.shape[0]
+    out = torch.empty(steps, dtype=torch.uint8, device=y.device)
+    if steps:
+        L.check(L.load().pf_observed_flags(y.data_ptr(), steps, y.numel() // steps, L.dtype_code(y.dtype), out.data_ptr(),
+                                           L.stream_ptr()), "pf_observed_flags")
+    return out
+
+
+def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
+    """``(B,)`` theta log-weights -> ``(2,)``: their effective sample size and a "all finite" flag, one launch
+    (pf_theta_ess; ``sequential/state.py:35-44``, ``smc2.py:59-62``)."""
+    L.require_gpu(log_w)
+    log_w = log_w.contiguous()
+    out = torch.empty(2, dtype=log_w.dtype, device=log_w.device)
+    L.check(L.load().pf_theta_ess(log_w.data_ptr(), log_w.numel(), L.dtype_code(log_w.dtype), out.data_ptr(), L.stream_ptr()),
+            "pf_theta_ess")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # smoothing over a recorded state history
 # ----------------------------------------------------------------------------------------------------------------

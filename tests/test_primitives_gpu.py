@@ -206,3 +206,49 @@ def test_residual_resampling(pf, dt):
     # all-deterministic corner: uniform weights
     iu = resampling.residual(torch.full((256,), 1.0 / 256, dtype=dtype).cuda(), normalized=True).cpu()
     assert torch.equal(iu, torch.arange(256))
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_observed_flags(pf, dt):
+    """pf_observed_flags against the reference's host test ``y.isnan().all()`` (filters/base.py:212), per observation."""
+    from pyfilter_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    for shape in [(37,), (64, 5), (19, 3, 2), (200, 130), (0, 4)]:
+        y = torch.randn(shape, generator=g, dtype=DT[dt])
+        if y.numel():
+            y[torch.rand(shape, generator=g) < 0.4] = float("nan")
+            y[::3] = float("nan")  # whole observations missing
+            if y.dim() > 1:
+                y[1].reshape(-1)[-1] = 0.5  # a single surviving element keeps the observation
+        want = (~y.reshape(y.shape[0], -1).isnan().all(dim=1)).to(torch.uint8) if y.numel() else torch.zeros(0, dtype=torch.uint8)
+        got = ops.observed_flags(y.cuda())
+        assert torch.equal(got.cpu(), want), shape
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_theta_ess(pf, dt):
+    """pf_theta_ess against ``get_ess(normalize(w))`` of the oracle (utils.py:8-20, 49-64) and ``isfinite(w).all()``."""
+    from pyfilter_amd import ops
+
+    g = torch.Generator().manual_seed(6)
+    tol = 1e-5 if dt == "f32" else 1e-12
+    for b in (1, 7, 256, 1024, 5000):
+        for kind in ("plain", "spread", "nan", "posinf", "neginf", "all_neginf"):
+            w = torch.randn(b, generator=g, dtype=DT[dt]) * (30.0 if kind == "spread" else 1.0) - 700.0
+            if kind == "nan":
+                w[b // 2] = float("nan")
+            if kind == "posinf":
+                w[0] = float("inf")
+            if kind == "neginf":
+                w[-1] = -float("inf")
+            if kind == "all_neginf":
+                w[:] = -float("inf")
+            ess, finite = ops.theta_ess(w.cuda()).tolist()
+            assert bool(finite) == bool(torch.isfinite(w).all()), (b, kind)
+            if not torch.isfinite(w).any():  # nothing left after the sanitising step: uniform weights (utils.py:60-62)
+                assert ess == b
+                continue
+            W = cpu_ref.normalize(w.clone().double())
+            want = float(1.0 / (W * W).sum())
+            assert abs(ess - want) <= tol * want, (b, kind, ess, want)
