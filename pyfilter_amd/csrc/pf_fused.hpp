@@ -540,6 +540,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 // taken from them) are bit-identical everywhere, which is what lets the step kernel do without a planning kernel.
 // redm: PF_NWAVES doubles, reds: (2 + NX) * PF_NWAVES doubles.  Ends with a barrier when TABLE (the table is readable).
 #define PF_COMBINE_ITERS (PF_MAX_TILES / PF_BLOCK)  // partial records per thread
+#define PF_PROBE_STEP 8  // spacing of the prologue's window-start probes (entries)
 struct ColSums {
     double M, S, Q;
 };
@@ -891,21 +892,43 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
         // no position and cost nothing but window capacity) - so the bracket the first round yields (<= tile / 64 entries
         // wide) is enough, and a second, dependent probe round (a further memory latency) is not spent.
         const int64_t len = last + 1 - first;
-        const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
-        int64_t probe = first + (lane + 1) * st - 1;
-        if (probe > last) probe = last;
-        T cprobe;
-        if constexpr (MULTI) {
-            const double* cg = a.ctab_r(b) + 2 * (probe / (PF_WAVE * VEC));
-            cprobe = cdf_from_local<T>(l_col[probe], cg[0], cg[1], Pk, fk, Pn, probe == last, probe == g.N - 1);
-        } else {
-            cprobe = cdf_from_local<T>(l_col[probe], Pk, fk, Pn, probe == last, probe == g.N - 1);
+        auto cdf_at = [&](int64_t q) -> T {
+            if constexpr (MULTI) {
+                const double* cg = a.ctab_r(b) + 2 * (q / (PF_WAVE * VEC));
+                return cdf_from_local<T>(l_col[q], cg[0], cg[1], Pk, fk, Pn, q == last, q == g.N - 1);
+            } else {
+                return cdf_from_local<T>(l_col[q], Pk, fk, Pn, q == last, q == g.N - 1);
+            }
+        };
+        // The 64 probes sit PF_PROBE_STEP entries apart around where p falls if the tile's weight were spread evenly (the
+        // cumulative sum of thousands of weights strays from the straight line by a few dozen entries): 16 cache lines the
+        // window load is about to read anyway, and a start known to 8 entries - instead of 64 lines spread over the whole
+        // tile (at 2^22 x 1 a quarter of the kernel's algorithmic reads) and a start known to tile / 64.
+        int64_t res;
+        bool found;
+        {
+            float fr = (float)((double)p - Pk) * __builtin_amdgcn_rcpf((float)(Pn - Pk));
+            fr = __builtin_fminf(__builtin_fmaxf(fr, 0.0f), 1.0f);  // (NaN -> 0)
+            int64_t g0 = first + (int64_t)(fr * (float)len) - (PF_WAVE / 2) * PF_PROBE_STEP;
+            const int64_t g0max = last - (PF_WAVE - 1) * PF_PROBE_STEP;
+            if (g0 > g0max) g0 = g0max;
+            if (g0 < first) g0 = first;
+            int64_t q = g0 + (int64_t)lane * PF_PROBE_STEP;
+            if (q > last) q = last;
+            const unsigned long long bal = __ballot(cdf_at(q) >= p);
+            const int f = bal ? __ffsll((long long)bal) - 1 : 0;
+            found = bal != 0 && (f > 0 || g0 == first);  // a probe below p precedes the first one at or above it
+            res = f > 0 ? g0 + (int64_t)(f - 1) * PF_PROBE_STEP + 1 : first;
         }
-        const bool ge = cprobe >= p;
-        const unsigned long long bal = __ballot(ge);
-        const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
-        int64_t res = first + (int64_t)f * st;
-        if (res > last) res = last;
+        if (!found) {  // (uniform) the tile's weight is concentrated: one probe round over the whole tile
+            const int64_t st = (len + PF_WAVE - 1) / PF_WAVE;
+            int64_t probe = first + (lane + 1) * st - 1;
+            if (probe > last) probe = last;
+            const unsigned long long bal = __ballot(cdf_at(probe) >= p);
+            const int f = bal ? __ffsll((long long)bal) - 1 : PF_WAVE - 1;  // (cdf(last) >= p by the choice of kt)
+            res = first + (int64_t)f * st;
+            if (res > last) res = last;
+        }
         if (lane == 0) {
             sh.sh_plan[0] = (int)res;
             sh.sh_plan[1] = kt;
