@@ -34,11 +34,13 @@ def build_model(theta):
     return ts.LinearStateSpaceModel(models.AR(t(0.0), theta["beta"], theta["sigma"]), (t(1.0), t(0.3)))
 
 
-def smc2(y: torch.Tensor, n_theta=256, n_state=2048, ess_frac=0.5, seed=0, verbose=False, **kernel_kwargs):
+def smc2(y: torch.Tensor, n_theta=256, n_state=2048, ess_frac=0.5, seed=0, verbose=False, block=1, **kernel_kwargs):
+    """``block = 1``: observation by observation (``step``, the online use); ``block > 1``: ``fit`` with the filters running
+    that many observations ahead of the rejuvenation test (one host decision point per block)."""
     filt = APF(build_model, n_state, proposal=proposals.LinearGaussianObservations(), seed=seed)
     alg = SMC2(filt, n_theta, PRIORS, threshold=ess_frac, device=y.device, seed=seed, **kernel_kwargs)
-    state = alg.initialize()
-    for t, yt in enumerate(y):
+    state = alg.fit(y, block=block) if block > 1 else alg.initialize()
+    for t, yt in enumerate(y if block <= 1 else []):
         before = len(alg._kernel.acceptance_history)
         state = alg.step(yt, state)
         if verbose and len(alg._kernel.acceptance_history) > before and alg.shard.rank == 0:
@@ -61,6 +63,6 @@ if __name__ == "__main__":
     for _ in range(T):
         x = beta * x + sigma * torch.randn((), generator=g).item()
         ys.append(x + 0.3 * torch.randn((), generator=g).item())
-    out = smc2(torch.tensor(ys, device="cuda"), n_theta, n_state, verbose=True)
+    out = smc2(torch.tensor(ys, device="cuda"), n_theta, n_state, verbose=True, block=int(os.environ.get("SMC2_BLOCK", 1)))
     if int(os.environ.get("RANK", 0)) == 0:
         print("posterior mean (beta, sigma):", out["mean"].tolist(), " truth:", (beta, sigma), " rejuvenations:", out["moves"])

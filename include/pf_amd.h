@@ -157,10 +157,11 @@ int pf_initial_sample(const double* m0, const double* s0, const void* z, uint64_
 int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems, int dtype, uint8_t* out, void* stream);
 
 /* theta-level bookkeeping of SMC^2 (inference/sequential/state.py:35-44 `get_ess(normalize(w))`, smc2.py:59-62
- * `(~isfinite(w)).any()`) in one launch: out[0] = effective sample size of the B log-weights under
- * pyfilter.utils.normalize (utils.py:49-64: NaN / +inf count as -inf, all -inf -> uniform), out[1] = 1 if every
- * weight is finite else 0.  `out`: two device values of `dtype`. */
-int pf_theta_ess(const void* logw, int64_t B, int dtype, void* out, void* stream);
+ * `(~isfinite(w)).any()`) in one launch, for `rows` weight vectors (rows, B) at once (the observations of a block):
+ * out[r][0] = effective sample size of row r's B log-weights under pyfilter.utils.normalize (utils.py:49-64: NaN /
+ * +inf count as -inf, all -inf -> uniform), out[r][1] = 1 if every weight of the row is finite else 0.
+ * `out`: (rows, 2) device values of `dtype`. */
+int pf_theta_ess(const void* logw, int64_t rows, int64_t B, int dtype, void* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------ *
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and

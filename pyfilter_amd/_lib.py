@@ -102,7 +102,7 @@ def load() -> C.CDLL:
     lib.pf_smooth_fixed_lag.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, vp]
     lib.pf_smooth_ffbs.argtypes = [C.POINTER(PfModel), vp, vp, vp, vp, u64, vp, i64, i64, i64, i32, vp]
     lib.pf_observed_flags.argtypes = [vp, i64, i64, i32, vp, vp]
-    lib.pf_theta_ess.argtypes = [vp, i64, i32, vp, vp]
+    lib.pf_theta_ess.argtypes = [vp, i64, i64, i32, vp, vp]
     lib.pf_debug_draw_normals.argtypes = [u64, u32, i64, vp, i64, i64, i64, i32, vp]
     lib.pf_debug_launch_trace.argtypes = [C.POINTER(C.c_int32), i32]
     for name in EXPORTS:

@@ -1460,6 +1460,12 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>:
         column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
 }
 
+// clears the per-column records of a fresh run (see filter_run_impl)
+template <typename W> __global__ __launch_bounds__(PF_BLOCK) void k_zero_words(W* __restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) p[i] = W(0);
+}
+
 // "Observation k carries information" (filters/base.py:212: an all-NaN observation is a propagate-only move): one wave per
 // step, flag[k] = any element of y[k] is not NaN.  Launched by pf_filter_run itself when the caller passes neither flag
 // array, and exported as pf_observed_flags.
@@ -1474,11 +1480,14 @@ __global__ __launch_bounds__(PF_WAVE) void k_observed_flags(const T* __restrict_
 
 // theta-level bookkeeping of SMC^2 in one launch (sequential/state.py:35-44, smc2.py:59-62): effective sample size of B
 // log-weights under pyfilter.utils.normalize (NaN / +inf count as -inf; all -inf -> uniform) and whether every weight is
-// finite.  One workgroup; B is the number of theta-particles (10^2 .. 10^5).  out[0] = ESS, out[1] = 1 if all finite.
+// finite.  One workgroup per row of B weights (B = the number of theta-particles, 10^2 .. 10^5; rows = the observations of
+// a speculative block).  out[r][0] = ESS, out[r][1] = 1 if all finite.
 template <typename T>
 __global__ __launch_bounds__(PF_BLOCK) void k_theta_ess(const T* __restrict__ w, int64_t B, T* __restrict__ out) {
     __shared__ T redm[PF_NWAVES];
     __shared__ double red[3 * PF_NWAVES];
+    w += (int64_t)blockIdx.x * B;
+    out += 2 * (int64_t)blockIdx.x;
     T m = -Lim<T>::inf();
     bool finite = true;
     for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {

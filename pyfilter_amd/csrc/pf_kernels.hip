@@ -1350,11 +1350,13 @@ extern "C" int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems
     return PF_OK;
 }
 
-extern "C" int pf_theta_ess(const void* logw, int64_t B, int dtype, void* out, void* stream) {
-    if (!logw || !out || B < 1) return PF_EINVAL;
+extern "C" int pf_theta_ess(const void* logw, int64_t rows, int64_t B, int dtype, void* out, void* stream) {
+    if (!logw || !out || B < 1 || rows < 0 || rows > 0x7fffffff) return PF_EINVAL;
+    if (rows == 0) return PF_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == PF_F32) hipLaunchKernelGGL((k_theta_ess<float>), dim3(1), dim3(PF_BLOCK), 0, st, (const float*)logw, B, (float*)out);
-    else if (dtype == PF_F64) hipLaunchKernelGGL((k_theta_ess<double>), dim3(1), dim3(PF_BLOCK), 0, st, (const double*)logw, B, (double*)out);
+    const dim3 grid((unsigned)rows);
+    if (dtype == PF_F32) hipLaunchKernelGGL((k_theta_ess<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)logw, B, (float*)out);
+    else if (dtype == PF_F64) hipLaunchKernelGGL((k_theta_ess<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)logw, B, (double*)out);
     else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;
@@ -1505,8 +1507,12 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
-        hipError_t e = hipMemsetAsync((char*)A->ws + wl.off_stat, 0, wl.off_ctr - wl.off_stat, st);
-        if (e != hipSuccess) return (int)e;
+        // (a kernel, not hipMemsetAsync: captured as a memset node the fill stopped clearing these records after ~195
+        // replays of the same executable graph on ROCm 7.2 - every log-likelihood of the run came back NaN, "poisoned" -
+        // tools/graph_replays.py)
+        const size_t words = (wl.off_ctr - wl.off_stat) / sizeof(uint32_t);  // (256-byte aligned regions)
+        hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3((unsigned)((words + PF_BLOCK - 1) / PF_BLOCK)), dim3(PF_BLOCK), 0, st,
+                           (uint32_t*)((char*)A->ws + wl.off_stat), words);
     }
     // state history: slot pointers per launch (the kernels keep addressing "buffer step & 1 is read, the other written")
     const int64_t ring = A->ring >= 3 ? A->ring : 0;

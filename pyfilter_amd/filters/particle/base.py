@@ -385,7 +385,28 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._obs_cache = (y, y._version, flags)
         return flags
 
-    def _batch_filter_fused(self, y: torch.Tensor, init_state=None) -> FilterResult:
+    def filter_block(self, y: torch.Tensor, state: ParticleFilterCorrection, observed: Optional[torch.Tensor] = None,
+                     replay=None):
+        """``len(y)`` consecutive moves from ``state`` as ONE fused run - what a caller that decides something on the host
+        after every observation (SMC^2: rejuvenate or not, ``smc2.py:59-62``) uses to look ahead: it runs a block, reads
+        the per-move log-likelihood increments once, and if its decision fell at move ``j`` inside the block asks for the
+        block again cut after that move - ``replay = token`` of the first run - which repeats exactly the same draws, so
+        the state it gets is the one the increments it already used belong to.
+
+        Returns ``(result, ll_steps, token)``: the run's ``FilterResult`` (moment rows incl. the incoming state's, total
+        log-likelihood, final state), the increments ``(len(y), *batch_shape)`` and the token for a replay.  ``observed``:
+        optional host flags (uint8, one per observation) when the caller already knows which observations are not
+        all-NaN (saves the device round trip per call).  None when the fused route does not apply."""
+        x = state.timeseries_state.value
+        if not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1 or self._record_intermediary:
+            return None
+        res = self._batch_filter_fused(y, state._restarted(), observed=observed, replay=replay)
+        run = self._last_run
+        ll = run["ll_steps"]
+        u = run["u"]  # (a cached plan's buffer, redrawn by the next run: the token keeps a copy)
+        return res, (ll if self._batched else ll[:, 0]), (run["seed_eff"], None if u is None else u.clone())
+
+    def _batch_filter_fused(self, y: torch.Tensor, init_state=None, observed=None, replay=None) -> FilterResult:
         state = init_state if init_state is not None else self.initialize()
         ctx = self._ensure_context()
         kind = ctx.kind
@@ -411,7 +432,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if y_dev.shape[1] not in (1, b):
             raise L.PfAmdError(f"observations of shape {tuple(y.shape)} do not broadcast against batch {b}")
         rows = y_dev.shape[1]
-        informative = self._observed_flags(y, y_dev)  # host (T_obs,) uint8
+        informative = observed if observed is not None else self._observed_flags(y, y_dev)  # host (T_obs,) uint8
         if steps == t_obs:
             y_steps, observed_host = y_dev, informative
         else:
@@ -433,7 +454,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             wanted = reported if keep_states is None else reported[-keep_states:]
             ring = max(3, steps - wanted[0] + 1)  # slots for the states wanted[0] .. steps
         taped = ctx.z_tape is not None or ctx.u_tape is not None
-        use_graph = ((not taped) and not ring and not getattr(self, "_time_kernels", False)
+        use_graph = ((not taped) and not ring and replay is None and not getattr(self, "_time_kernels", False)
                      and os.environ.get("PF_NO_GRAPH", "0") != "1")
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
                self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes())
@@ -454,7 +475,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         plan.ll_total.zero_()
         # fresh Philox draws for every call: the base seed is baked into the (captured) launch arguments, the kernels add
         # the device word `epoch` to it - set here so that base + epoch = this run's draw seed (mod 2^64)
-        seed_eff = self._next_draw_seed()
+        seed_eff = self._next_draw_seed() if replay is None else replay[0]
         word = (seed_eff - self._seed) & _M64
         plan.epoch.fill_(word - (1 << 64) if word >= (1 << 63) else word)
         a = plan.args
@@ -464,6 +485,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             assert z_tape.shape[0] == steps, "z tape shorter than the number of steps"
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + steps].contiguous()
+        elif replay is not None and replay[1] is not None:
+            u_tape = replay[1][:steps].contiguous()  # the offsets of the run being repeated
         elif self._resampler_kind() == L.RESAMPLE_SYSTEMATIC:
             # one uniform per (step, filter): T x B numbers drawn up front (a device generator seeded by the run's seed),
             # so no kernel spends a Philox chain on a per-column scalar
@@ -492,6 +515,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         shape_md = (lambda t: t if self._batched else t[:, 0])
         means_v, vars_v = shape_md(plan.means), shape_md(plan.vars)  # (steps + 1, [B], D): copied by the moment log
         ll_steps, ll_total = plan.ll_steps.clone(), plan.ll_total.clone()
+        self._last_run["ll_steps"] = ll_steps
         es = self._model.hidden.event_shape
 
         def state_of(q, x_soa, lw, anc32):

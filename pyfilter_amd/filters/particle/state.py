@@ -79,6 +79,15 @@ class ParticleFilterCorrection(Correction):
             return self._anc32[0]
         return ops.to_cols(self["_prev_inds"].to(torch.int32))
 
+    def _restarted(self) -> "ParticleFilterCorrection":
+        """The same particles / weights / ancestors (shared tensors) with a zero log-likelihood of their own: the incoming
+        state of a run whose result must not accumulate into this state's ``_ll`` (``FilterResult`` aliases it, result.py:34)."""
+        other = ParticleFilterCorrection.__new__(ParticleFilterCorrection)
+        dict.update(other, self)
+        other._anc32 = self._anc32
+        dict.__setitem__(other, "_ll", torch.zeros_like(self["_ll"]))
+        return other
+
     def _ensure_moments(self):
         if "_mean" not in self:
             self["_mean"], self["_var"] = get_filter_mean_and_variance(self["_x"], self.normalized_weights())

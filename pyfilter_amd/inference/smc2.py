@@ -186,13 +186,14 @@ class SMC2:
     ``particles`` is the TOTAL number of theta-particles; under a process group each rank holds its block."""
 
     def __init__(self, filter_, particles: int, priors, threshold: float = 0.2, kernel=None, max_increases: int = 5,
-                 device="cuda", dtype=torch.float32, seed: int = 0, group=None, **kwargs):
+                 device="cuda", dtype=torch.float32, seed: int = 0, group=None, block: int = 16, **kwargs):
         self.filter = filter_
         self.shard = Shard(particles, group)
         self.particles = torch.Size([particles])
         self.theta = ThetaParticles(priors, self.shard.local, device, dtype, self.shard)
         self.filter.set_batch_shape(torch.Size([self.shard.local]))
         self._threshold = threshold
+        self._block = max(1, int(block))  # observations ``fit`` runs ahead of its rejuvenation test (see ``_steps_ahead``)
         self._kernel = ParticleMetropolisHastings(proposal=kernel, max_increases=max_increases, **kwargs)
         self._gen = torch.Generator().manual_seed(seed)  # CPU: the same stream on every rank (theta-level draws)
         self._seed = seed
@@ -224,10 +225,67 @@ class SMC2:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
         return state
 
-    def fit(self, y: torch.Tensor) -> SMC2State:
+    def _steps_ahead(self, ys: torch.Tensor, flags: torch.Tensor, state: SMC2State):
+        """Up to ``len(ys)`` observations with ONE host decision point.  The reference tests the ESS of the theta-weights on
+        the host after every observation (``smc2.py:59-62``) - a device round trip per observation, which is what an
+        SMC^2 run on a GPU spends its time on.  Here the filters run the whole block as one fused sequence
+        (``filter_block``); the block's theta-weight paths ``w + cumsum(ll)`` (one all-gather per block when sharded) and
+        their ESS come back in one copy, and the test is applied to them in order.  No rejuvenation due (the rule, not the
+        exception): the block is committed.  Due at observation ``j``: the moves after it never happened - the block is
+        run again cut after ``j`` *on the same draws*, so state and weights belong to one particle system - and the
+        kernel takes over exactly where the reference's would.  Returns ``(observations consumed, state)``; 0 when the
+        filter has no fused block route."""
+        from .. import ops
+
+        filt, shard = self.filter, self.shard
+        sharded = shard.world > 1
+        latest = state.filter_state.latest_state
+        out = filt.filter_block(ys, latest, observed=flags)
+        if out is None:
+            return 0, state
+        thr = self._threshold * self.particles[0]
+
+        def paths(ll):
+            w_path = state.w + ll.cumsum(0)  # (n, B_local)
+            return w_path, ops.theta_ess(shard.all_gather(w_path, dim=1) if sharded else w_path)
+
+        res, ll, token = out
+        w_path, stats = paths(ll)
+        n = ys.shape[0]
+        hit = next((q for q, (ess, finite) in enumerate(stats.tolist()) if ess < thr or not finite), None)
+        take = n if hit is None else hit + 1
+        if take < n:
+            res, ll, _ = filt.filter_block(ys[:take], latest, observed=flags[:take], replay=token)
+            w_path, stats = paths(ll)
+        for q in range(take):
+            state.append_data(ys[q])
+        state.w.copy_(w_path[take - 1])
+        state.ess.extend(stats[:take, 0].unbind(0))
+        state.stats = stats[take - 1]
+        state.filter_state._extend_fused(res.filter_means[1:], res.filter_variance[1:], res.loglikelihood, res.latest_state)
+        state.current_iteration += take
+        if hit is not None:
+            state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
+        return take, state
+
+    def fit(self, y: torch.Tensor, block: Optional[int] = None) -> SMC2State:
+        """All observations of ``y``.  ``block`` (default: the constructor's) = how many observations the filters run
+        ahead of the rejuvenation test; 1 = the reference's observation-by-observation loop (``step``)."""
         state = self.initialize()
-        for yt in y:
-            state = self.step(yt, state)
+        k = self._block if block is None else max(1, int(block))
+        flags = None
+        if k > 1 and hasattr(self.filter, "filter_block") and isinstance(y, torch.Tensor) and y.is_cuda and y.is_floating_point():
+            from .. import ops
+
+            flags = ops.observed_flags(y if y.dtype in (torch.float32, torch.float64) else y.float()).cpu()
+        t, total = 0, y.shape[0]
+        while t < total:
+            n, done = min(k, total - t), 0
+            if flags is not None and n > 1:
+                done, state = self._steps_ahead(y[t:t + n], flags[t:t + n], state)
+            if done == 0:
+                state, done = self.step(y[t], state), 1
+            t += done
         return state
 
     def posterior_mean(self, state: SMC2State) -> torch.Tensor:

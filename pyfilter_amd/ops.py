@@ -333,12 +333,14 @@ def observed_flags(y: torch.Tensor) -> torch.Tensor:
 
 
 def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
-    """``(B,)`` theta log-weights -> ``(2,)``: their effective sample size and a "all finite" flag, one launch
-    (pf_theta_ess; ``sequential/state.py:35-44``, ``smc2.py:59-62``)."""
+    """``(B,)`` theta log-weights -> ``(2,)``: their effective sample size and a "all finite" flag; ``(rows, B)`` ->
+    ``(rows, 2)``.  One launch (pf_theta_ess; ``sequential/state.py:35-44``, ``smc2.py:59-62``)."""
     L.require_gpu(log_w)
     log_w = log_w.contiguous()
-    out = torch.empty(2, dtype=log_w.dtype, device=log_w.device)
-    L.check(L.load().pf_theta_ess(log_w.data_ptr(), log_w.numel(), L.dtype_code(log_w.dtype), out.data_ptr(), L.stream_ptr()),
+    b = log_w.shape[-1]
+    rows = log_w.numel() // b
+    out = torch.empty(log_w.shape[:-1] + (2,), dtype=log_w.dtype, device=log_w.device)
+    L.check(L.load().pf_theta_ess(log_w.data_ptr(), rows, b, L.dtype_code(log_w.dtype), out.data_ptr(), L.stream_ptr()),
             "pf_theta_ess")
     return out
 

@@ -190,3 +190,86 @@ def test_run_pmmh_moves_chains_towards_the_posterior():
     mean = theta.stack_parameters(True).mean(0).tolist()
     assert 0.02 < rate < 0.9, rate
     assert abs(mean[0] - 0.8) < 0.15 and abs(mean[1] - 0.4) < 0.12, mean
+
+
+def _theta_filter(b=48, n=2048, seed=11):
+    from torch.distributions import Uniform
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import ThetaParticles
+    from pyfilter_amd.timeseries import models
+
+    def build(theta):
+        t = lambda v: torch.tensor(v, device="cuda")  # noqa: E731
+        return ts.LinearStateSpaceModel(models.AR(t(0.0), theta["beta"], theta["sigma"]), (t(1.0), t(0.3)))
+
+    theta = ThetaParticles({"beta": Uniform(0.3, 0.95), "sigma": Uniform(0.2, 0.8)}, b, "cuda")
+    theta.initialize_parameters(torch.Generator().manual_seed(seed))
+    filt = APF(build, n, proposal=proposals.LinearGaussianObservations(), seed=seed)
+    filt.set_batch_shape(torch.Size([b]))
+    filt.initialize_model(theta)
+    return filt
+
+
+def test_filter_block_and_its_replay():
+    """``filter_block`` - k moves as one fused run - and its cut replay: the replay of the first j + 1 moves repeats the
+    block's draws, so its increments equal the block's (bit for bit before the last move, whose kernel variant differs:
+    within float rounding there), it is deterministic, and the incoming state's own log-likelihood is left alone."""
+    filt = _theta_filter()
+    y = _lg_data(40, seed=4)
+    res0 = filt.batch_filter(y[:8], bar=False)
+    s0 = res0.latest_state
+    ll_in = s0.get_loglikelihood().clone()
+    x_in = s0.timeseries_state.value.clone()
+    flags = torch.ones(12, dtype=torch.uint8)
+    res, ll, token = filt.filter_block(y[8:20], s0, observed=flags)
+    assert ll.shape == (12, 48) and torch.isfinite(ll).all()
+    assert torch.equal(s0.get_loglikelihood(), ll_in) and torch.equal(s0.timeseries_state.value, x_in)
+    torch.testing.assert_close(res.loglikelihood, ll.sum(0), rtol=1e-5, atol=1e-4)
+    assert res.filter_means.shape[0] == 13 and int(res.latest_state.timeseries_state.time_index) == 20
+    for j in (0, 4, 10):
+        r1, l1, _ = filt.filter_block(y[8:9 + j], s0, observed=flags[:j + 1], replay=token)
+        r2, l2, _ = filt.filter_block(y[8:9 + j], s0, observed=flags[:j + 1], replay=token)
+        assert torch.equal(l1, l2) and torch.equal(r1.latest_state.timeseries_state.value, r2.latest_state.timeseries_state.value)
+        assert torch.equal(l1[:j], ll[:j])
+        torch.testing.assert_close(l1[j], ll[j], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(r1.filter_means, res.filter_means[:j + 2], rtol=1e-5, atol=1e-6)
+    # a block continues exactly like the online moves do: same time index, same shapes, finite numbers
+    nxt, ll2, _ = filt.filter_block(y[20:24], res.latest_state)
+    assert int(nxt.latest_state.timeseries_state.time_index) == 24 and torch.isfinite(ll2).all()
+
+
+@pytest.mark.parametrize("block", [4, 16])
+def test_smc2_fit_running_ahead_of_the_rejuvenation_test(block):
+    """``SMC2.fit`` with the filters running ``block`` observations ahead of the host's rejuvenation test: the bookkeeping
+    is that of the observation-by-observation loop (one ESS / parsed observation / moment row per observation; a
+    rejuvenation cuts the block where the test fired), and the posterior lands on the data-generating parameters just as
+    the stepwise run's does."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "smc2_linear_gaussian.py")
+    spec = importlib.util.spec_from_file_location("smc2_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+
+    y = _lg_data(150)
+    filt = APF(mod.build_model, 1024, proposal=proposals.LinearGaussianObservations(), seed=3)
+    alg = SMC2(filt, 192, mod.PRIORS, threshold=0.5, device="cuda", seed=3)
+    state = alg.fit(y, block=block)
+    t_len = y.shape[0]
+    assert state.current_iteration == t_len and len(state.ess) == t_len + 1 and state.parsed_data.shape[0] == t_len
+    assert state.filter_state.filter_means.shape[0] == t_len + 1
+    assert int(state.filter_state.latest_state.timeseries_state.time_index) == t_len
+    moves = len(alg._kernel.acceptance_history)
+    assert moves >= 1
+    # every rejuvenation reset the weights right after an observation whose ESS fell below the threshold - and only those
+    ess = torch.stack(state.ess).cpu()
+    low = (ess[1:] < 0.5 * 192).sum().item()
+    assert low == moves, (low, moves)
+    b, s = alg.posterior_mean(state).tolist()
+    assert abs(b - 0.8) < 0.15 and abs(s - 0.4) < 0.12, (b, s)
+    assert torch.isfinite(state.filter_state.loglikelihood).all()

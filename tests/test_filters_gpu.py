@@ -754,3 +754,16 @@ def test_predict_path_from_the_latest_state(name):
     loc, scale = cpu_ref.M.mean_scale(spec, res.latest_state.timeseries_state.value.cpu())
     zscore = (x[0].cpu() - loc) / (scale * spec.inc_scale)
     assert abs(zscore.mean().item()) < 0.2 and abs(zscore.std().item() - 1.0) < 0.2
+
+
+def test_a_captured_graph_survives_hundreds_of_replays():
+    """One cached plan / executable hipGraph replayed 450 times (SMC^2 running blocks ahead, PMMH re-filtering one data
+    set): every run's log-likelihood increments stay finite.  (Regression: a memset node in the captured sequence stopped
+    clearing the per-column records after ~195 replays - tools/graph_replays.py.)"""
+    import importlib.util
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "graph_replays.py")
+    spec = importlib.util.spec_from_file_location("graph_replays", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.first_bad_replay(steps=2, b=64, n=2048, replays=450) is None

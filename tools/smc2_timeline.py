@@ -55,6 +55,21 @@ def main():
               f"p90 {1e6 * on[int(0.9 * len(on))]:6.1f} us | rejuvenations {len(rejuv)}: " +
               ", ".join(f"t={t} {1e3 * d:.1f} ms" for t, d in rejuv), flush=True)
 
+    # fit(): the filters run `block` observations ahead of the rejuvenation test (one host decision point per block)
+    for block in (1, 4, 8, 16, 32, 64):
+        best = None
+        for rep in range(3):
+            filt = APF(build, 8192, proposal=proposals.LinearGaussianObservations(), seed=2024 + rep)
+            alg = SMC2(filt, 1024, priors, threshold=0.2, device=device, dtype=dtype, seed=rep)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            state = alg.fit(y, block=block)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        print(f"fit(block={block:2d}): best of 3 {1e3 * best:7.1f} ms  ({1024 * 8192 * t_len / best:.3e} particle-steps/s), "
+              f"rejuvenations {len(alg._kernel.acceptance_history)}, posterior mean {[round(v, 4) for v in alg.posterior_mean(state).tolist()]}", flush=True)
+
 
 if __name__ == "__main__":
     main()
