@@ -28,7 +28,7 @@ def _data(t_len, seed=1, beta=0.8, sigma=0.4):
     return torch.tensor(ys)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, block):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
@@ -40,7 +40,7 @@ def _worker(rank, world, port, out):
         spec = importlib.util.spec_from_file_location("smc2_example", os.path.join(root, "examples", "smc2_linear_gaussian.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        res = mod.smc2(_data(80).cuda(), n_theta=96, n_state=1024, ess_frac=0.5, seed=3)
+        res = mod.smc2(_data(80).cuda(), n_theta=96, n_state=1024, ess_frac=0.5, seed=3, block=block)
         w = res["weights"]            # normalised weights of ALL theta-particles: must be identical on every rank
         gathered = [torch.empty_like(w) for _ in range(world)]
         dist.all_gather(gathered, w)
@@ -52,9 +52,12 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_smc2_two_ranks_on_the_hip_filters(tmp_path):
+@pytest.mark.parametrize("block", [1, 8])
+def test_smc2_two_ranks_on_the_hip_filters(tmp_path, block):
+    """``block = 1``: observation by observation (one all-gather of B weights each); ``block = 8``: ``fit`` with the filters
+    running ahead of the rejuvenation test (one all-gather of the block's ``(8, B)`` weight paths)."""
     out = str(tmp_path / "r0.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, block), nprocs=2, join=True)
     got = torch.load(out)
     assert got["same"], "the ranks disagree on the theta-weights"
     assert got["local_theta"] == 48 and got["w"].shape == (96,) and abs(got["w"].sum().item() - 1.0) < 1e-5
