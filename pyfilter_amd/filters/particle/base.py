@@ -501,7 +501,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             kms = (C.c_float * 3)()
             L.check(lib.pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")
             self.kernel_ms = tuple(kms)
-        elif use_graph:
+        elif use_graph and (plan.graph is not None or plan.runs >= 1):
+            # (a configuration's first run launches directly: capturing + instantiating T kernel nodes costs more host time
+            # than issuing them once - an SMC^2 rejuvenation re-filters t observations exactly once per t)
             if plan.graph is None:
                 h = C.c_void_p(None)
                 L.check(lib.pf_filter_graph_create(C.byref(a), 0, steps, 1, L.stream_ptr(), C.byref(h)), "pf_filter_graph_create")
@@ -509,6 +511,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             L.check(lib.pf_filter_graph_launch(plan.graph, L.stream_ptr()), "pf_filter_graph_launch")
         else:
             L.check(lib.pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
+        plan.runs += 1
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=seed_eff)  # keep device buffers alive
 
         # ---- hand the results over in the reference's shapes (copies: a cached plan's buffers are reused) ------------
@@ -653,6 +656,7 @@ class _FusedPlan:
 
     def __init__(self, filt, kind, n, b, d, o, steps, rows, dtype, device, observed_host, ring=0):
         self.ring = ring
+        self.runs = 0
         if ring:  # state history (pf_filter_args.ring): slot q % ring holds the state after move q - 1
             self.x_hist = torch.empty((ring, d, b, n), device=device, dtype=dtype)
             self.logw_hist = torch.empty((ring, b, n), device=device, dtype=dtype)
