@@ -82,7 +82,7 @@ class ParticleFilterCorrection(Correction):
     def _restarted(self) -> "ParticleFilterCorrection":
         """The same particles / weights / ancestors (shared tensors) with a zero log-likelihood of their own: the incoming
         state of a run whose result must not accumulate into this state's ``_ll`` (``FilterResult`` aliases it, result.py:34)."""
-        other = ParticleFilterCorrection.__new__(ParticleFilterCorrection)
+        other = type(self).__new__(type(self))
         dict.update(other, self)
         other._anc32 = self._anc32
         dict.__setitem__(other, "_ll", torch.zeros_like(self["_ll"]))

@@ -26,6 +26,18 @@ class TooManyIncreases(Exception):
     pass
 
 
+def _theta_stats(gw: torch.Tensor) -> torch.Tensor:
+    """``(..., B)`` theta log-weights -> ``(..., 2)``: ESS and an "every weight finite" flag per row - on the GPU one launch
+    (``pf_theta_ess``), plain torch for CPU tensors (the multi-process CPU tests)."""
+    if gw.is_cuda:
+        from .. import ops
+
+        return ops.theta_ess(gw)
+    rows = gw.reshape(-1, gw.shape[-1])
+    out = torch.stack([torch.stack([theta_ess(r), r.isfinite().all().to(r.dtype)]) for r in rows])
+    return out.reshape(gw.shape[:-1] + (2,))
+
+
 class SMC2State:
     """Algorithm state (``sequential/state.py:8-95``): theta log-weights ``w`` (this rank's block), the filters' result,
     the ESS history and the observations parsed so far (PMMH re-filters them)."""
@@ -44,13 +56,7 @@ class SMC2State:
     def _ess(self) -> torch.Tensor:
         """ESS of ALL theta-weights; ``self.stats`` keeps it together with the "every weight finite" flag - on the GPU both
         come out of one launch (``pf_theta_ess``), so an observation costs one small device -> host copy."""
-        gw = self.global_weights()
-        if gw.is_cuda:
-            from .. import ops
-
-            self.stats = ops.theta_ess(gw)
-        else:  # (the multi-process CPU tests)
-            self.stats = torch.stack([theta_ess(gw), gw.isfinite().all().to(gw.dtype)])
+        self.stats = _theta_stats(self.global_weights())
         return self.stats[0]
 
     def append(self, filter_state):
@@ -235,8 +241,6 @@ class SMC2:
         run again cut after ``j`` *on the same draws*, so state and weights belong to one particle system - and the
         kernel takes over exactly where the reference's would.  Returns ``(observations consumed, state)``; 0 when the
         filter has no fused block route."""
-        from .. import ops
-
         filt, shard = self.filter, self.shard
         sharded = shard.world > 1
         latest = state.filter_state.latest_state
@@ -247,7 +251,7 @@ class SMC2:
 
         def paths(ll):
             w_path = state.w + ll.cumsum(0)  # (n, B_local)
-            return w_path, ops.theta_ess(shard.all_gather(w_path, dim=1) if sharded else w_path)
+            return w_path, _theta_stats(shard.all_gather(w_path, dim=1) if sharded else w_path)
 
         res, ll, token = out
         w_path, stats = paths(ll)
@@ -274,10 +278,13 @@ class SMC2:
         state = self.initialize()
         k = self._block if block is None else max(1, int(block))
         flags = None
-        if k > 1 and hasattr(self.filter, "filter_block") and isinstance(y, torch.Tensor) and y.is_cuda and y.is_floating_point():
-            from .. import ops
+        if k > 1 and hasattr(self.filter, "filter_block") and isinstance(y, torch.Tensor) and y.is_floating_point():
+            if y.is_cuda:  # which observations are not all-NaN: one device round trip for the whole series
+                from .. import ops
 
-            flags = ops.observed_flags(y if y.dtype in (torch.float32, torch.float64) else y.float()).cpu()
+                flags = ops.observed_flags(y if y.dtype in (torch.float32, torch.float64) else y.float()).cpu()
+            else:
+                flags = (~y.isnan().reshape(y.shape[0], -1).all(dim=1)).to(torch.uint8)
         t, total = 0, y.shape[0]
         while t < total:
             n, done = min(k, total - t), 0

@@ -120,6 +120,17 @@ class OracleAPF:
             result.append(new)
         return new
 
+    def filter_block(self, y, state, observed=None, replay=None):
+        """The product's look-ahead interface (``ParticleFilter.filter_block``): the moves are keyed by (column, time, run),
+        so a cut replay repeats them exactly."""
+        start = state._restarted()
+        result = self.initialize_with_result(start)
+        lls, s = [], start
+        for yt in y:
+            s = self.filter(yt, s, result=result)
+            lls.append(s.get_loglikelihood())
+        return result, torch.stack(lls), None
+
     def batch_filter(self, y, bar=False, init_state=None):
         state = init_state if init_state is not None else self.initialize()
         result = self.initialize_with_result(state)

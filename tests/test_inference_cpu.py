@@ -69,6 +69,20 @@ def test_smc2_sharded_over_two_processes_equals_one_process(tmp_path):
         torch.testing.assert_close(multi[k], single[k], rtol=1e-12, atol=1e-12, msg=k)
 
 
+def test_fit_in_blocks_equals_observation_by_observation():
+    """``SMC2.fit`` with the filters running a block ahead of the rejuvenation test against the observation-by-observation
+    loop, on a filter whose moves are keyed by (column, time, run): the same decisions at the same observations, the same
+    weights / ESS history / theta-particles / log-likelihoods / moment series - blocks that end on a rejuvenation, are
+    cut by one (replayed) or contain none."""
+    ref = _fit(7, 64, block=1)
+    assert ref["moves"] >= 2
+    for block in (2, 5, 32):
+        got = _fit(7, 64, block=block)
+        assert got["moves"] == ref["moves"] and got["acc"] == ref["acc"], block
+        for k in ("theta", "w", "ll", "means", "ess", "post"):
+            torch.testing.assert_close(got[k], ref[k], rtol=1e-12, atol=1e-12, msg=f"{k} (block {block})")
+
+
 def test_low_acceptance_doubles_the_state_particles():
     """``ParticleMetropolisHastings._increase_states`` (kernels/mh.py:110-140; the reference's
     ``test_enforce_particle_increase``): with a handful of state particles the likelihood estimates are so noisy that the
