@@ -356,12 +356,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # development (tests on a one-GPU box): every rank on GPU 0, collectives over gloo - RCCL refuses two ranks per device
+    share = os.environ.get("PF_BENCH_SHARE_GPU", "0") == "1"
+    torch.cuda.set_device(0 if share else local_rank)
+    device = torch.device("cuda", 0 if share else local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
     dtype = {"f32": torch.float32, "f64": torch.float64}[args.dtype]
 
     import __graft_entry__ as ge
@@ -406,6 +411,10 @@ def main():
         res = filt.batch_filter(y, bar=False)
         ll = res.loglikelihood.reshape(-1)
         if world > 1:  # the path's only exchange: every rank learns every filter's log-likelihood
+            if share:
+                parts = [torch.empty_like(ll) for _ in range(world)]
+                dist.all_gather(parts, ll.contiguous())
+                return res, torch.cat(parts)
             out = torch.empty(world * ll.numel(), dtype=ll.dtype, device=device)
             dist.all_gather_into_tensor(out, ll.contiguous())
             return res, out

@@ -65,3 +65,27 @@ def test_smc2_two_ranks_on_the_hip_filters(tmp_path, block):
     b, s = got["mean"].tolist()
     assert abs(b - 0.8) < 0.2 and abs(s - 0.4) < 0.15, (b, s)
     assert torch.isfinite(got["ll"]).all()
+
+
+@pytest.mark.parametrize("workload,extra", [("apf_lgo_1m", ["--T", "12", "--N", "65536"]), ("smc2", ["--T", "30"])])
+def test_bench_under_torchrun_with_two_ranks(workload, extra):
+    """``bench.py`` the way the driver launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N``): the
+    rank-0 build + barrier, the barrier-bracketed timed region, the max-over-ranks reduction and the one JSON line.  Both
+    ranks share the test box's single GPU (``PF_BENCH_SHARE_GPU=1``: gloo instead of RCCL, nothing else changes)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", workload, "--no-traffic", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]  # rank 0 prints, once
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1
+    assert rec["value"] > 0 and rec["unit"] == "particle-steps/s" and rec["higher_is_better"] is True
+    assert rec["scaling"] == ("strong" if workload == "smc2" else "weak")
