@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef PF_BLOCK
 #define PF_BLOCK 256
+#endif
 #define PF_WAVE 64
 #define PF_NWAVES (PF_BLOCK / PF_WAVE)
 
