@@ -3,7 +3,7 @@
 data set with it (ONE fused ``batch_filter`` call for all B filters - a replayed hipGraph), accept per filter, swap the
 accepted filters in with the column-move kernels.  Everything stays on the device: there is no host branch per move."""
 import torch
-from torch.distributions import Distribution
+from torch.distributions import Distribution, Independent, Normal
 
 from .utils import construct_mvn, theta_normalize
 
@@ -25,6 +25,24 @@ class SymmetricMH:
         return
 
 
+class RandomWalk:
+    """The default proposal of PMMH (``proposals/random_walk.py``): theta* ~ N(theta, scale) around the chain's current
+    (unconstrained) value; after an accepted move the kernel is re-centred in place (``exchange``)."""
+
+    def __init__(self, scale=1e-2):
+        self._scale = scale
+
+    def build(self, theta, state, filter_, y) -> Distribution:
+        loc = theta.stack_parameters(constrained=False)
+        scale = torch.as_tensor(self._scale, device=loc.device, dtype=loc.dtype).expand_as(loc).clone()
+        return Independent(Normal(loc, scale), 1)
+
+    def exchange(self, latest, candidate, mask) -> None:
+        m = mask.unsqueeze(-1)
+        latest.base_dist.loc.copy_(torch.where(m, candidate.base_dist.loc, latest.base_dist.loc))
+        latest.base_dist.scale.copy_(torch.where(m, candidate.base_dist.scale, latest.base_dist.scale))
+
+
 def _draw(kernel: Distribution, size, shard, generator):
     """theta* ~ kernel.  With a (CPU) generator the draws of ALL theta-particles come from that one stream - every rank
     advances it identically and keeps its block, so a run's numbers do not depend on how many GPUs share it."""
@@ -34,8 +52,12 @@ def _draw(kernel: Distribution, size, shard, generator):
     eps = torch.randn((total,) + tuple(kernel.event_shape), generator=generator, dtype=torch.float64)
     if shard is not None:
         eps = shard.slice(eps)
-    eps = eps.to(device=kernel.loc.device, dtype=kernel.loc.dtype)
-    rvs = kernel.loc + (kernel.scale_tril @ eps.unsqueeze(-1)).squeeze(-1)
+    loc = kernel.mean if not hasattr(kernel, "loc") else kernel.loc
+    eps = eps.to(device=loc.device, dtype=loc.dtype)
+    if hasattr(kernel, "scale_tril"):
+        rvs = loc + (kernel.scale_tril @ eps.unsqueeze(-1)).squeeze(-1)
+    else:  # a diagonal kernel: Independent(Normal(loc, scale), 1) - the random walk
+        rvs = loc + kernel.stddev * eps
     return rvs if len(size) else rvs[0]
 
 
@@ -73,3 +95,87 @@ def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_fil
     if mutate_kernel:
         proposal.exchange(proposal_kernel, new_kernel, accepted)
     return accepted
+
+
+class PMMHState:
+    """Algorithm state of ``PMMH`` (``mcmc/state.py``): the chains' current filter results and every sample drawn so far -
+    one preallocated ``(num_samples + 1, B, P)`` device buffer written in place (constrained values, the parameters side
+    by side as in ``ThetaParticles.stack_parameters``), not a tensor re-concatenated per move."""
+
+    def __init__(self, filter_state, first: torch.Tensor, num_samples: int):
+        self.filter_state = filter_state
+        self.w = torch.zeros(first.shape[0], device=first.device, dtype=first.dtype)  # (equal weights: the chains are iid)
+        self.chain = first.new_empty((num_samples + 1,) + tuple(first.shape))
+        self.chain[0] = first
+        self.length = 1
+        self.accepted = torch.zeros(first.shape[0], device=first.device, dtype=first.dtype)
+
+    def replicate(self, filter_state) -> "PMMHState":
+        other = PMMHState.__new__(PMMHState)
+        other.filter_state, other.w, other.chain, other.length, other.accepted = filter_state, self.w, self.chain, self.length, self.accepted
+        return other
+
+    def update_chain(self, sample: torch.Tensor, accepted: torch.Tensor):
+        self.chain[self.length] = sample
+        self.length += 1
+        self.accepted += accepted.to(self.accepted.dtype)
+
+    @property
+    def samples(self) -> torch.Tensor:
+        """``(draws so far, B, P)``: the chains, initial values included."""
+        return self.chain[: self.length]
+
+    def acceptance_rate(self) -> torch.Tensor:
+        return self.accepted / max(1, self.length - 1)
+
+
+class PMMH:
+    """Particle marginal Metropolis-Hastings with ``num_chains`` parallel chains on the filter's batch dimension
+    (``inference/batch/mcmc/pmmh.py``): every move re-filters the whole data set for all chains in one fused
+    ``batch_filter`` call (a replayed hipGraph from the second move on) and nothing in the loop waits for the device.
+    ``filter_`` is built with a model builder ``theta -> StateSpaceModel``; ``priors`` maps names to distributions.
+    ``initializer="mean"``: the chains start at the priors' means (Monte-Carlo means where a prior has no closed form)."""
+
+    MONTE_CARLO_SAMPLES = 10_000
+
+    def __init__(self, filter_, num_samples: int, priors, num_chains: int = 4, proposal=None, initializer: str = "mean",
+                 device="cuda", dtype=torch.float32, seed: int = 0):
+        from .parameters import ThetaParticles
+
+        if initializer != "mean":
+            raise NotImplementedError(f"``{initializer}`` is not configured!")
+        self.filter = filter_
+        self.num_samples = int(num_samples)
+        self.theta = ThetaParticles(priors, num_chains, device, dtype)
+        self.filter.set_batch_shape(torch.Size([num_chains]))
+        self._proposal = proposal or RandomWalk()
+        self._gen = torch.Generator().manual_seed(seed)
+
+    def initialize(self, y: torch.Tensor) -> PMMHState:
+        self.theta.initialize_parameters(self._gen)
+        for name, prior in self.theta.priors.items():
+            d = prior.distribution
+            try:
+                mean = d.mean
+                if not torch.isfinite(mean).all():
+                    raise NotImplementedError
+            except NotImplementedError:
+                with torch.random.fork_rng(devices=[self.theta.device] if self.theta.device.type == "cuda" else []):
+                    torch.manual_seed(int(torch.randint(0, 2 ** 62, (), generator=self._gen)))
+                    mean = d.sample(torch.Size([self.MONTE_CARLO_SAMPLES])).mean(dim=0)
+            self.theta[name].copy_(mean.to(self.theta[name]).expand_as(self.theta[name]))
+        self.filter.initialize_model(self.theta)
+        first = self.filter.batch_filter(y, bar=False)
+        return PMMHState(first, self.theta.stack_parameters(True), self.num_samples)
+
+    def fit(self, y: torch.Tensor) -> PMMHState:
+        state = self.initialize(y)
+        kernel = self._proposal.build(self.theta, state, self.filter, y)
+        proposal_theta = self.theta.like()
+        proposal_filter = self.filter.copy()
+        proposal_filter.initialize_model(proposal_theta)
+        for _ in range(self.num_samples):
+            accepted = run_pmmh(self.theta, state, self._proposal, kernel, proposal_filter, proposal_theta, y,
+                                self.filter.batch_shape, mutate_kernel=True, generator=self._gen)
+            state.update_chain(self.theta.stack_parameters(True), accepted)
+        return state

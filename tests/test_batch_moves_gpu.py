@@ -273,3 +273,38 @@ def test_smc2_fit_running_ahead_of_the_rejuvenation_test(block):
     b, s = alg.posterior_mean(state).tolist()
     assert abs(b - 0.8) < 0.15 and abs(s - 0.4) < 0.12, (b, s)
     assert torch.isfinite(state.filter_state.loglikelihood).all()
+
+
+def test_pmmh_driver_with_the_random_walk_proposal():
+    """``PMMH`` (inference/batch/mcmc/pmmh.py) with its default ``RandomWalk`` proposal: parallel chains on the batch
+    dimension start at the priors' means, every move is one fused ``batch_filter`` of the whole series for all chains,
+    accepted moves re-centre the kernel in place; the chains climb the likelihood towards the data-generating values."""
+    from torch.distributions import Uniform
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import PMMH, RandomWalk
+    from pyfilter_amd.timeseries import models
+
+    y = _lg_data(120, seed=2)
+
+    def build(theta):
+        t = lambda v: torch.tensor(v, device="cuda")  # noqa: E731
+        return ts.LinearStateSpaceModel(models.AR(t(0.0), theta["beta"], theta["sigma"]), (t(1.0), t(0.3)))
+
+    chains, draws = 32, 200
+    filt = APF(build, 1024, proposal=proposals.LinearGaussianObservations(), seed=1)
+    alg = PMMH(filt, draws, {"beta": Uniform(0.0, 1.0), "sigma": Uniform(0.05, 1.0)}, num_chains=chains,
+               proposal=RandomWalk(scale=0.15), seed=4)
+    state = alg.fit(y)
+    s = state.samples
+    assert s.shape == (draws + 1, chains, 2) and torch.isfinite(s).all()
+    torch.testing.assert_close(s[0], torch.tensor([0.5, 0.525], device="cuda").expand(chains, 2))  # the priors' means
+    rate = state.acceptance_rate()
+    assert 0.02 < rate.mean().item() < 0.95, rate.mean().item()
+    # the chains' values change exactly where a move was accepted, and the kernel follows them
+    moved = (s[1:] != s[:-1]).any(-1).float().sum(0)
+    torch.testing.assert_close(moved, state.accepted)
+    tail = s[draws // 2:].mean((0, 1)).tolist()
+    assert abs(tail[0] - 0.8) < 0.15 and abs(tail[1] - 0.4) < 0.12, tail
+    assert torch.isfinite(state.filter_state.loglikelihood).all()
