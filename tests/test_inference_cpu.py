@@ -83,6 +83,26 @@ def test_fit_in_blocks_equals_observation_by_observation():
             torch.testing.assert_close(got[k], ref[k], rtol=1e-12, atol=1e-12, msg=f"{k} (block {block})")
 
 
+def test_pmmh_driver_on_cpu_is_reproducible():
+    """``PMMH`` (parallel chains, random-walk kernel re-centred in place) on the keyed CPU filter: the chain buffer holds
+    one row per move, rows differ exactly where a move was accepted, and the same seed repeats the same chains."""
+    from pyfilter_amd.inference import PMMH, RandomWalk
+    from tests.oracle_filter import OracleAPF
+
+    def run(seed):
+        OracleAPF.runs = 0
+        alg = PMMH(OracleAPF(None, 64), 12, PRIORS(), num_chains=5, proposal=RandomWalk(0.2), device="cpu",
+                   dtype=torch.float64, seed=seed)
+        return alg.fit(_data())
+
+    a, b, c = run(1), run(1), run(2)
+    assert a.samples.shape == (13, 5, 3) and torch.isfinite(a.samples).all()
+    assert torch.equal(a.samples, b.samples) and not torch.equal(a.samples, c.samples)
+    moved = (a.samples[1:] != a.samples[:-1]).any(-1).double().sum(0)
+    torch.testing.assert_close(moved, a.accepted)
+    assert 0 < a.accepted.sum() < 12 * 5
+
+
 def test_low_acceptance_doubles_the_state_particles():
     """``ParticleMetropolisHastings._increase_states`` (kernels/mh.py:110-140; the reference's
     ``test_enforce_particle_increase``): with a handful of state particles the likelihood estimates are so noisy that the
