@@ -81,8 +81,27 @@ class SMC2State:
         return other
 
     def state_dict(self):
-        return {"filter_state": self.filter_state.state_dict(), "w": self.w, "current_iteration": self.current_iteration,
-                "ess": torch.stack(self.ess), "parsed_data": self.parsed_data if self.parsed else torch.tensor([])}
+        """The reference's wire format (``inference/state.py:39-48``, ``sequential/state.py:56-66``, ``container.py:113-126``):
+        the ESS history and the parsed observations as unbounded tensor deques, the filters' result, the theta log-weights
+        (this rank's block) and the iteration counter."""
+        from collections import OrderedDict
+
+        series = OrderedDict([("tensor_deque_None__ess", torch.stack(self.ess)),
+                              ("tensor_deque_None__parsed_data", self.parsed_data if self.parsed else torch.tensor([]))])
+        return OrderedDict([("tensor_tuples", series), ("filter_state", self.filter_state.state_dict()), ("w", self.w),
+                            ("current_iteration", self.current_iteration)])
+
+    def load_state_dict(self, state_dict):
+        """Continues from a serialised run (``tests/inference/test_sequential.py:55-93``): the receiving state is a freshly
+        initialised one of the same shape."""
+        series = state_dict["tensor_tuples"]
+        self.ess = list(series["tensor_deque_None__ess"].to(self.w.device).unbind(0))
+        parsed = series["tensor_deque_None__parsed_data"]
+        self.parsed = list(parsed.to(self.w.device).unbind(0)) if parsed.numel() else []
+        self.filter_state.load_state_dict(state_dict["filter_state"])
+        self.w = state_dict["w"].to(self.w.device)
+        self.current_iteration = int(state_dict["current_iteration"])
+        self.stats = None
 
 
 def _take_filters(result: FilterResult, shard: Optional[Shard], mine: torch.Tensor):

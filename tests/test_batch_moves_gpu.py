@@ -308,3 +308,50 @@ def test_pmmh_driver_with_the_random_walk_proposal():
     tail = s[draws // 2:].mean((0, 1)).tolist()
     assert abs(tail[0] - 0.8) < 0.15 and abs(tail[1] - 0.4) < 0.12, tail
     assert torch.isfinite(state.filter_state.loglikelihood).all()
+
+
+def test_smc2_serialise_mid_run_and_continue():
+    """The reference's ``test_algorithms_serialize`` (tests/inference/test_sequential.py:55-93): fit the first half, take
+    ``state_dict()`` of the algorithm state and of the parameters, load both into a freshly built algorithm, check weights
+    and ESS history arrived, feed the second half observation by observation."""
+    import importlib.util
+    import io
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "smc2_linear_gaussian.py")
+    spec = importlib.util.spec_from_file_location("smc2_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+
+    y = _lg_data(100)
+    half = y.shape[0] // 2
+
+    def make(seed):
+        filt = APF(mod.build_model, 250, proposal=proposals.LinearGaussianObservations(), seed=seed)
+        return SMC2(filt, 128, mod.PRIORS, threshold=0.5, device="cuda", seed=seed)
+
+    alg = make(3)
+    result = alg.fit(y[:half])
+    buf = io.BytesIO()
+    torch.save({"algorithm": result.state_dict(), "theta": alg.theta.state_dict()}, buf)  # through the serialiser, as a user would
+    buf.seek(0)
+    saved = torch.load(buf)
+    assert list(saved["algorithm"]) == ["tensor_tuples", "filter_state", "w", "current_iteration"]
+    assert list(saved["algorithm"]["tensor_tuples"]) == ["tensor_deque_None__ess", "tensor_deque_None__parsed_data"]
+
+    new_alg = make(11)
+    new_result = new_alg.initialize()
+    new_alg.theta.load_state_dict(saved["theta"])
+    new_result.load_state_dict(saved["algorithm"])
+    assert torch.equal(torch.stack(new_result.ess), torch.stack(result.ess)) and torch.equal(new_result.w, result.w)
+    assert torch.equal(new_result.parsed_data, result.parsed_data) and new_result.current_iteration == half
+    torch.testing.assert_close(new_alg.theta.stack_parameters(True), alg.theta.stack_parameters(True), rtol=0, atol=0)
+    torch.testing.assert_close(new_result.filter_state.filter_means, result.filter_state.filter_means, rtol=0, atol=0)
+    for yt in y[half:]:
+        new_result = new_alg.step(yt, new_result)
+    assert len(new_result.ess) == y.shape[0] + 1 and new_result.current_iteration == y.shape[0]
+    assert int(new_result.filter_state.latest_state.timeseries_state.time_index) == y.shape[0]
+    b, s = new_alg.posterior_mean(new_result).tolist()
+    assert abs(b - 0.8) < 0.2 and abs(s - 0.4) < 0.15, (b, s)
