@@ -1,10 +1,10 @@
-"""
-Result containers mirroring ``pyfilter/container.py`` + ``pyfilter/state.py``: named, optionally length-bounded
-sequences of tensors that serialise as stacked tensors.  The ``state_dict`` key scheme
-(``tensor_tuple__<name>`` / ``tensor_deque_<maxlen>__<name>``, container.py:113-139) is kept so checkpoints interoperate.
-"""
+"""Named tensor sequences with the reference's serialised form (``pyfilter/container.py``): a result object keeps series such
+as ``filter_means`` either as fixed tuples or as (optionally length-bounded) deques; ``state_dict`` stacks each series into
+one tensor under ``tensor_tuple__<name>`` / ``tensor_deque_<maxlen>__<name>`` (container.py:113-139) - the key scheme that
+lets checkpoints travel between the two libraries.  Here the series live in ONE ordered mapping; whether an entry is a tuple
+or a deque is the type of the stored sequence."""
 from collections import OrderedDict, deque
-from typing import Any, Deque, Dict, Iterable, Tuple, Union
+from typing import Dict, Iterable, Sequence, Union
 
 import torch
 
@@ -12,83 +12,73 @@ BoolOrInt = Union[int, bool]
 
 
 def make_dequeue(maxlen: BoolOrInt = None) -> deque:
-    """``False`` -> keep only the latest entry, ``True``/``None`` -> unbounded, ``int`` -> that many (container.py:10-18)."""
+    """The reference's retention rule (container.py:10-18): ``False`` keeps the latest entry only, ``True`` / ``None``
+    everything, an ``int`` that many."""
     if maxlen is False:
         return deque(maxlen=1)
-    if maxlen is None or isinstance(maxlen, bool):
-        return deque()
-    return deque(maxlen=int(maxlen))
+    return deque(maxlen=None if (maxlen is None or maxlen is True) else int(maxlen))
+
+
+def _wire_key(name: str, seq: Sequence) -> str:
+    kind = f"deque_{seq.maxlen}" if isinstance(seq, deque) else "tuple"
+    return f"tensor_{kind}__{name}"
 
 
 class TensorContainer:
-    _KEY = "tensor_{kind}__{name}"
-
     def __init__(self):
-        self._tuples: Dict[str, Tuple[torch.Tensor, ...]] = OrderedDict()
-        self._deques: Dict[str, Deque[torch.Tensor]] = OrderedDict()
+        self._series: "OrderedDict[str, Sequence[torch.Tensor]]" = OrderedDict()
 
-    def make_tuple(self, name: str, values=None):
-        self._tuples[name] = tuple(values) if values is not None else tuple()
+    # ---- building ------------------------------------------------------------------------------------------------------
+    def make_tuple(self, name: str, values: Iterable[torch.Tensor] = None):
+        self._series[name] = () if values is None else tuple(values)
 
-    def make_deque(self, name: str, values=None, maxlen: BoolOrInt = None):
-        dq = self._deques[name] = make_dequeue(maxlen)
+    def make_deque(self, name: str, values: Iterable[torch.Tensor] = None, maxlen: BoolOrInt = None):
+        self._series[name] = make_dequeue(maxlen)
         if values is not None:
-            dq.extend(values)
+            self._series[name].extend(values)
 
-    def __getitem__(self, key: str) -> Iterable[torch.Tensor]:
-        if key in self._tuples:
-            return self._tuples[key]
-        if key in self._deques:
-            return self._deques[key]
-        raise KeyError(f"Could not find '{key}'!")
+    # ---- reading (tuples first, then deques - the reference's iteration order) -------------------------------------------
+    def _ordered(self):
+        tuples = [(k, v) for k, v in self._series.items() if not isinstance(v, deque)]
+        return tuples + [(k, v) for k, v in self._series.items() if isinstance(v, deque)]
 
-    def get_as_tensor(self, key: str) -> torch.Tensor:
-        items = self[key]
-        return torch.stack(tuple(items), dim=0) if len(items) else torch.tensor([])
+    def __getitem__(self, name: str) -> Sequence[torch.Tensor]:
+        try:
+            return self._series[name]
+        except KeyError:
+            raise KeyError(f"Could not find '{name}'!") from None
 
-    def __contains__(self, key):
-        return key in self._tuples or key in self._deques
+    def __contains__(self, name: str) -> bool:
+        return name in self._series
 
-    def __len__(self):
-        return len(self._tuples) + len(self._deques)
+    def __len__(self) -> int:
+        return len(self._series)
 
     def keys(self):
-        return list(self._tuples.keys()) + list(self._deques.keys())
+        return [k for k, _ in self._ordered()]
 
     def values(self):
-        return list(self._tuples.values()) + list(self._deques.values())
+        return [v for _, v in self._ordered()]
 
     def items(self):
-        return list(zip(self.keys(), self.values()))
+        return self._ordered()
 
+    def get_as_tensor(self, name: str) -> torch.Tensor:
+        seq = self[name]
+        return torch.stack(tuple(seq), dim=0) if len(seq) else torch.tensor([])
+
+    # ---- the wire format -------------------------------------------------------------------------------------------------
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
-        out = OrderedDict()
-        for name in self._tuples:
-            out[self._KEY.format(kind="tuple", name=name)] = self.get_as_tensor(name)
-        for name, dq in self._deques.items():
-            out[self._KEY.format(kind=f"deque_{dq.maxlen}", name=name)] = self.get_as_tensor(name)
-        return out
+        return OrderedDict((_wire_key(name, seq), self.get_as_tensor(name)) for name, seq in self._ordered())
 
-    def load_state_dict(self, state_dict: Dict[str, Any]):
-        for key in [k for k in state_dict if k.startswith("tensor_tuple__") or k.startswith("tensor_deque_")]:
-            value = state_dict.pop(key)
+    def load_state_dict(self, state_dict: Dict[str, torch.Tensor]):
+        """Takes its entries OUT of ``state_dict`` (as the reference does) and rebuilds the series from the stacked tensors."""
+        mine = [k for k in state_dict if k.startswith(("tensor_tuple__", "tensor_deque_"))]
+        for key in mine:
             kind, name = key[len("tensor_"):].split("__", 1)
+            stacked = state_dict.pop(key)
             if kind == "tuple":
-                self.make_tuple(name, value)
+                self.make_tuple(name, stacked)
             else:
-                maxlen = kind.split("_", 1)[1]
-                self.make_deque(name, value, maxlen=None if maxlen == "None" else int(maxlen))
-
-
-class BaseResult(dict):
-    """Base class for result objects (pyfilter/state.py:8-48)."""
-
-    def __init__(self):
-        super().__init__()
-        self.tensor_tuples = TensorContainer()
-
-    def state_dict(self):
-        return OrderedDict({"tensor_tuples": self.tensor_tuples.state_dict()})
-
-    def load_state_dict(self, state_dict):
-        self.tensor_tuples.load_state_dict(state_dict["tensor_tuples"])
+                bound = kind.partition("_")[2]
+                self.make_deque(name, stacked, maxlen=None if bound == "None" else int(bound))

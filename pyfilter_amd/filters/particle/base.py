@@ -262,6 +262,19 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             return L.RESAMPLE_MULTINOMIAL
         return None
 
+    def _ancestors_of(self, log_weights: torch.Tensor, time_index: int) -> torch.Tensor:
+        """Ancestors (int64, the shape of ``log_weights``) drawn for every filter from unnormalised log-weights on the
+        step-by-step route: the library's systematic / multinomial kernels, or the user's resampler as a callable."""
+        kind = self._resampler_kind()
+        if kind is None:
+            return self._resampler(log_weights)
+        cols = ops.to_cols(log_weights)
+        if kind == L.RESAMPLE_SYSTEMATIC:
+            picked = ops.systematic_cols(cols, self._uniforms(time_index, cols.shape[0], cols), normalized=False)
+        else:
+            picked = ops.multinomial_cols(ops.normalize_cols(cols, want_w=True)[0], self._run_seed, step=time_index)
+        return ops.from_cols(picked, log_weights.dim() > 1).long()
+
     def _uniforms(self, step: int, b: int, like: torch.Tensor) -> torch.Tensor:
         """The step's systematic offsets on the step-by-step route: the tape, or a device generator keyed by the run's
         draw seed (so a rebuilt filter with the same seed repeats them and a second run does not)."""

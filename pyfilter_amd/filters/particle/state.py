@@ -23,6 +23,12 @@ class ParticleFilterPrediction(Prediction):
         self.normalized_weights = normalized_weights
         self.indices = indices
 
+    @classmethod
+    def equally_weighted(cls, x: TimeseriesState, like: Tensor) -> "ParticleFilterPrediction":
+        """Freshly resampled particles: log-weights 0, normalised weights 1/N (``like``: any ``(N, [B])`` tensor)."""
+        zero = torch.zeros_like(like)
+        return cls(x, zero, torch.full_like(like, 1.0 / like.shape[0]), None)
+
     def get_timeseries_state(self) -> TimeseriesState:
         return self.prev_x
 

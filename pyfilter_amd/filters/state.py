@@ -1,36 +1,28 @@
-"""Abstract filter states (``pyfilter/filters/state.py``)."""
+"""The two state interfaces every filter speaks (``pyfilter/filters/state.py``): a *prediction* (what ``predict`` hands to
+``correct``) and a *correction* (a filter state: a ``dict`` of tensors with moments, log-likelihood, whole-filter moves and
+a serialised form).  Implementations: ``filters/particle/state.py``."""
 from abc import ABC
 
 
-class Prediction(ABC):
-    def get_timeseries_state(self):
-        raise NotImplementedError()
+def _required(name: str):
+    def method(self, *args, **kwargs):
+        raise NotImplementedError(f"{type(self).__name__} does not implement {name}()")
 
-    def create_state_from_prediction(self, model):
-        raise NotImplementedError()
+    method.__name__ = name
+    return method
+
+
+class Prediction(ABC):
+    pass
 
 
 class Correction(dict, ABC):
-    def get_mean(self):
-        raise NotImplementedError()
+    pass
 
-    def get_variance(self):
-        raise NotImplementedError()
 
-    def resample(self, indices):
-        raise NotImplementedError()
-
-    def get_loglikelihood(self):
-        raise NotImplementedError()
-
-    def exchange(self, other, mask):
-        raise NotImplementedError()
-
-    def get_timeseries_state(self):
-        raise NotImplementedError()
-
-    def state_dict(self):
-        raise NotImplementedError()
-
-    def load_state_dict(self, state_dict):
-        raise NotImplementedError()
+for _name in ("get_timeseries_state", "create_state_from_prediction"):
+    setattr(Prediction, _name, _required(_name))
+for _name in ("get_mean", "get_variance", "get_loglikelihood", "get_timeseries_state", "resample", "exchange", "state_dict",
+              "load_state_dict"):
+    setattr(Correction, _name, _required(_name))
+del _name
