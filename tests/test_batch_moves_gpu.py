@@ -240,8 +240,8 @@ def test_filter_block_and_its_replay():
     assert int(nxt.latest_state.timeseries_state.time_index) == 24 and torch.isfinite(ll2).all()
 
 
-@pytest.mark.parametrize("block", [4, 16])
-def test_smc2_fit_running_ahead_of_the_rejuvenation_test(block):
+@pytest.mark.parametrize("block,kind", [(4, "apf"), (16, "apf"), (8, "sisr")])
+def test_smc2_fit_running_ahead_of_the_rejuvenation_test(block, kind):
     """``SMC2.fit`` with the filters running ``block`` observations ahead of the host's rejuvenation test: the bookkeeping
     is that of the observation-by-observation loop (one ESS / parsed observation / moment row per observation; a
     rejuvenation cuts the block where the test fired), and the posterior lands on the data-generating parameters just as
@@ -253,11 +253,12 @@ def test_smc2_fit_running_ahead_of_the_rejuvenation_test(block):
     spec = importlib.util.spec_from_file_location("smc2_example", path)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
     from pyfilter_amd.inference import SMC2
 
     y = _lg_data(150)
-    filt = APF(mod.build_model, 1024, proposal=proposals.LinearGaussianObservations(), seed=3)
+    cls = APF if kind == "apf" else SISR  # (SISR: the kernels decide per filter and step whether to resample - replays too)
+    filt = cls(mod.build_model, 1024, proposal=proposals.LinearGaussianObservations(), seed=3)
     alg = SMC2(filt, 192, mod.PRIORS, threshold=0.5, device="cuda", seed=3)
     state = alg.fit(y, block=block)
     t_len = y.shape[0]
