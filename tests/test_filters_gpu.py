@@ -767,3 +767,55 @@ def test_a_captured_graph_survives_hundreds_of_replays():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.first_bad_replay(steps=2, b=64, n=2048, replays=450) is None
+
+
+def test_two_threads_two_streams_match_serial_runs():
+    """different threads may each drive their own filter (the reference's context stack is thread-local), so
+    the library must be re-entrant per (device, stream): two threads, each with its own HIP stream and filter, interleave
+    fused runs and online moves; every result equals the one the same filter (same seed) produces alone."""
+    import threading
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    g = torch.Generator().manual_seed(3)
+    y = (0.3 * torch.randn(60, generator=g)).cumsum(0).cuda()
+
+    def make(kind, seed):
+        t = lambda v: torch.tensor(v, device="cuda")  # noqa: E731
+        ssm = ts.LinearStateSpaceModel(models.SineDiffusion(t(0.0), t(1.0), dt=0.1), (t(1.0), t(0.1)))
+        return (APF if kind == "apf" else SISR)(ssm, 1 << 16, proposal=proposals.LinearGaussianObservations(), seed=seed)
+
+    def work(kind, seed, out, stream=None):
+        filt = make(kind, seed)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            rows = []
+            for _ in range(6):
+                res = filt.batch_filter(y, bar=False)
+                rows.append(torch.cat([res.loglikelihood.reshape(1), res.filter_means[-1].reshape(-1)]))
+            state = res.latest_state
+            for t in range(5):
+                state = filt.filter(y[t], state)
+                rows.append(torch.cat([state.get_loglikelihood().reshape(1), state.get_mean().reshape(-1)]))
+            out.append(torch.stack(rows))
+        if stream is not None:
+            stream.synchronize()
+
+    serial = {}
+    for kind, seed in (("apf", 5), ("sisr", 6)):
+        got = []
+        work(kind, seed, got)
+        torch.cuda.synchronize()
+        serial[kind] = got[0].cpu()
+    outs = {"apf": [], "sisr": []}
+    threads = [threading.Thread(target=work, args=(kind, seed, outs[kind], torch.cuda.Stream()))
+               for kind, seed in (("apf", 5), ("sisr", 6))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    for kind in ("apf", "sisr"):
+        assert torch.equal(outs[kind][0].cpu(), serial[kind]), kind
