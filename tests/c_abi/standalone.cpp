@@ -1,0 +1,139 @@
+// TEST PROGRAM - libpfamd.so driven through include/pf_amd.h alone: no Python, no PyTorch, device memory straight from
+// the HIP runtime.  It is what a binding from any other host language does: describe the model (pf_model), size the
+// workspace, hand over raw device pointers, run T steps (pf_filter_run), read the results back.  AR(1) + linear Gaussian
+// observation (tests/filters/models.py:13-15 of the reference), SISR + Bootstrap + systematic and APF + the optimal
+// proposal, checked against the exact Kalman filter computed here on the host.
+//   g++ -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I<repo>/include standalone.cpp -o standalone \
+//       -L<repo>/pyfilter_amd -lpfamd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,<repo>/pyfilter_amd
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "pf_amd.h"
+
+#define HIP_OK(call)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            std::fprintf(stderr, "%s failed: %s\n", #call, hipGetErrorString(e_));      \
+            return 2;                                                                   \
+        }                                                                               \
+    } while (0)
+#define PF_CALL(call)                                                                   \
+    do {                                                                                \
+        int rc_ = (call);                                                               \
+        if (rc_ != PF_OK) {                                                             \
+            std::fprintf(stderr, "%s failed: %s (%d)\n", #call, pf_error_string(rc_), rc_); \
+            return 3;                                                                   \
+        }                                                                               \
+    } while (0)
+
+static uint64_t lcg_state = 0x2545F4914F6CDD1Dull;
+static double uniform01() {
+    lcg_state = lcg_state * 6364136223846793005ull + 1442695040888963407ull;
+    return ((lcg_state >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+static double gauss() { return std::sqrt(-2.0 * std::log(uniform01())) * std::cos(6.283185307179586 * uniform01()); }
+
+int main() {
+    const int64_t N = 1 << 16, B = 2, D = 1, T = 64;
+    const double alpha = 0.0, beta = 0.99, sigma = 0.05, a = 1.0, b = 0.0, s = 0.15, m0 = 0.0, s0 = 0.05;
+
+    // data + exact Kalman filter (host, double)
+    std::vector<float> y(T);
+    double x = m0 + s0 * gauss();
+    for (int t = 0; t < T; ++t) {
+        x = alpha + beta * x + sigma * gauss();
+        y[t] = (float)(a * x + b + s * gauss());
+    }
+    double km = m0, kp = s0 * s0, kll = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double mp = alpha + beta * km, pp = beta * beta * kp + sigma * sigma;
+        const double S = a * a * pp + s * s, r = (double)y[t] - (a * mp + b);
+        kll += -0.5 * (std::log(2.0 * M_PI * S) + r * r / S);
+        const double K = pp * a / S;
+        km = mp + K * r;
+        kp = (1.0 - K * a) * pp;
+    }
+
+    // device buffers
+    float *x0, *x1, *w0, *w1, *cdf, *pos, *yd, *means, *vars, *ll_steps, *ll_total, *params;
+    int32_t* anc;
+    void* ws;
+    size_t ws_bytes = 0;
+    PF_CALL(pf_workspace_bytes(N, B, D, &ws_bytes));
+    const size_t plane = sizeof(float) * B * N;
+    HIP_OK(hipMalloc((void**)&x0, plane * D));
+    HIP_OK(hipMalloc((void**)&x1, plane * D));
+    HIP_OK(hipMalloc((void**)&w0, plane));
+    HIP_OK(hipMalloc((void**)&w1, plane));
+    HIP_OK(hipMalloc((void**)&cdf, plane));
+    HIP_OK(hipMalloc((void**)&pos, plane));
+    HIP_OK(hipMalloc((void**)&anc, sizeof(int32_t) * B * N));
+    HIP_OK(hipMalloc((void**)&yd, sizeof(float) * T));
+    HIP_OK(hipMalloc((void**)&means, sizeof(float) * (T + 1) * B * D));
+    HIP_OK(hipMalloc((void**)&vars, sizeof(float) * (T + 1) * B * D));
+    HIP_OK(hipMalloc((void**)&ll_steps, sizeof(float) * T * B));
+    HIP_OK(hipMalloc((void**)&ll_total, sizeof(float) * B));
+    HIP_OK(hipMalloc(&ws, ws_bytes));
+    const int NP = 4 * (int)D + 1 * (int)D + 2 * 1;  // [hp0 hp1 hp2 hp3 | A | b | s]
+    std::vector<float> prow(B * NP);
+    for (int c = 0; c < B; ++c) {
+        const float row[7] = {(float)alpha, (float)beta, (float)sigma, 0.f, (float)a, (float)b, (float)s};
+        for (int k = 0; k < NP; ++k) prow[c * NP + k] = row[k];
+    }
+    HIP_OK(hipMalloc((void**)&params, sizeof(float) * prow.size()));
+    HIP_OK(hipMemcpy(params, prow.data(), sizeof(float) * prow.size(), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(yd, y.data(), sizeof(float) * T, hipMemcpyHostToDevice));
+    std::vector<int32_t> iota(B * N);
+    for (int64_t i = 0; i < B * N; ++i) iota[i] = (int32_t)(i % N);
+    std::vector<uint8_t> observed(T, 1);
+
+    int failures = 0;
+    for (int variant = 0; variant < 2; ++variant) {
+        pf_filter_args A = {};
+        A.model.hid_kind = PF_HID_LINEAR;
+        A.model.obs_kind = PF_OBS_LINEAR;
+        A.model.dim = (int32_t)D;
+        A.model.obs_dim = 1;
+        A.model.dt = 1.0;
+        A.model.inc_scale = 1.0;
+        A.model.params = params;
+        A.filter = variant == 0 ? PF_FILTER_SISR : PF_FILTER_APF;
+        A.proposal = variant == 0 ? PF_PROP_BOOTSTRAP : PF_PROP_LGO;
+        A.resampler = PF_RESAMPLE_SYSTEMATIC;
+        A.dtype = PF_F32;
+        A.N = N;
+        A.B = B;
+        A.ess_threshold = 0.9;
+        A.seed = 1234 + variant;
+        A.x[0] = x0; A.x[1] = x1;
+        A.logw[0] = w0; A.logw[1] = w1;
+        A.anc = anc; A.cdf = cdf; A.pos = pos;
+        A.y = yd; A.y_rows = 1; A.observed = observed.data();
+        A.means = means; A.vars = vars; A.ll_steps = ll_steps; A.ll_total = ll_total;
+        A.ws = ws; A.ws_bytes = ws_bytes;
+        const double m0v[1] = {m0}, s0v[1] = {s0};
+        PF_CALL(pf_initial_sample(m0v, s0v, nullptr, A.seed ^ 0x9E3779B97F4A7C15ull, x0, N, B, D, PF_F32, nullptr));
+        HIP_OK(hipMemset(w0, 0, plane));
+        HIP_OK(hipMemset(ll_total, 0, sizeof(float) * B));
+        HIP_OK(hipMemcpy(anc, iota.data(), sizeof(int32_t) * B * N, hipMemcpyHostToDevice));
+        PF_CALL(pf_filter_run(&A, 0, T, 1, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        std::vector<float> h_means((T + 1) * B * D), h_ll(B);
+        HIP_OK(hipMemcpy(h_means.data(), means, sizeof(float) * h_means.size(), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(h_ll.data(), ll_total, sizeof(float) * B, hipMemcpyDeviceToHost));
+        for (int c = 0; c < B; ++c) {
+            const double last = h_means[(T * B + c) * D];
+            std::printf("%s column %d: loglikelihood %.4f (Kalman %.4f)  final mean %.5f (Kalman %.5f)\n",
+                        variant == 0 ? "SISR+Bootstrap" : "APF+LGO", c, h_ll[c], kll, last, km);
+            if (!(std::fabs(h_ll[c] - kll) < 0.25) || !(std::fabs(last - km) < 0.01)) ++failures;
+        }
+    }
+    std::printf("%s (%s)\n", failures ? "c-abi FAILED" : "c-abi ok", pf_version());
+    return failures ? 1 : 0;
+}
