@@ -371,3 +371,23 @@ def test_generic_driver_walks_the_schedule():
         F(ssm, nan_strategy="drop")
     with pytest.raises(ValueError):
         F(42)
+
+
+def test_standalone_cpp_program_compiles_and_links_against_the_header(tmp_path):
+    """``tests/c_abi/standalone.cpp`` (the C ABI from plain C++: no Python, no PyTorch) builds against ``include/pf_amd.h`` and
+    links ``libpfamd.so`` + the HIP runtime here; it runs in the ``-m gpu`` suite."""
+    import shutil
+    import subprocess
+
+    import __graft_entry__ as ge
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if shutil.which("g++") is None or not os.path.exists(os.path.join(rocm, "lib", "libamdhip64.so")):
+        pytest.skip("g++ / the HIP runtime are not installed here")
+    ge.build()
+    cmd = ["g++", "-O1", "-D__HIP_PLATFORM_AMD__", f"-I{rocm}/include", f"-I{root}/include",
+           os.path.join(root, "tests", "c_abi", "standalone.cpp"), "-o", str(tmp_path / "standalone"),
+           f"-L{root}/pyfilter_amd", "-lpfamd", f"-L{rocm}/lib", "-lamdhip64"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
