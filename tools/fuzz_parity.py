@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (development tool): random (model, filter, proposal, resampling threshold, N, B, T, NaN pattern,
+geometry knob) configurations, float64, identical draws - the fused route against the oracle (``oracle/cpu_ref.py``): filter
+means / log-likelihood to 1e-9 and identical final ancestors.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from oracle import cpu_ref
+    from oracle.cases import build_spec, simulate
+    from tests.helpers import build_filter_from_case
+
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for i in range(cases):
+        model = rng.choice(["lg1d", "sine", "sv_batched", "lorenz", "ou_batched"])
+        filt_name = rng.choice(["sisr", "apf"])
+        prop = rng.choice(["bootstrap", "lgo"]) if model != "sv_batched" else "bootstrap"
+        n = rng.choice([rng.randint(2, 40), rng.randint(41, 1100), rng.randint(1101, 9000), rng.choice([1024, 2048, 4096, 8192, 12288, 65536]),
+                        rng.randint(9001, 70000)])
+        b = rng.choice([1, 1, 2, 3, 5, 9, 17]) if n < 20000 else rng.choice([1, 2, 3])
+        t_len = rng.randint(1, 9)
+        ess = rng.choice([0.1, 0.5, 0.9, 0.97])  # (not 1.0: exactly uniform weights - after a NaN observation - sit ON that
+        # threshold, and which side of it ESS = 1 / sum W^2 lands on is a rounding tie between any two implementations)
+        target = rng.choice([None, None, 4, 64, 4096])  # geometry: few big tiles ... many small ones
+        seed = rng.randint(0, 10 ** 6)
+        case = dict(name="fuzz", model=model, filter=filt_name, proposal=prop, N=n, B=b, T=t_len, ess_threshold=ess, seed=seed)
+        spec = build_spec(case, torch.float64)
+        gen = torch.Generator().manual_seed(seed)
+        d = (spec.dim,) if spec.dim > 0 else ()
+        g = dict(z_tape=torch.randn((t_len, n, b) + d, generator=gen, dtype=torch.float32),
+                 u_tape=torch.rand(t_len, b, generator=gen, dtype=torch.float32),
+                 z0=torch.randn((n, b) + d, generator=gen, dtype=torch.float32))
+        y = simulate(case, spec, torch.float64)
+        for s in range(t_len):
+            if rng.random() < 0.15:
+                y[s] = float("nan")
+        if target is None:
+            os.environ.pop("PF_TARGET_WGS", None)
+        else:
+            os.environ["PF_TARGET_WGS"] = str(target)
+        x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
+        ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=ess)
+        route = rng.choice(["batch", "batch", "online", "recorded"])
+        filt = build_filter_from_case(case, g, torch.float64, "cuda", **({"record_states": True} if route == "recorded" else {}))
+        if route == "online":  # one fused move per observation (the SMC^2 entry point)
+            state = filt.initialize()
+            res = filt.initialize_with_result(state)
+            for yt in y.cuda():
+                state = filt.filter(yt, state, result=res)
+        else:
+            res = filt.batch_filter(y.cuda(), bar=False)
+            if route == "recorded":
+                assert len(res.states) == t_len + 1
+        ok = True
+        why = ""
+        try:
+            torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11, equal_nan=True)
+            torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9, equal_nan=True)
+            mism = (res.latest_state.previous_indices.cpu() != ref["prev_inds"]).sum().item()
+            if mism:
+                ok, why = False, f"{mism} ancestors differ"
+        except AssertionError as e:
+            ok, why = False, str(e).splitlines()[0][:160]
+        bad += 0 if ok else 1
+        print(f"{i:3d} {'ok ' if ok else 'BAD'} {model:10s} {filt_name:4s} {prop:9s} N={n:6d} B={b:2d} T={t_len} ess={ess} target_wgs={target} seed={seed} {route} {why}", flush=True)
+    print("failures:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
