@@ -819,3 +819,20 @@ def test_two_threads_two_streams_match_serial_runs():
     torch.cuda.synchronize()
     for kind in ("apf", "sisr"):
         assert torch.equal(outs[kind][0].cpu(), serial[kind]), kind
+
+
+def test_randomised_parity_sweep(monkeypatch):
+    """``tools/fuzz_parity.py`` with a fixed seed: 30 random (model, filter, proposal, threshold, N, B, T, NaN pattern, tile
+    geometry, route) configurations in float64 on identical draws - means / log-likelihood to 1e-9, identical ancestors."""
+    import importlib.util
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py")
+    spec = importlib.util.spec_from_file_location("fuzz_parity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr("sys.argv", ["fuzz_parity.py", "30", "11"])
+    monkeypatch.delenv("PF_TARGET_WGS", raising=False)
+    try:
+        assert mod.main() == 0
+    finally:
+        os.environ.pop("PF_TARGET_WGS", None)
