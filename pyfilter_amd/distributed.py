@@ -16,8 +16,9 @@ Exchanges (``Shard``), all along the filter (batch) dimension:
 * on a rejuvenation (``kernels/mh.py:52-108``): all-gather of the stacked theta ``(B, P)`` (the MVN proposal is built
   from all of them, identically everywhere), the identical systematic theta-resample on every rank, and the
   **redistribution of the surviving filters' states** to the ranks that own their new positions
-  (``Shard.take`` per buffer, driven by ``inference/smc2.py:_take_filters``: all-gather of the columns + local gather - <= N (4 D + 12) bytes per column, ~100 MB in
-  total at 1024 x 8192, once per rejuvenation).
+  (``Shard.route`` once per resampling, ``Route.take`` per buffer, driven by ``inference/smc2.py:_take_filters``: one
+  ``all_to_all_single`` of the DISTINCT columns that change owner - <= N (4 D + 12) bytes per moved column - and a local
+  gather; nothing a rank already holds travels).
 """
 from typing import List, Optional, Tuple
 
@@ -69,7 +70,10 @@ class Shard:
     def __init__(self, total: int, group=None):
         self.total = int(total)
         self.group = group
-        self.rank, self.world = world()
+        if group is not None and dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)  # a sub-group: ITS ranks, not the world's
+        else:
+            self.rank, self.world = world()
         self.spans: List[Tuple[int, int]] = [shard_bounds(self.total, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.spans[self.rank]
 
@@ -109,7 +113,82 @@ class Shard:
         dist.all_reduce(v, group=self.group)
         return (v[0] / v[1]).to(local_sum.dtype)
 
+    def all_max(self, local: torch.Tensor) -> torch.Tensor:
+        """Element-wise maximum over the ranks."""
+        if self.world == 1:
+            return local
+        out = local.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)
+        return out
+
+    def route(self, global_index: torch.Tensor) -> "Route":
+        """The exchange plan of a global gather along the filter dimension (see ``Route``); ``global_index`` = the global
+        ancestors of THIS rank's positions.  One small all-gather of the index vectors + a host copy: build it once per
+        resampling and move every buffer through it."""
+        return Route(self, global_index)
+
     def take(self, local: torch.Tensor, global_index: torch.Tensor, dim: int = 0) -> torch.Tensor:
         """``concat(all blocks)[global_index]`` along ``dim`` - this rank's new block after a global gather (resampling of
         theta-particles: ``global_index`` = the ancestors of this rank's positions)."""
-        return self.all_gather(local, dim).index_select(dim % local.dim(), global_index.to(local.device))
+        return self.route(global_index).take(local, dim)
+
+
+class Route:
+    """Who sends which columns to whom when the filters are gathered by a global index vector (the resampling of the
+    theta-particles in an SMC^2 rejuvenation, ``kernels/mh.py:53-57``).  Every rank learns every rank's wanted ancestors
+    (all-gather of B integers), from which both sides of every pair derive the same list: the DISTINCT columns rank r wants
+    from rank q, ascending.  ``take`` then moves a buffer with ONE ``all_to_all_single`` (RCCL over xGMI: point-to-point
+    sends, only the columns that actually change owner - a column wanted several times travels once, a rank's own columns
+    never leave it) and a local gather that puts the received columns in place.  SURVEY.md section 8(e): <= N (4 D + 12)
+    bytes per MOVED column, against world x that for an all-gather of everything."""
+
+    def __init__(self, shard: "Shard", global_index: torch.Tensor):
+        self.shard = shard
+        self.device = global_index.device
+        mine = global_index.to(torch.int64).reshape(-1)
+        if shard.world == 1:
+            self.local_index = mine
+            return
+        full = shard.all_gather(mine).cpu()  # (total,) in global position order: rank r's wants = full[lo_r:hi_r]
+        me = shard.rank
+        lo, hi = shard.spans[me]
+        wants = full[lo:hi]
+        send_cols, self.send_splits = [], []
+        for r, (rlo, rhi) in enumerate(shard.spans):  # what rank r wants from my block
+            if r == me:
+                self.send_splits.append(0)
+                continue
+            need = full[rlo:rhi]
+            u = torch.unique(need[(need >= lo) & (need < hi)]) - lo
+            send_cols.append(u)
+            self.send_splits.append(int(u.numel()))
+        self.send_index = (torch.cat(send_cols) if send_cols else torch.empty(0, dtype=torch.int64)).to(self.device)
+        # where each of my wanted columns ends up: my own block first (no transfer), then the received runs by owner
+        pos = torch.empty_like(wants)
+        own = (wants >= lo) & (wants < hi)
+        pos[own] = wants[own] - lo
+        offset = hi - lo
+        self.recv_splits = []
+        for q, (qlo, qhi) in enumerate(shard.spans):
+            if q == me:
+                self.recv_splits.append(0)
+                continue
+            sel = (wants >= qlo) & (wants < qhi)
+            u = torch.unique(wants[sel])
+            pos[sel] = offset + torch.searchsorted(u, wants[sel])
+            self.recv_splits.append(int(u.numel()))
+            offset += int(u.numel())
+        self.local_index = pos.to(self.device)
+        self.moved = sum(self.recv_splits)  # columns this rank receives over the fabric
+
+    def take(self, local: torch.Tensor, dim: int = 0) -> torch.Tensor:
+        dim = dim % local.dim()
+        if self.shard.world == 1:
+            return local.index_select(dim, self.local_index.to(local.device))
+        moved = local.movedim(dim, 0)
+        rest = tuple(moved.shape[1:])
+        send = moved.index_select(0, self.send_index.to(local.device)).contiguous()
+        recv = moved.new_empty((sum(self.recv_splits),) + rest)
+        dist.all_to_all_single(recv, send, self.recv_splits, self.send_splits, group=self.shard.group)
+        pool = torch.cat([moved, recv], dim=0) if recv.shape[0] else moved
+        return pool.index_select(0, self.local_index.to(local.device)).movedim(0, dim)

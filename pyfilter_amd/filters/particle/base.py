@@ -415,6 +415,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             return None
         res = self._batch_filter_fused(y, state._restarted(), observed=observed, replay=replay)
         run = self._last_run
+        res.block_rows = (run["rows"][0][1:], run["rows"][1][1:])  # the moves' own moment rows (row 0 = the incoming state)
         ll = run["ll_steps"]
         u = run["u"]  # (a cached plan's buffer, redrawn by the next run: the token keeps a copy)
         return res, (ll if self._batched else ll[:, 0]), (run["seed_eff"], None if u is None else u.clone())
@@ -557,6 +558,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             keep = torch.tensor([0] + reported, device=device)
             sel_m, sel_v = means_v[keep], vars_v[keep]
         result._extend_fused(sel_m, sel_v, ll_total if self._batched else ll_total[0], last, states=recorded)
+        self._last_run["rows"] = (sel_m, sel_v)  # every reported row of this run, whatever window the result's log keeps
         return result
 
     # ------------------------------------------------------------------------------------------------------------

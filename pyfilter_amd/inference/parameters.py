@@ -141,10 +141,13 @@ class ThetaParticles:
             m = mask.reshape(mask.shape + (1,) * (v.dim() - 1))
             v.copy_(torch.where(m, other._values[name], v))
 
-    def resample(self, indices: torch.Tensor):
-        """``theta <- theta[indices]`` in place.  Sharded: ``indices`` are GLOBAL ancestors of this rank's positions."""
+    def resample(self, indices: torch.Tensor, route=None):
+        """``theta <- theta[indices]`` in place.  Sharded: ``indices`` are GLOBAL ancestors of this rank's positions
+        (``route``: the exchange plan of that gather when the caller already built it, ``distributed.Route``)."""
+        if self.shard is not None and self.shard.world > 1 and route is None:
+            route = self.shard.route(indices)
         for name, v in self._values.items():
-            v.copy_(v[indices] if self.shard is None or self.shard.world == 1 else self.shard.take(v, indices))
+            v.copy_(v[indices] if route is None else route.take(v))
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._values.items())

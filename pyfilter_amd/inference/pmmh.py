@@ -43,13 +43,40 @@ class RandomWalk:
         latest.base_dist.scale.copy_(torch.where(m, candidate.base_dist.scale, latest.base_dist.scale))
 
 
-def _draw(kernel: Distribution, size, shard, generator):
-    """theta* ~ kernel.  With a (CPU) generator the draws of ALL theta-particles come from that one stream - every rank
-    advances it identically and keeps its block, so a run's numbers do not depend on how many GPUs share it."""
-    if generator is None:
+class ThetaDraws:
+    """Source of the theta-level random numbers of SMC^2 / PMMH (the reference takes them from torch's global generator:
+    ``kernels/mh.py:53`` the resampling uniform, ``mcmc/utils.py:48`` the proposal's standard normals, ``:69`` the
+    acceptance uniforms).  One CPU generator stream: every rank draws the numbers of ALL theta-particles in the same order
+    and keeps its block, so a run's numbers do not depend on how many GPUs share it.  The parity tests substitute a
+    replaying subclass that returns the reference's own (recorded) draws."""
+
+    def __init__(self, generator: torch.Generator):
+        self.generator = generator
+
+    def uniform(self, shape) -> torch.Tensor:
+        return torch.rand(tuple(shape), generator=self.generator, dtype=torch.float64)
+
+    def normal(self, shape) -> torch.Tensor:
+        return torch.randn(tuple(shape), generator=self.generator, dtype=torch.float64)
+
+
+def as_draws(source):
+    """``None`` (torch's global generator, like the reference), a ``torch.Generator`` or a ``ThetaDraws``."""
+    if source is None or isinstance(source, ThetaDraws):
+        return source
+    return ThetaDraws(source)
+
+
+def _draw(kernel: Distribution, size, shard, draws):
+    """theta* ~ kernel (``mcmc/utils.py:48``: ``proposal_kernel.sample(size)``): ``(B, P)`` for a kernel shared by all
+    filters (``size = (B,)``: SMC^2's Gaussian fit) and for a per-filter kernel (``size = ()``, ``batch_shape = (B,)``:
+    the random walk) alike."""
+    if draws is None:
         return kernel.sample(size)
-    total = shard.total if shard is not None else (size[0] if len(size) else 1)
-    eps = torch.randn((total,) + tuple(kernel.event_shape), generator=generator, dtype=torch.float64)
+    batched = len(kernel.batch_shape) > 0
+    local = kernel.batch_shape[0] if batched else (size[0] if len(size) else 1)
+    total = shard.total if shard is not None else local
+    eps = draws.normal((total,) + tuple(kernel.event_shape))
     if shard is not None:
         eps = shard.slice(eps)
     loc = kernel.mean if not hasattr(kernel, "loc") else kernel.loc
@@ -58,14 +85,14 @@ def _draw(kernel: Distribution, size, shard, generator):
         rvs = loc + (kernel.scale_tril @ eps.unsqueeze(-1)).squeeze(-1)
     else:  # a diagonal kernel: Independent(Normal(loc, scale), 1) - the random walk
         rvs = loc + kernel.stddev * eps
-    return rvs if len(size) else rvs[0]
+    return rvs if (len(size) or batched) else rvs[0]
 
 
-def _uniforms(like: torch.Tensor, shard, generator):
-    if generator is None:
+def _uniforms(like: torch.Tensor, shard, draws):
+    if draws is None:
         return torch.rand(like.shape, device=like.device, dtype=like.dtype)
     total = shard.total if shard is not None else like.shape[0]
-    u = torch.rand(total, generator=generator, dtype=torch.float64)
+    u = draws.uniform((total,))
     if shard is not None:
         u = shard.slice(u)
     return u.to(device=like.device, dtype=like.dtype)
@@ -77,8 +104,12 @@ def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_fil
     (``state.filter_state`` a ``FilterResult``); ``proposal_filter`` reads ``proposal_theta``.  Returns the ``(B,)``
     boolean mask of accepted proposals; ``state`` and ``theta`` are updated in place."""
     shard = getattr(theta, "shard", None)
-    rvs = _draw(proposal_kernel, size, shard, generator)
+    draws = as_draws(generator)
+    rvs = _draw(proposal_kernel, size, shard, draws)
     proposal_theta.unstack_parameters(rvs, constrained=False)
+    # the model is REBUILT from theta* (mcmc/utils.py:52-53): whatever the builder derives from the parameters - e.g. the
+    # stationary initial distribution of an Ornstein-Uhlenbeck process - belongs to the proposed values, not the old ones
+    proposal_filter.initialize_model(proposal_theta)
     new_res = proposal_filter.batch_filter(y, bar=False)
 
     diff_logl = new_res.loglikelihood - state.filter_state.loglikelihood
@@ -88,7 +119,7 @@ def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_fil
     diff_prop = new_kernel.log_prob(current) - proposal_kernel.log_prob(rvs)
 
     log_acc = diff_prop + diff_prior + diff_logl
-    accepted = _uniforms(log_acc, shard, generator).log() < log_acc  # (NaN compares False: a failed proposal is rejected)
+    accepted = _uniforms(log_acc, shard, draws).log() < log_acc  # (NaN compares False: a failed proposal is rejected)
 
     state.filter_state.exchange(new_res, accepted)
     theta.exchange(proposal_theta, accepted)

@@ -18,7 +18,7 @@ import torch
 from ..distributed import Shard
 from ..filters.result import FilterResult
 from .parameters import ThetaParticles
-from .pmmh import SymmetricMH, run_pmmh
+from .pmmh import SymmetricMH, as_draws, run_pmmh
 from .utils import theta_ess, theta_normalize, theta_systematic
 
 
@@ -104,30 +104,31 @@ class SMC2State:
         self.stats = None
 
 
-def _take_filters(result: FilterResult, shard: Optional[Shard], mine: torch.Tensor):
+def _take_filters(result: FilterResult, shard: Optional[Shard], mine: torch.Tensor, route=None):
     """``FilterResult.resample`` for a sharded set of filters: ``mine`` = the GLOBAL ancestors of this rank's positions
     (single process: all of them, and the reference's in-place gather - one ``pf_columns_gather`` per buffer)."""
     if shard is None or shard.world == 1:
         result.resample(mine)
         return
-    indices = mine
+    route = route or shard.route(mine)  # who sends which columns to whom: built once, every buffer moves through it
     # every per-filter quantity of the result travels as its block along the batch dimension
-    result._loglikelihood.copy_(shard.take(result._loglikelihood, indices))
+    result._loglikelihood.copy_(route.take(result._loglikelihood))
     log = result._moments
     if log._buf is not None:
         cols = log._live_columns()  # (1, B_local, rows * 2 dim)
-        log._buf = shard.take(cols[0], indices).reshape(log._buf.shape)
+        log._buf = route.take(cols[0]).reshape(log._buf.shape)
     from .. import ops
 
     for s in result._states:
         s._ensure_moments()
         ts = s.timeseries_state
         x = ops.to_soa(ts.value, True, ts.value.dim() > 2)              # (D, B_local, N)
-        s["_x"] = ts.copy(values=ops.from_soa(shard.take(x, indices, dim=1).contiguous(), True, ts.value.dim() > 2))
-        s["_w"] = ops.from_cols(shard.take(ops.to_cols(s["_w"]), indices).contiguous(), True)
-        s["_prev_inds"] = ops.from_cols(shard.take(ops.to_cols(s["_prev_inds"]), indices).contiguous(), True)
+        s["_x"] = ts.copy(values=ops.from_soa(route.take(x, dim=1).contiguous(), True, ts.value.dim() > 2))
+        s["_w"] = ops.from_cols(route.take(ops.to_cols(s["_w"])).contiguous(), True)
+        s["_prev_inds"] = ops.from_cols(route.take(ops.to_cols(s["_prev_inds"])).contiguous(), True)
         for k in ("_ll", "_mean", "_var"):
-            s[k] = shard.take(s[k], indices)
+            s[k] = route.take(s[k])
+    return route
 
 
 class ParticleMetropolisHastings:
@@ -150,14 +151,16 @@ class ParticleMetropolisHastings:
         sharded = shard is not None and shard.world > 1
         # the same resampling on every rank: same (gathered) weights, same uniform (the generator is a CPU stream seeded
         # identically everywhere and advanced in lock step - no broadcast needed)
+        draws = as_draws(generator)
         W = state.normalized_weights()
-        u = torch.rand((), generator=generator)
+        u = draws.uniform(()) if draws is not None else torch.rand(())
         indices = self._resampler(W, u)
         mine = shard.slice(indices) if sharded else indices
         dist = self._proposal.build(theta, state, filter_, state.parsed_data)
 
-        theta.resample(mine)
-        _take_filters(state.filter_state, shard, mine)
+        route = shard.route(mine) if sharded else None  # one exchange plan for the parameters and the filters' states
+        theta.resample(mine, route)
+        _take_filters(state.filter_state, shard, mine, route)
         shape = torch.Size([]) if any(dist.batch_shape) else filter_.batch_shape
 
         old = theta.stack_parameters(constrained=False)
@@ -168,7 +171,7 @@ class ParticleMetropolisHastings:
         previous_distance, acceptance_rate = 0.0, 0.0
         for i in range(self._n_steps):
             accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, state.parsed_data,
-                                shape, mutate_kernel=False, generator=generator)
+                                shape, mutate_kernel=False, generator=draws)
             rate = accepted.float().sum()
             rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
             acceptance_rate = (float(rate) + i * acceptance_rate) / (i + 1)  # the kernel's one host decision per move
@@ -178,10 +181,10 @@ class ParticleMetropolisHastings:
             if not self._is_adaptive:
                 continue
             new = theta.stack_parameters(constrained=False)
-            distance = (new - old).abs().amax(dim=0).mean()
+            reach = (new - old).abs().amax(dim=0)  # (P,): the largest move per parameter over the theta-particles ...
             if sharded:
-                distance = shard.all_mean(distance * new.shape[0], new.shape[0])
-            distance = float(distance)
+                reach = shard.all_max(reach)       # ... over ALL of them (mh.py:95: norm(dim=0, p=inf) of the full set)
+            distance = float(reach.mean())
             if abs(distance - previous_distance) <= self._dist_thresh * previous_distance:
                 break
             previous_distance = distance
@@ -285,7 +288,10 @@ class SMC2:
         state.w.copy_(w_path[take - 1])
         state.ess.extend(stats[:take, 0].unbind(0))
         state.stats = stats[take - 1]
-        state.filter_state._extend_fused(res.filter_means[1:], res.filter_variance[1:], res.loglikelihood, res.latest_state)
+        # the moves' moment rows as the run reported them - NOT a slice of the block result's series, whose window may be
+        # bounded (record_moments=False / an int) and then no longer starts at the incoming state
+        rows = getattr(res, "block_rows", None) or (res.filter_means[1:], res.filter_variance[1:])
+        state.filter_state._extend_fused(rows[0], rows[1], res.loglikelihood, res.latest_state)
         state.current_iteration += take
         if hit is not None:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)

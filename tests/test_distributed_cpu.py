@@ -79,3 +79,46 @@ def test_shard_bounds_cover_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _route_worker(rank, world, port, total):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyfilter_amd.distributed import Shard
+
+        sh = Shard(total)
+        g = torch.Generator().manual_seed(5)  # the same global data / index vectors on every rank
+        full2 = torch.randn(total, 6, generator=g, dtype=torch.float64)       # (B, ...): filters on dim 0
+        full3 = torch.randn(3, total, 5, generator=g, dtype=torch.float64)    # (D, B, N): filters on dim 1
+        fulli = torch.arange(total, dtype=torch.int32) * 7
+        cases = [torch.randint(0, total, (total,), generator=g) for _ in range(4)]
+        cases += [torch.arange(total), torch.zeros(total, dtype=torch.int64), torch.full((total,), total - 1)]
+        for idx in cases:
+            mine = sh.slice(idx)
+            route = sh.route(mine)
+            torch.testing.assert_close(route.take(sh.slice(full2)), full2[mine], rtol=0, atol=0)
+            torch.testing.assert_close(route.take(sh.slice(full3, dim=1), dim=1), full3[:, mine], rtol=0, atol=0)
+            assert torch.equal(route.take(sh.slice(fulli)), fulli[mine])
+            torch.testing.assert_close(sh.take(sh.slice(full2), mine), full2[mine], rtol=0, atol=0)
+            # only DISTINCT columns owned by somebody else cross the fabric
+            foreign = mine[(mine < sh.lo) | (mine >= sh.hi)]
+            assert route.moved == foreign.unique().numel()
+        # a sub-group is its own world: rank / world / spans follow the group, not the default process group
+        groups = [dist.new_group([r]) for r in range(world)]
+        solo = Shard(total, groups[rank])
+        assert (solo.rank, solo.world, solo.lo, solo.hi) == (0, 1, 0, total)
+        torch.testing.assert_close(solo.all_max(full2[rank]), full2[rank])
+        both = Shard(total, dist.new_group(list(range(world))))
+        assert (both.rank, both.world) == (rank, world)
+        m = both.all_max(torch.tensor([float(rank), -float(rank)], dtype=torch.float64))
+        assert m.tolist() == [float(world - 1), 0.0]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_route_moves_only_the_columns_that_change_owner():
+    """``Shard.route`` / ``Route.take`` (one ``all_to_all_single`` of the distinct moved columns + a local gather) against
+    plain indexing of the concatenated blocks: uneven shards, duplicates, all-from-one-rank, identity; 2 and 3 ranks."""
+    for world, total in ((2, 7), (3, 11)):
+        mp.spawn(_route_worker, args=(world, _free_port(), total), nprocs=world, join=True)

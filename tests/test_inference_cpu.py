@@ -30,11 +30,14 @@ def _data(t_len=14):
 
 
 def _fit(total, n_state, seed=3, threshold=0.6, **kw):
+    from pyfilter_amd import inference
     from pyfilter_amd.inference import SMC2
     from tests.oracle_filter import OracleAPF
 
     OracleAPF.runs = 0
     filt = OracleAPF(None, n_state)
+    if isinstance(kw.get("kernel"), str):  # (picklable across mp.spawn: the proposal by name)
+        kw["kernel"] = {"random_walk": lambda: inference.RandomWalk(0.05)}[kw["kernel"]]()
     alg = SMC2(filt, total, PRIORS(), threshold=threshold, device="cpu", dtype=torch.float64, seed=seed, **kw)
     state = alg.fit(_data())
     gathered = alg.shard.all_gather(alg.theta.stack_parameters(True))
@@ -44,11 +47,11 @@ def _fit(total, n_state, seed=3, threshold=0.6, **kw):
                 increases=alg._kernel._increases, n=filt.particles[0], post=alg.posterior_mean(state))
 
 
-def _worker(rank, world, port, out, total, n_state):
+def _worker(rank, world, port, out, total, n_state, kw=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = _fit(total, n_state)
+        res = _fit(total, n_state, **(kw or {}))
         if rank == 0:
             torch.save(res, out)
     finally:
@@ -66,6 +69,33 @@ def test_smc2_sharded_over_two_processes_equals_one_process(tmp_path):
     multi = torch.load(out)
     assert multi["moves"] == single["moves"] and multi["acc"] == single["acc"]
     for k in ("theta", "w", "ll", "means", "ess", "post"):
+        torch.testing.assert_close(multi[k], single[k], rtol=1e-12, atol=1e-12, msg=k)
+
+
+def test_adaptive_stopping_rule_does_not_depend_on_the_sharding(tmp_path):
+    """``distance_threshold`` (kernels/mh.py:92-100): the distance between consecutive PMMH moves is the mean over the
+    parameters of the LARGEST move among ALL theta-particles - a sharded run must stop at the same move as one process."""
+    kw = dict(num_steps=6, distance_threshold=0.5)
+    single = _fit(7, 64, **kw)
+    assert single["moves"] >= 2
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, 7, 64, kw), nprocs=2, join=True)
+    multi = torch.load(out)
+    assert multi["moves"] == single["moves"] and multi["acc"] == single["acc"]
+    for k in ("theta", "w", "ll", "ess", "post"):
+        torch.testing.assert_close(multi[k], single[k], rtol=1e-12, atol=1e-12, msg=k)
+
+
+def test_smc2_with_a_per_filter_random_walk_kernel(tmp_path):
+    """``SMC2(kernel=RandomWalk())``: the proposal's batch shape is the theta-particles', so ``update`` samples it with
+    ``size = ()`` (kernels/mh.py:60) and still gets one proposal per filter, ``(B, P)`` - sharded or not."""
+    single = _fit(7, 64, kernel="random_walk")
+    assert single["moves"] >= 1 and torch.isfinite(single["theta"]).all()
+    assert single["theta"].unique(dim=0).shape[0] > 1  # one proposal PER filter, not one shared by all
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, 7, 64, dict(kernel="random_walk")), nprocs=2, join=True)
+    multi = torch.load(out)
+    for k in ("theta", "w", "ll", "ess"):
         torch.testing.assert_close(multi[k], single[k], rtol=1e-12, atol=1e-12, msg=k)
 
 
