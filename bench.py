@@ -19,9 +19,14 @@ inputs already resident in HBM.  Workloads (``--workload``):
                  rejuvenations with filter-state redistribution.  Counts the T filtering moves of all theta-particles;
                  rejuvenation work is overhead inside the timed region.
 
-Multi-GPU (``torchrun --nproc-per-node N bench.py --gpus N``): one process per GPU; the path does not shard a single
-filter (that would need a cross-GPU scan), so every rank runs its own independent filters (weak scaling) and the
-only exchange is the RCCL all-gather of the per-filter log-likelihoods - the step SMC^2 / parallel PMMH chains need.
+Multi-GPU: one process per GPU over RCCL.  ``python bench.py --gpus N`` on its own spawns its N ranks (re-executes itself
+under ``python -m torch.distributed.run --nproc-per-node N``); launched under torchrun it reads RANK / WORLD_SIZE from the
+environment.  What shards is the filters' batch dimension - SMC^2's theta-particles - so with N > 1 the default workload is
+``smc2`` (BASELINE configs[4]: 1 024 theta-particles block-sharded over the ranks, STRONG scaling, the theta-weights
+all-gathered per block of observations, whole filters redistributed by all-to-all on a rejuvenation); its JSON line also
+carries the same job timed on ONE of the GPUs (``single_gpu_same_workload``) so that the strong-scaling ratio can be read
+off one line.  A single filter (configs[1], [3]) does not shard - that would need a cross-GPU scan - so
+``--workload apf_lgo_1m`` etc. with N > 1 run one replica per GPU (weak scaling) and all-gather the log-likelihoods.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) incl. ``roofline`` and ``cpu_baseline``.
 """
@@ -50,8 +55,9 @@ WORKLOADS = {
 }
 
 
-def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None):
-    """BASELINE configs[4] as the algorithm; returns (elapsed seconds for `steps` full fits, info)."""
+def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None, solo=False):
+    """BASELINE configs[4] as the algorithm; returns (elapsed seconds for `steps` full fits, info).  ``solo``: the whole
+    job on this rank alone, no sharding, no collectives (the single-GPU reference leg of a multi-GPU line)."""
     import torch.distributed as dist
     from torch.distributions import Exponential, LogNormal, Normal
 
@@ -75,13 +81,15 @@ def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None):
 
     def fit(seed):
         filt = APF(build, w["N"], proposal=proposals.LinearGaussianObservations(), seed=2024 + seed)
-        alg = SMC2(filt, w["B"], priors, threshold=0.2, device=device, dtype=dtype, seed=seed)
+        from pyfilter_amd.distributed import SOLO
+
+        alg = SMC2(filt, w["B"], priors, threshold=0.2, device=device, dtype=dtype, seed=seed, group=SOLO if solo else None)
         state = alg.fit(y)
         return alg, state
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 and not solo:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -284,12 +292,14 @@ def cpu_baseline(name, w, seconds_budget=12.0):
     best, sweep = None, {}
     for th in sorted({c for c in (8, 16, 32, 64, 128) if c <= cores} | {min(cores, 8)}):
         torch.set_num_threads(th)
-        run(1)
-        dt_ = run(2) / 2
-        sweep[th] = n * b / dt_
-        if best is None or dt_ < best[1]:
-            best = (th, dt_)
-        if dt_ > 3.0 * best[1]:
+        first = run(1)  # (warm-up of this thread count; also tells how many timed steps the sweep can afford)
+        reps = 5 if first < 0.5 else 2
+        times = sorted(run(1) for _ in range(reps))
+        dt_min, dt_med = times[0], times[len(times) // 2]
+        sweep[th] = {"min": n * b / times[-1], "median": n * b / dt_med, "max": n * b / dt_min, "steps_timed": reps}
+        if best is None or dt_med < best[1]:
+            best = (th, dt_med)
+        if dt_med > 3.0 * best[1]:
             break
     torch.set_num_threads(1)
     run(1)
@@ -303,11 +313,14 @@ def cpu_baseline(name, w, seconds_budget=12.0):
     return {
         "value": n * b * steps / dt, "unit": "particle-steps/s", "cores": cores_used, "kind": "port",
         "sample": f"{name}: N={n}, B={b}, {steps} time steps ({dt:.1f} s) of T={w['T']}, fp32, torch {torch.__version__} CPU, "
-                  f"{cores_used} threads (fastest of a 8..128 sweep on {os.cpu_count()} logical CPUs); oracle/cpu_ref.py (same "
-                  f"aten-op sequence as the reference; within +-6 % of the imported reference where both ran)",
+                  f"{cores_used} threads (best median of a 8..128 sweep, {sweep[cores_used]['steps_timed']} one-step timings per count, "
+                  f"on {os.cpu_count()} logical CPUs); oracle/cpu_ref.py (same aten-op sequence as the reference; timed against "
+                  f"the imported reference by tools/ref_vs_port.py -> profiles/r03_ref_vs_port.txt: the port is the faster "
+                  f"of the two, i.e. this baseline flatters the CPU)",
         "ms_per_filter_step": 1e3 * dt / steps,
         "one_thread": {"value": one_thread, "steps": k1, "ms_per_filter_step": 1e3 * dt1 / k1},
         "thread_sweep_particle_steps_per_s": sweep,
+        "range_over_sweep": [min(v["min"] for v in sweep.values()), max(v["max"] for v in sweep.values())],
         "host": host,
     }
 
@@ -359,7 +372,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="apf_lgo_1m", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: apf_lgo_1m on one GPU (BASELINE configs[1]), smc2 on several (configs[4], strong scaling)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--T", type=int, default=None, help="override the number of observations")
     ap.add_argument("--N", type=int, default=None, help="override the number of particles (development: shape studies)")
@@ -367,6 +381,22 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--_inner", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become N ranks, one per GPU (what the driver does for N > 1)
+        import socket
+        import subprocess
+
+        share = os.environ.get("PF_BENCH_SHARE_GPU", "0") == "1"
+        have = torch.cuda.device_count()
+        if have < args.gpus and not share:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible (one process per GPU over RCCL)")
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -384,6 +414,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)  # "nccl" is RCCL on ROCm
     dtype = {"f32": torch.float32, "f64": torch.float64}[args.dtype]
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    if args.workload is None:
+        args.workload = "apf_lgo_1m" if world == 1 else "smc2"
 
     import __graft_entry__ as ge
 
@@ -399,8 +433,18 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = tmax.item()
+        solo = None
+        if world > 1:  # the same job on ONE of these GPUs (rank 0 alone, the others wait): the strong-scaling reference
+            if rank == 0:
+                e1, _, _ = run_smc2(w, dtype, device, world, rank, max(1, min(2, args.steps)), 1, args.T, solo=True)
+                solo = {"value": w["N"] * w["B"] * info["T"] * max(1, min(2, args.steps)) / e1, "unit": "particle-steps/s",
+                        "what": "the whole 1024-theta job on rank 0's GPU alone (no sharding, no collectives), timed after the "
+                                "N-GPU region"}
+            dist.barrier()
         if rank == 0:
             value = w["N"] * w["B"] * info["T"] * args.steps / elapsed
+            if solo:
+                solo["speedup_over_it"] = value / solo["value"]
             print(json.dumps({
                 "metric": "particle-steps/sec (batch x particles x T), SMC^2 1024 theta x 8192 particles", "value": value,
                 "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -408,8 +452,9 @@ def main():
                 "dtype": args.dtype, "data": "synthetic", "world_size": world,
                 "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
                 "config": {"workload": f"smc2: SMC^2, APF + lgo, {w['B']} theta-particles (sharded {info['theta_per_rank']} per GPU) x "
-                                       f"{w['N']} state particles, T={info['T']}, per-observation all-gather of the theta-weights",
+                                       f"{w['N']} state particles, T={info['T']}, theta-weights all-gathered per block of 16 observations",
                            "parallelism": f"theta-particles block-sharded over {world} GPU(s)", **info},
+                "single_gpu_same_workload": solo,
                 "roofline": None, "cpu_baseline": None}))
         if world > 1:
             dist.destroy_process_group()

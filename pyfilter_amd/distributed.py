@@ -63,6 +63,9 @@ def theta_ess(log_weights: torch.Tensor) -> torch.Tensor:
     return 1.0 / (w * w).sum()
 
 
+SOLO = "solo"  # Shard(total, SOLO): this process alone holds every filter, whatever process group exists
+
+
 class Shard:
     """This rank's block of ``total`` filters and the collectives over the filter dimension.  With one process (no
     process group) every method is the identity / a local operation, so single-GPU code runs through the same calls."""
@@ -70,7 +73,9 @@ class Shard:
     def __init__(self, total: int, group=None):
         self.total = int(total)
         self.group = group
-        if group is not None and dist.is_available() and dist.is_initialized():
+        if group is SOLO:
+            self.group, self.rank, self.world = None, 0, 1
+        elif group is not None and dist.is_available() and dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)  # a sub-group: ITS ranks, not the world's
         else:
             self.rank, self.world = world()
