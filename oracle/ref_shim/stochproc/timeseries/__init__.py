@@ -60,7 +60,15 @@ class StructuralStochasticProcess:
         return len(self.event_shape)
 
     def initial_sample(self, shape=torch.Size([])):
-        return TimeseriesState(0, self.initial_distribution.sample(torch.Size(shape)), self.event_shape)
+        # the initial distribution is EXPANDED to the requested batch shape, not sampled `shape` times: with parameters of
+        # shape (B,) - theta-particles on the filters' batch dimension (inference/sequential/base.py:31-34) - its batch
+        # shape is already (B,) and pyfilter asks for (N, B) samples (filters/particle/base.py:88-90).  For an unbatched
+        # distribution the two are the same draw (one torch.normal call over the (N, B, [D]) expanded parameters).
+        dist = self.initial_distribution
+        shape = torch.Size(shape)
+        if len(shape):
+            dist = dist.expand(shape)
+        return TimeseriesState(0, dist.sample(), self.event_shape)
 
     def build_density(self, x):
         raise NotImplementedError()

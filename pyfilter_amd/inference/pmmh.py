@@ -99,10 +99,12 @@ def _uniforms(like: torch.Tensor, shard, draws):
 
 
 def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_filter, proposal_theta, y: torch.Tensor,
-             size=torch.Size([]), mutate_kernel: bool = False, generator=None) -> torch.Tensor:
+             size=torch.Size([]), mutate_kernel: bool = False, generator=None, trace=None) -> torch.Tensor:
     """One PMMH iteration (``mcmc/utils.py:14-77``).  ``theta`` / ``state``: the chains' parameters and algorithm state
     (``state.filter_state`` a ``FilterResult``); ``proposal_filter`` reads ``proposal_theta``.  Returns the ``(B,)``
-    boolean mask of accepted proposals; ``state`` and ``theta`` are updated in place."""
+    boolean mask of accepted proposals; ``state`` and ``theta`` are updated in place.  ``trace``: an optional list that
+    receives the move's intermediate quantities (references, no copies, no synchronisation) - diagnostics, and what the
+    parity tests compare with the reference's own values."""
     shard = getattr(theta, "shard", None)
     draws = as_draws(generator)
     rvs = _draw(proposal_kernel, size, shard, draws)
@@ -121,6 +123,9 @@ def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_fil
     log_acc = diff_prop + diff_prior + diff_logl
     accepted = _uniforms(log_acc, shard, draws).log() < log_acc  # (NaN compares False: a failed proposal is rejected)
 
+    if trace is not None:
+        trace.append(dict(kind="pmmh", rvs=rvs, proposed_ll=new_res.loglikelihood.clone(), log_acc=log_acc, accepted=accepted,
+                          new_kernel=new_kernel))
     state.filter_state.exchange(new_res, accepted)
     theta.exchange(proposal_theta, accepted)
     if mutate_kernel:

@@ -145,6 +145,7 @@ class ParticleMetropolisHastings:
         self._increases = 0
         self._resampler = resampler
         self.acceptance_history = []
+        self.trace = None  # set to a list to collect every update's intermediate quantities (see ``run_pmmh``)
 
     def update(self, theta: ThetaParticles, filter_, state: SMC2State, generator=None) -> SMC2State:
         shard = state.shard
@@ -158,6 +159,8 @@ class ParticleMetropolisHastings:
         mine = shard.slice(indices) if sharded else indices
         dist = self._proposal.build(theta, state, filter_, state.parsed_data)
 
+        if self.trace is not None:
+            self.trace.append(dict(kind="rejuvenate", indices=indices, kernel=dist))
         route = shard.route(mine) if sharded else None  # one exchange plan for the parameters and the filters' states
         theta.resample(mine, route)
         _take_filters(state.filter_state, shard, mine, route)
@@ -171,7 +174,7 @@ class ParticleMetropolisHastings:
         previous_distance, acceptance_rate = 0.0, 0.0
         for i in range(self._n_steps):
             accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, state.parsed_data,
-                                shape, mutate_kernel=False, generator=draws)
+                                shape, mutate_kernel=False, generator=draws, trace=self.trace)
             rate = accepted.float().sum()
             rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
             acceptance_rate = (float(rate) + i * acceptance_rate) / (i + 1)  # the kernel's one host decision per move
@@ -229,9 +232,14 @@ class SMC2:
             # the kernels key their Philox streams by the LOCAL column index: decorrelate the ranks' blocks
             self.filter._seed = (self.filter._seed + 0xD1B54A32D192ED03 * self.shard.rank) & 0xFFFFFFFFFFFFFFFF
 
-    def initialize(self) -> SMC2State:
+    def initialize(self, theta0: Optional[torch.Tensor] = None) -> SMC2State:
+        """Draws the theta-particles from their priors (``sequential/base.py:52-62``) - or starts from ``theta0``, the
+        ``(B, P)`` stacked constrained values of ALL theta-particles (every rank keeps its block)."""
         g = torch.Generator().manual_seed(self._seed * 7919 + 13)  # every rank draws all B and keeps its block
         self.theta.initialize_parameters(g)
+        if theta0 is not None:
+            mine = self.shard.slice(theta0) if self.shard.world > 1 else theta0
+            self.theta.unstack_parameters(mine.to(device=self.theta.device, dtype=self.theta.dtype), constrained=True)
         self.filter.initialize_model(self.theta)
         init_state = self.filter.initialize()
         w = torch.zeros(self.shard.local, device=init_state.get_loglikelihood().device, dtype=init_state.get_loglikelihood().dtype)

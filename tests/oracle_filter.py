@@ -53,9 +53,13 @@ class OracleAPF:
 
     runs = 0  # class-wide run counter: advanced identically in every process
 
-    def __init__(self, model_builder, particles, columns=None, seed=0):
+    PROPOSAL = "bootstrap"
+    STATIONARY_INIT = False  # True: x0 ~ N(gamma, sigma / sqrt(2 kappa)) - the OU model of tests/inference/models.py
+
+    def __init__(self, model_builder, particles, columns=None, seed=0, **_ignored):
         self._builder = model_builder
         self._n = particles
+        self._z_tape = self._u_tape = self._z0 = None
         self._b = 1
         self._columns = columns  # global ids of this rank's theta-particles (set by the test through `shard`)
         self._theta = None
@@ -81,22 +85,32 @@ class OracleAPF:
         self._n = int(self._n * factor)
 
     def copy(self):
-        f = OracleAPF(self._builder, self._n)
+        f = type(self)(self._builder, self._n)
         f._b = self._b
         return f
+
+    @property
+    def _base_particles(self):
+        return torch.Size([self._n])
+
+    def set_tape(self, z=None, u=None, z0=None):
+        """The product's parity-mode interface (``ParticleFilter.set_tape``): injected draws instead of the keyed streams."""
+        self._z_tape, self._u_tape, self._z0 = z, u, z0
 
     def _cols(self):
         return range(self.shard.lo, self.shard.hi) if self.shard is not None else range(self._b)
 
     def _spec(self):
         t = self._theta
-        return M.ModelSpec(M.HID_OU, (t["kappa"].double(), t["gamma"].double(), t["sigma"].double()), 0, 1.0, (0.0, 0.1),
-                           M.OBS_LINEAR, (1.0, 0.0, 0.05), 0)
+        k, g, s = t["kappa"].double(), t["gamma"].double(), t["sigma"].double()
+        init = (g, s / torch.sqrt(2.0 * k)) if self.STATIONARY_INIT else (0.0, 0.1)
+        return M.ModelSpec(M.HID_OU, (k, g, s), 0, 1.0, init, M.OBS_LINEAR, (1.0, 0.0, 0.05), 0)
 
     def initialize(self):
         OracleAPF.runs += 1
         self._run = OracleAPF.runs
-        x0 = M.initial_sample(self._spec(), _draws(self._cols(), -1, self._run, self._n, 0))
+        z0 = self._z0.double() if self._z0 is not None else _draws(self._cols(), -1, self._run, self._n, 0)
+        x0 = M.initial_sample(self._spec(), z0)
         w = torch.zeros(self._n, self._b, dtype=torch.float64)
         idx = torch.arange(self._n).unsqueeze(-1).expand(self._n, self._b)
         return self._state(0, x0, w, torch.zeros(self._b, dtype=torch.float64), idx)
@@ -111,9 +125,9 @@ class OracleAPF:
     def filter(self, y, state, result=None):
         t = int(state.timeseries_state.time_index)
         run = getattr(self, "_run", 0)
-        z = _draws(self._cols(), t, run, self._n, 0)
-        u = _draws(self._cols(), t, run, self._n, 1)
-        x, w, ll, idx = cpu_ref.apf_step(self._spec(), "bootstrap", y.double(), state.timeseries_state.value,
+        z = self._z_tape[t].double() if self._z_tape is not None else _draws(self._cols(), t, run, self._n, 0)
+        u = self._u_tape[t].double() if self._u_tape is not None else _draws(self._cols(), t, run, self._n, 1)
+        x, w, ll, idx = cpu_ref.apf_step(self._spec(), self.PROPOSAL, y.double(), state.timeseries_state.value,
                                          state.weights.clone(), z, u)
         new = self._state(t + 1, x, w, ll, idx)
         if result is not None:

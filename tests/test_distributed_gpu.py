@@ -89,3 +89,88 @@ def test_bench_under_torchrun_with_two_ranks(workload, extra):
     assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1
     assert rec["value"] > 0 and rec["unit"] == "particle-steps/s" and rec["higher_is_better"] is True
     assert rec["scaling"] == ("strong" if workload == "smc2" else "weak")
+
+
+def test_bench_spawns_its_own_ranks_and_defaults_to_smc2():
+    """``python bench.py --gpus 2`` with no launcher around it (the shape of the driver's N = 1 command): the script
+    re-executes itself under ``torch.distributed.run`` with two ranks, picks the sharded SMC^2 workload (BASELINE
+    configs[4], strong scaling) and reports ``n_gpus = world_size = 2`` plus the same job on one GPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "24"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "strong"
+    assert rec["config"]["workload"].startswith("smc2") and rec["config"]["theta_per_rank"] == 512
+    assert rec["value"] > 0 and rec["single_gpu_same_workload"]["value"] > 0
+
+
+def _rccl_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    device = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)  # "nccl" is RCCL on ROCm
+    try:
+        from pyfilter_amd.distributed import Shard
+
+        total = 64 * world
+        sh = Shard(total)
+        g = torch.Generator().manual_seed(11)
+        full = torch.randn(total, 4096, generator=g)
+        planes = torch.randn(3, total, 512, generator=g)
+        idx = torch.randint(0, total, (total,), generator=g)
+        mine = sh.slice(idx).to(device)
+        # even blocks on RCCL: all_gather_into_tensor straight into the concatenated tensor
+        got = sh.all_gather(sh.slice(full).to(device))
+        ok = torch.equal(got.cpu(), full)
+        got1 = sh.all_gather(sh.slice(planes, dim=1).to(device), dim=1)
+        ok &= torch.equal(got1.cpu(), planes)
+        route = sh.route(mine)  # all_to_all_single over xGMI: only the columns that change owner
+        ok &= torch.equal(route.take(sh.slice(full).to(device)).cpu(), full[sh.slice(idx)])
+        ok &= torch.equal(route.take(sh.slice(planes, dim=1).to(device), dim=1).cpu(), planes[:, sh.slice(idx)])
+        ok &= sh.all_max(torch.tensor([float(rank)], device=device)).item() == world - 1
+        ok &= abs(sh.all_mean(torch.tensor(float(rank + 1), device=device), 2).item() - (world + 1) / 4) < 1e-6
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(ok))
+        if rank == 0:
+            torch.save({"ok": all(flags), "rccl": torch.cuda.nccl.version(), "moved": route.moved}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs on multi-GPU nodes only")
+def test_rccl_collectives_of_the_sharded_driver(tmp_path):
+    """The three exchanges of the sharded SMC^2 driver over RCCL / xGMI, one rank per GPU: the ``all_gather_into_tensor``
+    fast path of ``Shard.all_gather``, ``Route.take`` (``all_to_all_single`` with uneven splits) and the small
+    all-reduces - against plain indexing of the same global data."""
+    world = min(torch.cuda.device_count(), 8)
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_rccl_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = torch.load(out)
+    assert got["ok"], got
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs on multi-GPU nodes only")
+def test_bench_smc2_over_rccl():
+    """``python bench.py --gpus N`` on a multi-GPU node: N ranks over RCCL, theta-particles sharded."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = min(torch.cuda.device_count(), 8)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "PF_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--T", "60"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == n and rec["rccl_version"] and rec["config"]["theta_per_rank"] == 1024 // n
