@@ -1,0 +1,410 @@
+// pf_column.hpp - the column-persistent time loop: ONE workgroup per filter runs ALL time steps of a run in ONE launch.
+//
+// The per-step route (pf_fused.hpp) splits a column into tiles and uses the kernel boundary as its grid-wide
+// synchronisation: right for 10^5 .. 10^6 particles per filter, but a filter of a few hundred particles - the reference's
+// own operating point: 1 000 theta-particles x 250-400 state particles (examples/stochastic-volatility.ipynb:157,
+// tests/inference/test_sequential.py:10-13) - is ONE partly filled tile, and a step then costs a whole launch (17-19 us at
+// 1024 x 256..512, profiles/r03_small_n_per_step_route.txt) for ~1 us of work.  Here a filter of N <= 4096 particles
+// lives in the registers of one workgroup (VEC particles per thread, N / VEC threads) for the whole run:
+//
+//   per step   [APF: first-stage weights]  ->  max / sum of the resampling weights (wave DPP + one LDS exchange)
+//              ->  cdf = fp64 inclusive scan, rounded once, last value 1 (resampling.py:44-49) -> LDS
+//              ->  ancestors: branch-free lower_bound of the VEC grid positions in the LDS cdf (searchsorted, side=left)
+//              ->  gather x[anc] from LDS, propagate (Philox / tape), weigh (the per-particle model code of the step kernel)
+//              ->  (max, sum e, sum e^2, pivoted moments) of the new weights: moments row, log-likelihood increment
+//   no kernel boundary, no per-tile partial tables, no window probing, no HBM traffic but the T result rows; the state is
+//   read once and written once per run.  Random numbers are keyed exactly as in the step kernel (seed, stream, step,
+//   b N + i), so the two routes consume the SAME draws.
+//
+// Mirrors the same reference code as the step kernel: sisr.py:14-56, apf.py:16-46, particle/utils.py:7-65,
+// resampling.py:24-52, filters/base.py:188-221 (NaN observation -> propagate only).
+#pragma once
+
+namespace pf {
+
+#define PFC_MAXW 16       // waves per workgroup (1024 threads)
+#define PFC_OBS_WORDS 64  // observed flags of a launch as kernel arguments: 2048 steps per launch (longer runs: several)
+
+struct ColumnRun {
+    int t0, n_steps;
+    int use_bits;                      // 1: obs_bits (the host's flags, baked into the launch); 0: FusedArgs::obs_dev[t]
+    uint32_t obs_bits[PFC_OBS_WORDS];  // bit s = step t0 + s weighs against y[t0 + s]
+};
+
+// workgroup collectives for a run-time number of waves `nw` (1 .. 16); a single-wave workgroup never touches LDS
+template <typename T> __device__ __forceinline__ T cb_max(T v, T* red, int nw) {
+    v = wave_max<T>(v);
+    if (nw == 1) return v;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    T r = red[0];
+    for (int w = 1; w < nw; ++w) r = red[w] > r ? red[w] : r;
+    return r;
+}
+template <int K> __device__ __forceinline__ void cb_sum(double (&v)[K], double* red, int nw) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    if (nw == 1) return;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[k * PFC_MAXW + wid] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double r = red[k * PFC_MAXW];
+        for (int w = 1; w < nw; ++w) r += red[k * PFC_MAXW + w];
+        v[k] = r;
+    }
+}
+__device__ __forceinline__ double cb_scan_excl(double v, double* red, int nw, double& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double incl = wave_scan_incl(v, lane);
+    if (nw == 1) {
+        total = lane_get(incl, 63);
+        return incl - v;
+    }
+    __syncthreads();
+    if (lane == 63) red[wid] = incl;
+    __syncthreads();
+    double off = 0.0, tot = 0.0;
+    for (int w = 0; w < nw; ++w) {
+        const double s = red[w];
+        if (w < wid) off += s;
+        tot += s;
+    }
+    total = tot;
+    return off + incl - v;
+}
+
+// BIG: workgroups of more than 256 threads (N > 1024 with VEC = 4) - a separate instantiation so that the small ones are
+// not register-limited by the 1024-thread launch bound
+template <typename T, int D, int VEC, bool BIG>
+__global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pfc_lds[];
+    const Geom& g = a.g;
+    const int N = (int)g.N;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int nw = (int)(blockDim.x >> 6);
+    int np2 = 64;
+    while (np2 < N) np2 <<= 1;
+    // LDS carve-up: cdf (np2 Ts, +inf beyond N) | x planes (D x N Ts) | reduction scratch
+    T* const cdfs = reinterpret_cast<T*>(pfc_lds);
+    T* const xs = cdfs + np2;
+    double* const red = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * N) * sizeof(T) + 15) & ~(size_t)15));
+    T* const redm = reinterpret_cast<T*>(red + (2 + 2 * D) * PFC_MAXW);
+
+    const bool apf = a.filter == PF_FILTER_APF;
+    const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
+    const int proposal = a.proposal;
+    const ModelDesc md = a.md;
+    const int O = md.obs_dim;
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    const int i0 = tid * VEC;
+    const bool on = i0 < N;
+    const T nT = T(N);
+
+    // ---- the incoming state -> registers ---------------------------------------------------------------------------------
+    const int slot_in = run.t0 & 1;
+    T x[D][VEC], lw[VEC];
+    int anc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        lw[j] = -Lim<T>::inf();
+        anc[j] = i0 + j;
+#pragma unroll
+        for (int d = 0; d < D; ++d) x[d][j] = T(0);
+    }
+    if (on) {
+        const T* lwc = a.logw[slot_in] + (int64_t)b * N + i0;
+        if (VEC == 1) lw[0] = lwc[0]; else load_vec<T, VEC>(lwc, lw);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const T* xc = a.x[slot_in] + ((int64_t)d * g.B + b) * N + i0;
+            if (VEC == 1) x[d][0] = xc[0]; else load_vec<T, VEC>(xc, x[d]);
+        }
+        const int32_t* ac = a.anc + (int64_t)b * N + i0;
+        if (VEC == 1) anc[0] = ac[0]; else load_vec<int, VEC>(ac, anc);
+    }
+    for (int q = N + tid; q < np2; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
+
+    // pivot of the weighted moments: the column's first particle, then the previous state's mean
+    T piv[D];
+    {
+        if (tid == 0) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) xs[d] = x[d][0];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < D; ++d) piv[d] = xs[d];
+        __syncthreads();
+    }
+
+    // (max, sum e, sum e^2, sum e (x - c), sum e (x - c)^2) of a state's weights; e[] = exp(lw - M) stays with the caller
+    double M1 = 0.0, S1 = 1.0, Q1 = 1.0;
+    auto reduce_state = [&](T (&e)[VEC], double (&mom)[2 * D]) {
+        T m = lw[0];
+#pragma unroll
+        for (int j = 1; j < VEC; ++j) m = lw[j] > m ? lw[j] : m;
+        const T M = cb_max<T>(m, redm, nw);
+        double v[2 + 2 * D];
+#pragma unroll
+        for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            T ej = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - M);
+            if (lw[j] != lw[j]) ej = lw[j];
+            e[j] = ej;
+            v[0] += (double)ej;
+            v[1] += (double)(ej * ej);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const T xd = x[d][j] - piv[d];
+                v[2 + d] += (double)(ej * xd);
+                v[2 + D + d] += (double)(ej * xd * xd);
+            }
+        }
+        cb_sum<2 + 2 * D>(v, red, nw);
+        M1 = (double)M;
+        S1 = v[0];
+        Q1 = v[1];
+#pragma unroll
+        for (int k = 0; k < 2 * D; ++k) mom[k] = v[2 + k];
+    };
+    // moments row `row` of filter_means / filter_variance from the sums above; the new pivot
+    auto write_moments = [&](int row, const double (&mom)[2 * D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const double dm = mom[d] / S1;
+            double var = mom[D + d] / S1 - dm * dm;
+            if (var < 0.0) var = 0.0;
+            const double mean = (double)piv[d] + dm;
+            if (tid == 0) {
+                a.means[((int64_t)row * g.B + b) * D + d] = (T)mean;
+                a.vars[((int64_t)row * g.B + b) * D + d] = (T)var;
+            }
+            piv[d] = (T)mean;
+        }
+    };
+
+    T e1[VEC];
+    {
+        double mom[2 * D];
+        reduce_state(e1, mom);
+        write_moments(run.t0, mom);
+    }
+    T ll_tot = (tid == 0) ? a.ll_total[b] : T(0);
+
+    for (int s = 0; s < run.n_steps; ++s) {
+        const int t = run.t0 + s;
+        const bool obs = run.use_bits ? ((run.obs_bits[s >> 5] >> (s & 31)) & 1u) != 0 : a.obs_dev[t] != 0;
+        const bool two = apf && obs;
+        ColParams<T, D> cp;
+        ColConsts<T, D> cc;
+        load_col_params<T, D>(a, b, t, obs, cp);
+        cc.prepare(md, cp);
+        bool poison = false;
+
+        // ---- resampling weights, the decision, the bases of this step's log-likelihood increment ---------------------------
+        const double lse_w = M1 + log(S1);
+        T rw[VEC], pre[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            pre[j] = T(0);
+            rw[j] = lw[j];
+        }
+        if (two) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                T xj[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xj[d] = x[d][j];
+                pre[j] = pre_weight<T, D>(md, proposal, cp, cc, xj);
+                if (on && is_nan_or_posinf(pre[j])) poison = true;
+                rw[j] = on ? sanitize_logw(pre[j] + lw[j]) : -Lim<T>::inf();
+            }
+        }
+        const bool resample = apf ? obs : (S1 * S1 / Q1 < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
+        double base_lse = lse_w;
+        int idx[VEC];
+        T xr[VEC][D];
+        if (resample) {
+            // ---- cdf of the normalised resampling weights: fp64 scan, rounded once per element (torch's cumsum), last = 1 ---
+            T er[VEC];
+            T Mr = (T)M1;
+            if (two) {
+                T m = rw[0];
+#pragma unroll
+                for (int j = 1; j < VEC; ++j) m = rw[j] > m ? rw[j] : m;
+                Mr = cb_max<T>(m, redm, nw);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) er[j] = (rw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(rw[j] - Mr);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) er[j] = e1[j];  // exp(lw - M1): the weights' own family
+            }
+            double incl[VEC], local = 0.0, total;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                local += on ? (double)er[j] : 0.0;
+                incl[j] = local;
+            }
+            const double excl = cb_scan_excl(local, red, nw, total);
+            const double inv_tot = 1.0 / total;
+            if (two) base_lse = a.logN - (((double)Mr + log(total)) - lse_w);  // apf.py:44
+            else base_lse = a.logN;                                            // W = 1 / N after resampling
+            if (on) {
+                T cv[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const T L = (T)(excl + incl[j]);
+                    double c = inv_tot * (double)L;
+                    if (c > 1.0) c = 1.0;
+                    cv[j] = (i0 + j == N - 1) ? T(1) : (T)c;  // resampling.py:49
+                }
+                if (VEC == 1) cdfs[i0] = cv[0]; else store_vec<T, VEC>(cdfs + i0, cv);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (VEC == 1) xs[d * N + i0] = x[d][0]; else store_vec<T, VEC>(xs + d * N + i0, x[d]);
+                }
+            }
+            // ---- positions: the systematic grid, or the order statistics of N uniforms (Exp(1) spacings) -------------------
+            T pp[VEC];
+            if (multinomial) {
+                T ev[VEC], tail[1];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) ev[j] = T(0);
+                if (on) draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), ev);
+                draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)t, (uint64_t)((int64_t)g.B * N + b), tail);
+                double ei[VEC], el = 0.0, etot;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    el += on ? (double)ev[j] : 0.0;
+                    ei[j] = el;
+                }
+                const double eexcl = cb_scan_excl(el, red, nw, etot);
+                const double invE = 1.0 / (etot + (double)tail[0]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pp[j] = (T)((eexcl + ei[j]) * invE);
+            } else {
+                const T u = a.u_tape ? a.u_tape[(int64_t)t * g.B + b] : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)t, (uint64_t)b);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) pp[j] = grid_position<T>(i0 + j, u, nT);
+            }
+            __syncthreads();  // cdf and x planes are in LDS
+            // ---- ancestors: first q with cdf[q] >= p (searchsorted side = left), all VEC probes of a round in flight -------
+            int q[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = 0;
+            for (int st = np2 >> 1; st >= 1; st >>= 1) {
+                T v[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[j] = cdfs[q[j] + st - 1];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) q[j] += (v[j] < pp[j]) ? st : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                q[j] += (cdfs[q[j]] < pp[j]) ? 1 : 0;
+                idx[j] = q[j] > N - 1 ? N - 1 : q[j];
+#pragma unroll
+                for (int d = 0; d < D; ++d) xr[j][d] = xs[d * N + idx[j]];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                idx[j] = (i0 + j < N) ? i0 + j : N - 1;
+#pragma unroll
+                for (int d = 0; d < D; ++d) xr[j][d] = x[d][j];
+            }
+        }
+
+        // ---- draws, propagate, weigh -----------------------------------------------------------------------------------------
+        T z[VEC][D];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+#pragma unroll
+            for (int d = 0; d < D; ++d) z[j][d] = T(0);
+        if (on) {
+            if (a.z_tape) {
+                const T* zs = a.z_tape + (int64_t)t * D * g.B * N;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    T zr[VEC];
+                    const T* zc = zs + ((int64_t)d * g.B + b) * N + i0;
+                    if (VEC == 1) zr[0] = zc[0]; else load_vec<T, VEC>(zc, zr);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) z[j][d] = zr[j];
+                }
+            } else {
+                draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
+            }
+        }
+        T lw_new[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            T xn[D], w_new;
+            if (obs) {
+                const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn);
+                if (apf) {
+                    w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j]);  // apf.py:43
+                    if (on && is_nan_or_posinf(w_new)) poison = true;
+                } else {
+                    if (on && is_nan_or_posinf(wi)) poison = true;
+                    w_new = resample ? wi : (wi + lw[j]);  // sisr.py:52-55
+                }
+            } else {  // NaN observation: propagate only, weights carried, ll = 0 (particle/state.py:38-42)
+                sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], z[j], xn);
+                w_new = resample ? T(0) : lw[j];
+            }
+            lw_new[j] = on ? sanitize_logw(w_new) : -Lim<T>::inf();
+#pragma unroll
+            for (int d = 0; d < D; ++d) xr[j][d] = xn[d];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            lw[j] = lw_new[j];
+            if (resample || apf) anc[j] = idx[j];  // SISR without resampling keeps its ancestors (sisr.py:25-26)
+#pragma unroll
+            for (int d = 0; d < D; ++d) x[d][j] = xr[j][d];
+        }
+
+        // ---- the new state's sums: moments row t + 1, log-likelihood increment of this step ------------------------------------
+        const int any_poison = __syncthreads_or(poison ? 1 : 0);  // (also orders this step's LDS reads before the next writes)
+        double mom[2 * D];
+        reduce_state(e1, mom);
+        write_moments(t + 1, mom);
+        if (tid == 0) {
+            double ll = 0.0;
+            if (obs) {
+                ll = (M1 + log(S1)) - base_lse;
+                if (any_poison) ll = __builtin_nan("");
+            }
+            a.ll_steps[(int64_t)t * g.B + b] = (T)ll;
+            ll_tot = (T)((double)ll_tot + ll);
+        }
+    }
+
+    // ---- the final state -> HBM (the slot the per-step route would have written last) ------------------------------------------
+    const int slot_out = (run.t0 + run.n_steps) & 1;
+    if (on) {
+        T* lwc = a.logw[slot_out] + (int64_t)b * N + i0;
+        if (VEC == 1) lwc[0] = lw[0]; else store_vec<T, VEC>(lwc, lw);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            T* xc = a.x[slot_out] + ((int64_t)d * g.B + b) * N + i0;
+            if (VEC == 1) xc[0] = x[d][0]; else store_vec<T, VEC>(xc, x[d]);
+        }
+        int32_t* ac = a.anc + (int64_t)b * N + i0;
+        if (VEC == 1) ac[0] = anc[0]; else store_vec<int, VEC>(ac, anc);
+    }
+    if (tid == 0) a.ll_total[b] = ll_tot;
+}
+
+}  // namespace pf

@@ -252,6 +252,37 @@ template <typename T, int VEC> __device__ __forceinline__ void store_vec(T* __re
     *reinterpret_cast<Pack<T, VEC>*>(p) = q;
 }
 
+// Stores of the step kernel's OUTPUT planes (x', logw', ancestors, the next local scans: 16 + 8 D bytes per particle, never
+// read again by the launch that writes them).  Plain stores leave these lines dirty in the write-back L2 until the
+// end-of-kernel release writes them back, and the next launch waits for that (MI355X_MICROARCH.md "boundary": + B / 6 TB/s
+// behind B dirty bytes - 16.8 MB per step at 2^20 particles).  `sc1` stores write through to the memory side while the
+// workgroup is still computing: measured (profiles/r03_out_store.txt, tools/out_store_variants.sh) 16.3 -> 14.9 us per step
+// at 2^20 x 1, 37.5 -> 36.9 at 2^22 x 1, 39.5 -> 38.3 at 64 x 65 536; non-temporal stores (policy 1) gain the same at
+// 2^20 but lose 4-9 % at the larger shapes; `sc0 sc1` (3) equals `sc1`.  PF_OUT_STORE: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1.
+#ifndef PF_OUT_STORE
+#define PF_OUT_STORE 2
+#endif
+template <typename T, int VEC> __device__ __forceinline__ void store_out(T* __restrict__ p, const T (&in)[VEC]) {
+    constexpr int BYTES = (int)sizeof(T) * VEC;
+    if constexpr (PF_OUT_STORE != 0 && BYTES % 16 == 0) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        Pack<T, VEC> q;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) q.v[j] = in[j];
+        const u4* src = reinterpret_cast<const u4*>(&q);
+        u4* dst = reinterpret_cast<u4*>(p);
+#pragma unroll
+        for (int k = 0; k < BYTES / 16; ++k) {
+            const u4 v = src[k];
+            if constexpr (PF_OUT_STORE == 1) __builtin_nontemporal_store(v, dst + k);
+            else if constexpr (PF_OUT_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + k), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + k), "v"(v) : "memory");
+        }
+    } else {
+        store_vec<T, VEC>(p, in);
+    }
+}
+
 // Online (max, sum-exp) accumulator; sums are carried in double, the exponentials are evaluated in T.
 template <typename T> struct OnlineLse {
     T m;

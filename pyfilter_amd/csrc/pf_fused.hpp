@@ -365,7 +365,7 @@ __device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T*
         T outv[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + incl[j]);
-        if (VEC == 1) l_dst[0] = outv[0]; else store_vec<T, VEC>(l_dst, outv);
+        if (VEC == 1) l_dst[0] = outv[0]; else store_out<T, VEC>(l_dst, outv);
     }
     if (lane == 63) {
         double* rec = lds_rec ? lds_rec + 2 * chunk : raw + 2 * chunk;
@@ -1336,11 +1336,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 T* xc = x_out + ((int64_t)d * g.B + b) * g.N + i0;
-                if (VEC == 1) xc[0] = xo[d][0]; else store_vec<T, VEC>(xc, xo[d]);
+                if (VEC == 1) xc[0] = xo[d][0]; else store_out<T, VEC>(xc, xo[d]);
             }
-            if (VEC == 1) lw_out[i0] = lwo[0]; else store_vec<T, VEC>(lw_out + i0, lwo);
+            if (VEC == 1) lw_out[i0] = lwo[0]; else store_out<T, VEC>(lw_out + i0, lwo);
             if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
-                if (VEC == 1) anc_col[i0] = idx[0]; else store_vec<int, VEC>(anc_col + i0, idx);
+                if (VEC == 1) anc_col[i0] = idx[0]; else store_out<int, VEC>(anc_col + i0, idx);
             } else if (la->anc_prev) {  // ... which, with a state history, means copying them into this state's slot
                 const int32_t* ap = la->anc_prev + (int64_t)b * g.N + i0;
                 int prev[VEC];
@@ -1403,7 +1403,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             T outv[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + e[j]);
-            if (VEC == 1) l_next[i0] = outv[0]; else store_vec<T, VEC>(l_next + i0, outv);
+            if (VEC == 1) l_next[i0] = outv[0]; else store_out<T, VEC>(l_next + i0, outv);
         }
     } else if (scan_next) {
         // the chunk table of the next step's resampling weights, and the tile's (max, sum) of that family from the same sums

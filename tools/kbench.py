@@ -64,6 +64,17 @@ CONFIGS = {
     "apf_lgo_2m": ("sine", "apf", "lgo", 1 << 21, 1),
     "apf_lgo_16x64k": ("sine", "apf", "lgo", 65536, 16),
     "apf_lgo_32x64k": ("sine", "apf", "lgo", 65536, 32),
+    # single-tile columns (the reference's own operating point: 1 000 theta x 250-400 particles)
+    "apf_lgo_1024x256": ("sine", "apf", "lgo", 256, 1024),
+    "apf_lgo_1000x400": ("sine", "apf", "lgo", 400, 1000),
+    "apf_lgo_1024x512": ("sine", "apf", "lgo", 512, 1024),
+    "sisr_boot_1024x512": ("sine", "sisr", "bootstrap", 512, 1024),
+    "apf_sv_1024x512": ("sv", "apf", "bootstrap", 512, 1024),
+    "apf_lgo_1024x1024": ("sine", "apf", "lgo", 1024, 1024),
+    "apf_lgo_1024x2048": ("sine", "apf", "lgo", 2048, 1024),
+    "apf_lgo_1024x4096": ("sine", "apf", "lgo", 4096, 1024),
+    "apf_lgo_64x4096": ("sine", "apf", "lgo", 4096, 64),
+    "sisr_lorenz_1024x512": ("lorenz", "sisr", "bootstrap", 512, 1024),
     "sisr_lorenz_4m": ("lorenz", "sisr", "bootstrap", 1 << 22, 1),
     "sisr_lorenz_4m_mn": ("lorenz", "sisr", "bootstrap", 1 << 22, 1, "multinomial"),
 }
@@ -74,7 +85,7 @@ def main():
     T = int(os.environ.get("KB_T", 100))
     for name in names:
         cfg = CONFIGS[name]
-        if cfg[0] == "lorenz":  # data simulated from the model (bench.py's generator), not noise
+        if cfg[0] == "lorenz" and cfg[4] == 1:  # data simulated from the model (bench.py's generator), not noise
             import bench
             from pyfilter_amd import resampling as rs_
             f, y, w = bench.build_problem("lorenz_mn", torch.float32, torch.device(dev), 1, 0, T)
