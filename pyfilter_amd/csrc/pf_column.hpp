@@ -404,7 +404,16 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
         int32_t* ac = a.anc + (int64_t)b * N + i0;
         if (VEC == 1) ac[0] = anc[0]; else store_vec<int, VEC>(ac, anc);
     }
-    if (tid == 0) a.ll_total[b] = ll_tot;
+    if (tid == 0) {
+        a.ll_total[b] = ll_tot;
+        // the per-step route's per-column record, as a finalised run leaves it (a later call on that route starts from it)
+        ColStat st{};
+        st.lse_w = M1 + log(S1);
+        st.ll_done = 1;
+        a.stat[b] = st;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a.poison[q * g.B + b] = 0;
+    }
 }
 
 }  // namespace pf

@@ -258,7 +258,10 @@ template <typename T, int VEC> __device__ __forceinline__ void store_vec(T* __re
 // behind B dirty bytes - 16.8 MB per step at 2^20 particles).  `sc1` stores write through to the memory side while the
 // workgroup is still computing: measured (profiles/r03_out_store.txt, tools/out_store_variants.sh) 16.3 -> 14.9 us per step
 // at 2^20 x 1, 37.5 -> 36.9 at 2^22 x 1, 39.5 -> 38.3 at 64 x 65 536; non-temporal stores (policy 1) gain the same at
-// 2^20 but lose 4-9 % at the larger shapes; `sc0 sc1` (3) equals `sc1`.  PF_OUT_STORE: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1.
+// 2^20 but lose 4-9 % at the larger shapes; `sc0 sc1` equals `sc1`.  PF_OUT_STORE: 0 plain, 1 non-temporal, 2 write-through.
+// Policy 2 is spelled as a VOLATILE vector store: on gfx940+ the backend's memory model emits volatile global accesses with
+// `sc0 sc1` (system scope, i.e. written through - measured equal to `sc1` alone) and, unlike an inline-asm store, the
+// compiler keeps tracking it (s_waitcnt before a dependent access, the > 64-bit store-data hazard).
 #ifndef PF_OUT_STORE
 #define PF_OUT_STORE 2
 #endif
@@ -269,14 +272,13 @@ template <typename T, int VEC> __device__ __forceinline__ void store_out(T* __re
         Pack<T, VEC> q;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) q.v[j] = in[j];
-        const u4* src = reinterpret_cast<const u4*>(&q);
         u4* dst = reinterpret_cast<u4*>(p);
 #pragma unroll
         for (int k = 0; k < BYTES / 16; ++k) {
-            const u4 v = src[k];
+            u4 v;
+            __builtin_memcpy(&v, reinterpret_cast<const char*>(&q) + 16 * k, 16);
             if constexpr (PF_OUT_STORE == 1) __builtin_nontemporal_store(v, dst + k);
-            else if constexpr (PF_OUT_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + k), "v"(v) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst + k), "v"(v) : "memory");
+            else *((__attribute__((address_space(1))) volatile u4*)(dst + k)) = v;  // (global_store_dwordx4 ... sc0 sc1)
         }
     } else {
         store_vec<T, VEC>(p, in);

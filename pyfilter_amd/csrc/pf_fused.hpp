@@ -345,7 +345,9 @@ template <typename T> struct CdfView {  // searches in the implied cdf of one co
 // One round of the chunk-local scan (see cdf_from_local): rw[j] the thread's VEC resampling log-weights (-inf beyond the
 // column), executed by every lane of every wave (wave-level reductions).  Stores L_i and leaves the chunk's raw record
 // (m_c, t_c) in LDS (`lds_rec`, tiles of <= PF_LDS_CHUNKS chunks) or in the tile's slice of the chunk table (`raw`).
-template <typename T, int VEC>
+// WT: the scans are an output plane of the step kernel (written through, store_out); k_fused_reduce re-reads its own
+// (single-round tiles fold (C, g) in) and keeps them in the cache.
+template <typename T, int VEC, bool WT = false>
 __device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T* __restrict__ l_dst, int chunk,
                                                  double* lds_rec, double* raw) {
     const int lane = threadIdx.x & 63;
@@ -365,7 +367,9 @@ __device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T*
         T outv[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + incl[j]);
-        if (VEC == 1) l_dst[0] = outv[0]; else store_out<T, VEC>(l_dst, outv);
+        if (VEC == 1) l_dst[0] = outv[0];
+        else if constexpr (WT) store_out<T, VEC>(l_dst, outv);
+        else store_vec<T, VEC>(l_dst, outv);
     }
     if (lane == 63) {
         double* rec = lds_rec ? lds_rec + 2 * chunk : raw + 2 * chunk;
@@ -1374,7 +1378,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             PF_STAMP(a, 13);
         }
         if (scan_next && !single) {  // (uniform) every lane of every wave: the chunk-local scan is wave-level
-            chunk_scan_round<T, VEC>(rwn, on, l_next + i0, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
+            chunk_scan_round<T, VEC, true>(rwn, on, l_next + i0, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) rwn[j] = -Lim<T>::inf();
             ++rk;

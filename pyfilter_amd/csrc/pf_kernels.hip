@@ -1035,9 +1035,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_ffbs(ModelDesc md, const T* __rest
 }  // namespace pf
 
 #include "pf_fused.hpp"
-
-namespace pf {
-}  // namespace pf
+#include "pf_column.hpp"
 
 // =================================================================================================================
 // C ABI
@@ -1081,6 +1079,15 @@ static inline ModelDesc to_desc(const pf_model* m) {
 //   ... each of the kernel units additionally with -DPF_TU_MULTI=0|1: only the kernels of single-round / multi-round
 //   tiles (the MULTI template argument of k_fused_step; entries carry the suffix _m0 / _m1)
 // Without any of the macros the file is a single self-contained unit.
+#if defined(PF_TU_COLUMN_F32) || defined(PF_TU_COLUMN_F64)  // the column-persistent kernels of one arithmetic type, nothing else
+#define PF_TU_NO_API
+#define PF_TU_NO_F64
+#define PF_TU_NO_F32DN
+#define PF_TU_NO_F32D1
+#endif
+#if defined(PF_TU_NO_F64) || defined(PF_TU_NO_F32DN) || defined(PF_TU_NO_F32D1) || defined(PF_TU_F64_ONLY) || defined(PF_TU_F32DN_ONLY) || defined(PF_TU_F32D1_ONLY)
+#define PF_TU_SPLIT  // a split build: the column kernels live in their own units (PF_TU_COLUMN_F32 / _F64)
+#endif
 #if defined(PF_TU_F64_ONLY) || defined(PF_TU_F32DN_ONLY) || defined(PF_TU_F32D1_ONLY)
 #define PF_TU_NO_API
 #endif
@@ -1451,9 +1458,9 @@ extern "C" int pf_debug_launch_trace(int32_t* out, int max_records) {
 }
 #endif
 
-template <typename T, int D, int VEC, bool MULTI>
-static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
-                           int finalize, hipStream_t st, float* kernel_ms) {
+// the launch arguments every fused kernel shares, from the C ABI's argument block
+template <typename T>
+static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0) {
     FusedArgs<T> a;
     a.md = to_desc(&A->model);
     a.params = (const T*)A->model.params;
@@ -1497,6 +1504,13 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         const char* dc = getenv("PF_DEBUG_CUT");
         a.debug_cut = dc ? atoi(dc) : 0;
     }
+    return a;
+}
+
+template <typename T, int D, int VEC, bool MULTI>
+static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
+                           int finalize, hipStream_t st, float* kernel_ms) {
+    FusedArgs<T> a = make_fused_args<T>(A, g, wl, t0);
     const uint8_t* observed = A->observed;  // host array
 
     const dim3 grid_tiles(g.tiles, g.B), block(PF_BLOCK);
@@ -1654,6 +1668,111 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? PF_OK : (int)e;
 }
+
+// ---- the column-persistent route (pf_column.hpp): filters of a few hundred .. a few thousand particles -----------------
+// One launch per run (per PFC_OBS_WORDS * 32 steps): no reduce / bookkeeping launches, no per-column records.
+static inline int column_threads(int64_t N, int vec) {
+    const int64_t need = (N + vec - 1) / vec;
+    return (int)(((need + PF_WAVE - 1) / PF_WAVE) * PF_WAVE);
+}
+static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize) {
+    int64_t np2 = 64;
+    while (np2 < N) np2 <<= 1;
+    const size_t planes = (((size_t)(np2 + (int64_t)D * N) * tsize) + 15) & ~(size_t)15;
+    return planes + sizeof(double) * (2 + 2 * D) * PFC_MAXW + tsize * PFC_MAXW + 16;
+}
+#ifndef PF_COLUMN_MAX_N
+#define PF_COLUMN_MAX_N 4096
+#endif
+// Which runs take it: self-contained runs (finalize: the last state's row is flushed by the same call), no state history,
+// a column that fits one workgroup.  PF_NO_COLUMN=1 keeps everything on the per-step route (tests compare the two).
+static inline bool column_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
+    if (!finalize || n_steps < 1 || A->ring >= 3) return false;
+    if (const char* e = getenv("PF_NO_COLUMN")) if (atoi(e) != 0) return false;
+    int64_t max_n = PF_COLUMN_MAX_N;
+    if (const char* e = getenv("PF_COLUMN_MAX_N")) max_n = atoll(e);
+    if (A->N > max_n || column_threads(A->N, g.vec) > 1024) return false;
+    return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4) <= 150 * 1024;
+}
+
+template <typename T, int D, int VEC>
+static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
+                           hipStream_t st, float* kernel_ms) {
+    FusedArgs<T> a = make_fused_args<T>(A, g, wl, t0);
+    const int nt = column_threads(A->N, VEC);
+    const bool big = nt > 256;
+    const size_t lds = column_lds_bytes(A->N, D, sizeof(T));
+    static bool attr_done[2] = {false, false};
+    if (lds > 64 * 1024 && !attr_done[big ? 1 : 0]) {
+        const void* fn = big ? (const void*)k_fused_column<T, D, VEC, true> : (const void*)k_fused_column<T, D, VEC, false>;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_done[big ? 1 : 0] = true;
+    }
+    // observed flags: the host's (baked into the launch arguments), the caller's device array, or derived from y here
+    const bool auto_flags = !A->observed && !A->observed_dev;
+    a.obs_dev = A->observed_dev;
+    if (auto_flags) {
+        uint8_t* fl = (uint8_t*)A->ws + wl.off_ctr + 64;
+        const int64_t row = A->y_rows * (int64_t)A->model.obs_dim;
+        hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * row, row, fl);
+        a.obs_dev = fl - t0;
+    }
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (kernel_ms) {
+        for (auto& e : ev)
+            if (hipEventCreate(&e) != hipSuccess) return (int)hipGetLastError();
+        (void)hipEventRecord(ev[0], st);
+    }
+    for (int64_t done = 0; done < n_steps;) {
+        ColumnRun r;
+        r.t0 = (int)(t0 + done);
+        r.n_steps = (int)((n_steps - done < 32 * PFC_OBS_WORDS) ? n_steps - done : 32 * PFC_OBS_WORDS);
+        r.use_bits = (a.obs_dev == nullptr) ? 1 : 0;
+        for (int w = 0; w < PFC_OBS_WORDS; ++w) r.obs_bits[w] = 0u;
+        if (r.use_bits)
+            for (int q = 0; q < r.n_steps; ++q)
+                if (A->observed[r.t0 + q]) r.obs_bits[q >> 5] |= 1u << (q & 31);
+        a.step = r.t0;
+        trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, 0, /*SPEC*/ 9, 0, 0);
+        if (big) hipLaunchKernelGGL((k_fused_column<T, D, VEC, true>), dim3(g.B), dim3(nt), lds, st, a, r);
+        else hipLaunchKernelGGL((k_fused_column<T, D, VEC, false>), dim3(g.B), dim3(nt), lds, st, a, r);
+        done += r.n_steps;
+    }
+    if (kernel_ms) {
+        (void)hipEventRecord(ev[1], st);
+        hipError_t se = hipStreamSynchronize(st);
+        if (se != hipSuccess) return (int)se;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        kernel_ms[0] = kernel_ms[2] = ms / (float)n_steps;  // the run's one kernel, per time step
+        kernel_ms[1] = 0.f;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PF_OK : (int)e;
+}
+#define PF_COL_ARGS const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, hipStream_t st, float* kernel_ms
+int pf_run_column_f32(PF_COL_ARGS);
+int pf_run_column_f64(PF_COL_ARGS);
+#define PF_DEFINE_COLUMN(NAME, T)                                                                     \
+    int NAME(PF_COL_ARGS) {                                                                           \
+        const int D = A->model.dim;                                                                   \
+        if (g.vec == 4) {                                                                             \
+            if (D == 1) return column_run_impl<T, 1, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
+            if (D == 2) return column_run_impl<T, 2, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
+            return column_run_impl<T, 3, 4>(A, g, wl, t0, n_steps, st, kernel_ms);                    \
+        }                                                                                             \
+        if (D == 1) return column_run_impl<T, 1, 1>(A, g, wl, t0, n_steps, st, kernel_ms);            \
+        if (D == 2) return column_run_impl<T, 2, 1>(A, g, wl, t0, n_steps, st, kernel_ms);            \
+        return column_run_impl<T, 3, 1>(A, g, wl, t0, n_steps, st, kernel_ms);                        \
+    }
+#if defined(PF_TU_COLUMN_F32) || !defined(PF_TU_SPLIT)
+PF_DEFINE_COLUMN(pf_run_column_f32, float)
+#endif
+#if defined(PF_TU_COLUMN_F64) || !defined(PF_TU_SPLIT)
+PF_DEFINE_COLUMN(pf_run_column_f64, double)
+#endif
 
 // one entry per arithmetic type / state dimension / vector width / tile geometry (see the translation-unit note above)
 #define PF_RUN_ARGS const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize, \
@@ -1818,6 +1937,11 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (column_eligible(A, g, n_steps, finalize)) {
+        if (A->dtype == PF_F32) return pf_run_column_f32(A, g, wl, t0, n_steps, st, kernel_ms);
+        if (A->dtype == PF_F64) return pf_run_column_f64(A, g, wl, t0, n_steps, st, kernel_ms);
+        return PF_EINVAL;
+    }
     if (A->dtype == PF_F32) return pf_run_f32(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
     if (A->dtype == PF_F64) return pf_run_f64(A, g, wl, t0, n_steps, finalize, st, kernel_ms);
     return PF_EINVAL;

@@ -1,0 +1,189 @@
+"""The column-persistent route (``pyfilter_amd/csrc/pf_column.hpp``: one workgroup per filter runs the whole time loop in
+ONE launch) against the per-step route (``k_fused_step``, one launch per time step) and the oracle.
+
+Both routes key their Philox draws by (seed, stream, step, filter x N + particle): a run with the same seed consumes
+the SAME random numbers on either route, so in float64 the two must agree to rounding - identical ancestors, moments and
+log-likelihoods to 1e-9 - for every filter / proposal / resampler / model / particle count the column route accepts.
+(The golden-fixture suites in ``tests/test_filters_gpu.py`` run on both routes as well: ``kernel_route``.)"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _t(v, dtype):
+    return torch.tensor(v, dtype=dtype, device=DEV)
+
+
+def _model(kind, b, dtype):
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.timeseries import models
+
+    if kind == "sine":
+        return ts.LinearStateSpaceModel(models.SineDiffusion(_t(0.0, dtype), _t(1.0, dtype), dt=0.1), (_t(1.0, dtype), _t(0.1, dtype))), ()
+    if kind == "lg":
+        return ts.LinearStateSpaceModel(models.AR(_t(0.0, dtype), _t(0.99, dtype), _t(0.05, dtype)), (_t(1.0, dtype), _t(0.15, dtype))), ()
+    if kind == "ou":
+        kappa = _t([0.02 + 0.01 * (i % 5) for i in range(b)], dtype)
+        gamma = _t([0.1 * (i % 3) for i in range(b)], dtype)
+        sigma = _t([0.05 + 0.01 * (i % 4) for i in range(b)], dtype)
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(kappa, gamma, sigma, dt=1.0), (_t(1.0, dtype), _t(0.05, dtype))), ()
+    if kind == "sv":
+        kappa = _t([0.05 + 0.01 * (i % 7) for i in range(b)], dtype)
+        gamma = _t([1.0 + 0.1 * (i % 5) for i in range(b)], dtype)
+        sigma = _t([0.10 + 0.02 * (i % 3) for i in range(b)], dtype)
+        mu = _t([0.05 * (i % 4) for i in range(b)], dtype)
+        return models.StochasticVolatilityModel(models.Verhulst(kappa, gamma, sigma, dt=0.2, initial=(_t(1.0, dtype), _t(0.1, dtype))), mu), ()
+    if kind == "lorenz":
+        hidden = models.Lorenz63(_t(10.0, dtype), _t(28.0, dtype), _t(8.0 / 3.0, dtype), _t(1.0, dtype), dt=0.01)
+        a = _t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]], dtype)
+        return ts.LinearStateSpaceModel(hidden, (a, _t([0.0], dtype), _t([math.sqrt(0.1)], dtype)), torch.Size([2])), (2,)
+    raise KeyError(kind)
+
+
+def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(), seed=7, ess=0.9):
+    from pyfilter_amd import ops, resampling
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+
+    ssm, o = _model(kind, b, dtype)
+    cls = {"sisr": SISR, "apf": APF}[filt_name]
+    p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
+    rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[resampler]
+    filt = cls(ssm, n, proposal=p, resampling=rs, seed=seed, ess_threshold=ess)
+    if b > 1:
+        filt.set_batch_shape(torch.Size([b]))
+    g = torch.Generator().manual_seed(3)
+    if kind == "lorenz":
+        y = torch.tensor([-4.7, 19.6]) + 0.5 * torch.randn((t_len, 2), generator=g)
+    elif kind == "sv":
+        y = 0.05 + torch.randn((t_len,), generator=g)
+    else:
+        y = (0.1 * torch.randn((t_len,) + o, generator=g)).cumsum(0)
+    y = y.to(dtype)
+    for k in nan_at:
+        y[k] = float("nan")
+    os.environ.pop("PF_NO_COLUMN", None)
+    if route == "per_step":
+        os.environ["PF_NO_COLUMN"] = "1"
+    try:
+        res = filt.batch_filter(y.to(DEV), bar=False)
+        torch.cuda.synchronize()
+        trace = ops.debug_launch_trace(4)
+    finally:
+        os.environ.pop("PF_NO_COLUMN", None)
+    last = res.latest_state
+    return dict(means=res.filter_means.cpu(), var=res.filter_variance.cpu(), ll=res.loglikelihood.cpu(),
+                x=last.timeseries_state.value.cpu(), w=last.weights.cpu(), idx=last.previous_indices.cpu(),
+                ll_last=last.get_loglikelihood().cpu(), SPEC=trace[-1]["SPEC"])
+
+
+CASES = [
+    # kind, filter, proposal, resampler, N, B, T, NaN observations
+    ("sine", "apf", "lgo", "systematic", 512, 5, 40, ()),
+    ("sine", "apf", "bootstrap", "systematic", 256, 3, 30, (4, 5)),
+    ("sine", "sisr", "bootstrap", "systematic", 400, 4, 40, (7,)),
+    ("sine", "sisr", "lgo", "systematic", 64, 2, 30, ()),
+    ("lg", "sisr", "bootstrap", "systematic", 1000, 1, 50, ()),
+    ("lg", "apf", "lgo", "systematic", 2048, 2, 25, ()),
+    ("lg", "apf", "lgo", "systematic", 4096, 3, 25, (0,)),
+    ("ou", "apf", "lgo", "systematic", 1024, 7, 30, ()),
+    ("ou", "sisr", "lgo", "systematic", 100, 3, 30, ()),       # N % 4 != 0: one particle per thread
+    ("ou", "apf", "bootstrap", "systematic", 333, 2, 20, (3,)),
+    ("sv", "apf", "bootstrap", "systematic", 512, 6, 40, ()),
+    ("sv", "sisr", "bootstrap", "systematic", 256, 4, 40, ()),
+    ("lorenz", "sisr", "bootstrap", "systematic", 512, 2, 20, ()),
+    ("lorenz", "apf", "lgo", "systematic", 256, 2, 15, (2,)),
+    ("lorenz", "apf", "bootstrap", "systematic", 2048, 1, 10, ()),
+    ("sine", "sisr", "bootstrap", "multinomial", 512, 3, 30, ()),
+    ("sine", "apf", "lgo", "multinomial", 1024, 2, 30, ()),
+    ("lorenz", "sisr", "bootstrap", "multinomial", 256, 2, 15, ()),
+    ("lg", "sisr", "bootstrap", "systematic", 2, 3, 12, ()),
+    ("lg", "apf", "bootstrap", "systematic", 1, 2, 8, ()),
+]
+
+
+@pytest.mark.parametrize("kind,filt_name,prop,resampler,n,b,t_len,nan_at", CASES)
+def test_column_route_equals_per_step_route_float64(kind, filt_name, prop, resampler, n, b, t_len, nan_at):
+    col = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at)
+    ref = _run("per_step", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at)
+    assert col["SPEC"] == 9 and ref["SPEC"] != 9, "the routes under test did not run"
+    assert torch.equal(col["idx"], ref["idx"]), "final ancestors differ"
+    tol = dict(rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(col["means"], ref["means"], **tol)
+    torch.testing.assert_close(col["var"], ref["var"], rtol=1e-8, atol=1e-11)
+    torch.testing.assert_close(col["ll"], ref["ll"], rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(col["ll_last"], ref["ll_last"], rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(col["x"], ref["x"], **tol)
+    torch.testing.assert_close(col["w"], ref["w"], equal_nan=True, **tol)
+
+
+@pytest.mark.parametrize("kind,filt_name,prop,resampler,n,b,t_len,nan_at", [c for c in CASES if c[4] >= 64][::2])
+def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_name, prop, resampler, n, b, t_len, nan_at):
+    """float32 production arithmetic: an ulp in a weight moves an ancestor across a cdf boundary, after which the runs are
+    different - equally valid - Monte-Carlo runs.  Bar: the float32 column run within 8 Monte-Carlo standard errors of the
+    float64 run (float32 and float64 Philox normals are different numbers: two independent runs; the bar of ``test_fused_batch_filter_matches_reference`` for float32 fixtures)."""
+    c32 = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
+    c64 = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at)
+    assert c32["SPEC"] == 9
+    se = (c64["var"] / n).sqrt()
+    diff = (c32["means"].double() - c64["means"]).abs()
+    assert (diff <= 8.0 * se + 1e-4 * c64["means"].abs() + 1e-5).all(), (diff / (se + 1e-12)).max()
+    assert torch.isfinite(c32["ll"]).all()
+    assert ((c32["ll"].double() - c64["ll"]).abs() <= 0.08 * math.sqrt(t_len) * max(1.0, float(c64["ll"].abs().max()) / t_len) + 1e-2).all()
+
+
+def test_runs_longer_than_one_launch_carries_the_state_through():
+    """2048 steps fit one launch's baked-in observed flags; a longer run is several launches with the state handed over in
+    HBM: identical to the per-step route, NaN observations on either side of the seam."""
+    t_len = 2100
+    nan_at = (5, 2047, 2048, 2060)
+    col = _run("column", "lg", "sisr", "bootstrap", "systematic", 128, 2, t_len, torch.float64, nan_at)
+    ref = _run("per_step", "lg", "sisr", "bootstrap", "systematic", 128, 2, t_len, torch.float64, nan_at)
+    assert col["means"].shape[0] == t_len + 1
+    torch.testing.assert_close(col["means"], ref["means"], rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(col["ll"], ref["ll"], rtol=1e-9, atol=1e-8)
+    assert torch.equal(col["idx"], ref["idx"])
+
+
+def test_column_route_against_the_oracle_on_taped_draws():
+    """Independent of the per-step route: the column kernel on injected draws against ``oracle/cpu_ref.py`` (float64, a
+    shape no golden fixture has: 3 000 particles x 3 filters, one particle per... four per thread, 12 waves)."""
+    from oracle import cpu_ref, models as M
+    from pyfilter_amd import ops, timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.timeseries import models
+
+    n, b, t_len, dtype = 3000, 3, 12, torch.float64
+    g = torch.Generator().manual_seed(5)
+    y = (0.3 * torch.randn(t_len, generator=g, dtype=dtype)).cumsum(0)
+    z0 = torch.randn(n, b, generator=g).to(dtype)
+    z = torch.randn(t_len, n, b, generator=g).to(dtype)
+    u = torch.rand(t_len, b, generator=g).to(dtype)
+    ssm = ts.LinearStateSpaceModel(models.SineDiffusion(_t(0.0, dtype), _t(1.0, dtype), dt=0.1), (_t(1.0, dtype), _t(0.1, dtype)))
+    filt = APF(ssm, n, proposal=proposals.LinearGaussianObservations())
+    filt.set_batch_shape(torch.Size([b]))
+    filt.set_tape(z=z, u=u, z0=z0)
+    res = filt.batch_filter(y.to(DEV), bar=False)
+    torch.cuda.synchronize()
+    assert ops.debug_launch_trace(1)[-1]["SPEC"] == 9
+    spec = M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
+    x0 = M.initial_sample(spec, z0)
+    ref = cpu_ref.batch_filter(spec, "apf", "lgo", y, x0, z, u)
+    torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9)
+    assert torch.equal(res.latest_state.previous_indices.cpu(), ref["prev_inds"])
+
+
+def test_smc2_shaped_workload_is_one_launch_per_run():
+    """The reference's own operating point (1 000 theta x 400 particles): ``batch_filter`` is ONE kernel launch."""
+    from pyfilter_amd import ops
+
+    r = _run("column", "ou", "apf", "lgo", "systematic", 400, 1000, 60, torch.float32)
+    assert r["SPEC"] == 9 and torch.isfinite(r["ll"]).all() and torch.isfinite(r["means"]).all()
+    recs = ops.debug_launch_trace(64)
+    assert recs[-1]["SPEC"] == 9 and (len(recs) < 2 or recs[-2]["SPEC"] != 9 or recs[-2]["step"] == 0)

@@ -12,6 +12,7 @@ import torch
 
 from oracle import cpu_ref
 from oracle.cases import CASES, build_spec
+from tests.conftest import both_routes
 from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -23,8 +24,9 @@ def _tols(dt):
     return dict(rtol=1e-9, atol=1e-11) if dt == "f64" else dict(rtol=2e-4, atol=2e-5)
 
 
+@both_routes
 @pytest.mark.parametrize("name,dt", PARAMS)
-def test_fused_batch_filter_matches_reference(name, dt):
+def test_fused_batch_filter_matches_reference(name, dt, kernel_route):
     case = next(c for c in CASES if c["name"] == name)
     g = load_golden(name, dt)
     filt = build_filter_from_case(case, g, DT[dt], "cuda")
@@ -53,8 +55,9 @@ def test_fused_batch_filter_matches_reference(name, dt):
         assert ((res.loglikelihood.cpu() - g["loglikelihood"]).abs() <= 0.05 * math.sqrt(t_len) + 1e-3).all()
 
 
+@both_routes
 @pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f32"])
-def test_float32_teacher_forced_steps(name, dt):
+def test_float32_teacher_forced_steps(name, dt, kernel_route):
     """float32, one step at a time from the reference's own previous state (so rounding cannot accumulate): new
     particles / weights / log-likelihood within 1e-5 (relative to the state's scale), ancestors identical except for
     the rare position that sits within an ulp of a CDF boundary."""
@@ -117,8 +120,9 @@ def test_step_by_step_route_matches_reference(name, dt, monkeypatch):
     torch.testing.assert_close(result.loglikelihood.cpu(), g["loglikelihood"], **tol)
 
 
+@both_routes
 @pytest.mark.parametrize("filt_name,prop", [("apf", "lgo"), ("sisr", "bootstrap"), ("apf", "bootstrap"), ("sisr", "lgo")])
-def test_unbatched_equals_batch_of_one(filt_name, prop):
+def test_unbatched_equals_batch_of_one(filt_name, prop, kernel_route):
     """batch_shape = [] (1-D weights) gives the same numbers as batch_shape = [1]."""
     case = dict(name="x", model="sine", filter=filt_name, proposal=prop, N=512, B=1, T=12, ess_threshold=0.6, seed=1)
     gen = torch.Generator().manual_seed(3)
@@ -415,8 +419,9 @@ def test_per_filter_initial_parameters():
     assert res.filter_means.shape == (6, 3, 1) and torch.isfinite(res.loglikelihood).all()
 
 
+@both_routes
 @pytest.mark.parametrize("filt_name,prop", [("apf", "bootstrap"), ("sisr", "bootstrap"), ("apf", "lgo")])
-def test_weight_collapse_paths(filt_name, prop):
+def test_weight_collapse_paths(filt_name, prop, kernel_route):
     """Outlier observations collapse the weights onto a handful of particles: grid positions then fall far outside the
     LDS window (global fallback search through the implied cdf), one ancestor owns many position tiles, most tiles
     carry ~zero mass.  float64, identical draws: ancestors and moments must still match the oracle."""
@@ -447,9 +452,10 @@ def test_weight_collapse_paths(filt_name, prop):
     assert uniq < n // 100, uniq
 
 
+@both_routes
 @pytest.mark.parametrize("name", ["sine_apf_lgo", "lg1d_sisr_boot", "sine_apf_boot_nan", "sine_sisr_boot_nan", "sv_apf_boot",
                                   "lorenz_sisr_boot", "lorenz_apf_lgo", "ou_apf_boot_theta", "ou_sisr_lgo_theta"])
-def test_fused_single_step_filter_matches_reference(name):
+def test_fused_single_step_filter_matches_reference(name, kernel_route):
     """``filter()`` one observation at a time (the online / SMC^2 entry point) through the fused single-step path:
     every step's particles, weights, log-likelihood and ancestors against the reference's golden run (float64,
     identical draws) - and identical to what the step-by-step route (PF_NO_FUSED_STEP=1) produces."""
@@ -543,9 +549,10 @@ def test_multi_round_tiles_pass_the_parity_suite():
         assert r.returncode == 0, f"PF_TARGET_WGS={wgs} (production kernels)\n" + r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@both_routes
 @pytest.mark.parametrize("n,b", [(1, 1), (2, 3), (7, 2), (64, 1), (257, 2)])
 @pytest.mark.parametrize("filt_name,prop", [("sisr", "bootstrap"), ("apf", "lgo")])
-def test_tiny_particle_counts(n, b, filt_name, prop):
+def test_tiny_particle_counts(n, b, filt_name, prop, kernel_route):
     """Degenerate sizes (a single particle, fewer particles than a wavefront, one more than a workgroup round): the
     fused route still reproduces the oracle on identical draws."""
     case, spec, g, y = _full_size_case("sine", filt_name, prop, n, b, 6, seed=5 + n)
@@ -821,7 +828,8 @@ def test_two_threads_two_streams_match_serial_runs():
         assert torch.equal(outs[kind][0].cpu(), serial[kind]), kind
 
 
-def test_randomised_parity_sweep(monkeypatch):
+@both_routes
+def test_randomised_parity_sweep(monkeypatch, kernel_route):
     """``tools/fuzz_parity.py`` with a fixed seed: 30 random (model, filter, proposal, threshold, N, B, T, NaN pattern, tile
     geometry, route) configurations in float64 on identical draws - means / log-likelihood to 1e-9, identical ancestors."""
     import importlib.util

@@ -23,6 +23,14 @@ from pyfilter_amd import ops
 from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _per_step_route(monkeypatch):
+    """These tests pin the STEP kernel's production instantiations (asserted through the launch trace), also at the golden
+    cases' small particle counts - which the library would otherwise hand to the column-persistent kernel
+    (tests/test_column_route_gpu.py covers that one)."""
+    monkeypatch.setenv("PF_NO_COLUMN", "1")
 F32 = torch.float32
 
 

@@ -53,7 +53,7 @@ def build_dev():
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-DPF_DEVTOOLS",
                                "-DPF_TU_F32D1_ONLY", "-DPF_TU_VEC=4", "-o", dev_obj], cwd=csrc)
         others = [os.path.join(objdir, f) for f in ("pf_main.o", "pf_f32d1_v1_m0.o", "pf_f32d1_v1_m1.o", "pf_f32dn_m0.o",
-                                                    "pf_f32dn_m1.o", "pf_f64_m0.o", "pf_f64_m1.o")]
+                                                    "pf_f32dn_m1.o", "pf_f64_m0.o", "pf_f64_m1.o", "pf_col_f32.o", "pf_col_f64.o")]
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", dev_obj] + others + ["-o", out], cwd=csrc)
     return out
 
