@@ -31,36 +31,7 @@ struct ColumnRun {
     uint32_t obs_bits[PFC_OBS_WORDS];  // bit s = step t0 + s weighs against y[t0 + s]
 };
 
-// workgroup collectives for a run-time number of waves `nw` (1 .. 16); a single-wave workgroup never touches LDS
-template <typename T> __device__ __forceinline__ T cb_max(T v, T* red, int nw) {
-    v = wave_max<T>(v);
-    if (nw == 1) return v;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) red[wid] = v;
-    __syncthreads();
-    T r = red[0];
-    for (int w = 1; w < nw; ++w) r = red[w] > r ? red[w] : r;
-    return r;
-}
-template <int K> __device__ __forceinline__ void cb_sum(double (&v)[K], double* red, int nw) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
-    if (nw == 1) return;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) red[k * PFC_MAXW + wid] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        double r = red[k * PFC_MAXW];
-        for (int w = 1; w < nw; ++w) r += red[k * PFC_MAXW + w];
-        v[k] = r;
-    }
-}
+// exclusive scan of one double per thread across a workgroup of `nw` waves (1 .. 16); a single wave never touches LDS
 __device__ __forceinline__ double cb_scan_excl(double v, double* red, int nw, double& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const double incl = wave_scan_incl(v, lane);
@@ -81,8 +52,30 @@ __device__ __forceinline__ double cb_scan_excl(double v, double* red, int nw, do
     return off + incl - v;
 }
 
+// log of a column sum / reciprocal of one, at the precision the filter's type needs: float filters take the hardware
+// log2 / rcp (their results are rounded to float anyway), double filters the exact forms (the parity path)
+template <typename T> __device__ __forceinline__ double log_sum(double s) {
+    if constexpr (sizeof(T) == 4) return (double)pf_log_g((float)s);
+    else return log(s);
+}
+template <typename T> __device__ __forceinline__ double inv_sum(double s) {
+    if constexpr (sizeof(T) == 4) {
+        double r = (double)__builtin_amdgcn_rcpf((float)s);
+        r = __builtin_fma(__builtin_fma(-s, r, 1.0), r, r);  // one Newton step: ~2^-46
+        return r;
+    } else {
+        return 1.0 / s;
+    }
+}
+
 // BIG: workgroups of more than 256 threads (N > 1024 with VEC = 4) - a separate instantiation so that the small ones are
 // not register-limited by the 1024-thread launch bound
+//
+// Cross-wave exchanges carry (max, sums relative to that max) records, one per wave - the (max, +) semiring of the step
+// kernel's per-tile partials - so a reduction is ONE LDS exchange (write record, barrier, every thread folds the <= 16
+// records) instead of a max exchange followed by a sum exchange; a single-wave workgroup (N <= 64 VEC) exchanges nothing.
+// Barriers per step: scan records, cdf + particle planes, the new state's records (+ none for SISR steps that keep
+// their weights).
 template <typename T, int D, int VEC, bool BIG>
 __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pfc_lds[];
@@ -90,14 +83,16 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     const int N = (int)g.N;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
     const int nw = (int)(blockDim.x >> 6);
     int np2 = 64;
     while (np2 < N) np2 <<= 1;
-    // LDS carve-up: cdf (np2 Ts, +inf beyond N) | x planes (D x N Ts) | reduction scratch
+    // LDS carve-up: cdf (np2 Ts, +inf beyond N) | x planes (D x N Ts) | wave records
+    constexpr int KB = 4 + 2 * D;  // the state's record: max, sum e, sum e^2, poison, sum e (x - c)[D], sum e (x - c)^2[D]
     T* const cdfs = reinterpret_cast<T*>(pfc_lds);
     T* const xs = cdfs + np2;
-    double* const red = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * N) * sizeof(T) + 15) & ~(size_t)15));
-    T* const redm = reinterpret_cast<T*>(red + (2 + 2 * D) * PFC_MAXW);
+    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * N) * sizeof(T) + 15) & ~(size_t)15));
+    double* const recB = recA + 2 * PFC_MAXW;  // [2][PFC_MAXW][KB]: double buffered by step parity
 
     const bool apf = a.filter == PF_FILTER_APF;
     const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
@@ -133,7 +128,17 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     }
     for (int q = N + tid; q < np2; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
 
-    // pivot of the weighted moments: the column's first particle, then the previous state's mean
+    // the column's parameters and everything derived from them alone: once per run
+    ColParams<T, D> cp;
+    ColConsts<T, D> cc;
+    load_col_params<T, D>(a, b, run.t0, false, cp);
+    cc.prepare(md, cp);
+    auto y_row = [&](int t) { return a.y + ((int64_t)t * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O; };
+    auto obs_flag = [&](int s) -> bool {
+        return run.use_bits ? ((run.obs_bits[s >> 5] >> (s & 31)) & 1u) != 0 : a.obs_dev[run.t0 + s] != 0;
+    };
+
+    // pivot of the weighted moments: the column's first particle, then (about) the previous state's mean
     T piv[D];
     {
         if (tid == 0) {
@@ -146,88 +151,136 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
         __syncthreads();
     }
 
-    // (max, sum e, sum e^2, sum e (x - c), sum e (x - c)^2) of a state's weights; e[] = exp(lw - M) stays with the caller
+    // The state's weight family: wave maximum mw1, e1 = exp(lw - mw1), and the column's (M1, S1, Q1, moments) folded from
+    // the waves' records.  Within a wave the sums run in T (float: 4 DPP adds per quantity), above it in fp64.
     double M1 = 0.0, S1 = 1.0, Q1 = 1.0;
-    auto reduce_state = [&](T (&e)[VEC], double (&mom)[2 * D]) {
+    T mw1 = T(0);
+    T e1[VEC];
+    int parity = 0;
+    auto reduce_state = [&](bool poison, double (&mom)[2 * D]) -> bool {
         T m = lw[0];
 #pragma unroll
         for (int j = 1; j < VEC; ++j) m = lw[j] > m ? lw[j] : m;
-        const T M = cb_max<T>(m, redm, nw);
-        double v[2 + 2 * D];
+        mw1 = wave_max<T>(m);
+        T v[2 + 2 * D];
 #pragma unroll
-        for (int k = 0; k < 2 + 2 * D; ++k) v[k] = 0.0;
+        for (int k = 0; k < 2 + 2 * D; ++k) v[k] = T(0);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            T ej = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - M);
+            T ej = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - mw1);
             if (lw[j] != lw[j]) ej = lw[j];
-            e[j] = ej;
-            v[0] += (double)ej;
-            v[1] += (double)(ej * ej);
+            e1[j] = ej;
+            v[0] += ej;
+            v[1] += ej * ej;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const T xd = x[d][j] - piv[d];
-                v[2 + d] += (double)(ej * xd);
-                v[2 + D + d] += (double)(ej * xd * xd);
+                v[2 + d] += ej * xd;
+                v[2 + D + d] += ej * xd * xd;
             }
         }
-        cb_sum<2 + 2 * D>(v, red, nw);
-        M1 = (double)M;
-        S1 = v[0];
-        Q1 = v[1];
 #pragma unroll
-        for (int k = 0; k < 2 * D; ++k) mom[k] = v[2 + k];
+        for (int k = 0; k < 2 + 2 * D; ++k) v[k] = wave_sum<T>(v[k]);
+        bool any = __ballot(poison) != 0ull;
+        if (nw == 1) {
+            M1 = (double)mw1;
+            S1 = (double)v[0];
+            Q1 = (double)v[1];
+#pragma unroll
+            for (int k = 0; k < 2 * D; ++k) mom[k] = (double)v[2 + k];
+            __syncthreads();  // (one wave: orders this step's LDS reads before the next step's writes)
+            return any;
+        }
+        double* rec = recB + (size_t)parity * PFC_MAXW * KB;
+        parity ^= 1;
+        if (lane == 0) {
+            double* r = rec + wid * KB;
+            r[0] = (double)mw1;
+            r[1] = (double)v[0];
+            r[2] = (double)v[1];
+            r[3] = any ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 2 * D; ++k) r[4 + k] = (double)v[2 + k];
+        }
+        __syncthreads();
+        double M = rec[0];
+        for (int w = 1; w < nw; ++w) M = rec[w * KB] > M ? rec[w * KB] : M;
+        double s = 0.0, q = 0.0, pz = 0.0;
+#pragma unroll
+        for (int k = 0; k < 2 * D; ++k) mom[k] = 0.0;
+        for (int w = 0; w < nw; ++w) {
+            const double* r = rec + w * KB;
+            const double f = exp_diff_t<T>(r[0], M);
+            s += r[1] * f;
+            q += r[2] * f * f;
+            pz += r[3];
+#pragma unroll
+            for (int k = 0; k < 2 * D; ++k) mom[k] += r[4 + k] * f;
+        }
+        M1 = M;
+        S1 = s;
+        Q1 = q;
+        return pz != 0.0;
     };
-    // moments row `row` of filter_means / filter_variance from the sums above; the new pivot
+    // moments row `row` of filter_means / filter_variance from the sums above (thread 0); every thread moves the pivot
     auto write_moments = [&](int row, const double (&mom)[2 * D]) {
+        const double inv = inv_sum<T>(S1);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const double dm = mom[d] / S1;
-            double var = mom[D + d] / S1 - dm * dm;
-            if (var < 0.0) var = 0.0;
-            const double mean = (double)piv[d] + dm;
+            const double dm = mom[d] * inv;
             if (tid == 0) {
-                a.means[((int64_t)row * g.B + b) * D + d] = (T)mean;
+                double var = mom[D + d] * inv - dm * dm;
+                if (var < 0.0) var = 0.0;
+                a.means[((int64_t)row * g.B + b) * D + d] = (T)((double)piv[d] + dm);
                 a.vars[((int64_t)row * g.B + b) * D + d] = (T)var;
             }
-            piv[d] = (T)mean;
+            piv[d] = (T)((double)piv[d] + dm);
         }
     };
 
-    T e1[VEC];
     {
         double mom[2 * D];
-        reduce_state(e1, mom);
+        reduce_state(false, mom);
         write_moments(run.t0, mom);
     }
     T ll_tot = (tid == 0) ? a.ll_total[b] : T(0);
+    double lse_w = M1 + log_sum<T>(S1);
+
+    // the first step's observation and offset; every later step's are requested one step ahead
+    T y_nx[ColParams<T, D>::MAXO], u_nx = T(0);
+    auto request_inputs = [&](int s) {
+        const int t = run.t0 + s;
+        const bool ob = s < run.n_steps && obs_flag(s);
+#pragma unroll
+        for (int o = 0; o < ColParams<T, D>::MAXO; ++o) y_nx[o] = (ob && o < O) ? y_row(t)[o] : T(0);
+        if (s < run.n_steps && !multinomial && a.u_tape) u_nx = a.u_tape[(int64_t)t * g.B + b];
+    };
+    request_inputs(0);
 
     for (int s = 0; s < run.n_steps; ++s) {
         const int t = run.t0 + s;
-        const bool obs = run.use_bits ? ((run.obs_bits[s >> 5] >> (s & 31)) & 1u) != 0 : a.obs_dev[t] != 0;
+        const bool obs = obs_flag(s);
         const bool two = apf && obs;
-        ColParams<T, D> cp;
-        ColConsts<T, D> cc;
-        load_col_params<T, D>(a, b, t, obs, cp);
-        cc.prepare(md, cp);
+#pragma unroll
+        for (int o = 0; o < ColParams<T, D>::MAXO; ++o) cp.y[o] = y_nx[o];
+        cc.set_obs(cp);
+        const T u_tape = u_nx;
+        request_inputs(s + 1);
         bool poison = false;
 
-        // ---- resampling weights, the decision, the bases of this step's log-likelihood increment ---------------------------
-        const double lse_w = M1 + log(S1);
-        T rw[VEC], pre[VEC];
+        // ---- resampling weights, the decision -----------------------------------------------------------------------------------
+        T rw[VEC];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            pre[j] = T(0);
-            rw[j] = lw[j];
-        }
+        for (int j = 0; j < VEC; ++j) rw[j] = lw[j];
         if (two) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 T xj[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = x[d][j];
-                pre[j] = pre_weight<T, D>(md, proposal, cp, cc, xj);
-                if (on && is_nan_or_posinf(pre[j])) poison = true;
-                rw[j] = on ? sanitize_logw(pre[j] + lw[j]) : -Lim<T>::inf();
+                const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj);
+                if (on && is_nan_or_posinf(pre)) poison = true;
+                rw[j] = on ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
             }
         }
         const bool resample = apf ? obs : (S1 * S1 / Q1 < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
@@ -235,36 +288,56 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
         int idx[VEC];
         T xr[VEC][D];
         if (resample) {
-            // ---- cdf of the normalised resampling weights: fp64 scan, rounded once per element (torch's cumsum), last = 1 ---
-            T er[VEC];
-            T Mr = (T)M1;
+            // ---- cdf of the normalised resampling weights: wave-local fp64 scans rounded once per element (the step kernel's
+            // chunk scans), made column-level by the waves' (max, total) records; last value 1 (resampling.py:44-49) -----------
+            T er[VEC], mw = mw1;
             if (two) {
                 T m = rw[0];
 #pragma unroll
                 for (int j = 1; j < VEC; ++j) m = rw[j] > m ? rw[j] : m;
-                Mr = cb_max<T>(m, redm, nw);
+                mw = wave_max<T>(m);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) er[j] = (rw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(rw[j] - Mr);
+                for (int j = 0; j < VEC; ++j) er[j] = (rw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(rw[j] - mw);
             } else {
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) er[j] = e1[j];  // exp(lw - M1): the weights' own family
+                for (int j = 0; j < VEC; ++j) er[j] = e1[j];  // the weights' own family: exp(lw - mw1)
             }
-            double incl[VEC], local = 0.0, total;
+            double incl[VEC], local = 0.0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 local += on ? (double)er[j] : 0.0;
                 incl[j] = local;
             }
-            const double excl = cb_scan_excl(local, red, nw, total);
-            const double inv_tot = 1.0 / total;
-            if (two) base_lse = a.logN - (((double)Mr + log(total)) - lse_w);  // apf.py:44
-            else base_lse = a.logN;                                            // W = 1 / N after resampling
+            const double iw = wave_scan_incl(local, lane);
+            const double excl = iw - local;
+            const double tw = lane_get(iw, 63);
+            double Mr = (double)mw, C = 0.0, gq = 1.0, S = tw;
+            if (nw > 1) {
+                if (lane == 63) {
+                    recA[2 * wid] = (double)mw;
+                    recA[2 * wid + 1] = tw;
+                }
+                __syncthreads();
+                Mr = recA[0];
+                for (int w = 1; w < nw; ++w) Mr = recA[2 * w] > Mr ? recA[2 * w] : Mr;
+                S = 0.0;
+                for (int w = 0; w < nw; ++w) {
+                    const double f = exp_diff_t<T>(recA[2 * w], Mr);
+                    const double v = recA[2 * w + 1] * f;
+                    if (w < wid) C += v;
+                    if (w == wid) gq = f;
+                    S += v;
+                }
+            }
+            const double inv_tot = inv_sum<T>(S);
+            if (two) base_lse = a.logN - ((Mr + log_sum<T>(S)) - lse_w);  // apf.py:44
+            else base_lse = a.logN;                                        // W = 1 / N after resampling
             if (on) {
                 T cv[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const T L = (T)(excl + incl[j]);
-                    double c = inv_tot * (double)L;
+                    double c = inv_tot * (C + gq * (double)L);
                     if (c > 1.0) c = 1.0;
                     cv[j] = (i0 + j == N - 1) ? T(1) : (T)c;  // resampling.py:49
                 }
@@ -288,12 +361,12 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
                     el += on ? (double)ev[j] : 0.0;
                     ei[j] = el;
                 }
-                const double eexcl = cb_scan_excl(el, red, nw, etot);
+                const double eexcl = cb_scan_excl(el, recA, nw, etot);  // (its own barriers; recA is free again by then)
                 const double invE = 1.0 / (etot + (double)tail[0]);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) pp[j] = (T)((eexcl + ei[j]) * invE);
             } else {
-                const T u = a.u_tape ? a.u_tape[(int64_t)t * g.B + b] : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)t, (uint64_t)b);
+                const T u = a.u_tape ? u_tape : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)t, (uint64_t)b);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) pp[j] = grid_position<T>(i0 + j, u, nT);
             }
@@ -376,14 +449,14 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
         }
 
         // ---- the new state's sums: moments row t + 1, log-likelihood increment of this step ------------------------------------
-        const int any_poison = __syncthreads_or(poison ? 1 : 0);  // (also orders this step's LDS reads before the next writes)
         double mom[2 * D];
-        reduce_state(e1, mom);
+        const bool any_poison = reduce_state(poison, mom);  // (its barrier also orders this step's LDS reads before the next writes)
         write_moments(t + 1, mom);
+        lse_w = M1 + log_sum<T>(S1);
         if (tid == 0) {
             double ll = 0.0;
             if (obs) {
-                ll = (M1 + log(S1)) - base_lse;
+                ll = lse_w - base_lse;
                 if (any_poison) ll = __builtin_nan("");
             }
             a.ll_steps[(int64_t)t * g.B + b] = (T)ll;
@@ -408,7 +481,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
         a.ll_total[b] = ll_tot;
         // the per-step route's per-column record, as a finalised run leaves it (a later call on that route starts from it)
         ColStat st{};
-        st.lse_w = M1 + log(S1);
+        st.lse_w = lse_w;
         st.ll_done = 1;
         a.stat[b] = st;
 #pragma unroll

@@ -259,29 +259,35 @@ template <typename T, int VEC> __device__ __forceinline__ void store_vec(T* __re
 // workgroup is still computing: measured (profiles/r03_out_store.txt, tools/out_store_variants.sh) 16.3 -> 14.9 us per step
 // at 2^20 x 1, 37.5 -> 36.9 at 2^22 x 1, 39.5 -> 38.3 at 64 x 65 536; non-temporal stores (policy 1) gain the same at
 // 2^20 but lose 4-9 % at the larger shapes; `sc0 sc1` equals `sc1`.  PF_OUT_STORE: 0 plain, 1 non-temporal, 2 write-through.
-// Policy 2 is spelled as a VOLATILE vector store: on gfx940+ the backend's memory model emits volatile global accesses with
-// `sc0 sc1` (system scope, i.e. written through - measured equal to `sc1` alone) and, unlike an inline-asm store, the
-// compiler keeps tracking it (s_waitcnt before a dependent access, the > 64-bit store-data hazard).
+// Policy 2 goes through a buffer descriptor - `buffer_store_dwordx4 ... offen sc1` from
+// __builtin_amdgcn_raw_buffer_store_b128(..., aux = 16) - which, unlike an inline-asm store, the compiler keeps tracking
+// (s_waitcnt before a dependent access, the > 64-bit store-data hazard); a volatile store would carry the same cache bits
+// but also an `s_waitcnt vmcnt(0)` per access (measured: slower than plain stores on the multi-round shapes).
+// `base` must be wave-uniform (it becomes the descriptor in SGPRs), `elem` is the lane's element offset from it.
 #ifndef PF_OUT_STORE
 #define PF_OUT_STORE 2
 #endif
-template <typename T, int VEC> __device__ __forceinline__ void store_out(T* __restrict__ p, const T (&in)[VEC]) {
+template <typename T, int VEC>
+__device__ __forceinline__ void store_out(T* __restrict__ base, int elem, const T (&in)[VEC]) {
     constexpr int BYTES = (int)sizeof(T) * VEC;
     if constexpr (PF_OUT_STORE != 0 && BYTES % 16 == 0) {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         Pack<T, VEC> q;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) q.v[j] = in[j];
-        u4* dst = reinterpret_cast<u4*>(p);
 #pragma unroll
         for (int k = 0; k < BYTES / 16; ++k) {
             u4 v;
             __builtin_memcpy(&v, reinterpret_cast<const char*>(&q) + 16 * k, 16);
-            if constexpr (PF_OUT_STORE == 1) __builtin_nontemporal_store(v, dst + k);
-            else *((__attribute__((address_space(1))) volatile u4*)(dst + k)) = v;  // (global_store_dwordx4 ... sc0 sc1)
+            if constexpr (PF_OUT_STORE == 1) {
+                __builtin_nontemporal_store(v, reinterpret_cast<u4*>(base + elem) + k);
+            } else {
+                const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, elem * (int)sizeof(T) + 16 * k, 0, /*sc1*/ 16);
+            }
         }
     } else {
-        store_vec<T, VEC>(p, in);
+        store_vec<T, VEC>(base + elem, in);
     }
 }
 

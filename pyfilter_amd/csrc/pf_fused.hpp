@@ -348,8 +348,9 @@ template <typename T> struct CdfView {  // searches in the implied cdf of one co
 // WT: the scans are an output plane of the step kernel (written through, store_out); k_fused_reduce re-reads its own
 // (single-round tiles fold (C, g) in) and keeps them in the cache.
 template <typename T, int VEC, bool WT = false>
-__device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T* __restrict__ l_dst, int chunk,
+__device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T* __restrict__ l_base, int l_elem, int chunk,
                                                  double* lds_rec, double* raw) {
+    T* const l_dst = l_base + l_elem;  // (l_base: the round's first element, uniform across the workgroup)
     const int lane = threadIdx.x & 63;
     T mt = rw[0];
 #pragma unroll
@@ -368,7 +369,7 @@ __device__ __forceinline__ void chunk_scan_round(const T (&rw)[VEC], bool on, T*
 #pragma unroll
         for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + incl[j]);
         if (VEC == 1) l_dst[0] = outv[0];
-        else if constexpr (WT) store_out<T, VEC>(l_dst, outv);
+        else if constexpr (WT) store_out<T, VEC>(l_base, l_elem, outv);
         else store_vec<T, VEC>(l_dst, outv);
     }
     if (lane == 63) {
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
                 for (int j = 0; j < VEC; ++j) acc.es += (double)ev[j];
             }
         }
-        chunk_scan_round<T, VEC>(rw, on, l_col + i0, r * PF_NWAVES + (threadIdx.x >> 6), use_lds ? crec : nullptr, ct_tile);
+        chunk_scan_round<T, VEC>(rw, on, l_col + r0, threadIdx.x * VEC, r * PF_NWAVES + (threadIdx.x >> 6), use_lds ? crec : nullptr, ct_tile);
     }
     T M1, M2, F1, F2;
     acc.template finish<true>(a.part_w(a.step), b, k, g.B, g.tiles, false, red, redm, &a.poison[(a.step & 3) * g.B + b], M1, M2, F1, F2);
@@ -1339,12 +1340,12 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             PF_STAMP(a, 12);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                T* xc = x_out + ((int64_t)d * g.B + b) * g.N + i0;
-                if (VEC == 1) xc[0] = xo[d][0]; else store_out<T, VEC>(xc, xo[d]);
+                T* xc = x_out + ((int64_t)d * g.B + b) * g.N + r0;  // (the round's first particle: uniform)
+                if (VEC == 1) xc[tid] = xo[d][0]; else store_out<T, VEC>(xc, tid * VEC, xo[d]);
             }
-            if (VEC == 1) lw_out[i0] = lwo[0]; else store_out<T, VEC>(lw_out + i0, lwo);
+            if (VEC == 1) lw_out[i0] = lwo[0]; else store_out<T, VEC>(lw_out + r0, tid * VEC, lwo);
             if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
-                if (VEC == 1) anc_col[i0] = idx[0]; else store_out<int, VEC>(anc_col + i0, idx);
+                if (VEC == 1) anc_col[i0] = idx[0]; else store_out<int, VEC>(anc_col + r0, tid * VEC, idx);
             } else if (la->anc_prev) {  // ... which, with a state history, means copying them into this state's slot
                 const int32_t* ap = la->anc_prev + (int64_t)b * g.N + i0;
                 int prev[VEC];
@@ -1378,7 +1379,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             PF_STAMP(a, 13);
         }
         if (scan_next && !single) {  // (uniform) every lane of every wave: the chunk-local scan is wave-level
-            chunk_scan_round<T, VEC, true>(rwn, on, l_next + i0, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
+            chunk_scan_round<T, VEC, true>(rwn, on, l_next + r0, tid * VEC, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) rwn[j] = -Lim<T>::inf();
             ++rk;
@@ -1407,7 +1408,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             T outv[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + e[j]);
-            if (VEC == 1) l_next[i0] = outv[0]; else store_out<T, VEC>(l_next + i0, outv);
+            if (VEC == 1) l_next[i0] = outv[0]; else store_out<T, VEC>(l_next + base, tid * VEC, outv);
         }
     } else if (scan_next) {
         // the chunk table of the next step's resampling weights, and the tile's (max, sum) of that family from the same sums

@@ -1679,7 +1679,7 @@ static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize) {
     int64_t np2 = 64;
     while (np2 < N) np2 <<= 1;
     const size_t planes = (((size_t)(np2 + (int64_t)D * N) * tsize) + 15) & ~(size_t)15;
-    return planes + sizeof(double) * (2 + 2 * D) * PFC_MAXW + tsize * PFC_MAXW + 16;
+    return planes + sizeof(double) * (2 + 2 * (4 + 2 * D)) * PFC_MAXW + 16;  // scan records + the state's records (x 2)
 }
 #ifndef PF_COLUMN_MAX_N
 #define PF_COLUMN_MAX_N 4096
@@ -1692,7 +1692,7 @@ static inline bool column_eligible(const pf_filter_args* A, const Geom& g, int64
     int64_t max_n = PF_COLUMN_MAX_N;
     if (const char* e = getenv("PF_COLUMN_MAX_N")) max_n = atoll(e);
     if (A->N > max_n || column_threads(A->N, g.vec) > 1024) return false;
-    return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4) <= 150 * 1024;
+    return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4) <= 64 * 1024;  // (the default dynamic-LDS limit)
 }
 
 template <typename T, int D, int VEC>
@@ -1702,13 +1702,6 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const int nt = column_threads(A->N, VEC);
     const bool big = nt > 256;
     const size_t lds = column_lds_bytes(A->N, D, sizeof(T));
-    static bool attr_done[2] = {false, false};
-    if (lds > 64 * 1024 && !attr_done[big ? 1 : 0]) {
-        const void* fn = big ? (const void*)k_fused_column<T, D, VEC, true> : (const void*)k_fused_column<T, D, VEC, false>;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_done[big ? 1 : 0] = true;
-    }
     // observed flags: the host's (baked into the launch arguments), the caller's device array, or derived from y here
     const bool auto_flags = !A->observed && !A->observed_dev;
     a.obs_dev = A->observed_dev;

@@ -190,6 +190,17 @@ template <typename T, int D> struct ColConsts {
         }
     }
 
+    // the entries that carry an observation, recomputed alone when only y changed since prepare() (the operations of
+    // prepare, in its order): the column-persistent kernel keeps one ColConsts per run and calls this once per step
+    __device__ __forceinline__ void set_obs(const ColParams<T, D>& cp) {
+        if constexpr (D == 1) {
+            if (!fast) return;
+            yb = cp.y[0] - cp.ob[0];
+            ybn = cp.yn[0] - cp.ob[0];
+            c_y = cov * (a * (ovi * yb));
+        }
+    }
+
     // one-step mean of the scalar state (the scale is `g`)
     __device__ __forceinline__ T loc1(const ModelDesc& md, const ColParams<T, D>& cp, T x) const {
         switch (md.hid_kind) {

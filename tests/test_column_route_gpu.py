@@ -90,7 +90,7 @@ CASES = [
     ("sine", "sisr", "lgo", "systematic", 64, 2, 30, ()),
     ("lg", "sisr", "bootstrap", "systematic", 1000, 1, 50, ()),
     ("lg", "apf", "lgo", "systematic", 2048, 2, 25, ()),
-    ("lg", "apf", "lgo", "systematic", 4096, 3, 25, (0,)),
+    ("lg", "apf", "lgo", "systematic", 3072, 3, 25, (0,)),    # 12 waves; (float64: 4096 particles exceed the 64 KB of LDS)
     ("ou", "apf", "lgo", "systematic", 1024, 7, 30, ()),
     ("ou", "sisr", "lgo", "systematic", 100, 3, 30, ()),       # N % 4 != 0: one particle per thread
     ("ou", "apf", "bootstrap", "systematic", 333, 2, 20, (3,)),
@@ -98,7 +98,7 @@ CASES = [
     ("sv", "sisr", "bootstrap", "systematic", 256, 4, 40, ()),
     ("lorenz", "sisr", "bootstrap", "systematic", 512, 2, 20, ()),
     ("lorenz", "apf", "lgo", "systematic", 256, 2, 15, (2,)),
-    ("lorenz", "apf", "bootstrap", "systematic", 2048, 1, 10, ()),
+    ("lorenz", "apf", "bootstrap", "systematic", 1536, 1, 10, ()),
     ("sine", "sisr", "bootstrap", "multinomial", 512, 3, 30, ()),
     ("sine", "apf", "lgo", "multinomial", 1024, 2, 30, ()),
     ("lorenz", "sisr", "bootstrap", "multinomial", 256, 2, 15, ()),
@@ -122,7 +122,18 @@ def test_column_route_equals_per_step_route_float64(kind, filt_name, prop, resam
     torch.testing.assert_close(col["w"], ref["w"], equal_nan=True, **tol)
 
 
-@pytest.mark.parametrize("kind,filt_name,prop,resampler,n,b,t_len,nan_at", [c for c in CASES if c[4] >= 64][::2])
+F32_CASES = [
+    ("sine", "apf", "lgo", "systematic", 512, 5, 40, ()),
+    ("sine", "sisr", "bootstrap", "systematic", 400, 4, 40, (7,)),
+    ("lg", "sisr", "bootstrap", "systematic", 1000, 1, 50, ()),
+    ("lg", "apf", "lgo", "systematic", 4096, 3, 25, (0,)),     # the largest column the route takes: 16 waves
+    ("ou", "apf", "lgo", "systematic", 1024, 7, 30, ()),
+    ("sv", "apf", "bootstrap", "systematic", 512, 6, 40, ()),
+    ("sine", "apf", "lgo", "multinomial", 1024, 2, 30, ()),
+]
+
+
+@pytest.mark.parametrize("kind,filt_name,prop,resampler,n,b,t_len,nan_at", F32_CASES)
 def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_name, prop, resampler, n, b, t_len, nan_at):
     """float32 production arithmetic: an ulp in a weight moves an ancestor across a cdf boundary, after which the runs are
     different - equally valid - Monte-Carlo runs.  Bar: the float32 column run within 8 Monte-Carlo standard errors of the
