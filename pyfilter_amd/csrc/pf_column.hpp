@@ -31,6 +31,16 @@ struct ColumnRun {
     uint32_t obs_bits[PFC_OBS_WORDS];  // bit s = step t0 + s weighs against y[t0 + s]
 };
 
+// Workgroup barrier for LDS exchanges ONLY: waits for this wave's outstanding LDS operations (lgkmcnt), not for its global
+// ones.  __syncthreads() carries a workgroup-scope fence, i.e. an `s_waitcnt vmcnt(0)` - it would make every step wait for
+// the result rows thread 0 has just stored (means / variances / log-likelihood: never read in this launch) and for the
+// next step's observation that was requested a step ahead precisely so that nobody waits for it.  A single-wave workgroup
+// needs no barrier at all (its LDS operations execute in order): a compiler fence.
+__device__ __forceinline__ void pfc_barrier(int nw) {
+    if (nw > 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("" ::: "memory");
+}
+
 // exclusive scan of one double per thread across a workgroup of `nw` waves (1 .. 16); a single wave never touches LDS
 __device__ __forceinline__ double cb_scan_excl(double v, double* red, int nw, double& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -39,9 +49,9 @@ __device__ __forceinline__ double cb_scan_excl(double v, double* red, int nw, do
         total = lane_get(incl, 63);
         return incl - v;
     }
-    __syncthreads();
+    pfc_barrier(nw);
     if (lane == 63) red[wid] = incl;
-    __syncthreads();
+    pfc_barrier(nw);
     double off = 0.0, tot = 0.0;
     for (int w = 0; w < nw; ++w) {
         const double s = red[w];
@@ -103,6 +113,8 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     const int i0 = tid * VEC;
     const bool on = i0 < N;
     const T nT = T(N);
+    const T rcN = T(1) / nT;
+    const bool pow2 = (N & (N - 1)) == 0;
 
     // ---- the incoming state -> registers ---------------------------------------------------------------------------------
     const int slot_in = run.t0 & 1;
@@ -134,9 +146,6 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     load_col_params<T, D>(a, b, run.t0, false, cp);
     cc.prepare(md, cp);
     auto y_row = [&](int t) { return a.y + ((int64_t)t * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O; };
-    auto obs_flag = [&](int s) -> bool {
-        return run.use_bits ? ((run.obs_bits[s >> 5] >> (s & 31)) & 1u) != 0 : a.obs_dev[run.t0 + s] != 0;
-    };
 
     // pivot of the weighted moments: the column's first particle, then (about) the previous state's mean
     T piv[D];
@@ -145,10 +154,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
 #pragma unroll
             for (int d = 0; d < D; ++d) xs[d] = x[d][0];
         }
-        __syncthreads();
+        pfc_barrier(nw);
 #pragma unroll
         for (int d = 0; d < D; ++d) piv[d] = xs[d];
-        __syncthreads();
+        pfc_barrier(nw);
     }
 
     // The state's weight family: wave maximum mw1, e1 = exp(lw - mw1), and the column's (M1, S1, Q1, moments) folded from
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
             Q1 = (double)v[1];
 #pragma unroll
             for (int k = 0; k < 2 * D; ++k) mom[k] = (double)v[2 + k];
-            __syncthreads();  // (one wave: orders this step's LDS reads before the next step's writes)
+            pfc_barrier(nw);  // (one wave: orders this step's LDS reads before the next step's writes)
             return any;
         }
         double* rec = recB + (size_t)parity * PFC_MAXW * KB;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
 #pragma unroll
             for (int k = 0; k < 2 * D; ++k) r[4 + k] = (double)v[2 + k];
         }
-        __syncthreads();
+        pfc_barrier(nw);
         double M = rec[0];
         for (int w = 1; w < nw; ++w) M = rec[w * KB] > M ? rec[w * KB] : M;
         double s = 0.0, q = 0.0, pz = 0.0;
@@ -247,22 +256,30 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     double lse_w = M1 + log_sum<T>(S1);
 
     // the first step's observation and offset; every later step's are requested one step ahead
+    // Requested a step ahead and consumed RAW one iteration later (nothing in the requesting iteration touches the values,
+    // so no wait for them is placed there): the next step's observation row, systematic offset and observed flag - from
+    // clamped, always valid addresses; whether they mean anything is decided when they are used.
     T y_nx[ColParams<T, D>::MAXO], u_nx = T(0);
+    unsigned char flag_nx = 0;
     auto request_inputs = [&](int s) {
-        const int t = run.t0 + s;
-        const bool ob = s < run.n_steps && obs_flag(s);
+        const int sc = s < run.n_steps ? s : run.n_steps - 1;
+        const int t = run.t0 + sc;
+        const T* yr = y_row(t);
 #pragma unroll
-        for (int o = 0; o < ColParams<T, D>::MAXO; ++o) y_nx[o] = (ob && o < O) ? y_row(t)[o] : T(0);
-        if (s < run.n_steps && !multinomial && a.u_tape) u_nx = a.u_tape[(int64_t)t * g.B + b];
+        for (int o = 0; o < ColParams<T, D>::MAXO; ++o) y_nx[o] = yr[o < O ? o : 0];
+        if (a.u_tape) u_nx = a.u_tape[(int64_t)t * g.B + b];
+        if (!run.use_bits) flag_nx = a.obs_dev[t];
     };
     request_inputs(0);
+    uint32_t bits = 0u;
 
     for (int s = 0; s < run.n_steps; ++s) {
         const int t = run.t0 + s;
-        const bool obs = obs_flag(s);
+        if ((s & 31) == 0) bits = run.obs_bits[s >> 5];  // (one scalar load per 32 steps)
+        const bool obs = run.use_bits ? ((bits >> (s & 31)) & 1u) != 0 : flag_nx != 0;
         const bool two = apf && obs;
 #pragma unroll
-        for (int o = 0; o < ColParams<T, D>::MAXO; ++o) cp.y[o] = y_nx[o];
+        for (int o = 0; o < ColParams<T, D>::MAXO; ++o) cp.y[o] = (obs && o < O) ? y_nx[o] : T(0);
         cc.set_obs(cp);
         const T u_tape = u_nx;
         request_inputs(s + 1);
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
                     recA[2 * wid] = (double)mw;
                     recA[2 * wid + 1] = tw;
                 }
-                __syncthreads();
+                pfc_barrier(nw);
                 Mr = recA[0];
                 for (int w = 1; w < nw; ++w) Mr = recA[2 * w] > Mr ? recA[2 * w] : Mr;
                 S = 0.0;
@@ -368,9 +385,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
             } else {
                 const T u = a.u_tape ? u_tape : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)t, (uint64_t)b);
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) pp[j] = grid_position<T>(i0 + j, u, nT);
+                for (int j = 0; j < VEC; ++j)  // (a power-of-two N: the division is an exact multiplication)
+                    pp[j] = pow2 ? (T(i0 + j) + u) * rcN : grid_position<T>(i0 + j, u, nT);
             }
-            __syncthreads();  // cdf and x planes are in LDS
+            pfc_barrier(nw);  // cdf and x planes are in LDS
             // ---- ancestors: first q with cdf[q] >= p (searchsorted side = left), all VEC probes of a round in flight -------
             int q[VEC];
 #pragma unroll

@@ -1681,8 +1681,10 @@ static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize) {
     const size_t planes = (((size_t)(np2 + (int64_t)D * N) * tsize) + 15) & ~(size_t)15;
     return planes + sizeof(double) * (2 + 2 * (4 + 2 * D)) * PFC_MAXW + 16;  // scan records + the state's records (x 2)
 }
+// (measured, profiles/r03_column_route.txt: 1024 x 2048 runs 21 us per step here against 29 on the per-step route, 1024 x
+// 4096 56 against 42 - sixteen waves of one workgroup issue-bound on one CU)
 #ifndef PF_COLUMN_MAX_N
-#define PF_COLUMN_MAX_N 4096
+#define PF_COLUMN_MAX_N 2048
 #endif
 // Which runs take it: self-contained runs (finalize: the last state's row is flushed by the same call), no state history,
 // a column that fits one workgroup.  PF_NO_COLUMN=1 keeps everything on the per-step route (tests compare the two).
