@@ -43,6 +43,12 @@ extern "C" {
 #define PF_HID_VERHULST_EM 2 /* loc = x + kappa (gamma - x) x dt,           scale = sigma x   hp = (kappa, gamma, sigma) */
 #define PF_HID_LORENZ63_EM 3 /* Lorenz-63 drift, Euler-Maruyama (D = 3),    scale = sigma     hp = (s, r, b, sigma)      */
 #define PF_HID_OU 4          /* exact OU step                                                 hp = (kappa, gamma, sigma) */
+#define PF_HID_USER_AFFINE 5 /* loc, scale EVALUATED BY THE CALLER for the incoming particles (the reference's plug-in seam: a user
+                              * lambda `mean_scale(x, *parameters)`, README.md:44-67, stochproc AffineProcess): the fused kernels
+                              * read them from pf_filter_args.user_loc / user_scale at the PARENT's index - mean_scale acts per
+                              * particle, so loc(x[anc]) = loc(x)[anc] - and do everything else (ancestors, gather, draws, Bootstrap
+                              * or the optimal linear-Gaussian proposal, weights, moments, log-likelihood) as for a built-in
+                              * kind.  One step per pf_filter_run call (the next step's planes need the new particles). */
 /* observation kinds */
 #define PF_OBS_LINEAR 0 /* y ~ N(b + A x, s)   (LinearStateSpaceModel; proposals/linear.py:48) */
 #define PF_OBS_SV 1     /* y ~ N(mu, scale = x)                                                 */
@@ -212,6 +218,8 @@ typedef struct pf_filter_args {
                    * it - live in slot (s + 1) % ring, the incoming state of step t0 in slot t0 % ring.  ring = n_steps + 1
                    * keeps every state of a run.  A SISR step that does not resample copies its ancestors forward, as the
                    * reference carries prev_inds (sisr.py:25-26). */
+    const void* user_loc;   /* PF_HID_USER_AFFINE only: (D, B, N) one-step mean of every particle of the INCOMING state ... */
+    const void* user_scale; /* ... and its transition scale, both in the state's layout and dtype (else NULL) */
 } pf_filter_args;
 
 /* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; ONE kernel launch per step

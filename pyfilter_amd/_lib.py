@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpfamd.so")
 
 PF_F32, PF_F64 = 0, 1
-HID_LINEAR, HID_SINE_EM, HID_VERHULST_EM, HID_LORENZ63_EM, HID_OU = 0, 1, 2, 3, 4
+HID_LINEAR, HID_SINE_EM, HID_VERHULST_EM, HID_LORENZ63_EM, HID_OU, HID_USER_AFFINE = 0, 1, 2, 3, 4, 5
 OBS_LINEAR, OBS_SV = 0, 1
 PROP_BOOTSTRAP, PROP_LGO = 0, 1
 FILTER_SISR, FILTER_APF = 0, 1
@@ -55,6 +55,7 @@ class PfFilterArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("observed_dev", C.c_void_p),
         ("ring", C.c_int64),
+        ("user_loc", C.c_void_p), ("user_scale", C.c_void_p),
     ]
 
 

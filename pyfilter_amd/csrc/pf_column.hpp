@@ -109,6 +109,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     const int proposal = a.proposal;
     const ModelDesc md = a.md;
     const int O = md.obs_dim;
+    const bool user = md.hid_kind == PF_HID_USER_AFFINE;
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const int i0 = tid * VEC;
     const bool on = i0 < N;
@@ -295,7 +296,9 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
                 T xj[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = x[d][j];
-                const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj);
+                UserMS<T, D> um = UserMS<T, D>::none();
+                if (user && on) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j);
+                const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj, false, um);
                 if (on && is_nan_or_posinf(pre)) poison = true;
                 rw[j] = on ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
             }
@@ -441,17 +444,19 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             T xn[D], w_new;
+            UserMS<T, D> um = UserMS<T, D>::none();
+            if (user) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j]);  // the parent's
             if (obs) {
-                const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn);
+                const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn, um);
                 if (apf) {
-                    w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j]);  // apf.py:43
+                    w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j], false, um);  // apf.py:43
                     if (on && is_nan_or_posinf(w_new)) poison = true;
                 } else {
                     if (on && is_nan_or_posinf(wi)) poison = true;
                     w_new = resample ? wi : (wi + lw[j]);  // sisr.py:52-55
                 }
             } else {  // NaN observation: propagate only, weights carried, ll = 0 (particle/state.py:38-42)
-                sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], z[j], xn);
+                sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], z[j], xn, um);
                 w_new = resample ? T(0) : lw[j];
             }
             lw_new[j] = on ? sanitize_logw(w_new) : -Lim<T>::inf();

@@ -66,6 +66,8 @@ template <typename T> struct FusedArgs {
     int y_rows;
     const T* z_tape;
     const T* u_tape;
+    const T* user_loc;    // PF_HID_USER_AFFINE: (D, B, N) one-step means / transition scales of the incoming particles, evaluated
+    const T* user_scale;  // by the caller's callable (pf_filter_args.user_loc / user_scale)
     T* means;
     T* vars;
     T* ll_steps;
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     const int b = blockIdx.y, k = blockIdx.x;
     const int slot = a.step & 1;
     const bool pre_on = a.is_obs() && a.filter == PF_FILTER_APF;
+    const bool user = a.md.hid_kind == PF_HID_USER_AFFINE;
     ColParams<T, D> cp;
     load_col_params<T, D>(a, b, a.step, pre_on, cp);
     ColConsts<T, D> cc;
@@ -491,7 +494,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
                 T xj[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
-                pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj) : T(0);
+                UserMS<T, D> um = UserMS<T, D>::none();
+                if (user && pre_on)  // the particle's own one-step mean / scale (the caller's planes)
+                    um.gather(a.user_loc, a.user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, i0 + j);
+                pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, false, um) : T(0);
                 if (pre_on && is_nan_or_posinf(pre[j])) acc.poison = true;
                 rw[j] = pre_on ? sanitize_logw(pre[j] + lw[j]) : lw[j];
             }
@@ -951,13 +957,15 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
 // MK: the model kinds as compile-time constants where the per-particle arithmetic switches on them.  Generic kernels: 0
 // run-time kinds, 1 Verhulst diffusion + stochastic-volatility observation (D = 1) - the switch statements fold, their
 // scalar branch instructions (one set per particle and density) vanish (SQ_INSTS_SALU 1798 -> 962 per wave on
-// 64 x 65 536).  Closed-form kernels (FAST): the shape of the one-step mean, 0 run time, 1 affine, 2 sine.
+// 64 x 65 536), 3 a user-defined affine process (PF_HID_USER_AFFINE: the one-step mean / scale of the PARENT come from the
+// caller's planes).  Closed-form kernels (FAST): the shape of the one-step mean, 0 run time, 1 affine, 2 sine.
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool RS, bool MULTI>
 __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, const StepPlan<T>& pl,
                                           const T (&z0)[VEC][D]) {
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     ModelDesc md = a.md;
     if constexpr (!FAST && MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
+    constexpr bool USER = !FAST && MK == 3;  // PF_HID_USER_AFFINE (one step per run: no next step is prepared here)
     constexpr int WIN = StepShared<T, D, VEC>::WIN;
     // the window of cdf entries a round stages: 256 * (VEC + V1).  The inverted-grid variant reads 256 entries beyond one
     // per position (its window starts within tile / 64 of the first ancestor; a stretch of negligible weights walks on
@@ -1304,18 +1312,21 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             for (int j = 0; j < VEC; ++j) {
                 T xn[D];
                 T w_new;
+                // user-defined affine models (MK = 3): the parent's one-step mean / scale from the caller's planes
+                UserMS<T, D> um = UserMS<T, D>::none();
+                if constexpr (USER) um.gather(la->user_loc, la->user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, idx[j]);
                 if (obs) {
                     T wi, pre_anc = T(0);
                     if constexpr (FAST) {
                         if (apf) wi = fc.template sample_and_weight_apf<FAST ? MK : 0>(proposal, xr[j][0], zt[j][0], xn[0], pre_anc);
                         else wi = fc.template sample_and_weight<FAST ? MK : 0>(proposal, xr[j][0], zt[j][0], xn[0]);
                     } else {
-                        wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], zt[j], xn);
+                        wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], zt[j], xn, um);
                     }
                     if (apf) {
                         // second-stage weight ws - pre_weight(x[anc]) (apf.py:43), the pre-weight recomputed in registers
                         if constexpr (FAST) w_new = wi - pre_anc;
-                        else w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j]);
+                        else w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j], false, um);
                         if (is_nan_or_posinf(w_new)) poison = true;
                     } else {
                         if (is_nan_or_posinf(wi)) poison = true;
@@ -1324,7 +1335,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 } else {
                     // propagate only (NaN observation / unobserved sub-step): weights carried, ll = 0 (state.py:38-42)
                     if constexpr (FAST) fc.template sample_and_weight<FAST ? MK : 0>(PF_PROP_BOOTSTRAP, xr[j][0], zt[j][0], xn[0]);
-                    else sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn);
+                    else sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], zt[j], xn, um);
                     w_new = resample ? T(0) : lw_old[j];
                 }
                 lwo[j] = sanitize_logw(w_new);

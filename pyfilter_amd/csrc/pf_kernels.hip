@@ -1050,11 +1050,14 @@ using namespace pf;
 
 static inline bool bad_shape(int64_t N, int64_t B) { return N < 1 || B < 1 || N > (int64_t)1 << 30 || B > 65535; }
 
-static inline int check_model(const pf_model* m) {
+// `fused`: the call is a fused filter run - the only place a user-defined affine process (whose mean / scale planes
+// travel in pf_filter_args) can be evaluated; the stand-alone model kernels take built-in kinds only
+static inline int check_model(const pf_model* m, bool fused = false) {
     if (!m || !m->params) return PF_EINVAL;
+    if (m->hid_kind == PF_HID_USER_AFFINE && !fused) return PF_EUNSUPPORTED;
     if (m->dim < 1 || m->dim > PF_MAXD || m->obs_dim < 1 || m->obs_dim > PF_MAXO) return PF_EUNSUPPORTED;
     if (m->dim == 1 && m->obs_dim != 1) return PF_EUNSUPPORTED;
-    if (m->hid_kind < 0 || m->hid_kind > PF_HID_OU) return PF_EUNSUPPORTED;
+    if (m->hid_kind < 0 || m->hid_kind > PF_HID_USER_AFFINE) return PF_EUNSUPPORTED;
     if (m->hid_kind == PF_HID_LORENZ63_EM && m->dim != 3) return PF_EUNSUPPORTED;
     if (m->obs_kind != PF_OBS_LINEAR && m->obs_kind != PF_OBS_SV) return PF_EUNSUPPORTED;
     if (m->obs_kind == PF_OBS_SV && m->dim != 1) return PF_EUNSUPPORTED;
@@ -1484,6 +1487,8 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
     a.y_rows = (int)A->y_rows;
     a.z_tape = (const T*)A->z_tape;
     a.u_tape = (const T*)A->u_tape;
+    a.user_loc = (const T*)A->user_loc;
+    a.user_scale = (const T*)A->user_scale;
     a.means = (T*)A->means;
     a.vars = (T*)A->vars;
     a.ll_steps = (T*)A->ll_steps;
@@ -1582,6 +1587,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             };
             // model kinds folded at compile time for the stochastic-volatility built-in (float runs; for Lorenz-63 the
             // same specialisation measured no gain)
+            if constexpr (!FAST) {  // user-defined affine process: the parent's (loc, scale) come from the caller's planes
+                if (a.md.hid_kind == PF_HID_USER_AFFINE) return launch(std::integral_constant<int, 3>{});
+            }
             if constexpr (sizeof(T) == 4 && !FAST && D == 1) {
                 if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) return launch(std::integral_constant<int, 1>{});
             }
@@ -1609,7 +1617,8 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         // scalar closed-form models: the proposal is a run-time switch inside one lean kernel (FAST); everything else gets
         // the proposal as a template constant so that Bootstrap runs do not carry the optimal proposal's registers
         bool fast = false;
-        if constexpr (D == 1) fast = a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM;
+        if constexpr (D == 1)
+            fast = a.md.obs_kind == PF_OBS_LINEAR && a.md.hid_kind != PF_HID_VERHULST_EM && a.md.hid_kind != PF_HID_USER_AFFINE;
         if (fast) {
             if constexpr (D == 1) {
                 if (a.proposal == PF_PROP_BOOTSTRAP) launch_step_as(std::integral_constant<int, PF_PROP_BOOTSTRAP>{}, std::true_type{});
@@ -1916,7 +1925,7 @@ extern "C" int pf_filter_graph_destroy(void* handle) {
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms) {
     if (!A) return PF_EINVAL;
-    int rc = check_model(&A->model);
+    int rc = check_model(&A->model, true);
     if (rc) return rc;
     if (bad_shape(A->N, A->B) || t0 < 0 || n_steps < 0) return PF_EINVAL;
     if (A->ring < 0 || A->ring == 1) return PF_EINVAL;
@@ -1926,6 +1935,10 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (n_steps > 0 && (!A->y || (!A->observed && !A->observed_dev && n_steps > PF_AUTO_FLAGS))) return PF_EINVAL;
     if (A->y_rows != 1 && A->y_rows != A->B) return PF_EINVAL;
     if (A->proposal == PF_PROP_LGO && A->model.obs_kind != PF_OBS_LINEAR) return PF_EUNSUPPORTED;
+    if (A->model.hid_kind == PF_HID_USER_AFFINE) {  // the planes describe ONE incoming state: one step per call, no history
+        if (!A->user_loc || !A->user_scale) return PF_EINVAL;
+        if (n_steps > 1 || A->ring >= 3) return PF_EUNSUPPORTED;
+    }
     if (A->filter != PF_FILTER_SISR && A->filter != PF_FILTER_APF) return PF_EUNSUPPORTED;
     if (!A->pos) return PF_EINVAL;
     const Geom g = make_geom(A->N, A->B);

@@ -152,7 +152,7 @@ template <typename T, int D> struct ColConsts {
             }
         }
         if constexpr (D == 1) {
-            if (md.obs_kind != PF_OBS_LINEAR || md.hid_kind == PF_HID_VERHULST_EM) return;
+            if (md.obs_kind != PF_OBS_LINEAR || md.hid_kind == PF_HID_VERHULST_EM || md.hid_kind == PF_HID_USER_AFFINE) return;
             fast = true;
             const T dt = (T)md.dt;
             switch (md.hid_kind) {
@@ -425,10 +425,39 @@ template <typename T, int K> __device__ __forceinline__ void spd_inverse(const T
         }
 }
 
+// PF_HID_USER_AFFINE: a particle's one-step mean and transition scale as the caller's callable evaluated them (the fused
+// kernels gather them from pf_filter_args.user_loc / user_scale).  Passed BY VALUE-LIKE REFERENCE to the inlined model
+// functions so that it stays in registers (a pointer to a local array that is sometimes null kept the array in scratch and
+// miscompiled the propagate-only path of the register-starved kernels: tests/test_column_route_gpu.py NaN cases).
+template <typename T, int D> struct UserMS {
+    bool on;
+    T loc[D], scale[D];
+    __device__ __forceinline__ static UserMS none() {
+        UserMS u;
+        u.on = false;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            u.loc[d] = T(0);
+            u.scale[d] = T(1);
+        }
+        return u;
+    }
+    // planes (D, B, N): `col0` = index of (component 0, this column, particle 0), `plane` = B * N, `i` = the particle
+    __device__ __forceinline__ void gather(const T* __restrict__ ploc, const T* __restrict__ pscale, int64_t col0, int64_t plane, int64_t i) {
+        on = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            loc[d] = ploc[col0 + d * plane + i];
+            scale[d] = pscale[col0 + d * plane + i];
+        }
+    }
+};
+
 // APF first-stage weight  (proposal.pre_weight(y, x))
 template <typename T, int D>
 __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
-                                        const ColConsts<T, D>& cc, const T (&x)[D], bool next = false) {
+                                        const ColConsts<T, D>& cc, const T (&x)[D], bool next = false,
+                                        const UserMS<T, D>& um = UserMS<T, D>::none()) {
     if constexpr (D == 1) {
         if (cc.fast) {
             if (proposal == PF_PROP_BOOTSTRAP) return cc.obs_lp(cc.loc1(md, cp, x[0]), next);  // log p(y | E[x_t | x_{t-1}])
@@ -437,7 +466,15 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
         }
     }
     T loc[D], scale[D];
-    mean_scale<T, D>(md, cp, x, loc, scale);
+    if (um.on) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            loc[d] = um.loc[d];
+            scale[d] = um.scale[d];
+        }
+    } else {
+        mean_scale<T, D>(md, cp, x, loc, scale);
+    }
     if (proposal == PF_PROP_BOOTSTRAP) return cc.lin_fast ? cc.obs_lp_lin(cp, loc, next) : obs_logpdf<T, D>(md, cp, loc, next);
 
     // LinearGaussianObservations.pre_weight: N(y; b + A x_{t-1}, diag(s^2) + A diag(g^2) A^T)  (linear.py:57-86)
@@ -481,7 +518,8 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
 // proposal.sample_and_weight(y, prediction): new state and importance weight given the draws z
 template <typename T, int D>
 __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal, const ColParams<T, D>& cp,
-                                               const ColConsts<T, D>& cc, const T (&x)[D], const T (&z)[D], T (&xn)[D]) {
+                                               const ColConsts<T, D>& cc, const T (&x)[D], const T (&z)[D], T (&xn)[D],
+                                               const UserMS<T, D>& um = UserMS<T, D>::none()) {
     if constexpr (D == 1) {
         if (cc.fast) {
             const T loc = cc.loc1(md, cp, x[0]);
@@ -497,7 +535,15 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
         }
     }
     T loc[D], scale[D];
-    mean_scale<T, D>(md, cp, x, loc, scale);
+    if (um.on) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            loc[d] = um.loc[d];
+            scale[d] = um.scale[d];
+        }
+    } else {
+        mean_scale<T, D>(md, cp, x, loc, scale);
+    }
     if (proposal == PF_PROP_BOOTSTRAP) {
         const T inc = (T)md.inc_scale;
 #pragma unroll

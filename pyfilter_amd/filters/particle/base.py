@@ -299,7 +299,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             and type(self._proposal) in (Bootstrap, LinearGaussianObservations)
             and not self._proposal._custom_pre_weight
             and self._resampler_kind() is not None
-            and hasattr(self._model.hidden, "init_mean")
+            and (hasattr(self._model.hidden, "init_mean") or self._kernel_kind().is_user)
         )
 
     def filter(self, y: torch.Tensor, correction: ParticleFilterCorrection, result: FilterResult = None):
@@ -351,6 +351,16 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
 
         a = plan.args
         a.model.params = ctx.params.data_ptr()
+        planes = None
+        if kind.is_user:
+            # The user's mean_scale callable, ONCE per step, on the incoming particles (torch ops on the device): it acts per
+            # particle, so loc(x[anc]) = loc(x)[anc] - the kernels gather these planes at the ancestors instead of
+            # evaluating a built-in closed form.  Everything else of the step stays in the fused kernels.
+            loc, scale = self._model.hidden.mean_scale(ts_in)
+            full = ts_in.value.shape
+            planes = (ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event).contiguous(),
+                      ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event).contiguous())
+            a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
         a.y = y_dev.data_ptr()
         a.seed = self._next_draw_seed()  # fresh Philox draws per move
         a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
@@ -367,7 +377,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: every workgroup draws its column's u (Philox)
         L.check(L.load().pf_filter_run(C.byref(a), 0, 1, 1, L.stream_ptr()), "pf_filter_run")
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
-                              keep=(x_in, lw_in, y_dev, ctx.params))
+                              keep=(x_in, lw_in, y_dev, ctx.params, planes))
 
         final_x = TimeseriesState(t_start + 1, ops.from_soa(x_out, self._batched, self._has_event),
                                   self._model.hidden.event_shape)
@@ -382,7 +392,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         assert self._model is not None, "Model has not been initialized!"
         device, _ = self._device_dtype()
         if (not self._fused_capable(device) or not isinstance(y, torch.Tensor)
-                or os.environ.get("PF_NO_FUSED_BATCH", "0") == "1"):
+                or os.environ.get("PF_NO_FUSED_BATCH", "0") == "1" or self._kernel_kind().is_user):
+            # (a user-defined affine process: the driver's loop over fused single steps - the callable runs between them)
             return super().batch_filter(y, bar=bar, init_state=init_state)
         return self._batch_filter_fused(y, init_state)
 
@@ -411,7 +422,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         optional host flags (uint8, one per observation) when the caller already knows which observations are not
         all-NaN (saves the device round trip per call).  None when the fused route does not apply."""
         x = state.timeseries_state.value
-        if not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1 or self._record_intermediary:
+        if (not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1 or self._record_intermediary
+                or self._kernel_kind().is_user):
             return None
         res = self._batch_filter_fused(y, state._restarted(), observed=observed, replay=replay)
         run = self._last_run
@@ -610,7 +622,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
 
         start = batched_gather(x_last, idx, 0)
         ctx = self._ensure_context()
-        if ctx is not None and on_gpu:
+        if ctx is not None and on_gpu and not ctx.kind.is_user:
             x_hist, w_hist, _ = self._history(states)
             u = getattr(self, "_ffbs_u", None)
             if u is not None:

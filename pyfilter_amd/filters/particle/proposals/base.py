@@ -68,7 +68,10 @@ class Proposal(ABC):
 
     @property
     def uses_kernels(self) -> bool:
-        return self._ctx is not None and self._KERNEL_PROPOSAL is not None and not self._custom_pre_weight
+        # (a user-defined affine process has no stand-alone model kernel: its callables run as torch ops on this route; the
+        # fused single step takes its (loc, scale) planes)
+        return (self._ctx is not None and self._KERNEL_PROPOSAL is not None and not self._custom_pre_weight
+                and not self._ctx.kind.is_user)
 
     # -- kernel route ------------------------------------------------------------------------------------------
     def _kernel_sample_and_weight(self, y, x: TimeseriesState, weigh=True):

@@ -73,6 +73,12 @@ class KernelKind:
         self.obs_kind = None
         self.obs_dim = None
 
+    @property
+    def is_user(self) -> bool:
+        """A user-defined affine process: its ``mean_scale`` callable is evaluated with PyTorch-ROCm ops once per step and
+        handed to the fused kernels as (loc, scale) planes (``PF_HID_USER_AFFINE``)."""
+        return self.hid_kind == L.HID_USER_AFFINE
+
 
 class StructuralStochasticProcess:
     def __init__(self, parameters: Sequence, initial_kernel: Callable[..., Distribution], initial_parameters=None):
@@ -165,6 +171,24 @@ class AffineEulerMaruyama(AffineProcess):
         super().__init__(_ms, parameters, increment_distribution, initial_kernel, initial_parameters)
 
 
+def _user_affine_kind(hidden: "AffineProcess") -> Optional[KernelKind]:
+    """The kernel kind of a USER-DEFINED affine process (the reference's plug-in seam: ``AffineProcess(lambda x, *p: (loc,
+    scale), parameters, increment_distribution, ...)``, README.md:44-67) - available when its increments are centred
+    Gaussians of one common scale (``Normal(0, s)``, possibly ``.to_event(1)``): then ``x' = loc(x) + scale(x) s e`` is what
+    the fused kernels compute from the (loc, scale) planes.  Anything else stays on the step-by-step route."""
+    inc = hidden.increment_distribution
+    base = inc.base_dist if isinstance(inc, Independent) else inc
+    if not isinstance(base, Normal):
+        return None
+    loc, scale = base.loc.reshape(-1), base.scale.reshape(-1)
+    if loc.numel() == 0 or bool((loc != 0).any()) or bool((scale != scale[0]).any()):
+        return None
+    dim = hidden.n_dim and hidden.event_shape.numel()
+    if dim > L.MAX_D:
+        return None
+    return KernelKind(L.HID_USER_AFFINE, dim, 1.0, float(scale[0]))
+
+
 class StateSpacePath:
     """Sampled hidden states and observations (the slice of ``stochproc.timeseries.result.StateSpacePath`` that
     ``ParticleFilterCorrection.predict_path`` exposes): ``get_paths() -> (x (steps, *shape), y (steps, *shape))``."""
@@ -241,6 +265,8 @@ class LinearStateSpaceModel(StateSpaceModel):
         super().__init__(hidden, _f, parameters, observe_every_step)
         self._event_shape = obs_event
         hk = getattr(hidden, "kernel_kind", None)
+        if hk is None and isinstance(hidden, AffineProcess):
+            hk = _user_affine_kind(hidden)
         if hk is not None:
             o = obs_event.numel() if len(obs_event) else 1
             if hk.dim <= L.MAX_D and o <= L.MAX_O and (hk.dim > 1 or o == 1):

@@ -193,7 +193,7 @@ def pack_params(ssm: StateSpaceModel, b: int, dtype, device) -> torch.Tensor:
         raise L.PfAmdError("model has no built-in kernel kind")
     d, o = kind.dim, kind.obs_dim
     cols = []
-    hp = list(ssm.hidden.parameters)
+    hp = [] if kind.is_user else list(ssm.hidden.parameters)  # (a user process keeps its parameters in its callable)
     for k in range(4):
         if k < len(hp):
             cols.append(_expand(hp[k], b, (d,), dtype, device))

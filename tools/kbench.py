@@ -36,6 +36,12 @@ def make(model, filt, prop, n, b, dtype=torch.float32, resampler="systematic"):
         hidden = models.Verhulst(kappa, gamma, sigma, dt=0.2, initial=(t(1.0, dtype), t(0.1, dtype)))
         ssm = models.StochasticVolatilityModel(hidden, mu)
         o = ()
+    elif model == "user_sine":  # the README's sine diffusion the reference's way: a python lambda (README.md:44-67)
+        from torch.distributions import Normal
+        hidden = ts.AffineEulerMaruyama(lambda x, gm, s: (torch.sin(x.value - gm), s), (t(0.0, dtype), t(1.0, dtype)),
+                                        Normal(t(0.0, dtype), t(math.sqrt(0.1), dtype)), 0.1, lambda gm, s: Normal(t(0.0, dtype), t(1.0, dtype)))
+        ssm = ts.LinearStateSpaceModel(hidden, (t(1.0, dtype), t(0.1, dtype)))
+        o = ()
     elif model == "lorenz":
         hidden = models.Lorenz63(t(10.0, dtype), t(28.0, dtype), t(8.0 / 3.0, dtype), t(1.0, dtype), dt=0.01)
         a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]], dtype)
@@ -52,6 +58,9 @@ def make(model, filt, prop, n, b, dtype=torch.float32, resampler="systematic"):
 
 CONFIGS = {
     "apf_lgo_1m": ("sine", "apf", "lgo", 1 << 20, 1),
+    "user_apf_lgo_1m": ("user_sine", "apf", "lgo", 1 << 20, 1),       # lambda-defined model on the fused single-step route
+    "user_sisr_boot_1m": ("user_sine", "sisr", "bootstrap", 1 << 20, 1),
+    "user_apf_lgo_1024x512": ("user_sine", "apf", "lgo", 512, 1024),
     "apf_boot_1m": ("sine", "apf", "bootstrap", 1 << 20, 1),
     "sisr_boot_1m": ("sine", "sisr", "bootstrap", 1 << 20, 1),
     "sisr_boot_lg_1m": ("lg", "sisr", "bootstrap", 1 << 20, 1),
@@ -104,7 +113,7 @@ def main():
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / reps
         k = [0.0, 0.0, 0.0]
-        if not os.environ.get("KB_NO_TIMED"):  # (the replays of the timed run would pollute a PMC profile)
+        if not os.environ.get("KB_NO_TIMED") and not cfg[0].startswith("user"):  # (the replays of the timed run would pollute a PMC profile)
             f._time_kernels = True
             f.batch_filter(y, bar=False)
             k = f.kernel_ms
