@@ -71,8 +71,9 @@ def _compare_step(tag, x_gpu, w_gpu, ll_gpu, idx_gpu, ref64, ref32, n):
     A particle *matches* when its ancestor equals the float64 oracle's - or the float32 oracle's: a grid position within
     an ulp of a CDF boundary may legitimately fall either way - and its new state / log-weight are within the bars of
     the oracle that owns that ancestor (x: 1e-5 of the state's scale, w: 2e-5 relative + 2e-4).  With the ancestors at
-    hand a matching ancestor with an off value fails at once; for the intermediate step of a 2-step run (ancestors not
-    kept) a non-matching particle counts as a flip.  Allowance: 2e-4 of the particles (the bar of the golden
+    hand a matching ancestor with an off value fails at once (the runs record their states, so the intermediate step of a
+    2-step APF run - the SPEC = 1 kernel - hands out its ancestors too; without ancestors a non-matching particle would
+    count as a flip).  Allowance: 2e-4 of the particles (the bar of the golden
     teacher-forced test, N <= 1000) or 3 x the flips between the two oracles themselves - at 2^20 particles a CDF
     increment is 16 float32 ulps, so the reference's own float32 path flips that often against exact arithmetic."""
     x64, w64, ll64, idx64 = ref64
@@ -133,7 +134,9 @@ def test_production_step_kernels_match_oracle_on_their_own_draws(name):
     d = max(1, spec64.dim)
     has_event = spec64.dim > 0
     seen_spec = set()
-    filt = build_filter_from_case(case, g, F32, "cuda", tape=False)
+    # recorded states: the kernels keep every state of the run WITH the ancestors that led to it (pf_filter_args.ring), so
+    # the intermediate step of the 2-step APF runs - the SPEC = 1 kernel - hands out its ancestors for a direct comparison
+    filt = build_filter_from_case(case, g, F32, "cuda", tape=False, record_states=True)
     filt.set_tape(u=g["u_tape"].to(F32))  # uniforms injected, normals stay Philox: the production kernels are selected
     es = filt._model.hidden.event_shape
     for t in range(0, t_len - run_len + 1):
@@ -158,12 +161,12 @@ def test_production_step_kernels_match_oracle_on_their_own_draws(name):
         plan = filt._last_run["plan"]
         last = res.latest_state
         if apf:
-            # step 0 (SPEC = 1 when both steps are observed): its output state sits in the run's odd buffers
-            x1 = ops.from_soa(plan.x[1], True, has_event).cpu()
-            w1 = ops.from_cols(plan.logw[1], True).cpu()
+            # step 0 (SPEC = 1 when both steps are observed): its recorded state, ancestors included
+            mid = res.states[-2]
+            x1, w1 = mid.timeseries_state.value.cpu(), mid.weights.cpu()
             r64 = _oracle_step(spec64, case, y[t], x_prev, w_prev, idx_prev, z[0], u[t], torch.float64)
             r32 = _oracle_step(spec32, case, y[t], x_prev, w_prev, idx_prev, z[0], u[t], F32)
-            _compare_step(f"{name} t={t} step0", x1, w1, plan.ll_steps[0].cpu(), None, r64, r32, n)
+            _compare_step(f"{name} t={t} step0", x1, w1, plan.ll_steps[0].cpu(), mid.previous_indices.cpu(), r64, r32, n)
             # step 1 (generic variant: the run's last step), teacher-forced from the kernel's own step-0 state
             r64 = _oracle_step(spec64, case, y[t + 1], x1, w1, r64[3], z[1], u[t + 1], torch.float64)
             r32 = _oracle_step(spec32, case, y[t + 1], x1, w1, r32[3], z[1], u[t + 1], F32)
@@ -207,7 +210,7 @@ def test_production_step_kernels_at_benchmark_shapes(model, filt_name, prop, n, 
 
     cls = APF if apf else SISR
     filt = cls(ssm, n, proposal={"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop](),
-               ess_threshold=case["ess_threshold"], seed=99)
+               ess_threshold=case["ess_threshold"], seed=99, record_states=True)  # (recorded: the intermediate ancestors)
     filt.set_batch_shape(torch.Size([b]))
     filt.set_tape(u=u)
     state = filt.initialize()
@@ -224,11 +227,11 @@ def test_production_step_kernels_at_benchmark_shapes(model, filt_name, prop, n, 
         plan = filt._last_run["plan"]
         last = res.latest_state
         if apf:
-            x1 = ops.from_soa(plan.x[1], True, has_event).cpu()
-            w1 = ops.from_cols(plan.logw[1], True).cpu()
+            mid = res.states[-2]  # the SPEC = 1 step's own output, ancestors included
+            x1, w1 = mid.timeseries_state.value.cpu(), mid.weights.cpu()
             r64 = _oracle_step(spec64, case, y[t], xs, ws, idx_prev, z[0], u[t], torch.float64)
             r32 = _oracle_step(spec32, case, y[t], xs, ws, idx_prev, z[0], u[t], F32)
-            _compare_step(f"{case['name']} t={t} step0", x1, w1, plan.ll_steps[0].cpu(), None, r64, r32, n)
+            _compare_step(f"{case['name']} t={t} step0", x1, w1, plan.ll_steps[0].cpu(), mid.previous_indices.cpu(), r64, r32, n)
             r64 = _oracle_step(spec64, case, y[t + 1], x1, w1, r64[3], z[1], u[t + 1], torch.float64)
             r32 = _oracle_step(spec32, case, y[t + 1], x1, w1, r32[3], z[1], u[t + 1], F32)
         else:

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Where the HOST spends an SMC^2 fit (development tool): cProfile of one ``SMC2.fit`` at 128 theta-particles x 8 192 state
+particles, T = 500 - the per-rank job of an 8-GPU run, which is host-bound (tools/smc2_scaling_model.py).
+Usage: python tools/smc2_host_profile.py [n_theta]"""
+import cProfile
+import math
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from torch.distributions import Exponential, LogNormal, Normal
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    n_theta = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    device, dtype, t_len = torch.device("cuda"), torch.float32, 500
+    g = torch.Generator().manual_seed(123)
+    x, ys = 0.0, []
+    for _ in range(t_len):
+        x = x * math.exp(-0.025) + 0.05 * math.sqrt((1 - math.exp(-0.05)) / 0.05) * torch.randn((), generator=g).item()
+        ys.append(x + 0.05 * torch.randn((), generator=g).item())
+    y = torch.tensor(ys, dtype=dtype, device=device)
+    priors = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+
+    def build(theta):
+        t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
+
+    def fit(seed):
+        filt = APF(build, 8192, proposal=proposals.LinearGaussianObservations(), seed=2024 + seed)
+        alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=seed)
+        alg.fit(y)
+        torch.cuda.synchronize()
+        return alg
+
+    fit(0)
+    t0 = time.perf_counter()
+    fit(1)
+    print(f"fit at {n_theta} theta: {1e3 * (time.perf_counter() - t0):.1f} ms")
+    pr = cProfile.Profile()
+    pr.enable()
+    fit(2)
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+
+
+if __name__ == "__main__":
+    main()
