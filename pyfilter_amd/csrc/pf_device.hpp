@@ -267,10 +267,13 @@ template <typename T, int VEC> __device__ __forceinline__ void store_vec(T* __re
 #ifndef PF_OUT_STORE
 #define PF_OUT_STORE 2
 #endif
-template <typename T, int VEC>
+// WT = false: a plain store.  The step kernels of multi-round tiles take those: written through, their shapes measured
+// within +-3 % of plain stores either way (profiles/r03_out_store_multi_round_ab.txt) and the descriptors cost them
+// registers (24 - 150 B / lane of additional scratch in the 128-VGPR instantiations).
+template <typename T, int VEC, bool WT = true>
 __device__ __forceinline__ void store_out(T* __restrict__ base, int elem, const T (&in)[VEC]) {
     constexpr int BYTES = (int)sizeof(T) * VEC;
-    if constexpr (PF_OUT_STORE != 0 && BYTES % 16 == 0) {
+    if constexpr (WT && PF_OUT_STORE != 0 && BYTES % 16 == 0) {
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         Pack<T, VEC> q;
 #pragma unroll

@@ -766,12 +766,19 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_book(FusedArgs<T> a) {
 #ifndef PF_WAVES_D1_GENERIC
 #define PF_WAVES_D1_GENERIC 4
 #endif
+#ifndef PF_WAVES_D1_MN
+// scalar-state multinomial kernels of multi-round tiles (the spacing scan's registers on top of the search's): at 4 waves
+// they spill 130 - 250 B / lane; at 3 (<= 168 VGPRs) none - 60.6 -> 56.6 us per step at 2^22 x 1, 75.8 -> 60.1 at 64 x 65 536
+// (profiles/r03_multinomial_scalar_waves.txt).  Single-round tiles stay at 4: 2^20 x 1 APF ran 20.4 -> 25.2 us at 3.
+#define PF_WAVES_D1_MN 3
+#endif
 #ifndef PF_WAVES_DN_A
 #define PF_WAVES_DN_A 3  // (4 waves = 128 VGPRs spill 128 B / lane once the prologue lives in this kernel: measured slower)
 #endif
 // resident waves per SIMD the register allocation is tuned for (float; measured per variant, tools/kbench.py)
-template <typename T, int D, int MODE, int PROP, bool FAST, int SPEC> struct StepWaves {
+template <typename T, int D, int MODE, int PROP, bool FAST, int SPEC, bool MULTI> struct StepWaves {
     static constexpr int value = sizeof(T) != 4 ? 1
+                                 : (D == 1 && MODE == 1 && MULTI) ? PF_WAVES_D1_MN
                                  : D == 1     ? (FAST ? 4 : PF_WAVES_D1_GENERIC)
                                  : PROP == PF_PROP_LGO ? 2
                                  : (MODE == 1 || SPEC == 2) ? PF_WAVES_DN_A
@@ -1352,11 +1359,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 T* xc = x_out + ((int64_t)d * g.B + b) * g.N + r0;  // (the round's first particle: uniform)
-                if (VEC == 1) xc[tid] = xo[d][0]; else store_out<T, VEC>(xc, tid * VEC, xo[d]);
+                if (VEC == 1) xc[tid] = xo[d][0]; else store_out<T, VEC, !MULTI>(xc, tid * VEC, xo[d]);
             }
-            if (VEC == 1) lw_out[i0] = lwo[0]; else store_out<T, VEC>(lw_out + r0, tid * VEC, lwo);
+            if (VEC == 1) lw_out[i0] = lwo[0]; else store_out<T, VEC, !MULTI>(lw_out + r0, tid * VEC, lwo);
             if (resample || apf) {  // SISR without resampling keeps the previous ancestors (sisr.py:25-26)
-                if (VEC == 1) anc_col[i0] = idx[0]; else store_out<int, VEC>(anc_col + r0, tid * VEC, idx);
+                if (VEC == 1) anc_col[i0] = idx[0]; else store_out<int, VEC, !MULTI>(anc_col + r0, tid * VEC, idx);
             } else if (la->anc_prev) {  // ... which, with a state history, means copying them into this state's slot
                 const int32_t* ap = la->anc_prev + (int64_t)b * g.N + i0;
                 int prev[VEC];
@@ -1390,7 +1397,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             PF_STAMP(a, 13);
         }
         if (scan_next && !single) {  // (uniform) every lane of every wave: the chunk-local scan is wave-level
-            chunk_scan_round<T, VEC, true>(rwn, on, l_next + r0, tid * VEC, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
+            chunk_scan_round<T, VEC, false>(rwn, on, l_next + r0, tid * VEC, r * PF_NWAVES + (tid >> 6), use_lds ? sh.crec : nullptr, ct_tile);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) rwn[j] = -Lim<T>::inf();
             ++rk;
@@ -1419,7 +1426,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             T outv[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) outv[j] = (T)(excl + e[j]);
-            if (VEC == 1) l_next[i0] = outv[0]; else store_out<T, VEC>(l_next + base, tid * VEC, outv);
+            if (VEC == 1) l_next[i0] = outv[0]; else store_out<T, VEC, !MULTI>(l_next + base, tid * VEC, outv);
         }
     } else if (scan_next) {
         // the chunk table of the next step's resampling weights, and the tile's (max, sum) of that family from the same sums
@@ -1442,7 +1449,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
 }
 
 template <typename T, int D, int VEC, int MODE, int PROP, bool FAST, int SPEC, int MK, bool MULTI>
-__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC>::value)) void k_fused_step(FusedArgs<T> a) {
+__global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC, MULTI>::value)) void k_fused_step(FusedArgs<T> a) {
     using SH = StepShared<T, D, VEC>;
     __shared__ __attribute__((aligned(32))) T win[SH::WIN];
     __shared__ __attribute__((aligned(32))) T xwin[SH::XWIN ? D * SH::WIN : VEC];

@@ -86,6 +86,10 @@ CONFIGS = {
     "sisr_lorenz_1024x512": ("lorenz", "sisr", "bootstrap", 512, 1024),
     "sisr_lorenz_4m": ("lorenz", "sisr", "bootstrap", 1 << 22, 1),
     "sisr_lorenz_4m_mn": ("lorenz", "sisr", "bootstrap", 1 << 22, 1, "multinomial"),
+    "sisr_boot_1m_mn": ("sine", "sisr", "bootstrap", 1 << 20, 1, "multinomial"),
+    "apf_lgo_1m_mn": ("sine", "apf", "lgo", 1 << 20, 1, "multinomial"),
+    "apf_lgo_4m_mn": ("sine", "apf", "lgo", 1 << 22, 1, "multinomial"),
+    "apf_sv_64x64k_mn": ("sv", "apf", "bootstrap", 65536, 64, "multinomial"),
 }
 
 
