@@ -515,7 +515,11 @@ def main():
     units = w["N"] * w["B"]  # particles one launch processes
     gbs = {k: v * units / (step_ms * 1e-3) / 1e9 for k, v in bm.items()}
     roofline = {
-        "bound": "hbm", "kernel": "k_fused_step", "achieved": gbs["survey_8d"],
+        "bound": "hbm",  # the roofline this kernel class is priced against (no dense contraction: MFMA does not apply) ...
+        # ... what actually limits it at this shape (rocprofv3 --pmc SQ_INSTS_VALU per wave, dev-tools stamps)
+        "limited_by": "VALU issue + dependent-load latency inside one resident wave of workgroups, and the launch boundary - "
+                      "not HBM bandwidth (the as_built bytes would take 3.1 us at peak)",
+        "kernel": "k_fused_step", "achieved": gbs["survey_8d"],
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs["survey_8d"] / HBM_PEAK_GBS, "traffic": None,
         "byte_model": "survey_8d: SURVEY.md 8(d) algorithmic bytes per particle-step (the reference dataflow's compulsory "
                       "traffic) x particles per launch / the step kernel's in-sequence duration",

@@ -391,3 +391,36 @@ def test_standalone_cpp_program_compiles_and_links_against_the_header(tmp_path):
            f"-L{root}/pyfilter_amd", "-lpfamd", f"-L{rocm}/lib", "-lamdhip64"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_user_defined_affine_processes_get_the_fused_kernel_kind():
+    """A lambda-defined ``AffineProcess`` (the reference's plug-in seam) under a ``LinearStateSpaceModel`` is given the
+    ``PF_HID_USER_AFFINE`` kernel kind when its increments are centred Gaussians of one scale - and only then."""
+    from torch.distributions import Exponential, Independent, Normal
+
+    from pyfilter_amd import _lib as L, timeseries as ts
+    from pyfilter_amd.timeseries.models import pack_params
+
+    f = lambda x, a, s: (a * x.value, s)  # noqa: E731
+    init = lambda a, s: Normal(torch.tensor(0.0), torch.tensor(1.0))  # noqa: E731
+    hid = ts.AffineProcess(f, (0.9, 0.3), Normal(torch.tensor(0.0), torch.tensor(0.5)), init)
+    ssm = ts.LinearStateSpaceModel(hid, (1.0, 0.1))
+    k = ssm.kernel_kind
+    assert k is not None and k.is_user and k.hid_kind == L.HID_USER_AFFINE and k.dim == 1 and k.inc_scale == 0.5 and k.obs_kind == L.OBS_LINEAR
+    rows = pack_params(ssm, 3, torch.float64, torch.device("cpu"))
+    assert rows.shape == (3, 4 + 1 + 2) and (rows[:, :4] == 0).all() and torch.allclose(rows[0, 4:], torch.tensor([1.0, 0.0, 0.1], dtype=torch.float64))
+    # a vector state with independent increments of one scale
+    init3 = lambda *_: Independent(Normal(torch.zeros(3), torch.ones(3)), 1)  # noqa: E731
+    hid3 = ts.AffineProcess(lambda x, s: (x.value, s), (0.2,), Independent(Normal(torch.zeros(3), torch.full((3,), 0.1)), 1), init3)
+    k3 = ts.LinearStateSpaceModel(hid3, (torch.eye(3)[:2], torch.zeros(2), torch.full((2,), 0.3)), torch.Size([2])).kernel_kind
+    assert k3 is not None and k3.is_user and k3.dim == 3 and k3.obs_dim == 2 and abs(k3.inc_scale - 0.1) < 1e-7
+    # not Gaussian / not centred / component-wise scales: the step-by-step route keeps those
+    for inc in (Exponential(torch.tensor(1.0)), Normal(torch.tensor(0.2), torch.tensor(1.0))):
+        assert ts.LinearStateSpaceModel(ts.AffineProcess(f, (0.9, 0.3), inc, init), (1.0, 0.1)).kernel_kind is None
+    uneven = Independent(Normal(torch.zeros(3), torch.tensor([0.1, 0.2, 0.1])), 1)
+    assert ts.LinearStateSpaceModel(ts.AffineProcess(lambda x, s: (x.value, s), (0.2,), uneven, init3),
+                                    (torch.eye(3)[:2], torch.zeros(2), torch.full((2,), 0.3)), torch.Size([2])).kernel_kind is None
+    # built-in kinds are not "user"
+    from pyfilter_amd.timeseries import models
+
+    assert not ts.LinearStateSpaceModel(models.AR(0.0, 0.9, 0.1), (1.0, 0.1)).kernel_kind.is_user
