@@ -191,7 +191,11 @@ typedef struct pf_filter_args {
     /* observations */
     const void* y;            /* (T, y_rows, O) */
     int64_t y_rows;           /* 1 or B */
-    const uint8_t* observed;  /* HOST array (T): 0 = all-NaN observation or unobserved sub-step: propagate only,
+    const uint8_t* observed;  /* OPTIONAL HOST array (T) - the one exception to "every pointer is a device pointer", kept for
+                               * callers that already know the flags on the host (a hipGraph capture bakes them into the
+                               * launches).  The DEFAULT is `observed_dev` below (or neither: the library derives the flags
+                               * from y on the device) - no host-resident argument, no synchronisation.  Meaning:
+                               * 0 = all-NaN observation or unobserved sub-step: propagate only,
                                * ll = 0.  The only host-resident argument: the launch loop reads it to set each
                                * kernel's flags, so no kernel needs a dependent flag load before its first data load.
                                * NULL together with `observed_dev` (runs of <= 128 steps): the library derives the
@@ -208,7 +212,8 @@ typedef struct pf_filter_args {
                             * graph draw fresh Philox numbers on every replay */
     void* ws;
     size_t ws_bytes;
-    const uint8_t* observed_dev; /* optional DEVICE array (T) with the meaning of `observed`; when non-NULL it is used
+    const uint8_t* observed_dev; /* the DEFAULT way to pass the flags: DEVICE array (T) with the meaning of `observed` (e.g.
+                                  * written by pf_observed_flags); when non-NULL it is used
                                   * instead (every kernel reads its step's flag with one scalar load), so the caller
                                   * needs no host-side knowledge of NaN observations - `filter()` runs without a sync */
     int64_t ring; /* state history (FilterResult's recorded states, particle/base.py:105-157 smoothing): 0 or 2 = none - x[0] /

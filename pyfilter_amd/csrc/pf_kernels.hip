@@ -1588,7 +1588,11 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             // model kinds folded at compile time for the stochastic-volatility built-in (float runs; for Lorenz-63 the
             // same specialisation measured no gain)
             if constexpr (!FAST) {  // user-defined affine process: the parent's (loc, scale) come from the caller's planes
-                if (a.md.hid_kind == PF_HID_USER_AFFINE) return launch(std::integral_constant<int, 3>{});
+                if (a.md.hid_kind == PF_HID_USER_AFFINE) {
+                    // (one step per run: no next step, so the APF steady-state specialisation never applies - not instantiated)
+                    if constexpr (SPEC != 1) launch(std::integral_constant<int, 3>{});
+                    return;
+                }
             }
             if constexpr (sizeof(T) == 4 && !FAST && D == 1) {
                 if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) return launch(std::integral_constant<int, 1>{});

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""SMC^2 at the reference's own operating point (development tool): 1 000 theta-particles x 400 state particles, T = 500
+(examples/stochastic-volatility.ipynb:157 runs 1 000 x 250-400) on the OU model of tests/inference/models.py - the
+column-persistent route (one launch per fused run) against one launch per time step (PF_NO_COLUMN=1).
+Usage: python tools/smc2_small.py [n_theta] [n_state] [T]"""
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    from torch.distributions import Exponential, LogNormal, Normal
+
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    n_theta = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    n_state = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    t_len = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+    device, dtype = torch.device("cuda"), torch.float32
+    g = torch.Generator().manual_seed(123)
+    x, ys = 0.0, []
+    for _ in range(t_len):
+        x = x * math.exp(-0.025) + 0.05 * math.sqrt((1 - math.exp(-0.05)) / 0.05) * torch.randn((), generator=g).item()
+        ys.append(x + 0.05 * torch.randn((), generator=g).item())
+    y = torch.tensor(ys, dtype=dtype, device=device)
+    priors = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+
+    def build(theta):
+        t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
+
+    for route in ("column", "per_step"):
+        os.environ.pop("PF_NO_COLUMN", None)
+        if route == "per_step":
+            os.environ["PF_NO_COLUMN"] = "1"
+        for mode in ("fit(block=16)", "step()"):
+            best = None
+            for rep in range(4):
+                filt = APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=2024 + rep)
+                alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=rep)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if mode.startswith("fit"):
+                    state = alg.fit(y)
+                else:
+                    state = alg.initialize()
+                    for yt in y:
+                        state = alg.step(yt, state)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                if rep and (best is None or dt < best[0]):
+                    best = (dt, len(alg._kernel.acceptance_history), int(filt.particles[0]), alg.posterior_mean(state).tolist())
+            print(f"{route:9s} {mode:14s}: {1e3 * best[0]:8.1f} ms  ({n_theta * n_state * t_len / best[0]:.3e} particle-steps/s)  PMMH moves {best[1]}, "
+                  f"state particles at the end {best[2]}, posterior mean {[round(v, 3) for v in best[3]]}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
