@@ -27,7 +27,11 @@ def main():
         n = rng.choice([rng.randint(2, 40), rng.randint(41, 1100), rng.randint(1101, 9000), rng.choice([1024, 2048, 4096, 8192, 12288, 65536]),
                         rng.randint(9001, 70000)])
         b = rng.choice([1, 1, 2, 3, 5, 9, 17]) if n < 20000 else rng.choice([1, 2, 3])
-        t_len = rng.randint(1, 9)
+        t_len = rng.randint(1, 9) if (n > 4096 or rng.random() < 0.5) else rng.randint(10, 40)  # (long runs: the column loop)
+        if rng.random() < 0.3:  # columns of 2 049 .. 4 096 particles on the column-persistent route too (16-wave workgroups)
+            os.environ["PF_COLUMN_MAX_N"] = "4096"
+        else:
+            os.environ.pop("PF_COLUMN_MAX_N", None)
         ess = rng.choice([0.1, 0.5, 0.9, 0.97])  # (not 1.0: exactly uniform weights - after a NaN observation - sit ON that
         # threshold, and which side of it ESS = 1 / sum W^2 lands on is a rounding tie between any two implementations)
         target = rng.choice([None, None, 4, 64, 4096])  # geometry: few big tiles ... many small ones
@@ -64,7 +68,12 @@ def main():
         why = ""
         try:
             torch.testing.assert_close(res.filter_means.cpu(), ref["filter_means"], rtol=1e-9, atol=1e-11, equal_nan=True)
-            torch.testing.assert_close(res.loglikelihood.cpu(), ref["loglikelihood"], rtol=1e-9, atol=1e-9, equal_nan=True)
+            # (documented deviation, DESIGN.md section 3: the reference's APF log-likelihood has an unshifted second term that
+            # underflows to -inf when every first-stage weight does - two particles on a hopeless model - where the kernels'
+            # max-shifted form stays finite: those columns are not compared)
+            ll_ref, ll_got = ref["loglikelihood"].reshape(-1), res.loglikelihood.cpu().reshape(-1)
+            keep = ~(torch.isinf(ll_ref) & (ll_ref < 0) & torch.isfinite(ll_got))
+            torch.testing.assert_close(ll_got[keep], ll_ref[keep], rtol=1e-9, atol=1e-9, equal_nan=True)
             mism = (res.latest_state.previous_indices.cpu() != ref["prev_inds"]).sum().item()
             if mism:
                 ok, why = False, f"{mism} ancestors differ"
