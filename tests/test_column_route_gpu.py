@@ -200,3 +200,33 @@ def test_smc2_shaped_workload_is_one_launch_per_run():
     assert r["SPEC"] == 9 and torch.isfinite(r["ll"]).all() and torch.isfinite(r["means"]).all()
     recs = ops.debug_launch_trace(64)
     assert recs[-1]["SPEC"] == 9 and (len(recs) < 2 or recs[-2]["SPEC"] != 9 or recs[-2]["step"] == 0)
+
+
+def test_random_cross_route_sweep():
+    """60 random (model, filter, proposal, resampler, N in [1, 2048], B, T, NaN pattern, ESS threshold) configurations, float64,
+    Philox draws: the column-persistent kernel and the per-step kernels consume the same random numbers and must agree -
+    identical ancestors, 1e-9.  Unlike ``tools/fuzz_parity.py`` (oracle, taped draws, systematic only) this covers the
+    multinomial resampler and the kernels' own generators."""
+    import random
+
+    rng = random.Random(5)
+    for i in range(60):
+        kind = rng.choice(["sine", "lg", "ou", "sv", "lorenz"])
+        filt_name = rng.choice(["sisr", "apf"])
+        prop = "bootstrap" if kind == "sv" else rng.choice(["bootstrap", "lgo"])
+        resampler = rng.choice(["systematic", "systematic", "multinomial"])
+        n = rng.choice([rng.randint(1, 70), rng.randint(71, 700), rng.randint(701, 2048), rng.choice([64, 256, 1024, 2048])])
+        if n > 1024:
+            n -= n % 4  # (one particle per thread - N % 4 != 0 - fits a workgroup up to 1 024 particles only)
+        b = rng.choice([1, 2, 3, 7, 33])
+        t_len = rng.randint(1, 30)
+        nan_at = tuple(k for k in range(t_len) if rng.random() < 0.12)
+        ess = rng.choice([0.1, 0.5, 0.9])
+        tag = f"#{i} {kind} {filt_name} {prop} {resampler} N={n} B={b} T={t_len} nan={nan_at} ess={ess}"
+        col = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at, seed=100 + i, ess=ess)
+        ref = _run("per_step", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at, seed=100 + i, ess=ess)
+        assert col["SPEC"] == 9 and ref["SPEC"] != 9, tag
+        assert torch.equal(col["idx"], ref["idx"]), tag + ": final ancestors differ"
+        torch.testing.assert_close(col["means"], ref["means"], rtol=1e-9, atol=1e-11, equal_nan=True, msg=lambda m: tag + ": " + m)
+        torch.testing.assert_close(col["ll"], ref["ll"], rtol=1e-9, atol=1e-9, equal_nan=True, msg=lambda m: tag + ": " + m)
+        torch.testing.assert_close(col["w"], ref["w"], rtol=1e-9, atol=1e-11, equal_nan=True, msg=lambda m: tag + ": " + m)
