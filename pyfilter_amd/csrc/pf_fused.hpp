@@ -1154,9 +1154,9 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
         }
         PF_STAMP(a, 10);
 #ifdef PF_DEVTOOLS
-        if (PF_CUT(a, 4)) {  // development: keep the draws alive, stop here
-            if (on) lw_out[i0] = zt[0][0] + zt[VEC - 1][D - 1];
-            return;
+        if (PF_CUT(a, 4)) {  // development: keep the draws alive, skip the rest of the ROUND (every round runs: the cuts
+            if (on) lw_out[i0] = zt[0][0] + zt[VEC - 1][D - 1];  // nest for multi-round tiles too)
+            continue;
         }
 #endif
 
@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             }
             if (PF_CUT(a, 5)) {
                 if (pre_next) { if (VEC == 1) lw_out[i0] = pre_n[0]; else store_vec<T, VEC>(lw_out + i0, pre_n); }
-                return;
+                continue;
             }
             T piv[D];  // pivot of the moments of state step + 1: the mean of state step - 1, or the run's record (FusedArgs::pivot)
 #pragma unroll

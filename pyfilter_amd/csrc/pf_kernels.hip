@@ -1688,6 +1688,14 @@ static inline int column_threads(int64_t N, int vec) {
     const int64_t need = (N + vec - 1) / vec;
     return (int)(((need + PF_WAVE - 1) / PF_WAVE) * PF_WAVE);
 }
+// Particles per lane on the column route: the per-step geometry's (4 when N % 4 == 0) unless that leaves most of the chip
+// idle - few, small filters: one particle per lane then spreads a filter over four times the waves (a filter's waves share
+// a CU, so up to 4 SIMDs work on it instead of 1).  The state's layout in HBM and the Philox addressing do not depend on it.
+static inline int column_vec(const pf_filter_args* A, const Geom& g) {
+    if (g.vec == 1) return 1;
+    if (const char* e = getenv("PF_COLUMN_VEC")) return atoi(e) == 1 ? 1 : g.vec;  // development knob
+    return g.vec;
+}
 static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize) {
     int64_t np2 = 64;
     while (np2 < N) np2 <<= 1;
@@ -1706,7 +1714,7 @@ static inline bool column_eligible(const pf_filter_args* A, const Geom& g, int64
     if (const char* e = getenv("PF_NO_COLUMN")) if (atoi(e) != 0) return false;
     int64_t max_n = PF_COLUMN_MAX_N;
     if (const char* e = getenv("PF_COLUMN_MAX_N")) max_n = atoll(e);
-    if (A->N > max_n || column_threads(A->N, g.vec) > 1024) return false;
+    if (A->N > max_n || column_threads(A->N, g.vec) > 1024) return false;  // (at the geometry's width; column_vec() narrows only when it fits)
     return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4) <= 64 * 1024;  // (the default dynamic-LDS limit)
 }
 
@@ -1766,7 +1774,9 @@ int pf_run_column_f64(PF_COL_ARGS);
 #define PF_DEFINE_COLUMN(NAME, T)                                                                     \
     int NAME(PF_COL_ARGS) {                                                                           \
         const int D = A->model.dim;                                                                   \
-        if (g.vec == 4) {                                                                             \
+        int vec = column_vec(A, g);                                                                   \
+        if (vec == 1 && column_threads(A->N, 1) > 1024) vec = g.vec;                                  \
+        if (vec == 4) {                                                                               \
             if (D == 1) return column_run_impl<T, 1, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
             if (D == 2) return column_run_impl<T, 2, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
             return column_run_impl<T, 3, 4>(A, g, wl, t0, n_steps, st, kernel_ms);                    \

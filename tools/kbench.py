@@ -93,11 +93,19 @@ CONFIGS = {
 }
 
 
+def parse_shape(name):
+    """``<filter>_<lgo|boot|sv|lorenz>_<B>x<N>`` for shapes without a named entry, e.g. ``apf_lgo_128x512``."""
+    filt, kind, shape = name.split("_")[:3]
+    b, n = (int(v) for v in shape.split("x"))
+    model, prop = {"lgo": ("sine", "lgo"), "boot": ("sine", "bootstrap"), "sv": ("sv", "bootstrap"), "lorenz": ("lorenz", "bootstrap")}[kind]
+    return (model, filt, prop, n, b)
+
+
 def main():
     names = sys.argv[1:] or ["apf_lgo_1m", "apf_boot_1m", "sisr_boot_1m"]
     T = int(os.environ.get("KB_T", 100))
     for name in names:
-        cfg = CONFIGS[name]
+        cfg = CONFIGS.get(name) or parse_shape(name)
         if cfg[0] == "lorenz" and cfg[4] == 1:  # data simulated from the model (bench.py's generator), not noise
             import bench
             from pyfilter_amd import resampling as rs_

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where the HOST spends an SMC^2 fit (development tool): cProfile of one ``SMC2.fit`` at 128 theta-particles x 8 192 state
 particles, T = 500 - the per-rank job of an 8-GPU run, which is host-bound (tools/smc2_scaling_model.py).
-Usage: python tools/smc2_host_profile.py [n_theta]"""
+Usage: python tools/smc2_host_profile.py [n_theta] [n_state]"""
 import cProfile
 import math
 import os
@@ -23,6 +23,8 @@ def main():
     from pyfilter_amd.timeseries import models
 
     n_theta = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    n_state = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+    kw = {"block": int(os.environ["SMC2_BLOCK"])} if "SMC2_BLOCK" in os.environ else {}
     device, dtype, t_len = torch.device("cuda"), torch.float32, 500
     g = torch.Generator().manual_seed(123)
     x, ys = 0.0, []
@@ -37,8 +39,8 @@ def main():
         return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
 
     def fit(seed):
-        filt = APF(build, 8192, proposal=proposals.LinearGaussianObservations(), seed=2024 + seed)
-        alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=seed)
+        filt = APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=2024 + seed)
+        alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=seed, **kw)
         alg.fit(y)
         torch.cuda.synchronize()
         return alg
@@ -46,7 +48,7 @@ def main():
     fit(0)
     t0 = time.perf_counter()
     fit(1)
-    print(f"fit at {n_theta} theta: {1e3 * (time.perf_counter() - t0):.1f} ms")
+    print(f"fit at {n_theta} theta x {n_state}: {1e3 * (time.perf_counter() - t0):.1f} ms")
     pr = cProfile.Profile()
     pr.enable()
     fit(2)

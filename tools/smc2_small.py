@@ -45,7 +45,8 @@ def main():
             best = None
             for rep in range(4):
                 filt = APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=2024 + rep)
-                alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=rep)
+                alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=rep,
+                           **({"block": int(os.environ["SMC2_BLOCK"])} if "SMC2_BLOCK" in os.environ else {}))
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if mode.startswith("fit"):
