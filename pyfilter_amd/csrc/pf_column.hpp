@@ -22,6 +22,9 @@
 
 namespace pf {
 
+#ifndef PFC_EXP
+#define PFC_EXP 0  // development: compile-time ablations that price the stages of a column step (tools/column_ablation.sh)
+#endif
 #define PFC_MAXW 16       // waves per workgroup (1024 threads)
 #define PFC_OBS_WORDS 64  // observed flags of a launch as kernel arguments: 2048 steps per launch (longer runs: several)
 
@@ -78,16 +81,19 @@ template <typename T> __device__ __forceinline__ double inv_sum(double s) {
     }
 }
 
-// BIG: workgroups of more than 256 threads (N > 1024 with VEC = 4) - a separate instantiation so that the small ones are
-// not register-limited by the 1024-thread launch bound
+// TPB: the launch bound - 256 or 1024 threads per workgroup, each its own instantiation, so that the filters of <= 1024
+// particles are not register-limited by the bound the larger ones need (1024 threads: 128 VGPRs and, for D > 1, scratch)
+// USER: PF_HID_USER_AFFINE runs (the caller's (loc, scale) planes gathered at the ancestors) are their own instantiation -
+// carried as a run-time branch the planes' registers cost every built-in model occupancy (D = 3: 220 -> 256 VGPRs + AGPR
+// spills, one wave per SIMD instead of two: 7.7 -> 12.8 us per step at 1024 x 512, measured)
 //
 // Cross-wave exchanges carry (max, sums relative to that max) records, one per wave - the (max, +) semiring of the step
 // kernel's per-tile partials - so a reduction is ONE LDS exchange (write record, barrier, every thread folds the <= 16
 // records) instead of a max exchange followed by a sum exchange; a single-wave workgroup (N <= 64 VEC) exchanges nothing.
 // Barriers per step: scan records, cdf + particle planes, the new state's records (+ none for SISR steps that keep
 // their weights).
-template <typename T, int D, int VEC, bool BIG>
-__global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
+template <typename T, int D, int VEC, int TPB, bool USER>
+__global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pfc_lds[];
     const Geom& g = a.g;
     const int N = (int)g.N;
@@ -107,9 +113,10 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
     const bool apf = a.filter == PF_FILTER_APF;
     const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
     const int proposal = a.proposal;
-    const ModelDesc md = a.md;
+    ModelDesc md = a.md;
+    if constexpr (USER) md.hid_kind = PF_HID_USER_AFFINE;
     const int O = md.obs_dim;
-    const bool user = md.hid_kind == PF_HID_USER_AFFINE;
+    constexpr bool user = USER;
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const int i0 = tid * VEC;
     const bool on = i0 < N;
@@ -182,15 +189,17 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
             e1[j] = ej;
             v[0] += ej;
             v[1] += ej * ej;
+#if !(PFC_EXP & 8)
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const T xd = x[d][j] - piv[d];
                 v[2 + d] += ej * xd;
                 v[2 + D + d] += ej * xd * xd;
             }
+#endif
         }
 #pragma unroll
-        for (int k = 0; k < 2 + 2 * D; ++k) v[k] = wave_sum<T>(v[k]);
+        for (int k = 0; k < ((PFC_EXP & 8) ? 2 : 2 + 2 * D); ++k) v[k] = wave_sum<T>(v[k]);
         bool any = __ballot(poison) != 0ull;
         if (nw == 1) {
             M1 = (double)mw1;
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = x[d][j];
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if (user && on) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j);
+                if constexpr (user) { if (on) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j); }
                 const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj, false, um);
                 if (on && is_nan_or_posinf(pre)) poison = true;
                 rw[j] = on ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
@@ -393,9 +402,17 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
             }
             pfc_barrier(nw);  // cdf and x planes are in LDS
             // ---- ancestors: first q with cdf[q] >= p (searchsorted side = left), all VEC probes of a round in flight -------
+            // (measured against the step kernel's inverted grid - closed-form offspring ranges, head scatter, max-scan: three
+            // LDS round trips instead of log2 N + 2, but one more barrier and the range arithmetic - on one box: within
+            // -4 .. +4 %, slower at 5 of 9 shapes, profiles/r03_column_search_vs_inverted_grid.txt; the search stays)
             int q[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) q[j] = 0;
+#if PFC_EXP & 1
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] = (int)(pp[j] * nT);
+            if (false)
+#endif
             for (int st = np2 >> 1; st >= 1; st >>= 1) {
                 T v[VEC];
 #pragma unroll
@@ -437,7 +454,14 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
                     for (int j = 0; j < VEC; ++j) z[j][d] = zr[j];
                 }
             } else {
+#if PFC_EXP & 2
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (int d = 0; d < D; ++d) z[j][d] = T(0.25) * T(j + d) - T(0.3) + T(1e-3) * T(lane);
+#else
                 draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
+#endif
             }
         }
         T lw_new[VEC];
@@ -445,11 +469,15 @@ __global__ __launch_bounds__(BIG ? 1024 : 256) void k_fused_column(FusedArgs<T> 
         for (int j = 0; j < VEC; ++j) {
             T xn[D], w_new;
             UserMS<T, D> um = UserMS<T, D>::none();
-            if (user) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j]);  // the parent's
+            if constexpr (user) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j]);  // the parent's
             if (obs) {
                 const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn, um);
                 if (apf) {
+#if PFC_EXP & 4
+                    w_new = wi;
+#else
                     w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j], false, um);  // apf.py:43
+#endif
                     if (on && is_nan_or_posinf(w_new)) poison = true;
                 } else {
                     if (on && is_nan_or_posinf(wi)) poison = true;

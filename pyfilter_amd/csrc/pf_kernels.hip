@@ -1723,7 +1723,6 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                            hipStream_t st, float* kernel_ms) {
     FusedArgs<T> a = make_fused_args<T>(A, g, wl, t0);
     const int nt = column_threads(A->N, VEC);
-    const bool big = nt > 256;
     const size_t lds = column_lds_bytes(A->N, D, sizeof(T));
     // observed flags: the host's (baked into the launch arguments), the caller's device array, or derived from y here
     const bool auto_flags = !A->observed && !A->observed_dev;
@@ -1751,8 +1750,16 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                 if (A->observed[r.t0 + q]) r.obs_bits[q >> 5] |= 1u << (q & 31);
         a.step = r.t0;
         trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, 0, /*SPEC*/ 9, 0, 0);
-        if (big) hipLaunchKernelGGL((k_fused_column<T, D, VEC, true>), dim3(g.B), dim3(nt), lds, st, a, r);
-        else hipLaunchKernelGGL((k_fused_column<T, D, VEC, false>), dim3(g.B), dim3(nt), lds, st, a, r);
+        const bool user = A->model.hid_kind == PF_HID_USER_AFFINE;
+        auto launch = [&](auto tpb_c) {
+            constexpr int TPB = decltype(tpb_c)::value;
+            if (user) hipLaunchKernelGGL((k_fused_column<T, D, VEC, TPB, true>), dim3(g.B), dim3(nt), lds, st, a, r);
+            else hipLaunchKernelGGL((k_fused_column<T, D, VEC, TPB, false>), dim3(g.B), dim3(nt), lds, st, a, r);
+        };
+        // (a 512-thread bound would lift the scratch of the D > 1 kernels - but at > 128 VGPRs only ONE 8-wave workgroup fits
+        // a CU instead of two: 1024 x 2048 measured 33 us per step against 21)
+        if (nt <= 256) launch(std::integral_constant<int, 256>{});
+        else launch(std::integral_constant<int, 1024>{});
         done += r.n_steps;
     }
     if (kernel_ms) {
