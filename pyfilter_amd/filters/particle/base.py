@@ -392,8 +392,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         assert self._model is not None, "Model has not been initialized!"
         device, _ = self._device_dtype()
         if (not self._fused_capable(device) or not isinstance(y, torch.Tensor)
-                or os.environ.get("PF_NO_FUSED_BATCH", "0") == "1" or self._kernel_kind().is_user):
-            # (a user-defined affine process: the driver's loop over fused single steps - the callable runs between them)
+                or os.environ.get("PF_NO_FUSED_BATCH", "0") == "1"
+                or (self._kernel_kind().is_user and FilterResult.states_kept(self.record_states) != 1)):
+            # (a user-defined affine process with recorded states: the driver's loop over fused single steps)
             return super().batch_filter(y, bar=bar, init_state=init_state)
         return self._batch_filter_fused(y, init_state)
 
@@ -481,7 +482,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             ring = max(3, steps - wanted[0] + 1)  # slots for the states wanted[0] .. steps
         taped = ctx.z_tape is not None or ctx.u_tape is not None
         use_graph = ((not taped) and not ring and replay is None and not getattr(self, "_time_kernels", False)
-                     and os.environ.get("PF_NO_GRAPH", "0") != "1")
+                     and os.environ.get("PF_NO_GRAPH", "0") != "1" and not kind.is_user)
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
                self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes())
         plan = self._fused_plans.get(key) if use_graph else None
@@ -523,7 +524,20 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
 
         # NB the kernels index tapes / observations by the *local* step 0..steps-1 and draw Philox numbers by it too
         lib = L.load()
-        if getattr(self, "_time_kernels", False):
+        if kind.is_user:
+            # A user-defined affine process (PF_HID_USER_AFFINE): the caller's mean_scale callable runs ONCE per move, with
+            # torch ops on the current particles (a view of the plan's state buffer), into the plan's (loc, scale) planes; the
+            # move itself is one run of the fused kernels on the same buffers - no per-move state objects, allocations or
+            # copies (the driver's loop over filter() spends ~2x the time of the kernels on those).
+            hidden, full = self._model.hidden, x0.shape
+            es_u = hidden.event_shape
+            for s_ in range(steps):
+                ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
+                loc, scale = hidden.mean_scale(ts)
+                plan.user_loc.copy_(ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event))
+                plan.user_scale.copy_(ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event))
+                L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
+        elif getattr(self, "_time_kernels", False):
             kms = (C.c_float * 3)()
             L.check(lib.pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")
             self.kernel_ms = tuple(kms)
@@ -706,6 +720,10 @@ class _FusedPlan:
         self.params = torch.empty_like(filt._ctx.params)
         self.ws = L.new_workspace(n, b, device)
         self.observed_host = observed_host
+        self.user_loc = self.user_scale = None
+        if kind.is_user:  # the callable's one-step mean / scale of the current particles, refreshed before every move
+            self.user_loc = torch.empty((d, b, n), device=device, dtype=dtype)
+            self.user_scale = torch.empty((d, b, n), device=device, dtype=dtype)
         self.graph = None
 
         a = L.PfFilterArgs()
@@ -725,6 +743,7 @@ class _FusedPlan:
         a.step_counter = self.epoch.data_ptr()
         a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         a.ring = ring
+        a.user_loc, a.user_scale = L.ptr(self.user_loc), L.ptr(self.user_scale)
         self.args = a
 
     def destroy(self):

@@ -60,8 +60,13 @@ NAMES = ["lg1d_sisr_boot", "lg1d_apf_lgo", "sine_apf_lgo", "sine_sisr_lgo", "sin
 
 
 @both_routes
+@pytest.mark.parametrize("loop", ["run", "moves"])
 @pytest.mark.parametrize("name", NAMES)
-def test_lambda_defined_models_reproduce_the_reference_fixtures(name, kernel_route):
+def test_lambda_defined_models_reproduce_the_reference_fixtures(name, loop, kernel_route, monkeypatch):
+    """``loop``: "run" - ``batch_filter``'s own loop over the moves (callable -> planes -> one fused run per move, on the
+    plan's buffers); "moves" - the reference's driver loop over ``filter()`` (one fused single-step move per call)."""
+    if loop == "moves":
+        monkeypatch.setenv("PF_NO_FUSED_BATCH", "1")
     from pyfilter_amd import ops
     from pyfilter_amd.filters.particle import APF, SISR, proposals
     from pyfilter_amd.filters.particle.state import ParticleFilterCorrection

@@ -54,6 +54,7 @@ def main():
     fit(2)
     pr.disable()
     pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(40)
 
 
 if __name__ == "__main__":
