@@ -231,7 +231,11 @@ typedef struct pf_filter_args {
  * (prologue: the column's tile-prefix table + window start from the previous launch's per-tile partials; body: ancestors
  * + gather + propagate + weight + the next state's partials and tile-local scans; one workgroup per column keeps the
  * books: moments row, log-likelihood increment) plus one reduce launch for the incoming state.
- * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps). */
+ * finalize != 0 additionally flushes the moments / log-likelihood of the last state (row t0 + n_steps).
+ * A run may be issued in pieces on ONE argument block - e.g. move by move, (t0 = s, n_steps = 1, finalize = 1) for
+ * s = 0, 1, ...: the workspace carries the per-filter bookkeeping (log-likelihood bases, what has been flushed) from call
+ * to call, ll_total keeps accumulating, and the result rows land where the one-piece run writes them; t0 = 0 starts a
+ * fresh filter.  (PF_HID_USER_AFFINE runs are issued this way: the planes of move s + 1 need the particles move s wrote.) */
 int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
 
 /* hipGraph variant: captures the launch sequence pf_filter_run would issue (every pointer, the step flags and the

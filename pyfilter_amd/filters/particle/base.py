@@ -534,9 +534,14 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             for s_ in range(steps):
                 ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
                 loc, scale = hidden.mean_scale(ts)
-                plan.user_loc.copy_(ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event))
-                plan.user_scale.copy_(ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event))
+                planes = []
+                for val, buf in ((loc, plan.user_loc), (scale, plan.user_scale)):
+                    v = ops.to_soa(val.to(dtype).expand(full), self._batched, self._has_event)
+                    # (already a (D, B, N) plane - an unbatched scalar state's loc: read in place, kept alive past the launch)
+                    planes.append(v if v.is_contiguous() else buf.copy_(v))
+                a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
                 L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
+            a.user_loc, a.user_scale = plan.user_loc.data_ptr(), plan.user_scale.data_ptr()
         elif getattr(self, "_time_kernels", False):
             kms = (C.c_float * 3)()
             L.check(lib.pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")
