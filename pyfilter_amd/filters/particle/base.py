@@ -66,6 +66,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._z0 = None
         self._fused_plans = {}   # (shape, schedule) -> _FusedPlan (captured hipGraphs; a handful, evicted oldest first)
         self._single_plans = {}  # shape -> _SingleStepPlan (scratch of the online move; never evicted)
+        self._move_by_move = False  # testing knob: a fused run issued as its pieces (pf_filter_run(args, s, 1, 1), s = 0, 1, ..)
         self._draws = 0          # draw epoch: every new stream of random numbers (initial sample, fused run, online
                                  # move, step-by-step run) takes the next one - repeated calls are independent runs
         self._copies = 0
@@ -482,7 +483,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             ring = max(3, steps - wanted[0] + 1)  # slots for the states wanted[0] .. steps
         taped = ctx.z_tape is not None or ctx.u_tape is not None
         use_graph = ((not taped) and not ring and replay is None and not getattr(self, "_time_kernels", False)
-                     and os.environ.get("PF_NO_GRAPH", "0") != "1" and not kind.is_user)
+                     and os.environ.get("PF_NO_GRAPH", "0") != "1" and not kind.is_user and not self._move_by_move)
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
                self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes())
         plan = self._fused_plans.get(key) if use_graph else None
@@ -524,7 +525,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
 
         # NB the kernels index tapes / observations by the *local* step 0..steps-1 and draw Philox numbers by it too
         lib = L.load()
-        if kind.is_user:
+        if kind.is_user or self._move_by_move:
             # A user-defined affine process (PF_HID_USER_AFFINE): the caller's mean_scale callable runs ONCE per move, with
             # torch ops on the current particles (a view of the plan's state buffer), into the plan's (loc, scale) planes; the
             # move itself is one run of the fused kernels on the same buffers - no per-move state objects, allocations or
@@ -532,6 +533,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             hidden, full = self._model.hidden, x0.shape
             es_u = hidden.event_shape
             for s_ in range(steps):
+                if not kind.is_user:  # (``_move_by_move``: a built-in model issued the same way - the pieces of one run)
+                    L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
+                    continue
                 ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
                 loc, scale = hidden.mean_scale(ts)
                 planes = []
@@ -541,7 +545,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                     planes.append(v if v.is_contiguous() else buf.copy_(v))
                 a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
                 L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
-            a.user_loc, a.user_scale = plan.user_loc.data_ptr(), plan.user_scale.data_ptr()
+            if kind.is_user:
+                a.user_loc, a.user_scale = plan.user_loc.data_ptr(), plan.user_scale.data_ptr()
         elif getattr(self, "_time_kernels", False):
             kms = (C.c_float * 3)()
             L.check(lib.pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")

@@ -56,6 +56,29 @@ def test_fused_batch_filter_matches_reference(name, dt, kernel_route):
 
 
 @both_routes
+@pytest.mark.parametrize("name", [p[0] for p in PARAMS if p[1] == "f64"])
+def test_a_run_issued_move_by_move_equals_the_run(name, kernel_route):
+    """``pf_filter_run(args, s, 1, finalize = 1)`` for s = 0, 1, ... on ONE argument block (include/pf_amd.h: the workspace
+    carries the bookkeeping from call to call) lands on the reference's numbers like the one-piece run does - the way the
+    user-defined-model loop drives the kernels."""
+    case = next(c for c in CASES if c["name"] == name)
+    g = load_golden(name, "f64")
+    if case.get("observe_every_step", 1) != 1 or case.get("record_states"):
+        pytest.skip("the move-by-move knob covers plain runs")
+    filt = build_filter_from_case(case, g, DT["f64"], "cuda")
+    filt._move_by_move = True
+    res = filt.batch_filter(g["y"].cuda(), bar=False)
+    tol = _tols("f64")
+    torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
+    torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=tol["rtol"] * 10, atol=tol["atol"])
+    torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], **tol)
+    last = res.latest_state
+    assert torch.equal(last.previous_indices.cpu(), g["step_idx"][-1]), "final ancestors differ"
+    torch.testing.assert_close(last.timeseries_state.value.cpu(), g["step_x"][-1], **tol)
+    torch.testing.assert_close(last.weights.cpu(), g["step_w"][-1], equal_nan=True, **tol)
+
+
+@both_routes
 @pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f32"])
 def test_float32_teacher_forced_steps(name, dt, kernel_route):
     """float32, one step at a time from the reference's own previous state (so rounding cannot accumulate): new
