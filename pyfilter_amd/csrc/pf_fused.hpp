@@ -649,6 +649,25 @@ __device__ __forceinline__ ColSums column_sums(const ColPartials<WITH_Q, NX>& in
     }
     return ColSums{MR, tot, qtot};
 }
+// A column of ONE tile (many filters of a few thousand particles - SMC^2's 1024 x 8192): the table is (0, ~1) and its scale
+// 1 / S - the operations column_sums performs on a single record, in its order (so the bookkeeper, which runs column_sums
+// on the same record, agrees bit for bit), without the workgroup scan, its exchanges and the three padded records per thread.
+template <typename T, bool WITH_Q>
+__device__ __forceinline__ ColSums column_sums_one_tile(double m, double s, double q, double* ptl, double* ftl) {
+#pragma clang fp contract(off)
+    const double MR = (double)(T)m;
+    const double ef = exp_diff_t<T>(m, MR);
+    const double run = s * ef;
+    const double qs = WITH_Q ? q * ef * ef : 0.0;
+    const double inv_tot = 1.0 / run;
+    if (threadIdx.x == 0) {
+        ptl[0] = 0.0;
+        ptl[1] = run * inv_tot;
+        ftl[0] = ef * inv_tot;
+    }
+    __syncthreads();
+    return ColSums{MR, run, qs};
+}
 // multinomial: exclusive prefixes of the tiles' Exp(1) spacing sums in pel[0 .. tiles) and, one slot behind them
 // (pel[tiles + 1]), the grand total including the closing spacing `tail`.  Same thread-to-tile mapping as column_sums.
 __device__ __forceinline__ void spacing_table(const double* part, int64_t stride, int64_t cb, int tiles, double tail,
@@ -853,7 +872,14 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
     // the column's partials are requested ...
     ColPartials<true, 0> p1;
     ColPartials<false, 0> p2;
-    if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
+    const bool one_tile = g.tiles == 1 && a.debug_cut != 77;  // (uniform; PF_DEBUG_CUT=77: the general path - A/B tests)
+    double m1 = 0.0, s1 = 0.0, q1 = 0.0;
+    if (one_tile) {
+        const double* part = a.part_r();
+        m1 = part[(two ? PQ_M2 : PQ_M1) * stride + cb];
+        s1 = part[(two ? PQ_S2 : PQ_S1) * stride + cb];
+        q1 = two ? 0.0 : part[PQ_Q1 * stride + cb];
+    } else if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
     else load_col_partials<true, 0>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, 0, p1);
     // ... and, while they travel (written by other CUs one launch ago: an Infinity-Cache round trip), the first round's
     // standard normals are drawn: ~150 VALU instructions per thread that depend on nothing but the thread's index
@@ -864,7 +890,15 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
         if (i0 < g.N) draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)step, (uint64_t)((int64_t)b * g.N + i0), z0);
         pl.have_z0 = true;
     }
-    if (two) {
+    if (one_tile) {
+        if (two) {
+            column_sums_one_tile<T, false>(m1, s1, q1, sh.ptl, sh.ftl);
+            pl.resample = true;
+        } else {
+            const ColSums c = column_sums_one_tile<T, true>(m1, s1, q1, sh.ptl, sh.ftl);
+            pl.resample = c.S * c.S / c.Q < a.thr_abs;
+        }
+    } else if (two) {
         column_sums<T, false, true>(p2, g.tiles, sh.ptl, sh.ftl, redm_d, sh.red);
         pl.resample = true;  // apf.py:29-31
     } else {
@@ -880,6 +914,15 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
     } else {
         pl.ub = a.u_tape ? u_taped : uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)step, (uint64_t)b);
         p = grid_position<T>((int64_t)k * g.tile_elems, pl.ub, T(g.N));
+    }
+    if (one_tile && a.debug_cut != 78) {
+        // ONE tile: its first position is the column's first - index 0 is "at or before its ancestor" by definition, so the
+        // window needs no probing (a dependent round of loads on every workgroup's critical path).  Should the first
+        // ancestor lie beyond the first window - the column's weight concentrated at its end - the body walks on window by
+        // window, as it does for any stretch of negligible weights.
+        pl.j0 = 0;
+        pl.kt0 = 0;
+        return pl;
     }
     if (threadIdx.x < PF_WAVE) {
         const int lane = threadIdx.x;
