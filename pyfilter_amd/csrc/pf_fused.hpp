@@ -668,6 +668,39 @@ __device__ __forceinline__ ColSums column_sums_one_tile(double m, double s, doub
     __syncthreads();
     return ColSums{MR, run, qs};
 }
+// A column of 2 .. 64 tiles (64 x 65 536, 128 x 8 192, ...): one record per LANE - every wave computes the sums on its own
+// (wave maximum, wave scan: no workgroup exchange, no padded records), wave 0 writes the table.  The operations are the
+// ones column_sums performs when thread t holds tile t alone (IT = 1: the other waves contribute exact zeros), in its order,
+// so the bookkeeper's column_sums on the same records agrees bit for bit.  Ends with a barrier (the table is readable).
+template <typename T, bool WITH_Q>
+__device__ __forceinline__ ColSums column_sums_wave(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
+                                                    int slot_s, double* ptl, double* ftl) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool on = lane < tiles;
+    const double m = on ? part[slot_m * stride + cb + lane] : -__builtin_huge_val();
+    const double s = on ? part[slot_s * stride + cb + lane] : 0.0;
+    const double q = (WITH_Q && on) ? part[PQ_Q1 * stride + cb + lane] : 0.0;
+    const double MR = (double)wave_max<T>((T)m);
+    const double ef = exp_diff_t<T>(m, MR);
+    double run = 0.0, qs = 0.0;
+    run += s * ef;
+    if (WITH_Q) qs += q * ef * ef;
+    const double incl_w = wave_scan_incl(run, lane);
+    const double qtot = WITH_Q ? 0.0 + wave_sum(qs) : 0.0;
+    const double tot = 0.0 + lane_get(incl_w, 63);
+    const double excl = 0.0 + incl_w - run;
+    const double inv_tot = 1.0 / tot;
+    if (wid == 0) {
+        if (lane == 0) ptl[0] = 0.0;
+        if (on) {
+            ptl[lane + 1] = (excl + run) * inv_tot;
+            ftl[lane] = ef * inv_tot;
+        }
+    }
+    __syncthreads();
+    return ColSums{MR, tot, qtot};
+}
 // multinomial: exclusive prefixes of the tiles' Exp(1) spacing sums in pel[0 .. tiles) and, one slot behind them
 // (pel[tiles + 1]), the grand total including the closing spacing `tail`.  Same thread-to-tile mapping as column_sums.
 __device__ __forceinline__ void spacing_table(const double* part, int64_t stride, int64_t cb, int tiles, double tail,
@@ -879,8 +912,12 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
         m1 = part[(two ? PQ_M2 : PQ_M1) * stride + cb];
         s1 = part[(two ? PQ_S2 : PQ_S1) * stride + cb];
         q1 = two ? 0.0 : part[PQ_Q1 * stride + cb];
-    } else if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
-    else load_col_partials<true, 0>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, 0, p1);
+    }
+    const bool few_tiles = !one_tile && g.tiles <= PF_WAVE && a.debug_cut != 79;  // (uniform; 79: the general path - A/B tests)
+    if (!one_tile && !few_tiles) {
+        if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
+        else load_col_partials<true, 0>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, 0, p1);
+    }
     // ... and, while they travel (written by other CUs one launch ago: an Infinity-Cache round trip), the first round's
     // standard normals are drawn: ~150 VALU instructions per thread that depend on nothing but the thread's index
     // (EARLY_Z: only the kernels with registers to spare - holding the draws across the prologue costs the D = 3 and the
@@ -896,6 +933,14 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
             pl.resample = true;
         } else {
             const ColSums c = column_sums_one_tile<T, true>(m1, s1, q1, sh.ptl, sh.ftl);
+            pl.resample = c.S * c.S / c.Q < a.thr_abs;
+        }
+    } else if (few_tiles) {
+        if (two) {
+            column_sums_wave<T, false>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, sh.ptl, sh.ftl);
+            pl.resample = true;
+        } else {
+            const ColSums c = column_sums_wave<T, true>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, sh.ptl, sh.ftl);
             pl.resample = c.S * c.S / c.Q < a.thr_abs;
         }
     } else if (two) {
