@@ -153,9 +153,11 @@ def workspace(n: int, b: int, device: torch.device) -> torch.Tensor:
     """Scratch for the stand-alone primitives, cached per (N, B, device, stream)."""
     key = (n, b, device.index, stream_ptr())
     ws = _ws_cache.get(key)
-    if ws is None:
-        nbytes = C.c_size_t(0)
-        check(load().pf_workspace_bytes(n, b, MAX_D, C.byref(nbytes)), "pf_workspace_bytes")
+    nbytes = C.c_size_t(0)
+    # (asked every time - a host-side formula: the tile geometry, hence the size, follows development knobs such as
+    # PF_TARGET_WGS that a process may change between calls; a cached buffer sized under another setting is replaced)
+    check(load().pf_workspace_bytes(n, b, MAX_D, C.byref(nbytes)), "pf_workspace_bytes")
+    if ws is None or ws.numel() < nbytes.value:
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
         if len(_ws_cache) > 64:
             _ws_cache.clear()

@@ -110,9 +110,14 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * N) * sizeof(T) + 15) & ~(size_t)15));
     double* const recB = recA + 2 * PFC_MAXW;  // [2][PFC_MAXW][KB]: double buffered by step parity
 
+#if PFC_EXP & 16  // (ablation: what compile-time knowledge of the run's kind would buy - APF + LGO + systematic + sine, Philox)
+    constexpr bool apf = true, multinomial = false;
+    constexpr int proposal = PF_PROP_LGO;
+#else
     const bool apf = a.filter == PF_FILTER_APF;
     const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
     const int proposal = a.proposal;
+#endif
     ModelDesc md = a.md;
     if constexpr (USER) md.hid_kind = PF_HID_USER_AFFINE;
     const int O = md.obs_dim;
@@ -152,7 +157,16 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
     load_col_params<T, D>(a, b, run.t0, false, cp);
+#if PFC_EXP & 16
+    md.hid_kind = PF_HID_SINE_EM;
+    md.obs_kind = PF_OBS_LINEAR;
+    md.obs_dim = 1;
+    a.z_tape = nullptr;
+#endif
     cc.prepare(md, cp);
+#if PFC_EXP & 16
+    __builtin_assume(cc.fast);
+#endif
     auto y_row = [&](int t) { return a.y + ((int64_t)t * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O; };
 
     // pivot of the weighted moments: the column's first particle, then (about) the previous state's mean
