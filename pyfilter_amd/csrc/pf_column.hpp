@@ -92,7 +92,12 @@ template <typename T> __device__ __forceinline__ double inv_sum(double s) {
 // records) instead of a max exchange followed by a sum exchange; a single-wave workgroup (N <= 64 VEC) exchanges nothing.
 // Barriers per step: scan records, cdf + particle planes, the new state's records (+ none for SISR steps that keep
 // their weights).
-template <typename T, int D, int VEC, int TPB, bool USER>
+// KIND / FILT / PROP: the run's hidden-process kind (scalar state: PF_HID_LINEAR / _SINE_EM / _OU with a linear-Gaussian
+// observation - the closed forms - or _VERHULST_EM with the stochastic-volatility observation), filter and proposal as compile-time constants, -1 = run-time values.  Specialised instantiations
+// (float, four particles per lane, <= 256 threads, Philox normals) drop the model-kind switches, the generic
+// (non-closed-form) arithmetic and the other filter's / proposal's paths from the loop: 17 - 19 % per step
+// (profiles/r03_column_specialisation_bound.txt); everything else takes the run-time kernel.
+template <typename T, int D, int VEC, int TPB, bool USER, int KIND = -1, int FILT = -1, int PROP = -1>
 __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pfc_lds[];
     const Geom& g = a.g;
@@ -110,14 +115,9 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * N) * sizeof(T) + 15) & ~(size_t)15));
     double* const recB = recA + 2 * PFC_MAXW;  // [2][PFC_MAXW][KB]: double buffered by step parity
 
-#if PFC_EXP & 16  // (ablation: what compile-time knowledge of the run's kind would buy - APF + LGO + systematic + sine, Philox)
-    constexpr bool apf = true, multinomial = false;
-    constexpr int proposal = PF_PROP_LGO;
-#else
-    const bool apf = a.filter == PF_FILTER_APF;
+    const bool apf = FILT >= 0 ? (FILT == PF_FILTER_APF) : (a.filter == PF_FILTER_APF);
     const bool multinomial = a.resampler == PF_RESAMPLE_MULTINOMIAL;
-    const int proposal = a.proposal;
-#endif
+    const int proposal = PROP >= 0 ? PROP : a.proposal;
     ModelDesc md = a.md;
     if constexpr (USER) md.hid_kind = PF_HID_USER_AFFINE;
     const int O = md.obs_dim;
@@ -157,16 +157,15 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     ColParams<T, D> cp;
     ColConsts<T, D> cc;
     load_col_params<T, D>(a, b, run.t0, false, cp);
-#if PFC_EXP & 16
-    md.hid_kind = PF_HID_SINE_EM;
-    md.obs_kind = PF_OBS_LINEAR;
-    md.obs_dim = 1;
-    a.z_tape = nullptr;
-#endif
+    if constexpr (KIND >= 0) {  // (the host selects these instantiations for exactly such runs)
+        static_assert(D == 1 && !USER, "specialised column kernels: scalar built-in closed-form models");
+        md.hid_kind = KIND;
+        md.obs_kind = (KIND == PF_HID_VERHULST_EM) ? PF_OBS_SV : PF_OBS_LINEAR;  // (Verhulst: the stochastic-volatility built-in)
+        md.obs_dim = 1;
+    }
+    const T* const z_tape = (KIND >= 0) ? nullptr : a.z_tape;  // (specialised runs draw their normals: Philox)
     cc.prepare(md, cp);
-#if PFC_EXP & 16
-    __builtin_assume(cc.fast);
-#endif
+    if constexpr (KIND >= 0) __builtin_assume(cc.fast == (KIND != PF_HID_VERHULST_EM));
     auto y_row = [&](int t) { return a.y + ((int64_t)t * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O; };
 
     // pivot of the weighted moments: the column's first particle, then (about) the previous state's mean
@@ -457,8 +456,8 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
             for (int d = 0; d < D; ++d) z[j][d] = T(0);
         if (on) {
-            if (a.z_tape) {
-                const T* zs = a.z_tape + (int64_t)t * D * g.B * N;
+            if (z_tape) {
+                const T* zs = z_tape + (int64_t)t * D * g.B * N;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     T zr[VEC];

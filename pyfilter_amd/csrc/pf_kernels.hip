@@ -1749,7 +1749,18 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             for (int q = 0; q < r.n_steps; ++q)
                 if (A->observed[r.t0 + q]) r.obs_bits[q >> 5] |= 1u << (q & 31);
         a.step = r.t0;
-        trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, 0, /*SPEC*/ 9, 0, 0);
+        bool spec_ok = false;  // a specialised instantiation exists for this run (see below)
+        if constexpr (sizeof(T) == 4 && D == 1 && VEC == 4) {
+            const int hk = A->model.hid_kind;
+            const char* ge = getenv("PF_COLUMN_GENERIC");  // (read per run: tests switch it)
+            const bool generic_only = ge != nullptr && atoi(ge) != 0;
+            const bool closed = A->model.obs_kind == PF_OBS_LINEAR && (hk == PF_HID_LINEAR || hk == PF_HID_SINE_EM || hk == PF_HID_OU) &&
+                                (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
+            const bool sv = A->model.obs_kind == PF_OBS_SV && hk == PF_HID_VERHULST_EM && A->proposal == PF_PROP_BOOTSTRAP;
+            spec_ok = nt <= 256 && !A->z_tape && !generic_only && (closed || sv);
+        }
+        trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, spec_ok ? 1 : 0,
+                     /*SPEC*/ 9, spec_ok ? A->model.hid_kind : 0, 0);
         const bool user = A->model.hid_kind == PF_HID_USER_AFFINE;
         auto launch = [&](auto tpb_c) {
             constexpr int TPB = decltype(tpb_c)::value;
@@ -1758,7 +1769,36 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         };
         // (a 512-thread bound would lift the scratch of the D > 1 kernels - but at > 128 VGPRs only ONE 8-wave workgroup fits
         // a CU instead of two: 1024 x 2048 measured 33 us per step against 21)
-        if (nt <= 256) launch(std::integral_constant<int, 256>{});
+        // specialised instantiations (pf_column.hpp: KIND / FILT / PROP): float, scalar closed-form models, four particles
+        // per lane, <= 256 threads, Philox normals; PF_COLUMN_GENERIC=1 keeps the run-time kernel (tests compare the two)
+        bool specialised = false;
+        if constexpr (sizeof(T) == 4 && D == 1 && VEC == 4) {
+            const int hk = A->model.hid_kind;
+            if (spec_ok) {
+                specialised = true;
+                auto go = [&](auto kind_c, auto filt_c, auto prop_c) {
+                    hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, decltype(kind_c)::value, decltype(filt_c)::value,
+                                                       decltype(prop_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                };
+                auto with_prop = [&](auto kind_c, auto filt_c) {
+                    if (A->proposal == PF_PROP_LGO) go(kind_c, filt_c, std::integral_constant<int, PF_PROP_LGO>{});
+                    else go(kind_c, filt_c, std::integral_constant<int, PF_PROP_BOOTSTRAP>{});
+                };
+                auto with_filt = [&](auto kind_c) {
+                    if (A->filter == PF_FILTER_APF) with_prop(kind_c, std::integral_constant<int, PF_FILTER_APF>{});
+                    else with_prop(kind_c, std::integral_constant<int, PF_FILTER_SISR>{});
+                };
+                if (hk == PF_HID_LINEAR) with_filt(std::integral_constant<int, PF_HID_LINEAR>{});
+                else if (hk == PF_HID_SINE_EM) with_filt(std::integral_constant<int, PF_HID_SINE_EM>{});
+                else if (hk == PF_HID_OU) with_filt(std::integral_constant<int, PF_HID_OU>{});
+                else if (A->filter == PF_FILTER_APF)  // Verhulst + stochastic volatility: Bootstrap only
+                    go(std::integral_constant<int, PF_HID_VERHULST_EM>{}, std::integral_constant<int, PF_FILTER_APF>{}, std::integral_constant<int, PF_PROP_BOOTSTRAP>{});
+                else
+                    go(std::integral_constant<int, PF_HID_VERHULST_EM>{}, std::integral_constant<int, PF_FILTER_SISR>{}, std::integral_constant<int, PF_PROP_BOOTSTRAP>{});
+            }
+        }
+        if (specialised) {
+        } else if (nt <= 256) launch(std::integral_constant<int, 256>{});
         else launch(std::integral_constant<int, 1024>{});
         done += r.n_steps;
     }

@@ -81,7 +81,7 @@ def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(),
     last = res.latest_state
     return dict(means=res.filter_means.cpu(), var=res.filter_variance.cpu(), ll=res.loglikelihood.cpu(),
                 x=last.timeseries_state.value.cpu(), w=last.weights.cpu(), idx=last.previous_indices.cpu(),
-                ll_last=last.get_loglikelihood().cpu(), SPEC=trace[-1]["SPEC"])
+                ll_last=last.get_loglikelihood().cpu(), SPEC=trace[-1]["SPEC"], FAST=trace[-1]["FAST"])
 
 
 CASES = [
@@ -148,6 +148,27 @@ def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_nam
     assert (diff <= 8.0 * se + 1e-4 * c64["means"].abs() + 1e-5).all(), (diff / (se + 1e-12)).max()
     assert torch.isfinite(c32["ll"]).all()
     assert ((c32["ll"].double() - c64["ll"]).abs() <= 0.08 * math.sqrt(t_len) * max(1.0, float(c64["ll"].abs().max()) / t_len) + 1e-2).all()
+
+
+@pytest.mark.parametrize("resampler", ["systematic", "multinomial"])
+@pytest.mark.parametrize("prop", ["bootstrap", "lgo"])
+@pytest.mark.parametrize("filt_name", ["sisr", "apf"])
+@pytest.mark.parametrize("kind", ["lg", "sine", "ou", "sv"])
+def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, prop, resampler, monkeypatch):
+    """float32 runs of the scalar closed-form models take instantiations of the column kernel with the model kind, filter
+    and proposal as compile-time constants (``pf_column.hpp``: KIND / FILT / PROP).  Same draws, same arithmetic: they
+    must reproduce the run-time kernel (``PF_COLUMN_GENERIC=1``) - NaN observations included - and be the ones that ran."""
+    if kind == "sv" and prop == "lgo":
+        pytest.skip("the stochastic-volatility observation has no linear-Gaussian proposal")
+    n, b, t_len, nan_at = 512, 5, 40, (3, 17)
+    spec = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
+    monkeypatch.setenv("PF_COLUMN_GENERIC", "1")
+    gen = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
+    assert spec["SPEC"] == 9 and spec["FAST"] == 1 and gen["SPEC"] == 9 and gen["FAST"] == 0
+    assert torch.equal(spec["idx"], gen["idx"]), "ancestors differ"
+    torch.testing.assert_close(spec["means"], gen["means"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(spec["ll"], gen["ll"], rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(spec["x"], gen["x"], rtol=1e-6, atol=1e-7)
 
 
 def test_runs_longer_than_one_launch_carries_the_state_through():
