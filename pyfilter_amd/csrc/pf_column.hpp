@@ -158,14 +158,14 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     ColConsts<T, D> cc;
     load_col_params<T, D>(a, b, run.t0, false, cp);
     if constexpr (KIND >= 0) {  // (the host selects these instantiations for exactly such runs)
-        static_assert(D == 1 && !USER, "specialised column kernels: scalar built-in closed-form models");
+        static_assert(!USER && (D == 1) == (KIND != PF_HID_LORENZ63_EM), "specialised column kernels: built-in models");
         md.hid_kind = KIND;
         md.obs_kind = (KIND == PF_HID_VERHULST_EM) ? PF_OBS_SV : PF_OBS_LINEAR;  // (Verhulst: the stochastic-volatility built-in)
-        md.obs_dim = 1;
+        if constexpr (D == 1) md.obs_dim = 1;
     }
     const T* const z_tape = (KIND >= 0) ? nullptr : a.z_tape;  // (specialised runs draw their normals: Philox)
     cc.prepare(md, cp);
-    if constexpr (KIND >= 0) __builtin_assume(cc.fast == (KIND != PF_HID_VERHULST_EM));
+    if constexpr (KIND >= 0) __builtin_assume(cc.fast == (D == 1 && KIND != PF_HID_VERHULST_EM));
     auto y_row = [&](int t) { return a.y + ((int64_t)t * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O; };
 
     // pivot of the weighted moments: the column's first particle, then (about) the previous state's mean

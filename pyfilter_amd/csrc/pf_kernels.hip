@@ -1759,6 +1759,11 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             const bool sv = A->model.obs_kind == PF_OBS_SV && hk == PF_HID_VERHULST_EM && A->proposal == PF_PROP_BOOTSTRAP;
             spec_ok = nt <= 256 && !A->z_tape && !generic_only && (closed || sv);
         }
+        if constexpr (sizeof(T) == 4 && D == 3 && VEC == 4) {  // Lorenz-63
+            const char* ge = getenv("PF_COLUMN_GENERIC");
+            spec_ok = nt <= 256 && !A->z_tape && !(ge != nullptr && atoi(ge) != 0) && A->model.obs_kind == PF_OBS_LINEAR &&
+                      A->model.hid_kind == PF_HID_LORENZ63_EM && (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
+        }
         trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, spec_ok ? 1 : 0,
                      /*SPEC*/ 9, spec_ok ? A->model.hid_kind : 0, 0);
         const bool user = A->model.hid_kind == PF_HID_USER_AFFINE;
@@ -1795,6 +1800,21 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                     go(std::integral_constant<int, PF_HID_VERHULST_EM>{}, std::integral_constant<int, PF_FILTER_APF>{}, std::integral_constant<int, PF_PROP_BOOTSTRAP>{});
                 else
                     go(std::integral_constant<int, PF_HID_VERHULST_EM>{}, std::integral_constant<int, PF_FILTER_SISR>{}, std::integral_constant<int, PF_PROP_BOOTSTRAP>{});
+            }
+        }
+        if constexpr (sizeof(T) == 4 && D == 3 && VEC == 4) {
+            if (spec_ok) {
+                specialised = true;
+                auto go3 = [&](auto filt_c, auto prop_c) {
+                    hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, PF_HID_LORENZ63_EM, decltype(filt_c)::value,
+                                                       decltype(prop_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                };
+                auto with_prop3 = [&](auto filt_c) {
+                    if (A->proposal == PF_PROP_LGO) go3(filt_c, std::integral_constant<int, PF_PROP_LGO>{});
+                    else go3(filt_c, std::integral_constant<int, PF_PROP_BOOTSTRAP>{});
+                };
+                if (A->filter == PF_FILTER_APF) with_prop3(std::integral_constant<int, PF_FILTER_APF>{});
+                else with_prop3(std::integral_constant<int, PF_FILTER_SISR>{});
             }
         }
         if (specialised) {

@@ -153,7 +153,7 @@ def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_nam
 @pytest.mark.parametrize("resampler", ["systematic", "multinomial"])
 @pytest.mark.parametrize("prop", ["bootstrap", "lgo"])
 @pytest.mark.parametrize("filt_name", ["sisr", "apf"])
-@pytest.mark.parametrize("kind", ["lg", "sine", "ou", "sv"])
+@pytest.mark.parametrize("kind", ["lg", "sine", "ou", "sv", "lorenz"])
 def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, prop, resampler, monkeypatch):
     """float32 runs of the scalar closed-form models take instantiations of the column kernel with the model kind, filter
     and proposal as compile-time constants (``pf_column.hpp``: KIND / FILT / PROP).  Same draws, same arithmetic: they
@@ -165,6 +165,20 @@ def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, p
     monkeypatch.setenv("PF_COLUMN_GENERIC", "1")
     gen = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
     assert spec["SPEC"] == 9 and spec["FAST"] == 1 and gen["SPEC"] == 9 and gen["FAST"] == 0
+    if kind == "lorenz" and prop == "bootstrap":
+        # the Lorenz drift folds into different fused multiply-adds once its kind is a constant: an ulp in a chaotic state
+        # moves an ancestor, after which the two are different - equally valid - Monte-Carlo runs.  What can be pinned: ONE
+        # move from the same state (same ancestors, new particles and moments to float rounding), and that long runs stay finite.
+        assert torch.isfinite(spec["ll"]).all() and torch.isfinite(spec["means"]).all()
+        one_s = _run("column", kind, filt_name, prop, resampler, n, b, 1, torch.float32)
+        monkeypatch.delenv("PF_COLUMN_GENERIC")
+        one_f = _run("column", kind, filt_name, prop, resampler, n, b, 1, torch.float32)
+        assert one_s["FAST"] == 0 and one_f["FAST"] == 1
+        assert torch.equal(one_s["idx"], one_f["idx"])
+        torch.testing.assert_close(one_f["x"], one_s["x"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(one_f["means"], one_s["means"], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(one_f["ll"], one_s["ll"], rtol=1e-4, atol=1e-3)
+        return
     assert torch.equal(spec["idx"], gen["idx"]), "ancestors differ"
     torch.testing.assert_close(spec["means"], gen["means"], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(spec["ll"], gen["ll"], rtol=1e-6, atol=1e-5)

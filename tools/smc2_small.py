@@ -45,8 +45,22 @@ def main():
             best = None
             for rep in range(4):
                 filt = APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=2024 + rep)
+                phases = {"update": 0.0, "filter_block": 0.0, "batch_filter": 0.0}
                 alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=rep,
                            **({"block": int(os.environ["SMC2_BLOCK"])} if "SMC2_BLOCK" in os.environ else {}))
+                if os.environ.get("SMC2_PHASES"):  # host wall time inside the rejuvenation kernel / the fused calls (no syncs added)
+                    def timed(obj, name, key):
+                        f = getattr(obj, name)
+
+                        def g(*a, **k):
+                            t1 = time.perf_counter()
+                            try:
+                                return f(*a, **k)
+                            finally:
+                                phases[key] += time.perf_counter() - t1
+                        setattr(obj, name, g)
+                    timed(alg._kernel, "update", "update")
+                    timed(filt, "filter_block", "filter_block")
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 if mode.startswith("fit"):
@@ -58,9 +72,10 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 if rep and (best is None or dt < best[0]):
-                    best = (dt, len(alg._kernel.acceptance_history), int(filt.particles[0]), alg.posterior_mean(state).tolist())
+                    best = (dt, len(alg._kernel.acceptance_history), int(filt.particles[0]), alg.posterior_mean(state).tolist(), dict(phases))
             print(f"{route:9s} {mode:14s}: {1e3 * best[0]:8.1f} ms  ({n_theta * n_state * t_len / best[0]:.3e} particle-steps/s)  PMMH moves {best[1]}, "
-                  f"state particles at the end {best[2]}, posterior mean {[round(v, 3) for v in best[3]]}", flush=True)
+                  f"state particles at the end {best[2]}, posterior mean {[round(v, 3) for v in best[3]]}"
+                  + ("  host ms inside: " + str({k: round(1e3 * v, 1) for k, v in best[4].items()}) if os.environ.get("SMC2_PHASES") else ""), flush=True)
 
 
 if __name__ == "__main__":
