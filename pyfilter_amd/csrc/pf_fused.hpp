@@ -905,7 +905,12 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
     // the column's partials are requested ...
     ColPartials<true, 0> p1;
     ColPartials<false, 0> p2;
-    const bool one_tile = g.tiles == 1 && a.debug_cut != 77;  // (uniform; PF_DEBUG_CUT=77: the general path - A/B tests)
+    // Both shortcuts below exist in the MULTI-round instantiations only (1024 x 8192, 64 x 65 536, ...): compiled into the
+    // single-round kernels as well they cost the headline shape (2^20 x 1: 1024 tiles, neither branch taken) 0.3 us per
+    // step - 14.55 -> 14.9, same box, three alternations (profiles/r03_prologue_shortcuts_single_round_ab.txt) - through
+    // nothing but code layout / scheduling; branch hints and out-of-line helpers did not recover it.
+    constexpr bool SHORT = MULTI;
+    const bool one_tile = SHORT && g.tiles == 1 && a.debug_cut != 77;  // (uniform; PF_DEBUG_CUT=77: the general path - A/B tests)
     double m1 = 0.0, s1 = 0.0, q1 = 0.0;
     if (one_tile) {
         const double* part = a.part_r();
@@ -913,7 +918,7 @@ __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, cons
         s1 = part[(two ? PQ_S2 : PQ_S1) * stride + cb];
         q1 = two ? 0.0 : part[PQ_Q1 * stride + cb];
     }
-    const bool few_tiles = !one_tile && g.tiles <= PF_WAVE && a.debug_cut != 79;  // (uniform; 79: the general path - A/B tests)
+    const bool few_tiles = SHORT && !one_tile && g.tiles <= PF_WAVE && a.debug_cut != 79;  // (uniform; 79: the general path)
     if (!one_tile && !few_tiles) {
         if (two) load_col_partials<false, 0>(a.part_r(), stride, cb, g.tiles, PQ_M2, PQ_S2, 0, p2);
         else load_col_partials<true, 0>(a.part_r(), stride, cb, g.tiles, PQ_M1, PQ_S1, 0, p1);
@@ -1060,6 +1065,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     const int proposal = (PROP >= 0) ? PROP : a.proposal;
     ModelDesc md = a.md;
     if constexpr (!FAST && MK == 1) { md.hid_kind = PF_HID_VERHULST_EM; md.obs_kind = PF_OBS_SV; md.obs_dim = 1; }
+    if constexpr (!FAST && MK == 4) { md.hid_kind = PF_HID_LORENZ63_EM; md.obs_kind = PF_OBS_LINEAR; }  // (D = 3)
     constexpr bool USER = !FAST && MK == 3;  // PF_HID_USER_AFFINE (one step per run: no next step is prepared here)
     constexpr int WIN = StepShared<T, D, VEC>::WIN;
     // the window of cdf entries a round stages: 256 * (VEC + V1).  The inverted-grid variant reads 256 entries beyond one

@@ -1597,6 +1597,11 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             if constexpr (sizeof(T) == 4 && !FAST && D == 1) {
                 if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) return launch(std::integral_constant<int, 1>{});
             }
+            if constexpr (sizeof(T) == 4 && !FAST && D == 3) {  // Lorenz-63 (PF_STEP_LORENZ_MK=0: the run-time kernel - A/B tests)
+                const char* e = getenv("PF_STEP_LORENZ_MK");
+                if (a.md.hid_kind == PF_HID_LORENZ63_EM && a.md.obs_kind == PF_OBS_LINEAR && !(e && atoi(e) == 0))
+                    return launch(std::integral_constant<int, 4>{});
+            }
             if constexpr (sizeof(T) == 4 && FAST && D == 1) {  // shape of the one-step mean of the closed-form models
                 if (a.md.hid_kind == PF_HID_SINE_EM) return launch(std::integral_constant<int, 2>{});
                 return launch(std::integral_constant<int, 1>{});
