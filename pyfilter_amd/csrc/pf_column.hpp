@@ -94,11 +94,14 @@ template <typename T> __device__ __forceinline__ double inv_sum(double s) {
 // their weights).
 // KIND / FILT / PROP: the run's hidden-process kind (scalar state: PF_HID_LINEAR / _SINE_EM / _OU with a linear-Gaussian
 // observation - the closed forms - or _VERHULST_EM with the stochastic-volatility observation), filter and proposal as compile-time constants, -1 = run-time values.  Specialised instantiations
-// (float, four particles per lane, <= 256 threads, Philox normals) drop the model-kind switches, the generic
+// (float, <= 256 threads, Philox normals; Lorenz-63: four particles per lane) drop the model-kind switches, the generic
 // (non-closed-form) arithmetic and the other filter's / proposal's paths from the loop: 17 - 19 % per step
 // (profiles/r03_column_specialisation_bound.txt); everything else takes the run-time kernel.
-template <typename T, int D, int VEC, int TPB, bool USER, int KIND = -1, int FILT = -1, int PROP = -1>
+// RAGGED: columns of N % VEC != 0 particles (scalar states, four particles per lane) - their own instantiations: carried as a
+// run-time branch the ragged paths cost the aligned shapes 3 - 6 % per step (same-box A/B, profiles/r03_column_ragged.txt).
+template <typename T, int D, int VEC, int TPB, bool USER, int KIND = -1, int FILT = -1, int PROP = -1, bool RAGGED = false>
 __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
+    static_assert(!RAGGED || (D == 1 && VEC > 1), "ragged columns: scalar states, several particles per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char pfc_lds[];
     const Geom& g = a.g;
     const int N = (int)g.N;
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     constexpr int KB = 4 + 2 * D;  // the state's record: max, sum e, sum e^2, poison, sum e (x - c)[D], sum e (x - c)^2[D]
     T* const cdfs = reinterpret_cast<T*>(pfc_lds);
     T* const xs = cdfs + np2;
-    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * N) * sizeof(T) + 15) & ~(size_t)15));
+    const int NP = ((N + VEC - 1) / VEC) * VEC;  // stride of a particle plane in LDS: N rounded up to the lanes' VEC particles
+    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * NP) * sizeof(T) + 15) & ~(size_t)15));
     double* const recB = recA + 2 * PFC_MAXW;  // [2][PFC_MAXW][KB]: double buffered by step parity
 
     const bool apf = FILT >= 0 ? (FILT == PF_FILTER_APF) : (a.filter == PF_FILTER_APF);
@@ -125,6 +129,16 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
     const int i0 = tid * VEC;
     const bool on = i0 < N;
+    // N % VEC != 0: the last lane holds fewer than VEC particles and a column starts at no vector boundary of the (B, N)
+    // planes - the state is then loaded / stored element by element and the per-particle validity `ok[j]` stands in for
+    // `on` (an invalid slot carries log-weight -inf, i.e. weight 0, through every sum and scan)
+    // (scalar states only: for D > 1 the extra paths cost the kernels registers - D = 2: 164 -> 241 VGPRs - and such columns
+    // keep one particle per lane when N % 4 != 0)
+    constexpr bool RAG = RAGGED;
+    constexpr bool ragged = RAGGED;  // (the host launches the RAGGED instantiations for exactly the N % VEC != 0 columns)
+    bool ok[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ok[j] = RAG ? (i0 + j < N) : on;
     const T nT = T(N);
     const T rcN = T(1) / nT;
     const bool pow2 = (N & (N - 1)) == 0;
@@ -140,7 +154,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
         for (int d = 0; d < D; ++d) x[d][j] = T(0);
     }
-    if (on) {
+    if (on && !ragged) {
         const T* lwc = a.logw[slot_in] + (int64_t)b * N + i0;
         if (VEC == 1) lw[0] = lwc[0]; else load_vec<T, VEC>(lwc, lw);
 #pragma unroll
@@ -150,6 +164,16 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
         }
         const int32_t* ac = a.anc + (int64_t)b * N + i0;
         if (VEC == 1) anc[0] = ac[0]; else load_vec<int, VEC>(ac, anc);
+    } else if (on) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (ok[j]) {
+                lw[j] = a.logw[slot_in][(int64_t)b * N + i0 + j];
+                anc[j] = a.anc[(int64_t)b * N + i0 + j];
+#pragma unroll
+                for (int d = 0; d < D; ++d) x[d][j] = a.x[slot_in][((int64_t)d * g.B + b) * N + i0 + j];
+            }
+        }
     }
     for (int q = N + tid; q < np2; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
 
@@ -319,10 +343,10 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = x[d][j];
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if constexpr (user) { if (on) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j); }
+                if constexpr (user) { if (ok[j]) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j); }
                 const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj, false, um);
-                if (on && is_nan_or_posinf(pre)) poison = true;
-                rw[j] = on ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
+                if (ok[j] && is_nan_or_posinf(pre)) poison = true;
+                rw[j] = ok[j] ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
             }
         }
         const bool resample = apf ? obs : (S1 * S1 / Q1 < a.thr_abs);  // apf.py:29-31 | sisr.py:18-19
@@ -347,7 +371,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             double incl[VEC], local = 0.0;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                local += on ? (double)er[j] : 0.0;
+                local += ok[j] ? (double)er[j] : 0.0;
                 incl[j] = local;
             }
             const double iw = wave_scan_incl(local, lane);
@@ -382,11 +406,12 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
                     double c = inv_tot * (C + gq * (double)L);
                     if (c > 1.0) c = 1.0;
                     cv[j] = (i0 + j == N - 1) ? T(1) : (T)c;  // resampling.py:49
+                    if (!ok[j]) cv[j] = Lim<T>::inf();         // (slots beyond the column: the search's sentinels)
                 }
                 if (VEC == 1) cdfs[i0] = cv[0]; else store_vec<T, VEC>(cdfs + i0, cv);
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    if (VEC == 1) xs[d * N + i0] = x[d][0]; else store_vec<T, VEC>(xs + d * N + i0, x[d]);
+                    if (VEC == 1) xs[d * NP + i0] = x[d][0]; else store_vec<T, VEC>(xs + d * NP + i0, x[d]);
                 }
             }
             // ---- positions: the systematic grid, or the order statistics of N uniforms (Exp(1) spacings) -------------------
@@ -395,12 +420,21 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
                 T ev[VEC], tail[1];
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) ev[j] = T(0);
-                if (on) draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), ev);
+                if (on && !ragged) {
+                    draw_exponentials<T, VEC>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), ev);
+                } else if (on) {  // (no vector boundary: the draws of the elements one by one - the same numbers)
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        T e1v[1] = {T(0)};
+                        if (ok[j]) draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0 + j), e1v);
+                        ev[j] = e1v[0];
+                    }
+                }
                 draw_exponentials<T, 1>(seed, PF_STREAM_MULTINOMIAL, (uint32_t)t, (uint64_t)((int64_t)g.B * N + b), tail);
                 double ei[VEC], el = 0.0, etot;
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    el += on ? (double)ev[j] : 0.0;
+                    el += ok[j] ? (double)ev[j] : 0.0;
                     ei[j] = el;
                 }
                 const double eexcl = cb_scan_excl(el, recA, nw, etot);  // (its own barriers; recA is free again by then)
@@ -438,7 +472,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
                 q[j] += (cdfs[q[j]] < pp[j]) ? 1 : 0;
                 idx[j] = q[j] > N - 1 ? N - 1 : q[j];
 #pragma unroll
-                for (int d = 0; d < D; ++d) xr[j][d] = xs[d * N + idx[j]];
+                for (int d = 0; d < D; ++d) xr[j][d] = xs[d * NP + idx[j]];
             }
         } else {
 #pragma unroll
@@ -462,7 +496,12 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
                 for (int d = 0; d < D; ++d) {
                     T zr[VEC];
                     const T* zc = zs + ((int64_t)d * g.B + b) * N + i0;
-                    if (VEC == 1) zr[0] = zc[0]; else load_vec<T, VEC>(zc, zr);
+                    if (VEC == 1) zr[0] = zc[0];
+                    else if (!ragged) load_vec<T, VEC>(zc, zr);
+                    else {
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) zr[j] = ok[j] ? zc[j] : T(0);
+                    }
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) z[j][d] = zr[j];
                 }
@@ -473,7 +512,8 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
                     for (int d = 0; d < D; ++d) z[j][d] = T(0.25) * T(j + d) - T(0.3) + T(1e-3) * T(lane);
 #else
-                draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
+                if (!ragged) draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
+                else draw_normals_ragged<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
 #endif
             }
         }
@@ -491,18 +531,24 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #else
                     w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j], false, um);  // apf.py:43
 #endif
-                    if (on && is_nan_or_posinf(w_new)) poison = true;
+                    if (ok[j] && is_nan_or_posinf(w_new)) poison = true;
                 } else {
-                    if (on && is_nan_or_posinf(wi)) poison = true;
+                    if (ok[j] && is_nan_or_posinf(wi)) poison = true;
                     w_new = resample ? wi : (wi + lw[j]);  // sisr.py:52-55
                 }
             } else {  // NaN observation: propagate only, weights carried, ll = 0 (particle/state.py:38-42)
                 sample_and_weight<T, D>(md, PF_PROP_BOOTSTRAP, cp, cc, xr[j], z[j], xn, um);
                 w_new = resample ? T(0) : lw[j];
             }
-            lw_new[j] = on ? sanitize_logw(w_new) : -Lim<T>::inf();
+            lw_new[j] = ok[j] ? sanitize_logw(w_new) : -Lim<T>::inf();
 #pragma unroll
             for (int d = 0; d < D; ++d) xr[j][d] = xn[d];
+        }
+        if (ragged) {  // (slots beyond the column stay at 0: nothing of theirs may ever become inf / NaN and meet a zero weight)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                for (int d = 0; d < D; ++d) xr[j][d] = ok[j] ? xr[j][d] : T(0);
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -530,7 +576,17 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 
     // ---- the final state -> HBM (the slot the per-step route would have written last) ------------------------------------------
     const int slot_out = (run.t0 + run.n_steps) & 1;
-    if (on) {
+    if (on && ragged) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            if (ok[j]) {
+                a.logw[slot_out][(int64_t)b * N + i0 + j] = lw[j];
+                a.anc[(int64_t)b * N + i0 + j] = anc[j];
+#pragma unroll
+                for (int d = 0; d < D; ++d) a.x[slot_out][((int64_t)d * g.B + b) * N + i0 + j] = x[d][j];
+            }
+        }
+    } else if (on) {
         T* lwc = a.logw[slot_out] + (int64_t)b * N + i0;
         if (VEC == 1) lwc[0] = lw[0]; else store_vec<T, VEC>(lwc, lw);
 #pragma unroll

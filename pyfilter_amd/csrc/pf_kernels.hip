@@ -1693,18 +1693,18 @@ static inline int column_threads(int64_t N, int vec) {
     const int64_t need = (N + vec - 1) / vec;
     return (int)(((need + PF_WAVE - 1) / PF_WAVE) * PF_WAVE);
 }
-// Particles per lane on the column route: the per-step geometry's (4 when N % 4 == 0) unless that leaves most of the chip
-// idle - few, small filters: one particle per lane then spreads a filter over four times the waves (a filter's waves share
-// a CU, so up to 4 SIMDs work on it instead of 1).  The state's layout in HBM and the Philox addressing do not depend on it.
-static inline int column_vec(const pf_filter_args* A, const Geom& g) {
-    if (g.vec == 1) return 1;
-    if (const char* e = getenv("PF_COLUMN_VEC")) return atoi(e) == 1 ? 1 : g.vec;  // development knob
-    return g.vec;
-}
-static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize) {
+// Particles per lane on the column route: four - for scalar states also when N % 4 != 0 (the per-step geometry's
+// one-particle lanes need four times the waves per filter, and past 256 of them the 1024-thread kernel: 1 000 x 333 ran
+// 16.3 us per step against 5.4 for 1 000 x 400): the kernel handles the ragged last lane and the unaligned columns itself
+// (pf_column.hpp: `ragged`).  D > 1 keeps the geometry's width.  The state's layout in HBM and the Philox addressing do not
+// depend on it.  (One particle per lane for ALIGNED columns measured <= 16 % faster below 512 filters x 256 particles and
+// up to 3x slower above: profiles/r03_column_vec1_vs_vec4.txt - not adopted.)
+static inline int column_vec(const pf_filter_args* A, const Geom& g) { return A->model.dim == 1 ? 4 : g.vec; }
+static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize, int vec) {
     int64_t np2 = 64;
     while (np2 < N) np2 <<= 1;
-    const size_t planes = (((size_t)(np2 + (int64_t)D * N) * tsize) + 15) & ~(size_t)15;
+    const int64_t NP = ((N + vec - 1) / vec) * vec;  // (the kernel's padded plane stride)
+    const size_t planes = (((size_t)(np2 + (int64_t)D * NP) * tsize) + 15) & ~(size_t)15;
     return planes + sizeof(double) * (2 + 2 * (4 + 2 * D)) * PFC_MAXW + 16;  // scan records + the state's records (x 2)
 }
 // (measured, profiles/r03_column_route.txt: 1024 x 2048 runs 21 us per step here against 29 on the per-step route, 1024 x
@@ -1719,8 +1719,8 @@ static inline bool column_eligible(const pf_filter_args* A, const Geom& g, int64
     if (const char* e = getenv("PF_NO_COLUMN")) if (atoi(e) != 0) return false;
     int64_t max_n = PF_COLUMN_MAX_N;
     if (const char* e = getenv("PF_COLUMN_MAX_N")) max_n = atoll(e);
-    if (A->N > max_n || column_threads(A->N, g.vec) > 1024) return false;  // (at the geometry's width; column_vec() narrows only when it fits)
-    return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4) <= 64 * 1024;  // (the default dynamic-LDS limit)
+    if (A->N > max_n || column_threads(A->N, column_vec(A, g)) > 1024) return false;
+    return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4, column_vec(A, g)) <= 64 * 1024;  // (the default dynamic-LDS limit)
 }
 
 template <typename T, int D, int VEC>
@@ -1728,7 +1728,7 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                            hipStream_t st, float* kernel_ms) {
     FusedArgs<T> a = make_fused_args<T>(A, g, wl, t0);
     const int nt = column_threads(A->N, VEC);
-    const size_t lds = column_lds_bytes(A->N, D, sizeof(T));
+    const size_t lds = column_lds_bytes(A->N, D, sizeof(T), VEC);
     // observed flags: the host's (baked into the launch arguments), the caller's device array, or derived from y here
     const bool auto_flags = !A->observed && !A->observed_dev;
     a.obs_dev = A->observed_dev;
@@ -1772,23 +1772,35 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, spec_ok ? 1 : 0,
                      /*SPEC*/ 9, spec_ok ? A->model.hid_kind : 0, 0);
         const bool user = A->model.hid_kind == PF_HID_USER_AFFINE;
+        // columns of N % 4 != 0 particles (scalar states): the RAGGED instantiations
+        auto with_rag = [&](auto&& f) {
+            if constexpr (D == 1 && VEC == 4) {
+                if (A->N % VEC != 0) return f(std::true_type{});
+            }
+            f(std::false_type{});
+        };
         auto launch = [&](auto tpb_c) {
             constexpr int TPB = decltype(tpb_c)::value;
-            if (user) hipLaunchKernelGGL((k_fused_column<T, D, VEC, TPB, true>), dim3(g.B), dim3(nt), lds, st, a, r);
-            else hipLaunchKernelGGL((k_fused_column<T, D, VEC, TPB, false>), dim3(g.B), dim3(nt), lds, st, a, r);
+            with_rag([&](auto rag_c) {
+                constexpr bool RAG = decltype(rag_c)::value;
+                if (user) hipLaunchKernelGGL((k_fused_column<T, D, VEC, TPB, true, -1, -1, -1, RAG>), dim3(g.B), dim3(nt), lds, st, a, r);
+                else hipLaunchKernelGGL((k_fused_column<T, D, VEC, TPB, false, -1, -1, -1, RAG>), dim3(g.B), dim3(nt), lds, st, a, r);
+            });
         };
         // (a 512-thread bound would lift the scratch of the D > 1 kernels - but at > 128 VGPRs only ONE 8-wave workgroup fits
         // a CU instead of two: 1024 x 2048 measured 33 us per step against 21)
-        // specialised instantiations (pf_column.hpp: KIND / FILT / PROP): float, scalar closed-form models, four particles
-        // per lane, <= 256 threads, Philox normals; PF_COLUMN_GENERIC=1 keeps the run-time kernel (tests compare the two)
+        // specialised instantiations (pf_column.hpp: KIND / FILT / PROP): float, built-in models, four particles per lane,
+        // <= 256 threads, Philox normals; PF_COLUMN_GENERIC=1 keeps the run-time kernel (tests compare the two)
         bool specialised = false;
         if constexpr (sizeof(T) == 4 && D == 1 && VEC == 4) {
             const int hk = A->model.hid_kind;
             if (spec_ok) {
                 specialised = true;
                 auto go = [&](auto kind_c, auto filt_c, auto prop_c) {
-                    hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, decltype(kind_c)::value, decltype(filt_c)::value,
-                                                       decltype(prop_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                    with_rag([&](auto rag_c) {
+                        hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, decltype(kind_c)::value, decltype(filt_c)::value,
+                                                           decltype(prop_c)::value, decltype(rag_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                    });
                 };
                 auto with_prop = [&](auto kind_c, auto filt_c) {
                     if (A->proposal == PF_PROP_LGO) go(kind_c, filt_c, std::integral_constant<int, PF_PROP_LGO>{});
@@ -1846,14 +1858,11 @@ int pf_run_column_f64(PF_COL_ARGS);
 #define PF_DEFINE_COLUMN(NAME, T)                                                                     \
     int NAME(PF_COL_ARGS) {                                                                           \
         const int D = A->model.dim;                                                                   \
-        int vec = column_vec(A, g);                                                                   \
-        if (vec == 1 && column_threads(A->N, 1) > 1024) vec = g.vec;                                  \
-        if (vec == 4) {                                                                               \
-            if (D == 1) return column_run_impl<T, 1, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
+        if (D == 1) return column_run_impl<T, 1, 4>(A, g, wl, t0, n_steps, st, kernel_ms);            \
+        if (g.vec == 4) {                                                                             \
             if (D == 2) return column_run_impl<T, 2, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
             return column_run_impl<T, 3, 4>(A, g, wl, t0, n_steps, st, kernel_ms);                    \
         }                                                                                             \
-        if (D == 1) return column_run_impl<T, 1, 1>(A, g, wl, t0, n_steps, st, kernel_ms);            \
         if (D == 2) return column_run_impl<T, 2, 1>(A, g, wl, t0, n_steps, st, kernel_ms);            \
         return column_run_impl<T, 3, 1>(A, g, wl, t0, n_steps, st, kernel_ms);                        \
     }

@@ -128,6 +128,34 @@ __device__ __forceinline__ void draw_normals(uint64_t seed, uint32_t stream, uin
     }
 }
 
+// The same numbers for VEC consecutive particles starting at ANY element (no vector boundary: a column of N % VEC != 0
+// particles in the column-persistent kernel): the calls covering flat indices [elem0 D, (elem0 + VEC) D) - one more than
+// the aligned case needs - and a select by the start's offset inside its call.
+template <typename T, int D, int VEC>
+__device__ __forceinline__ void draw_normals_ragged(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem0, T (&z)[VEC][D]) {
+    constexpr int NPC = NormalCall<T>::NPC;
+    constexpr int TOT = VEC * D;
+    constexpr int K = (TOT + NPC - 1) / NPC + 1;
+    const uint64_t n0 = elem0 * D;
+    const uint64_t c0 = n0 / NPC;
+    const int r = (int)(n0 % NPC);
+    T buf[K * NPC];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        T zz[NPC];
+        NormalCall<T>::call(seed, stream, step, c0 + k, zz);
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) buf[k * NPC + q] = zz[q];
+    }
+#pragma unroll
+    for (int n = 0; n < TOT; ++n) {
+        T v = buf[n];
+#pragma unroll
+        for (int q = 1; q < NPC; ++q) v = (r == q) ? buf[n + q] : v;
+        z[n / D][n % D] = v;
+    }
+}
+
 // D (<= 4) standard normals for the single element `elem`
 template <typename T, int D> struct NormalDraw {
     __device__ __forceinline__ static void draw(uint64_t seed, uint32_t stream, uint32_t step, uint64_t elem, T (&z)[D]) {
