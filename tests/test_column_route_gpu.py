@@ -150,19 +150,20 @@ def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_nam
     assert ((c32["ll"].double() - c64["ll"]).abs() <= 0.08 * math.sqrt(t_len) * max(1.0, float(c64["ll"].abs().max()) / t_len) + 1e-2).all()
 
 
+@pytest.mark.parametrize("n", [512, 333])
 @pytest.mark.parametrize("resampler", ["systematic", "multinomial"])
 @pytest.mark.parametrize("prop", ["bootstrap", "lgo"])
 @pytest.mark.parametrize("filt_name", ["sisr", "apf"])
 @pytest.mark.parametrize("kind", ["lg", "sine", "ou", "sv", "lorenz"])
-def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, prop, resampler, monkeypatch):
+def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, prop, resampler, n, monkeypatch):
     """float32 runs of the scalar closed-form models take instantiations of the column kernel with the model kind, filter
     and proposal as compile-time constants (``pf_column.hpp``: KIND / FILT / PROP).  Same draws, same arithmetic: they
     must reproduce the run-time kernel (``PF_COLUMN_GENERIC=1``) - NaN observations included - and be the ones that ran."""
     if kind == "sv" and prop == "lgo":
         pytest.skip("the stochastic-volatility observation has no linear-Gaussian proposal")
-    n, b, t_len, nan_at = 512, 5, 40, (3, 17)
-    if resampler == "multinomial" and kind in ("lg", "ou"):
-        n = 250  # (N % 4 != 0: one particle per lane - the reference's nutria example runs 250 particles)
+    if kind == "lorenz" and n % 4:
+        pytest.skip("D > 1: columns of N % 4 != 0 particles keep one particle per lane and the run-time kernel")
+    b, t_len, nan_at = 5, 40, (3, 17)  # (n = 333: the RAGGED instantiations - four particles per lane, N % 4 != 0)
     spec = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
     monkeypatch.setenv("PF_COLUMN_GENERIC", "1")
     gen = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
