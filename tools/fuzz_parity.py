@@ -19,7 +19,7 @@ def main():
 
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    bad = 0
+    bad = ties = 0
     for i in range(cases):
         model = rng.choice(["lg1d", "sine", "sv_batched", "lorenz", "ou_batched"])
         filt_name = rng.choice(["sisr", "apf"])
@@ -47,13 +47,20 @@ def main():
         for s in range(t_len):
             if rng.random() < 0.15:
                 y[s] = float("nan")
+        if os.environ.get("FUZZ_TARGET"):  # (overrides for dissecting a single case: FUZZ_ONLY=<i> FUZZ_TARGET=<n|none> FUZZ_ROUTE=<route>)
+            target = None if os.environ["FUZZ_TARGET"] == "none" else int(os.environ["FUZZ_TARGET"])
         if target is None:
             os.environ.pop("PF_TARGET_WGS", None)
         else:
             os.environ["PF_TARGET_WGS"] = str(target)
+        only = os.environ.get("FUZZ_ONLY")  # e.g. "655": re-run single cases of a sweep (the random stream is consumed as usual)
+        if only and str(i) not in only.split(","):
+            rng.choice(["batch", "batch", "online", "recorded"])
+            continue
         x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
         ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=ess)
         route = rng.choice(["batch", "batch", "online", "recorded"])
+        route = os.environ.get("FUZZ_ROUTE", route)
         filt = build_filter_from_case(case, g, torch.float64, "cuda", **({"record_states": True} if route == "recorded" else {}))
         if route == "online":  # one fused move per observation (the SMC^2 entry point)
             state = filt.initialize()
@@ -78,10 +85,49 @@ def main():
             if mism:
                 ok, why = False, f"{mism} ancestors differ"
         except AssertionError as e:
-            ok, why = False, str(e).splitlines()[0][:160]
+            ok, why = False, " | ".join(str(e).splitlines()[:6])[:400]
+        if not ok:
+            # A knife-edge tie is not a parity failure: the oracle's cumsum and the kernels' scan add the same float64 weights in
+            # different orders, so a cdf value may differ in its last bit - and when a resampling position falls between the
+            # two, ONE ancestor moves to its neighbour; from then on the two are different (equally valid) particle systems.
+            # Recognised by its signature: everything identical up to a step whose only difference is <= 2 ancestors per filter,
+            # each off by exactly one.
+            ref1 = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=ess,
+                                        record_steps=True)
+            f1 = build_filter_from_case(case, g, torch.float64, "cuda", record_states=True)
+            r1 = f1.batch_filter(y.cuda(), bar=False)
+            for s_ in range(t_len):
+                ig, ir = r1.states[s_ + 1].previous_indices.cpu().reshape(n, -1), ref1["step_idx"][s_].reshape(n, -1)
+                mm = ig != ir
+                if mm.any():
+                    if int(mm.sum(0).max()) <= 2 and int((ig - ir).abs().max()) == 1 and (s_ == 0 or torch.allclose(
+                            r1.states[s_].timeseries_state.value.cpu(), ref1["step_x"][s_ - 1], rtol=1e-9, atol=1e-11)):
+                        ok, why = True, f"(rounding tie: {int(mm.sum())} ancestor(s) off by one at step {s_}, identical before)"
+                        ties += 1
+                    break
+        if not ok and os.environ.get("FUZZ_DEBUG"):  # where the two part: per-step ancestors / weights of a recorded run
+            ref2 = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=ess,
+                                        record_steps=True)
+            f2 = build_filter_from_case(case, g, torch.float64, "cuda", record_states=True)
+            r2 = f2.batch_filter(y.cuda(), bar=False)
+            print("   y:", [round(float(v), 4) if v == v else "nan" for v in y.reshape(t_len, -1)[:, 0]], " u:", g["u_tape"].double().tolist())
+            for s_ in range(t_len):
+                st = r2.states[s_ + 1]
+                idx_g, idx_r = st.previous_indices.cpu(), ref2["step_idx"][s_]
+                mm = (idx_g != idx_r)
+                wd = (st.weights.cpu() - ref2["step_w"][s_]).abs()
+                wd = torch.where(torch.isnan(wd), torch.zeros_like(wd), wd)
+                xd = (st.timeseries_state.value.cpu() - ref2["step_x"][s_]).abs()
+                per_col = mm.reshape(mm.shape[0], -1).sum(0).tolist()
+                first = [int(mm[:, c].nonzero()[0]) if mm[:, c].any() else -1 for c in range(mm.shape[1])] if mm.dim() > 1 else []
+                print(f"   step {s_}: ancestors differing per column {per_col} first at {first}  max |dw| {float(wd.max()):.3e}  max |dx| {float(xd.max()):.3e}")
+                for c, fi in enumerate(first):
+                    if fi >= 0:
+                        print(f"      column {c}: position {fi}: kernel {int(idx_g[fi, c])} oracle {int(idx_r[fi, c])}; neighbours kernel {idx_g[max(fi-2,0):fi+3, c].tolist()} oracle {idx_r[max(fi-2,0):fi+3, c].tolist()}")
+                        break
         bad += 0 if ok else 1
         print(f"{i:3d} {'ok ' if ok else 'BAD'} {model:10s} {filt_name:4s} {prop:9s} N={n:6d} B={b:2d} T={t_len} ess={ess} target_wgs={target} seed={seed} {route} {why}", flush=True)
-    print("failures:", bad)
+    print("failures:", bad, " rounding ties:", ties)
     return 1 if bad else 0
 
 
