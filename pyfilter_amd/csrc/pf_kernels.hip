@@ -1762,7 +1762,7 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             const bool closed = A->model.obs_kind == PF_OBS_LINEAR && (hk == PF_HID_LINEAR || hk == PF_HID_SINE_EM || hk == PF_HID_OU) &&
                                 (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
             const bool sv = A->model.obs_kind == PF_OBS_SV && hk == PF_HID_VERHULST_EM && A->proposal == PF_PROP_BOOTSTRAP;
-            spec_ok = nt <= 256 && !A->z_tape && !generic_only && (closed || sv);
+            spec_ok = !A->z_tape && !generic_only && (closed || sv);  // (any workgroup size: the 256- or the 1024-thread bound)
         }
         if constexpr (sizeof(T) == 4 && D == 3 && VEC == 4) {  // Lorenz-63
             const char* ge = getenv("PF_COLUMN_GENERIC");
@@ -1798,8 +1798,12 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
                 specialised = true;
                 auto go = [&](auto kind_c, auto filt_c, auto prop_c) {
                     with_rag([&](auto rag_c) {
-                        hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, decltype(kind_c)::value, decltype(filt_c)::value,
-                                                           decltype(prop_c)::value, decltype(rag_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                        if (nt <= 256)
+                            hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, decltype(kind_c)::value, decltype(filt_c)::value,
+                                                               decltype(prop_c)::value, decltype(rag_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                        else
+                            hipLaunchKernelGGL((k_fused_column<T, D, VEC, 1024, false, decltype(kind_c)::value, decltype(filt_c)::value,
+                                                               decltype(prop_c)::value, decltype(rag_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
                     });
                 };
                 auto with_prop = [&](auto kind_c, auto filt_c) {

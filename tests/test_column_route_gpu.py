@@ -150,7 +150,7 @@ def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_nam
     assert ((c32["ll"].double() - c64["ll"]).abs() <= 0.08 * math.sqrt(t_len) * max(1.0, float(c64["ll"].abs().max()) / t_len) + 1e-2).all()
 
 
-@pytest.mark.parametrize("n", [512, 333])
+@pytest.mark.parametrize("n", [512, 333, 1502])
 @pytest.mark.parametrize("resampler", ["systematic", "multinomial"])
 @pytest.mark.parametrize("prop", ["bootstrap", "lgo"])
 @pytest.mark.parametrize("filt_name", ["sisr", "apf"])
@@ -163,7 +163,8 @@ def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, p
         pytest.skip("the stochastic-volatility observation has no linear-Gaussian proposal")
     if kind == "lorenz" and n % 4:
         pytest.skip("D > 1: columns of N % 4 != 0 particles keep one particle per lane and the run-time kernel")
-    b, t_len, nan_at = 5, 40, (3, 17)  # (n = 333: the RAGGED instantiations - four particles per lane, N % 4 != 0)
+    # (n = 333: the RAGGED instantiations - four particles per lane, N % 4 != 0; n = 1502: ragged AND the 1024-thread bound)
+    b, t_len, nan_at = (5, 40, (3, 17)) if n < 1024 else (3, 12, (3,))
     spec = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
     monkeypatch.setenv("PF_COLUMN_GENERIC", "1")
     gen = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
