@@ -4,7 +4,9 @@ only) and ``tests/`` (consumers; they only need the spec, the inputs come from t
 
 Model constants follow SURVEY.md §8(c)/(d): AR(1) of tests/filters/models.py:10-15, the README sine diffusion,
 the Verhulst SV model of examples/stochastic-volatility.ipynb, Lorenz-63 of examples/lorenz.ipynb and the OU model
-of tests/inference/models.py:12-19.
+of tests/inference/models.py:12-19, and the reference's own 2-D acceptance model - the random walk with sigma = (0.05, 0.1),
+A = I2, s = 0.15 of tests/filters/models.py:28-52 (``rw2d``; B in {1, 3} and 10 % NaN rows as tests/filters/test_particle.py:44-63
+runs it).
 """
 import math
 
@@ -41,6 +43,15 @@ CASES = [
          ess_threshold=0.8, seed=111, dtypes=("f64",)),
     dict(name="ou_apf_boot_theta", model="ou_batched", filter="apf", proposal="bootstrap", N=128, B=3, T=20,
          ess_threshold=0.9, seed=112, dtypes=("f64",)),
+    # D = 2 / O = 2: the reference's 2-D random walk (tests/filters/models.py:28-52), its MVN / Cholesky LGO path included
+    dict(name="rw2d_sisr_boot", model="rw2d", filter="sisr", proposal="bootstrap", N=512, B=3, T=25,
+         ess_threshold=0.9, seed=113, dtypes=("f64", "f32")),
+    dict(name="rw2d_apf_lgo", model="rw2d", filter="apf", proposal="lgo", N=256, B=3, T=25,
+         ess_threshold=0.9, seed=114, nan_steps=(4, 13, 14), dtypes=("f64", "f32")),
+    dict(name="rw2d_sisr_lgo", model="rw2d", filter="sisr", proposal="lgo", N=300, B=1, T=20,
+         ess_threshold=0.5, seed=115, dtypes=("f64",)),
+    dict(name="rw2d_apf_boot", model="rw2d", filter="apf", proposal="bootstrap", N=333, B=2, T=20,
+         ess_threshold=0.9, seed=116, nan_steps=(7,), dtypes=("f64",)),
 ]
 
 CASE_BY_NAME = {c["name"]: c for c in CASES}
@@ -65,6 +76,12 @@ def build_spec(case, dtype=torch.float64) -> M.ModelSpec:
         return M.ModelSpec(
             M.HID_LORENZ63_EM, (10.0, 28.0, 8.0 / 3.0, 1.0), 3, 0.01, (t(_LORENZ_INIT[0]), t(_LORENZ_INIT[1])),
             M.OBS_LINEAR, (t(_LORENZ_A), t([0.0]), t([math.sqrt(0.1)])), 2,
+        )
+    if m == "rw2d":  # tests/filters/models.py:28-52: x' = I2 x + (0.05, 0.1) e, x0 ~ N(0, sigma), y ~ N(I2 x, 0.15)
+        sig = t([0.05, 0.1])
+        return M.ModelSpec(
+            M.HID_LINEAR, (torch.zeros_like(sig), torch.ones_like(sig), sig), 2, 1.0, (torch.zeros_like(sig), sig),
+            M.OBS_LINEAR, (torch.eye(2, dtype=dtype), t([0.0, 0.0]), t([0.15, 0.15])), 2,
         )
     if m == "ou_batched":  # tests/inference/models.py:12-33 with theta on the batch dim
         kappa = t([0.025 * (i + 1) for i in range(b)])

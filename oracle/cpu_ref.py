@@ -408,3 +408,29 @@ def kalman_filter_1d(y, alpha, beta, sigma, a, b, s, m0, p0):
             m, p = m + k * r, (1 - k * a) * p
         means.append(m)
     return torch.tensor(means, dtype=torch.float64), ll
+
+
+def kalman_filter(y, F, Q, H, R, m0, P0, c=None, d=None):
+    """Exact Kalman filter of ``x' = c + F x + N(0, Q)``, ``y = d + H x + N(0, R)`` in NumPy float64 - the role pykalman's
+    ``KalmanFilter`` plays in the reference's acceptance test of its 2-D model (tests/filters/models.py:40-47,
+    tests/filters/test_particle.py:63-111).  ``y`` is ``(T, O)``; a row with any NaN is a missing observation (predict
+    only).  ``(m0, P0)`` is the law of the state BEFORE the first transition.  Returns (filtered means ``(T, D)``, total
+    log-likelihood)."""
+    import numpy as np
+
+    y = np.asarray(y, dtype=np.float64)
+    F, Q, H, R = (np.atleast_2d(np.asarray(a, dtype=np.float64)) for a in (F, Q, H, R))
+    m, P = np.atleast_1d(np.asarray(m0, dtype=np.float64)), np.atleast_2d(np.asarray(P0, dtype=np.float64))
+    c = np.zeros(F.shape[0]) if c is None else np.asarray(c, dtype=np.float64)
+    d = np.zeros(H.shape[0]) if d is None else np.asarray(d, dtype=np.float64)
+    means, ll = [], 0.0
+    for yt in y.reshape(y.shape[0], -1):
+        m, P = c + F @ m, F @ P @ F.T + Q
+        if not np.isnan(yt).any():
+            S = H @ P @ H.T + R
+            K = np.linalg.solve(S, H @ P).T
+            r = yt - (d + H @ m)
+            ll += -0.5 * (len(yt) * math.log(2 * math.pi) + np.linalg.slogdet(S)[1] + r @ np.linalg.solve(S, r))
+            m, P = m + K @ r, (np.eye(len(m)) - K @ H) @ P
+        means.append(m.copy())
+    return torch.from_numpy(np.stack(means)), float(ll)

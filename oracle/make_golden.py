@@ -28,8 +28,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-FFBS_CASES = ("lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot")
-STATE_DICT_CASES = ("lg1d_apf_lgo", "lorenz_sisr_boot", "sv_sisr_boot")
+FFBS_CASES = ("lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot", "rw2d_sisr_boot")
+STATE_DICT_CASES = ("lg1d_apf_lgo", "lorenz_sisr_boot", "sv_sisr_boot", "rw2d_apf_lgo")
 STATE_DICT_AT = 12  # observations consumed when the checkpoint is taken
 
 
@@ -99,7 +99,12 @@ def _main_child(dtype_name: str):
         if d > 0:
             inc = Independent(inc.expand(torch.Size([d])), 1)
 
-        if k == M.HID_LINEAR:
+        if k == M.HID_LINEAR and d > 0:
+            # the reference's own construction of its 2-D model (tests/filters/models.py:31-38): LinearModel((A, sigma), ...)
+            # with A the identity - the diagonal walk the product's RandomWalk(dim=2) restates
+            assert all(bool((q == v).all()) for q, v in zip(hp[:2], (0.0, 1.0)))
+            hidden = ts.LinearModel((torch.eye(d, dtype=dtype), hp[2]), inc, init_kernel)
+        elif k == M.HID_LINEAR:
             hidden = ts.AffineProcess(lambda x, a, b, s: (a + b * x.value, s), hp, inc, init_kernel)
         elif k == M.HID_SINE_EM:
             hidden = ts.AffineEulerMaruyama(

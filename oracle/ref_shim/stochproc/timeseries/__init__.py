@@ -107,6 +107,26 @@ class AffineEulerMaruyama(AffineProcess):
         super().__init__(_ms, parameters, increment_distribution, initial_kernel, initial_parameters)
 
 
+class LinearModel(AffineProcess):
+    """``x' = b + A x + s * eps`` - the process the reference's own 2-D acceptance model is built from
+    (tests/filters/models.py:28-38: ``ts.LinearModel((a, sigma), inc_dist, initial_kernel)``).  ``parameters`` is
+    ``(a, s)`` or ``(a, b, s)``; the initial kernel is called with ``(a, b, s)`` (the reference's lambda takes
+    ``m_, _, s_``).  A scalar / vector ``a`` multiplies elementwise, a matrix acts through ``matmul``."""
+
+    def __init__(self, parameters, increment_distribution, initial_kernel, initial_parameters=None):
+        parameters = tuple(_as_tensor(p) for p in parameters)
+        if len(parameters) == 2:
+            a, s = parameters
+            parameters = (a, torch.zeros_like(s), s)
+
+        def _ms(x, a, b, s):
+            v = x.value
+            loc = b + (a @ v.unsqueeze(-1)).squeeze(-1) if a.dim() >= 2 else b + a * v
+            return loc, s
+
+        super().__init__(_ms, parameters, increment_distribution, initial_kernel, initial_parameters)
+
+
 class StateSpaceModel:
     def __init__(self, hidden, f, parameters, observe_every_step=1):
         self.hidden = hidden

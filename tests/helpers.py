@@ -40,6 +40,10 @@ def build_ssm_from_case(case, dtype, device):
                                  initial_mean=t([-5.91652, -5.52332, 24.5723]), initial_scale=t([math.sqrt(10.0)] * 3))
         a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]])
         ssm = ts.LinearStateSpaceModel(hidden, (a, t([0.0]), t([math.sqrt(0.1)])), torch.Size([2]))
+    elif m == "rw2d":  # the reference's own 2-D model (tests/filters/models.py:28-52)
+        sig = t([0.05, 0.1])
+        hidden = models.RandomWalk(sig, initial_mean=t([0.0, 0.0]), initial_scale=sig, dim=2)
+        ssm = ts.LinearStateSpaceModel(hidden, (torch.eye(2, dtype=dtype, device=device), t([0.15, 0.15])), torch.Size([2]))
     elif m == "ou_batched":
         kappa = t([0.025 * (i + 1) for i in range(b)])
         gamma = t([0.0 + 0.1 * i for i in range(b)])

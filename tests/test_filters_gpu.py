@@ -207,6 +207,56 @@ def test_kalman_statistical_parity_philox(filt_name, prop, resampler):
         assert abs((ll - kll) / kll) < 0.1, (ll, kll)
 
 
+@pytest.mark.parametrize("filt_name,prop,resampler", [("sisr", "bootstrap", "systematic"), ("apf", "lgo", "systematic"),
+                                                      ("sisr", "lgo", "systematic"), ("apf", "bootstrap", "systematic"),
+                                                      ("sisr", "bootstrap", "multinomial"), ("apf", "lgo", "multinomial")])
+@pytest.mark.parametrize("n,kernel_route", [(1500, "column"), (1500, "per_step"), (8192, "per_step")], indirect=["kernel_route"])
+def test_kalman_statistical_parity_2d_philox(filt_name, prop, resampler, n, kernel_route):
+    """The reference's acceptance test on ITS 2-D model (tests/filters/models.py:28-52: random walk sigma = (0.05, 0.1),
+    A = I2, s = 0.15; tests/filters/test_particle.py:63-111: T = 100, 10 % missing rows, batch () and (3,)): median
+    relative deviation of the filter means / of the log-likelihood from the exact Kalman filter below 10 % - here on the
+    D = 2 kernels with in-kernel Philox draws, float32.  N = 1500 runs on the column route / the per-step route (fixture),
+    8192 on the per-step route (multi-round tiles at B = 3: VEC = 4 D = 2 step kernels)."""
+    import numpy as np
+
+    from pyfilter_amd import resampling, timeseries as ts
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device="cuda")  # noqa: E731
+    sig = np.array([0.05, 0.1])
+    g = torch.Generator().manual_seed(19)
+    x = torch.tensor(sig) * torch.randn(2, generator=g, dtype=torch.float64)
+    ys = []
+    for _ in range(100):
+        x = x + torch.tensor(sig) * torch.randn(2, generator=g, dtype=torch.float64)
+        ys.append(x + 0.15 * torch.randn(2, generator=g, dtype=torch.float64))
+    y = torch.stack(ys).float()
+    y[torch.rand(100, generator=g) < 0.1] = float("nan")
+    km, kll = cpu_ref.kalman_filter(y.double(), np.eye(2), np.diag(sig ** 2), np.eye(2), 0.15 ** 2 * np.eye(2),
+                                    np.zeros(2), np.diag(sig ** 2))
+
+    hidden = models.RandomWalk(t([0.05, 0.1]), dim=2)
+    ssm = ts.LinearStateSpaceModel(hidden, (torch.eye(2, device="cuda"), t([0.15, 0.15])), torch.Size([2]))
+    cls = {"sisr": SISR, "apf": APF}[filt_name]
+    p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
+    rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[resampler]
+    for batch in (torch.Size([]), torch.Size([3])):
+        filt = cls(ssm, n, proposal=p.copy(), resampling=rs, seed=78)
+        filt.set_batch_shape(batch)
+        res = filt.batch_filter(y.cuda(), bar=False)
+        means = res.filter_means[1:].cpu().double()
+        lls = res.loglikelihood.reshape(-1).cpu().double()
+        means = means if batch else means[:, None]
+        assert means.shape == (100, len(lls), 2)
+        for j in range(len(lls)):
+            dev = ((means[:, j] - km) / km).abs().median().item()
+            assert dev < 0.1, (dev, j)
+            assert abs((lls[j].item() - kll) / kll) < 0.1, (lls[j].item(), kll)
+        # far inside the reference's 10 %: the log-likelihood estimate of N particles is within a few percent of exact
+        assert abs(lls.mean().item() - kll) < 0.02 * abs(kll) + 1.0, (lls.tolist(), kll)
+
+
 def test_generic_route_with_user_callables():
     """A model defined the reference's way (python callables, README.md:44-67) runs on the GPU through the HIP
     primitives and agrees statistically with the built-in kind of the same model."""

@@ -78,7 +78,7 @@ def test_fixed_lag_smoothing_matches_reference(golden_dir, name, dt):
     assert torch.equal(cpu_ref.smooth_fl(xs, inds), g["smooth_fl"])
 
 
-@pytest.mark.parametrize("name", ["lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot"])
+@pytest.mark.parametrize("name", ["lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot", "rw2d_sisr_boot"])
 def test_ffbs_oracle_against_reference_statistics(golden_dir, name):
     """``smooth(states, "ffbs")``: the reference's ``Categorical`` draws cannot be injected, so the oracle (inverse CDF on
     the same logits) is pinned statistically - the per-time mean over trajectories of 4 independent backward passes of

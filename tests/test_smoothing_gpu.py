@@ -106,7 +106,7 @@ def test_recorded_states_with_unobserved_substeps():
         torch.testing.assert_close(a.loglikelihood, r.loglikelihood, **TOL)
 
 
-@pytest.mark.parametrize("name", ["lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot"])
+@pytest.mark.parametrize("name", ["lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sv_apf_boot", "rw2d_sisr_boot"])
 def test_ffbs_matches_oracle_on_identical_uniforms_and_reference_statistics(name):
     """Backward simulation (``pf_smooth_ffbs``): (i) against the oracle's restatement of ``_do_sample_ffbs`` with the same
     uniforms - identical trajectories (float64); (ii) against the reference's own FFBS statistics (fixture)."""
