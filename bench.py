@@ -54,6 +54,30 @@ WORKLOADS = {
     "smc2": dict(filter="apf", proposal="lgo", resampler="systematic", N=8192, B=1024, D=1, T=500),
 }
 
+# What the timed passes must compute: the log-likelihood of rank 0's seeded observations (build_problem: generator seed 123)
+# under the workload's model, from the ORACLE (oracle/cpu_ref.py, float64, CPU, the workload's own N and T) - two independent
+# draw seeds of tools/bench_reference_ll.py (profiles/r04_bench_reference_ll.txt): -88.282269 and -88.299229.  `tol`: Monte-Carlo
+# spread of a 2^20-particle filter over 250 steps (0.02) + the float32 path's distance from exact arithmetic (BASELINE.md
+# section 2), with room.  bench.py refuses to print a throughput for a pass that computed something else.
+EXPECTED_LL = {"apf_lgo_1m": {"loglikelihood": -88.2907, "tol": 0.15, "N": 1 << 20, "T": 250,
+                              "source": "oracle/cpu_ref.py float64, tools/bench_reference_ll.py"}}
+
+
+def check_loglikelihood(workload, w, ll_all):
+    """Every timed pass's output is checked, not just printed: finite for every filter of the job, and - for a workload with
+    a committed oracle value at its default size - within the stored tolerance of it."""
+    ll = ll_all.reshape(-1).double().cpu()
+    out = {"finite": bool(torch.isfinite(ll).all()), "sample": float(ll[0])}
+    if not out["finite"]:
+        raise AssertionError(f"bench: non-finite log-likelihood in the timed pass of {workload}: {ll[:8].tolist()}")
+    exp = EXPECTED_LL.get(workload)
+    if exp is not None and w["N"] == exp["N"] and w["T"] == exp["T"]:
+        out.update(expected=exp["loglikelihood"], tol=exp["tol"], abs_diff=abs(out["sample"] - exp["loglikelihood"]), source=exp["source"])
+        if out["abs_diff"] > exp["tol"]:
+            raise AssertionError(f"bench: the timed pass of {workload} computed loglikelihood {out['sample']:.4f}, the oracle's "
+                                 f"float64 value for this data is {exp['loglikelihood']:.4f} (tolerance {exp['tol']})")
+    return out
+
 
 def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None, solo=False):
     """BASELINE configs[4] as the algorithm; returns (elapsed seconds for `steps` full fits, info).  ``solo``: the whole
@@ -500,6 +524,7 @@ def main():
 
     units_per_pass = w["N"] * w["B"] * w["T"] * world
     value = units_per_pass * args.steps / elapsed
+    ll_check = check_loglikelihood(args.workload, w, ll_all)  # (raises: no throughput line for a wrong answer)
 
     if args._inner:  # profiled child of pmc_traffic(): the timed passes above are all it needs
         return
@@ -571,6 +596,7 @@ def main():
                 "ms_per_filter_step": 1e3 * elapsed / args.steps / w["T"],
                 "parallelism": "independent filters per GPU + all-gather of log-likelihoods" if world > 1 else "single GPU",
                 "loglikelihood_sample": float(ll_all.reshape(-1)[0]),
+                "loglikelihood_check": ll_check,
             },
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -309,6 +309,9 @@ def debug_draw_normals(seed: int, steps: int, n: int, b: int, d: int, dtype, dev
     return out
 
 
+TRACE_LEN = 64  # launch records the library keeps per thread (PF_TRACE_LEN)
+
+
 def debug_launch_trace(last: int = 64):
     """The step-kernel instantiations of this thread's latest fused launches, oldest first, as dicts (pf_debug_launch_trace)."""
     buf = (C.c_int32 * (len(TRACE_FIELDS) * last))()

@@ -46,13 +46,20 @@ def test_fused_batch_filter_matches_reference(name, dt, kernel_route):
         # float32 end to end: one ulp in a weight can move an ancestor across a CDF boundary (and, for SISR, an ESS
         # across the threshold), after which the two fp32 trajectories are different - equally valid - Monte-Carlo
         # runs; the reference's own fp32 path sits that far from its fp64 path.  Bar: within
-        # 6 Monte-Carlo standard errors of the reference run.  The tight fp32 bar is the teacher-forced test below.
-        n = case["N"]
-        se = (g["filter_variance"] / n).sqrt()
-        diff = (res.filter_means.cpu() - g["filter_means"]).abs()
-        assert (diff <= 6.0 * se + 1e-5 * g["filter_means"].abs() + 1e-6).all(), (diff / (se + 1e-12)).max()
-        t_len = g["y"].shape[0]
-        assert ((res.loglikelihood.cpu() - g["loglikelihood"]).abs() <= 0.05 * math.sqrt(t_len) + 1e-3).all()
+        # 6 Monte-Carlo standard errors of the reference's float32 run - or of its float64 run on the same draws where
+        # the reference's own two runs part by more than that (rw2d_sisr_boot: its float32 ESS crosses the threshold at
+        # step 6 where its float64 one does not, 8.1 standard errors between the reference's two outputs; the kernels'
+        # fp64-accumulated sums take the float64 side).  The tight fp32 bar is the teacher-forced test below.
+        n, t_len = case["N"], g["y"].shape[0]
+        ok = torch.zeros(case["B"], dtype=torch.bool)
+        for ref in (g, load_golden(name, "f64")):  # (every float32 case also has a float64 fixture on the same draws)
+            fm = ref["filter_means"].double().reshape(t_len + 1, case["B"], -1)
+            se = (ref["filter_variance"].double().reshape(fm.shape) / n).sqrt()
+            diff = (res.filter_means.cpu().double().reshape(fm.shape) - fm).abs()
+            dll = (res.loglikelihood.cpu().double().reshape(-1) - ref["loglikelihood"].double().reshape(-1)).abs()
+            # per filter: the WHOLE run within the bar of this reference run
+            ok |= (diff <= 6.0 * se + 1e-5 * fm.abs() + 1e-6).all(2).all(0) & (dll <= 0.05 * math.sqrt(t_len) + 1e-3)
+        assert ok.all(), "a float32 filter is further than 6 standard errors from both of the reference's runs"
 
 
 @both_routes
@@ -216,7 +223,14 @@ def test_kalman_statistical_parity_2d_philox(filt_name, prop, resampler, n, kern
     A = I2, s = 0.15; tests/filters/test_particle.py:63-111: T = 100, 10 % missing rows, batch () and (3,)): median
     relative deviation of the filter means / of the log-likelihood from the exact Kalman filter below 10 % - here on the
     D = 2 kernels with in-kernel Philox draws, float32.  N = 1500 runs on the column route / the per-step route (fixture),
-    8192 on the per-step route (multi-round tiles at B = 3: VEC = 4 D = 2 step kernels)."""
+    8192 on the per-step route (multi-round tiles: the VEC = 4, D = 2 step kernels).
+
+    The 10 % bar is loose (a log-likelihood of 20.7 may be off by 2); two sharper, size-independent properties ride along on
+    a batch of 64 independent filters of the same data: a particle filter's likelihood estimate is UNBIASED, so the mean of
+    exp(ll - ll_Kalman) over the filters is 1 within its own standard error (a kernel that loses or double-counts a
+    weight term shifts every filter's ll the same way - the random walk's long memory spreads single log-likelihoods by
+    0.4 - 0.7 at N = 1500, oracle runs - which is why single values cannot carry a tight bar), and the filter means
+    averaged over the filters sit on the Kalman means within a few standard errors of that average."""
     import numpy as np
 
     from pyfilter_amd import resampling, timeseries as ts
@@ -241,7 +255,7 @@ def test_kalman_statistical_parity_2d_philox(filt_name, prop, resampler, n, kern
     cls = {"sisr": SISR, "apf": APF}[filt_name]
     p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
     rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[resampler]
-    for batch in (torch.Size([]), torch.Size([3])):
+    for batch in (torch.Size([]), torch.Size([3]), torch.Size([64])):
         filt = cls(ssm, n, proposal=p.copy(), resampling=rs, seed=78)
         filt.set_batch_shape(batch)
         res = filt.batch_filter(y.cuda(), bar=False)
@@ -249,12 +263,16 @@ def test_kalman_statistical_parity_2d_philox(filt_name, prop, resampler, n, kern
         lls = res.loglikelihood.reshape(-1).cpu().double()
         means = means if batch else means[:, None]
         assert means.shape == (100, len(lls), 2)
-        for j in range(len(lls)):
+        for j in range(len(lls)):  # the reference's criterion, per filter
             dev = ((means[:, j] - km) / km).abs().median().item()
             assert dev < 0.1, (dev, j)
             assert abs((lls[j].item() - kll) / kll) < 0.1, (lls[j].item(), kll)
-        # far inside the reference's 10 %: the log-likelihood estimate of N particles is within a few percent of exact
-        assert abs(lls.mean().item() - kll) < 0.02 * abs(kll) + 1.0, (lls.tolist(), kll)
+        if len(lls) >= 64:
+            r = (lls - kll).exp()
+            se = r.std().item() / math.sqrt(len(r))
+            assert abs(r.mean().item() - 1.0) < 5.0 * se + 0.02, (r.mean().item(), se, lls.mean().item(), kll)
+            avg, spread = means.mean(1), means.std(1) / math.sqrt(len(lls))
+            assert ((avg - km).abs() <= 6.0 * spread + 2e-4).all(), ((avg - km).abs() / (spread + 1e-12)).max()
 
 
 def test_generic_route_with_user_callables():

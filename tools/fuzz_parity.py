@@ -21,7 +21,7 @@ def main():
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = ties = 0
     for i in range(cases):
-        model = rng.choice(["lg1d", "sine", "sv_batched", "lorenz", "ou_batched"])
+        model = rng.choice(["lg1d", "sine", "sv_batched", "lorenz", "ou_batched", "rw2d"])
         filt_name = rng.choice(["sisr", "apf"])
         prop = rng.choice(["bootstrap", "lgo"]) if model != "sv_batched" else "bootstrap"
         n = rng.choice([rng.randint(2, 40), rng.randint(41, 1100), rng.randint(1101, 9000), rng.choice([1024, 2048, 4096, 8192, 12288, 65536]),
