@@ -31,11 +31,3 @@ def get_ess(weights: torch.Tensor, normalized: bool = False) -> torch.Tensor:
     if cols.data_ptr() != weights.data_ptr():
         weights.copy_(ops.from_cols(cols, weights.dim() > 1))
     return ess if weights.dim() > 1 else ess[0]
-
-
-def construct_diag_from_flat(x: torch.Tensor, event_shape: torch.Size) -> torch.Tensor:
-    """utils.py:23-46 (used by user-defined proposals on the generic path)."""
-    assert len(event_shape) <= 1
-    eye = torch.eye(event_shape.numel(), device=x.device, dtype=x.dtype)
-    diag = x.view(*x.shape, 1, 1) if len(event_shape) == 0 else x.unsqueeze(-1)
-    return eye * diag

@@ -424,3 +424,51 @@ def test_user_defined_affine_processes_get_the_fused_kernel_kind():
     from pyfilter_amd.timeseries import models
 
     assert not ts.LinearStateSpaceModel(models.AR(0.0, 0.9, 0.1), (1.0, 0.1)).kernel_kind.is_user
+
+
+def test_optimal_proposal_innovation_form_equals_the_precision_form():
+    """``proposals/linear.py::_ObservationUpdate`` (the step-by-step route's optimal proposal for user-defined affine models,
+    written in innovation form) against a per-particle brute force of the textbook precision form - posterior mean /
+    covariance and the first-stage marginal - for scalar / vector states and observations, shared and per-filter ``A``."""
+    from torch.distributions import MultivariateNormal
+
+    from pyfilter_amd.filters.particle.proposals.linear import _ObservationUpdate
+
+    class Obj:
+        pass
+
+    def check(vx, vy, batched_a, N=5, B=3, D=3, O=2):
+        f64 = torch.float64
+        g = torch.Generator().manual_seed(1)
+        ev = (D,) if vx else ()
+        m, xcur = torch.randn((N, B) + ev, generator=g, dtype=f64), torch.randn((N, B) + ev, generator=g, dtype=f64)
+        h = 0.3 + torch.rand((N, B) + ev, generator=g, dtype=f64)
+        shape_a = ((O, D) if vy else (D,)) if vx else ((O,) if vy else ())
+        a = torch.randn(((B,) if batched_a else ()) + shape_a, generator=g, dtype=f64)
+        oe = (O,) if vy else ()
+        b, y = torch.randn(oe, generator=g, dtype=f64), torch.randn(oe, generator=g, dtype=f64)
+        s = 0.2 + torch.rand(oe, generator=g, dtype=f64)
+        model = Obj()
+        model.hidden = Obj()
+        model.hidden.n_dim, model.n_dim, model.parameters = int(vx), int(vy), (a, b, s)
+        up = _ObservationUpdate(model, h)
+        post, lm = up.posterior(y, m), up.log_marginal(y, xcur)
+        assert post.batch_shape == (N, B) and lm.shape == (N, B)
+        dd, oo = (D if vx else 1), (O if vy else 1)
+        for n in range(N):
+            for k in range(B):
+                A = (a[k] if batched_a else a).reshape(oo, dd)
+                Hm, R = torch.diag(h[n, k].reshape(-1) ** 2), torch.diag(s.reshape(-1).expand(oo) ** 2)
+                cov = torch.linalg.inv(torch.linalg.inv(Hm) + A.T @ torch.linalg.inv(R) @ A)
+                mean = cov @ (torch.linalg.inv(Hm) @ m[n, k].reshape(-1) + A.T @ torch.linalg.inv(R) @ (y - b).reshape(-1))
+                torch.testing.assert_close(post.mean[n, k].reshape(-1), mean, rtol=1e-10, atol=1e-12)
+                got_cov = post.covariance_matrix[n, k] if vx else (post.scale[n, k] ** 2).reshape(1, 1)
+                torch.testing.assert_close(got_cov, cov, rtol=1e-9, atol=1e-12)
+                ref = MultivariateNormal(b.reshape(-1).expand(oo) + A @ xcur[n, k].reshape(-1),
+                                         covariance_matrix=R + A @ Hm @ A.T).log_prob(y.reshape(-1).expand(oo))
+                torch.testing.assert_close(lm[n, k], ref, rtol=1e-10, atol=1e-12)
+
+    for vx in (False, True):
+        for vy in (False, True):
+            for batched_a in (False, True):
+                check(vx, vy, batched_a)
