@@ -63,6 +63,19 @@ __device__ __forceinline__ float pf_sin(float x) {
     return ((int)k & 1) ? -sres : sres;
 }
 __device__ __forceinline__ double pf_sin(double x) { return sin(x); }
+// float sine of the closed-form (FAST) production kernels: the hardware's v_sin_f32 on x / 2 pi (two instructions; absolute
+// error <= 2^-21.4 = 3.6e-7 on [-pi, pi] plus the reduction's |x| * 6e-8 - the one-step mean x + sin(x - gamma) dt carries a
+// tenth of that, two orders below the 1e-5 bar of the teacher-forced tests; valid for |x / 2 pi| <= 256).  Larger arguments -
+// a diverged particle - take the Cody-Waite form.  The float64 parity path never comes here.
+#ifndef PF_NO_NATIVE_SIN
+__device__ __forceinline__ float pf_sin_fast(float x) {
+    if (!(fabsf(x) < 1.0e3f)) return pf_sin(x);
+    return __builtin_amdgcn_sinf(x * 0.159154943091895335769f);
+}
+#else
+__device__ __forceinline__ float pf_sin_fast(float x) { return pf_sin(x); }
+#endif
+__device__ __forceinline__ double pf_sin_fast(double x) { return sin(x); }
 // exp for importance weights: float -> the bare v_exp_f32 (2^x) on x * log2(e): two instructions (clang's __expf
 // expands to 13 with its range handling).  Relative error ~|x| * 6e-8, irrelevant next to the fp32 rounding of the
 // weights themselves; results below 2^-126 flush to zero, exp(-inf) = 0.  double -> libm
@@ -137,7 +150,21 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     v += dpp_get<PF_DPP_ROW_MIRROR>(v, T(0));
     return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
+#ifndef PF_NO_FMAX_WAVE_MAX
+// float: v_max_f32 takes the DPP operand directly - one instruction per exchange instead of move + compare + select (inputs
+// are NaN-free maxima of sanitised log-weights; -inf is an ordinary operand of v_max)
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = __builtin_fmaxf(v, dpp_get<PF_DPP_QUAD_XOR1>(v, v));
+    v = __builtin_fmaxf(v, dpp_get<PF_DPP_QUAD_XOR2>(v, v));
+    v = __builtin_fmaxf(v, dpp_get<PF_DPP_ROW_HALF_MIRROR>(v, v));
+    v = __builtin_fmaxf(v, dpp_get<PF_DPP_ROW_MIRROR>(v, v));
+    return __builtin_fmaxf(__builtin_fmaxf(lane_get(v, 0), lane_get(v, 16)), __builtin_fmaxf(lane_get(v, 32), lane_get(v, 48)));
+}
+#endif
 template <typename T> __device__ __forceinline__ T wave_max(T v) {
+#ifndef PF_NO_FMAX_WAVE_MAX
+    if constexpr (sizeof(T) == 4) return wave_max_f32(v);
+#endif
     // NaN-free inputs (maxima of sanitised log-weights); the comparison form keeps -inf working
     T o = dpp_get<PF_DPP_QUAD_XOR1>(v, v);
     v = (o > v) ? o : v;

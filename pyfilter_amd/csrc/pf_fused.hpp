@@ -551,6 +551,21 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 // taken from them) are bit-identical everywhere, which is what lets the step kernel do without a planning kernel.
 // redm: PF_NWAVES doubles, reds: (2 + NX) * PF_NWAVES doubles.  Ends with a barrier when TABLE (the table is readable).
 #define PF_COMBINE_ITERS (PF_MAX_TILES / PF_BLOCK)  // partial records per thread
+// 1 / (the column's sum of shifted weights) - the scale of the tile-prefix table.  double filters (the parity path): the IEEE
+// division (~30 instructions).  float filters: v_rcp_f64 + two Newton steps (8 instructions, <= 1 ulp of the quotient in
+// double - 2^-29 of a float ulp of any cdf value; every workgroup of a column performs the same operations on the same sums,
+// so they still agree bit for bit)
+template <typename T> __device__ __forceinline__ double pf_rcp_tot(double tot) {
+#ifndef PF_NO_FAST_RCP_TOT
+    if constexpr (sizeof(T) == 4) {
+        double r = __builtin_amdgcn_rcp(tot);
+        r = __builtin_fma(__builtin_fma(-tot, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-tot, r, 1.0), r, r);
+        return r;
+    }
+#endif
+    return 1.0 / tot;
+}
 #define PF_PROBE_STEP 8  // spacing of the prologue's window-start probes (entries)
 struct ColSums {
     double M, S, Q;
@@ -635,7 +650,7 @@ __device__ __forceinline__ ColSums column_sums(const ColPartials<WITH_Q, NX>& in
     }
     if constexpr (TABLE) {
         const double excl = wave_off + incl_w - run;
-        const double inv_tot = 1.0 / tot;  // one division per thread, not 2 IT (an fp64 division is ~30 instructions)
+        const double inv_tot = pf_rcp_tot<T>(tot);  // one reciprocal per thread, not 2 IT divisions
         if (threadIdx.x == 0) ptl[0] = 0.0;
 #pragma unroll
         for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
@@ -659,7 +674,7 @@ __device__ __forceinline__ ColSums column_sums_one_tile(double m, double s, doub
     const double ef = exp_diff_t<T>(m, MR);
     const double run = s * ef;
     const double qs = WITH_Q ? q * ef * ef : 0.0;
-    const double inv_tot = 1.0 / run;
+    const double inv_tot = pf_rcp_tot<T>(run);
     if (threadIdx.x == 0) {
         ptl[0] = 0.0;
         ptl[1] = run * inv_tot;
@@ -690,7 +705,7 @@ __device__ __forceinline__ ColSums column_sums_wave(const double* part, int64_t 
     const double qtot = WITH_Q ? 0.0 + wave_sum(qs) : 0.0;
     const double tot = 0.0 + lane_get(incl_w, 63);
     const double excl = 0.0 + incl_w - run;
-    const double inv_tot = 1.0 / tot;
+    const double inv_tot = pf_rcp_tot<T>(tot);
     if (wid == 0) {
         if (lane == 0) ptl[0] = 0.0;
         if (on) {

@@ -276,8 +276,8 @@ template <typename T> struct FastCol {
     // LK: the shape of the one-step mean as a compile-time constant (0 decided by A2 at run time, 1 affine, 2 sine)
     template <int LK = 0> __device__ __forceinline__ T loc(T x) const {
         if constexpr (LK == 1) return A0 + (x - A3) * A1;
-        if constexpr (LK == 2) return x + pf_sin(x - A3) * A2;
-        if (A2 != T(0)) return x + pf_sin(x - A3) * A2;
+        if constexpr (LK == 2) return x + pf_sin_fast(x - A3) * A2;
+        if (A2 != T(0)) return x + pf_sin_fast(x - A3) * A2;
         return A0 + (x - A3) * A1;
     }
     __device__ __forceinline__ T obs_lp(T x, bool next = false) const {
