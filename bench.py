@@ -368,7 +368,7 @@ def pmc_traffic(kernel_substr, workload, dtype_name, t_len=20, n_override=None):
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "p", "--",
                sys.executable, os.path.abspath(__file__), "--_inner", "--workload", workload, "--dtype", dtype_name,
                "--T", str(t_len), "--steps", "1", "--warmup", "1", "--no-cpu-baseline"] + (["--N", str(n_override)] if n_override else [])
-        env = dict(os.environ, TMPDIR="/tmp", PF_NO_GRAPH="1")
+        env = dict(os.environ, TMPDIR="/tmp")  # (the child - `--_inner` - issues its launches directly: one dispatch row each)
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -405,6 +405,10 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--_inner", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args._inner:  # profiled child of pmc_traffic(): no hipGraph replays (per-dispatch counter rows)
+        from pyfilter_amd.hints import HINTS
+
+        HINTS.graph = False
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: become N ranks, one per GPU (what the driver does for N > 1)

@@ -29,6 +29,10 @@
 extern "C" {
 #endif
 
+#define PF_ABI_VERSION 2 /* 2: pf_filter_args starts with its own size and ends with pf_run_hints; the library has no
+                          * environment variables and no process-wide switches - every choice a caller can override is an
+                          * argument */
+
 #define PF_OK 0
 #define PF_EINVAL (-1)     /* bad argument (shape, dtype, null pointer) */
 #define PF_EWORKSPACE (-2) /* workspace too small */
@@ -77,10 +81,14 @@ typedef struct pf_model {
     const void* params;
 } pf_model;
 
+/* "pfamd <version> (gfx950) abi <PF_ABI_VERSION> src:<sha256 of the concatenated sources the binary was built from>" -
+ * __graft_entry__.build() passes the digest; a log line with it shows which tree a shipped binary belongs to. */
 const char* pf_version(void);
+int pf_abi_version(void);
 const char* pf_error_string(int code);
 
-/* Scratch bytes any call below needs for an (N, B, D) problem. */
+/* Scratch bytes any call below needs for an (N, B, D) problem - an upper bound over every tile geometry a call may be
+ * given (pf_run_hints.tile_target), so a workspace of this size serves all of them. */
 int pf_workspace_bytes(int64_t N, int64_t B, int64_t D, size_t* bytes);
 
 /* ------------------------------------------------------------------------------------------------------------ *
@@ -173,7 +181,22 @@ int pf_theta_ess(const void* logw, int64_t rows, int64_t B, int dtype, void* out
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and
  * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; one kernel per step.
  * ------------------------------------------------------------------------------------------------------------ */
+/* Choices pf_filter_run normally takes itself, overridable PER CALL (tests pin both kernel routes against the reference,
+ * tools measure them).  All zero = the library's own choices.  Nothing in the library reads the environment. */
+#define PF_ROUTE_AUTO 0           /* filters of <= column_max_n particles: the column-persistent kernel, else one kernel per step */
+#define PF_ROUTE_PER_STEP 1       /* always one k_fused_step launch per time step */
+#define PF_ROUTE_COLUMN_GENERIC 2 /* as AUTO, but the column kernel's run-time instantiation (no model kind folded in) */
+typedef struct pf_run_hints {
+    int32_t route;           /* PF_ROUTE_* */
+    int32_t column_max_n;    /* largest filter the column-persistent kernel takes; 0 = the default (2048) */
+    int32_t tile_target;     /* workgroups per launch the tile size aims at; 0 = the default (1024 = 4 per CU) */
+    int32_t ancestor_search; /* != 0: systematic ancestors by searching the staged window at any size (default: only float
+                              * grids beyond 2^22 positions, where the inverted grid's closed form is not exact) */
+} pf_run_hints;
+
 typedef struct pf_filter_args {
+    uint64_t struct_size; /* sizeof(pf_filter_args) of the header the caller was built against: a caller of another ABI
+                           * version is refused (PF_EINVAL) instead of being read past its end */
     pf_model model;
     int32_t filter;    /* PF_FILTER_* */
     int32_t proposal;  /* PF_PROP_* */
@@ -225,6 +248,7 @@ typedef struct pf_filter_args {
                    * reference carries prev_inds (sisr.py:25-26). */
     const void* user_loc;   /* PF_HID_USER_AFFINE only: (D, B, N) one-step mean of every particle of the INCOMING state ... */
     const void* user_scale; /* ... and its transition scale, both in the state's layout and dtype (else NULL) */
+    pf_run_hints hints;     /* all zero = the library's own choices */
 } pf_filter_args;
 
 /* Runs steps [t0, t0 + n_steps) - indices into y / observed / the tapes / the result rows; ONE kernel launch per step
@@ -281,7 +305,7 @@ int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_steps, void* 
                           int dtype, void* stream);
 
 /* The step-kernel instantiations the calling thread's most recent pf_filter_run launches selected, oldest first:
- * out[i] = { step, sizeof(T), D, VEC, MODE, PROP, FAST, SPEC, MK, MULTI } (10 int32 per record, at most 64 are kept).
+ * out[i] = { step, sizeof(T), D, VEC, MODE, PROP, FAST, SPEC, MK, MULTI } (10 int32 per record, the last 2048 are kept).
  * Returns the number of records written (>= 0) or a negative PF_E* code. */
 int pf_debug_launch_trace(int32_t* out, int max_records);
 

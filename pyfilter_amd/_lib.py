@@ -24,7 +24,7 @@ MAX_D = 3
 MAX_O = 3
 
 EXPORTS = (
-    "pf_version", "pf_error_string", "pf_workspace_bytes", "pf_normalize", "pf_systematic", "pf_systematic_logw",
+    "pf_version", "pf_abi_version", "pf_error_string", "pf_workspace_bytes", "pf_normalize", "pf_systematic", "pf_systematic_logw",
     "pf_multinomial", "pf_gather", "pf_loglik", "pf_moments", "pf_pre_weight", "pf_sample_and_weight",
     "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed", "pf_filter_graph_create", "pf_filter_graph_launch",
     "pf_filter_graph_destroy", "pf_columns_gather", "pf_columns_exchange", "pf_debug_draw_normals", "pf_debug_launch_trace",
@@ -39,8 +39,18 @@ class PfModel(C.Structure):
     ]
 
 
+ABI_VERSION = 2  # include/pf_amd.h: PF_ABI_VERSION
+
+
+class PfRunHints(C.Structure):
+    _fields_ = [("route", C.c_int32), ("column_max_n", C.c_int32), ("tile_target", C.c_int32), ("ancestor_search", C.c_int32)]
+
+
 class PfFilterArgs(C.Structure):
+    """``pf_filter_args``; a fresh instance carries its own size (the library refuses a block of another ABI version)."""
+
     _fields_ = [
+        ("struct_size", C.c_uint64),
         ("model", PfModel),
         ("filter", C.c_int32), ("proposal", C.c_int32), ("resampler", C.c_int32), ("dtype", C.c_int32),
         ("N", C.c_int64), ("B", C.c_int64),
@@ -56,7 +66,12 @@ class PfFilterArgs(C.Structure):
         ("observed_dev", C.c_void_p),
         ("ring", C.c_int64),
         ("user_loc", C.c_void_p), ("user_scale", C.c_void_p),
+        ("hints", PfRunHints),
     ]
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.struct_size = C.sizeof(PfFilterArgs)
 
 
 _lib = None
@@ -71,7 +86,7 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("PF_AMD_LIB", LIB_PATH)  # development: an instrumented build of the same sources
+    path = LIB_PATH  # (development tools load an instrumented build of the same sources by setting ``_lib.LIB_PATH`` first)
     if not os.path.exists(path):
         raise PfAmdError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -110,8 +125,16 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         if name not in ("pf_version", "pf_error_string"):
             fn.restype = C.c_int
+    if lib.pf_abi_version() != ABI_VERSION:
+        raise PfAmdError(f"{path} implements ABI {lib.pf_abi_version()}, this package speaks ABI {ABI_VERSION}: rebuild it "
+                         "(python -c 'import __graft_entry__ as g; g.build()')")
     _lib = lib
     return lib
+
+
+def version() -> str:
+    """``pf_version()``: library version, ABI and the sha256 of the sources the binary was built from."""
+    return load().pf_version().decode()
 
 
 def check(rc: int, what: str):
@@ -154,10 +177,8 @@ def workspace(n: int, b: int, device: torch.device) -> torch.Tensor:
     key = (n, b, device.index, stream_ptr())
     ws = _ws_cache.get(key)
     nbytes = C.c_size_t(0)
-    # (asked every time - a host-side formula: the tile geometry, hence the size, follows development knobs such as
-    # PF_TARGET_WGS that a process may change between calls; a cached buffer sized under another setting is replaced)
-    check(load().pf_workspace_bytes(n, b, MAX_D, C.byref(nbytes)), "pf_workspace_bytes")
-    if ws is None or ws.numel() < nbytes.value:
+    if ws is None:  # (the size is a bound over every tile geometry: include/pf_amd.h)
+        check(load().pf_workspace_bytes(n, b, MAX_D, C.byref(nbytes)), "pf_workspace_bytes")
         ws = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
         if len(_ws_cache) > 64:
             _ws_cache.clear()

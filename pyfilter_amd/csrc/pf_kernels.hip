@@ -38,7 +38,8 @@ struct Geom {
     int tiles;          // per column
 };
 
-static inline Geom make_geom(int64_t N, int64_t B) {
+// `target`: workgroups per launch the tile size aims at (pf_run_hints.tile_target; 0 = PF_TARGET_WGS)
+static inline Geom make_geom(int64_t N, int64_t B, int64_t target = 0) {
     Geom g;
     g.N = N;
     g.B = (int)B;
@@ -48,8 +49,7 @@ static inline Geom make_geom(int64_t N, int64_t B) {
     // Tile size: every workgroup pays a fixed price (column combine, constants, reductions), so tiles grow until the
     // grid is down to ~PF_TARGET_WGS workgroups (4 per CU) - but never more than PF_MAX_TILES tiles per column.
     int min_r = (g.vec == 4) ? 1 : 4;  // >= 1024-particle tiles
-    int64_t target = PF_TARGET_WGS;
-    if (const char* ev = getenv("PF_TARGET_WGS")) target = atoll(ev) > 0 ? atoll(ev) : target;  // development knob
+    if (target <= 0) target = PF_TARGET_WGS;
     int64_t r = (rounds_total * B) / target;
     if (r > rounds_total) r = rounds_total;
     const int64_t r_cap = (rounds_total + PF_MAX_TILES - 1) / PF_MAX_TILES;
@@ -111,6 +111,19 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     o = align256(o + 2 * sizeof(double) * w.ctab_elems);
     w.total = o;
     return w;
+}
+
+// Upper bound of make_ws(...).total over every tile geometry make_geom can produce for (N, B) (any `target`): the partials
+// are largest with the most tiles per column (the smallest tiles), the chunk table never holds more than
+// rounds_total + one tile's rounds per column.
+static inline size_t ws_bound(int64_t N, int64_t B, int D) {
+    Geom g = make_geom(N, B, (int64_t)1 << 40);  // a huge target = the smallest tiles = the most tiles per column
+    const int64_t rounds_total = (N + g.round_elems - 1) / g.round_elems;
+    const size_t most_tiles = make_ws(g, D).total;
+    g.tiles = 1;
+    g.rounds_per_tile = (int)(2 * rounds_total + 2);  // tiles * rounds_per_tile <= rounds_total + rounds_per_tile <= 2 rounds_total
+    const size_t most_chunks = make_ws(g, D).total;
+    return most_tiles + most_chunks;
 }
 
 // partial slots
@@ -1095,7 +1108,13 @@ static inline ModelDesc to_desc(const pf_model* m) {
 #define PF_TU_NO_API
 #endif
 #ifndef PF_TU_NO_API
-extern "C" const char* pf_version(void) { return "pfamd 0.1.0 (gfx950)"; }
+#ifndef PF_SOURCE_SHA256
+#define PF_SOURCE_SHA256 "unknown"
+#endif
+#define PF_STR2(x) #x
+#define PF_STR(x) PF_STR2(x)
+extern "C" const char* pf_version(void) { return "pfamd 0.2.0 (gfx950) abi " PF_STR(PF_ABI_VERSION) " src:" PF_SOURCE_SHA256; }
+extern "C" int pf_abi_version(void) { return PF_ABI_VERSION; }
 
 extern "C" const char* pf_error_string(int code) {
     switch (code) {
@@ -1117,8 +1136,7 @@ extern "C" int pf_debug_offset(int64_t N, int64_t B, size_t* off) {
 
 extern "C" int pf_workspace_bytes(int64_t N, int64_t B, int64_t D, size_t* bytes) {
     if (!bytes || bad_shape(N, B) || D < 1 || D > PF_MAXD) return PF_EINVAL;
-    const Geom g = make_geom(N, B);
-    *bytes = make_ws(g, PF_MAXD).total;
+    *bytes = ws_bound(N, B, PF_MAXD);
     return PF_OK;
 }
 
@@ -1170,8 +1188,7 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
                            (const double*)part, g);                                                                  \
     }                                                                                                                \
     hipLaunchKernelGGL((k_search<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u, u_per_elem,        \
-                       (const T*)v, multinomial, seed, step, colmask, idx, g, force_search);
-    static const int force_search = getenv("PF_FORCE_SEARCH") != nullptr;  // testing knob: the searching variant at any size
+                       (const T*)v, multinomial, seed, step, colmask, idx, g, /*force_search*/ 0);
     PF_DISPATCH_T_VEC(dtype, g.vec, CALL)
 #undef CALL
     PF_CHECK_LAUNCH();
@@ -1432,7 +1449,7 @@ extern "C" int pf_debug_draw_normals(uint64_t seed, uint32_t step0, int64_t n_st
 
 // Test support: which step-kernel instantiation each launch of the calling thread's most recent fused runs selected
 // (pf_debug_launch_trace).  A per-thread ring, written on the host at launch time - nothing a kernel ever reads.
-#define PF_TRACE_LEN 64
+#define PF_TRACE_LEN 2048
 #define PF_TRACE_FIELDS 10
 struct LaunchTrace {
     int32_t rec[PF_TRACE_LEN][PF_TRACE_FIELDS];
@@ -1505,10 +1522,10 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
     static_assert(PK_N == 24, "workspace layout reserves 24 slots per column record");
     a.finalize_only = 0;
     a.t0 = (int)t0;
-    {
-        const char* dc = getenv("PF_DEBUG_CUT");
-        a.debug_cut = dc ? atoi(dc) : 0;
-    }
+    a.debug_cut = 0;
+#ifdef PF_DEVTOOLS  // (the instrumented build of tools/pmc_stages.py: stage cuts / cycle stamps selected per process)
+    if (const char* dc = getenv("PF_DEBUG_CUT")) a.debug_cut = atoi(dc);
+#endif
     return a;
 }
 
@@ -1522,7 +1539,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     // the step kernel: one workgroup per tile + the column's bookkeeper - an extra workgroup when the column has many
     // tiles, else its last step workgroup (PF_BOOK_INLINE=0/1 overrides: development)
     a.book_inline = g.tiles < 8 ? 1 : 0;
+#ifdef PF_DEVTOOLS
     if (const char* bi = getenv("PF_BOOK_INLINE")) a.book_inline = atoi(bi);  // (2: nobody keeps the books - timing experiments)
+#endif
     const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
@@ -1564,7 +1583,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
 
     // ancestor stage of the step kernel: 0 inverted grid (systematic), 1 multinomial, 2 systematic by search - float
     // grids beyond 2^22 positions, where the closed form is not exact (PF_FORCE_SEARCH=1 selects it for testing)
-    static const bool force_search = getenv("PF_FORCE_SEARCH") != nullptr;
+    const bool force_search = A->hints.ancestor_search != 0;
     const int mode = (A->resampler == PF_RESAMPLE_MULTINOMIAL)
                          ? 1
                          : ((sizeof(T) == 4 && (g.N > ((int64_t)1 << 22) || force_search)) ? 2 : 0);
@@ -1597,9 +1616,8 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             if constexpr (sizeof(T) == 4 && !FAST && D == 1) {
                 if (a.md.hid_kind == PF_HID_VERHULST_EM && a.md.obs_kind == PF_OBS_SV) return launch(std::integral_constant<int, 1>{});
             }
-            if constexpr (sizeof(T) == 4 && !FAST && D == 3) {  // Lorenz-63 (PF_STEP_LORENZ_MK=0: the run-time kernel - A/B tests)
-                const char* e = getenv("PF_STEP_LORENZ_MK");
-                if (a.md.hid_kind == PF_HID_LORENZ63_EM && a.md.obs_kind == PF_OBS_LINEAR && !(e && atoi(e) == 0))
+            if constexpr (sizeof(T) == 4 && !FAST && D == 3) {  // Lorenz-63
+                if (a.md.hid_kind == PF_HID_LORENZ63_EM && a.md.obs_kind == PF_OBS_LINEAR)
                     return launch(std::integral_constant<int, 4>{});
             }
             if constexpr (sizeof(T) == 4 && FAST && D == 1) {  // shape of the one-step mean of the closed-form models
@@ -1716,9 +1734,8 @@ static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize, int vec) {
 // a column that fits one workgroup.  PF_NO_COLUMN=1 keeps everything on the per-step route (tests compare the two).
 static inline bool column_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
     if (!finalize || n_steps < 1 || A->ring >= 3) return false;
-    if (const char* e = getenv("PF_NO_COLUMN")) if (atoi(e) != 0) return false;
-    int64_t max_n = PF_COLUMN_MAX_N;
-    if (const char* e = getenv("PF_COLUMN_MAX_N")) max_n = atoll(e);
+    if (A->hints.route == PF_ROUTE_PER_STEP) return false;
+    const int64_t max_n = A->hints.column_max_n > 0 ? A->hints.column_max_n : PF_COLUMN_MAX_N;
     if (A->N > max_n || column_threads(A->N, column_vec(A, g)) > 1024) return false;
     return column_lds_bytes(A->N, A->model.dim, A->dtype == PF_F64 ? 8 : 4, column_vec(A, g)) <= 64 * 1024;  // (the default dynamic-LDS limit)
 }
@@ -1757,16 +1774,14 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         bool spec_ok = false;  // a specialised instantiation exists for this run (see below)
         if constexpr (sizeof(T) == 4 && D == 1 && VEC == 4) {
             const int hk = A->model.hid_kind;
-            const char* ge = getenv("PF_COLUMN_GENERIC");  // (read per run: tests switch it)
-            const bool generic_only = ge != nullptr && atoi(ge) != 0;
+            const bool generic_only = A->hints.route == PF_ROUTE_COLUMN_GENERIC;
             const bool closed = A->model.obs_kind == PF_OBS_LINEAR && (hk == PF_HID_LINEAR || hk == PF_HID_SINE_EM || hk == PF_HID_OU) &&
                                 (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
             const bool sv = A->model.obs_kind == PF_OBS_SV && hk == PF_HID_VERHULST_EM && A->proposal == PF_PROP_BOOTSTRAP;
             spec_ok = !A->z_tape && !generic_only && (closed || sv);  // (any workgroup size: the 256- or the 1024-thread bound)
         }
         if constexpr (sizeof(T) == 4 && D == 3 && VEC == 4) {  // Lorenz-63
-            const char* ge = getenv("PF_COLUMN_GENERIC");
-            spec_ok = nt <= 256 && !A->z_tape && !(ge != nullptr && atoi(ge) != 0) && A->model.obs_kind == PF_OBS_LINEAR &&
+            spec_ok = nt <= 256 && !A->z_tape && A->hints.route != PF_ROUTE_COLUMN_GENERIC && A->model.obs_kind == PF_OBS_LINEAR &&
                       A->model.hid_kind == PF_HID_LORENZ63_EM && (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
         }
         trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, spec_ok ? 1 : 0,
@@ -2023,7 +2038,9 @@ extern "C" int pf_filter_graph_destroy(void* handle) {
 
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms) {
-    if (!A) return PF_EINVAL;
+    if (!A || A->struct_size != sizeof(pf_filter_args)) return PF_EINVAL;  // (another ABI version: include/pf_amd.h)
+    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_COLUMN_GENERIC || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
+        return PF_EINVAL;
     int rc = check_model(&A->model, true);
     if (rc) return rc;
     if (bad_shape(A->N, A->B) || t0 < 0 || n_steps < 0) return PF_EINVAL;
@@ -2040,7 +2057,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     }
     if (A->filter != PF_FILTER_SISR && A->filter != PF_FILTER_APF) return PF_EUNSUPPORTED;
     if (!A->pos) return PF_EINVAL;
-    const Geom g = make_geom(A->N, A->B);
+    const Geom g = make_geom(A->N, A->B, A->hints.tile_target);
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;

@@ -9,13 +9,13 @@ route through ``predict`` / ``correct`` - which still calls the HIP primitives f
 moments and evaluates only the user's model callables with PyTorch-ROCm ops.
 """
 import ctypes as C
-import os
 from typing import Callable, Optional, Union
 
 import torch
 
 from ... import _lib as L
 from ... import ops
+from ...hints import HINTS
 from ...resampling import multinomial, systematic
 from ...timeseries import StateSpaceModel, TimeseriesState
 from ...timeseries.models import pack_params
@@ -309,7 +309,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         reference's predict / correct sequence over the stand-alone kernels."""
         x = correction.timeseries_state.value
         if (not isinstance(y, torch.Tensor) or not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1
-                or self._record_intermediary or os.environ.get("PF_NO_FUSED_STEP", "0") == "1"):
+                or self._record_intermediary or not HINTS.fused_step):
             return super().filter(y, correction, result=result)
         new = self._filter_fused_single(y, correction)
         if result is not None:
@@ -351,6 +351,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ll_steps, ll_total = stats[4 * d].reshape(1, b), stats[4 * d + 1]
 
         a = plan.args
+        HINTS.fill(a)
         a.model.params = ctx.params.data_ptr()
         planes = None
         if kind.is_user:
@@ -393,7 +394,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         assert self._model is not None, "Model has not been initialized!"
         device, _ = self._device_dtype()
         if (not self._fused_capable(device) or not isinstance(y, torch.Tensor)
-                or os.environ.get("PF_NO_FUSED_BATCH", "0") == "1"
+                or not HINTS.fused_batch
                 or (self._kernel_kind().is_user and FilterResult.states_kept(self.record_states) != 1)):
             # (a user-defined affine process with recorded states: the driver's loop over fused single steps)
             return super().batch_filter(y, bar=bar, init_state=init_state)
@@ -483,9 +484,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             ring = max(3, steps - wanted[0] + 1)  # slots for the states wanted[0] .. steps
         taped = ctx.z_tape is not None or ctx.u_tape is not None
         use_graph = ((not taped) and not ring and replay is None and not getattr(self, "_time_kernels", False)
-                     and os.environ.get("PF_NO_GRAPH", "0") != "1" and not kind.is_user and not self._move_by_move)
+                     and HINTS.graph and not kind.is_user and not self._move_by_move)
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
-               self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes())
+               self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes(), HINTS.key())
         plan = self._fused_plans.get(key) if use_graph else None
         if plan is None:
             plan = _FusedPlan(self, kind, n, b, d, o, steps, rows, dtype, device, observed_host, ring=ring)
@@ -507,6 +508,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         word = (seed_eff - self._seed) & _M64
         plan.epoch.fill_(word - (1 << 64) if word >= (1 << 63) else word)
         a = plan.args
+        HINTS.fill(a)  # (a cached plan was keyed by them; a fresh one takes the current ones)
         z_tape = u_tape = None
         if ctx.z_tape is not None:
             z_tape = ctx.z_tape[t_start:t_start + steps].contiguous()

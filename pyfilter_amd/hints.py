@@ -1,0 +1,48 @@
+"""Per-process overrides of choices the library normally takes itself - which fused kernel route a run takes, the tile
+geometry, whether runs are captured as hipGraphs.  The defaults ARE the product; tests set attributes of ``HINTS`` to pin
+both kernel routes against the reference, development tools to measure them.  Nothing in the package reads the
+environment: ``apply_mapping`` exists so that *test / tool* infrastructure can translate a mapping it owns (its own
+command line, the ``PF_*`` variables of a test driver's subprocess) - the package never calls it.
+
+The kernel-side choices travel to the library per call in ``pf_filter_args.hints`` (``include/pf_amd.h: pf_run_hints``)."""
+
+ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC = 0, 1, 2
+
+
+class RunHints:
+    __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph")
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.route = ROUTE_AUTO      # pf_run_hints.route
+        self.column_max_n = 0        # pf_run_hints.column_max_n (0 = the library's 2048)
+        self.tile_target = 0         # pf_run_hints.tile_target (0 = the library's 1024 workgroups per launch)
+        self.ancestor_search = 0     # pf_run_hints.ancestor_search
+        self.fused_step = True       # ``filter()`` of a built-in model takes the fused single-step move
+        self.fused_batch = True      # ``batch_filter()`` of a built-in model takes the fused run
+        self.graph = True            # repeated fused runs of one configuration replay a captured hipGraph
+
+    def key(self):
+        """What a cached launch plan depends on."""
+        return (self.route, self.column_max_n, self.tile_target, self.ancestor_search)
+
+    def fill(self, args):
+        """Writes the kernel-side choices into a ``PfFilterArgs``."""
+        h = args.hints
+        h.route, h.column_max_n, h.tile_target, h.ancestor_search = self.route, self.column_max_n, self.tile_target, self.ancestor_search
+
+    def apply_mapping(self, m):
+        """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
+        PF_NO_FUSED_BATCH / PF_NO_GRAPH`` of a mapping the CALLER owns -> attributes (absent keys: the defaults)."""
+        on = lambda k: str(m.get(k, "0")) not in ("", "0")  # noqa: E731
+        self.route = ROUTE_PER_STEP if on("PF_NO_COLUMN") else (ROUTE_COLUMN_GENERIC if on("PF_COLUMN_GENERIC") else ROUTE_AUTO)
+        self.column_max_n = int(m.get("PF_COLUMN_MAX_N", 0) or 0)
+        self.tile_target = int(m.get("PF_TARGET_WGS", 0) or 0)
+        self.ancestor_search = 1 if on("PF_FORCE_SEARCH") else 0
+        self.fused_step, self.fused_batch, self.graph = not on("PF_NO_FUSED_STEP"), not on("PF_NO_FUSED_BATCH"), not on("PF_NO_GRAPH")
+        return self
+
+
+HINTS = RunHints()

@@ -92,7 +92,7 @@ def gather_filters(t: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
         return t[:, indices]  # a different number of filters out than in: not the in-place resample of the reference
     # bounds check without a host round trip where torch offers the asynchronous assert (as torch's own CUDA indexing does)
     ok = ((idx >= -b) & (idx < b)).all()
-    if hasattr(torch, "_assert_async") and os.environ.get("PF_SYNC_CHECKS", "0") != "1":
+    if hasattr(torch, "_assert_async") and not SYNC_CHECKS:
         torch._assert_async(ok)
     elif not bool(ok):
         raise IndexError(f"index out of bounds for dimension 1 with size {b}")
@@ -296,6 +296,9 @@ def initial_sample_soa(m0, s0, n: int, b: int, d: int, dtype, device, seed: int,
 # ----------------------------------------------------------------------------------------------------------------
 # test support
 # ----------------------------------------------------------------------------------------------------------------
+SYNC_CHECKS = False  # True: index bounds of whole-filter moves are checked with a host round trip (an IndexError) instead
+# of torch's asynchronous device-side assert
+
 TRACE_FIELDS = ("step", "tbytes", "D", "VEC", "MODE", "PROP", "FAST", "SPEC", "MK", "MULTI")
 
 
@@ -309,7 +312,7 @@ def debug_draw_normals(seed: int, steps: int, n: int, b: int, d: int, dtype, dev
     return out
 
 
-TRACE_LEN = 64  # launch records the library keeps per thread (PF_TRACE_LEN)
+TRACE_LEN = 2048  # launch records the library keeps per thread (PF_TRACE_LEN)
 
 
 def debug_launch_trace(last: int = 64):

@@ -96,6 +96,7 @@ int main() {
     int failures = 0;
     for (int variant = 0; variant < 2; ++variant) {
         pf_filter_args A = {};
+        A.struct_size = sizeof(A);  // ABI 2: the block names the header it was built against (hints: all zero = the library's choices)
         A.model.hid_kind = PF_HID_LINEAR;
         A.model.obs_kind = PF_OBS_LINEAR;
         A.model.dim = (int32_t)D;

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+from pyfilter_amd.hints import HINTS
+
+# A driver test may start this suite in a subprocess with kernel-side choices in ITS environment (PF_TARGET_WGS: multi-round
+# tiles at test sizes; PF_FORCE_SEARCH: the searching ancestor stage): the test infrastructure translates them - the package
+# itself never reads the environment (pyfilter_amd/hints.py)
+HINTS.apply_mapping(os.environ)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -14,6 +21,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """Which binary the tests load, and whether it was built from this tree (``pf_version()`` carries the sources' sha256)."""
+    try:
+        import hashlib
+
+        import __graft_entry__ as ge
+        from pyfilter_amd import _lib
+
+        with open(_lib.LIB_PATH, "rb") as f:
+            digest = hashlib.sha256(f.read()).hexdigest()
+        return [f"libpfamd.so sha256:{digest}", f"{_lib.version()}",
+                "built from this tree's sources: " + ("yes" if ge.binary_matches_sources() else "NO - rebuild (__graft_entry__.build())")]
+    except Exception as e:  # (no library yet: the tests that need it say so themselves)
+        return [f"libpfamd.so: {e}"]
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
@@ -23,12 +46,9 @@ def golden_dir():
 def kernel_route(request, monkeypatch):
     """Which fused route a small filter (N <= 4096) takes: "column" - the column-persistent kernel, one launch per run
     (``pf_column.hpp``; the library's default for such shapes) - or "per_step" - one ``k_fused_step`` launch per time step
-    (``PF_NO_COLUMN=1``; what larger filters always take).  Tests parametrised over it pin BOTH against the reference."""
+    (``HINTS.route = 1``; what larger filters always take).  Tests parametrised over it pin BOTH against the reference."""
     route = getattr(request, "param", "column")
-    if route == "per_step":
-        monkeypatch.setenv("PF_NO_COLUMN", "1")
-    else:
-        monkeypatch.delenv("PF_NO_COLUMN", raising=False)
+    monkeypatch.setattr(HINTS, "route", 1 if route == "per_step" else 0)
     return route
 
 

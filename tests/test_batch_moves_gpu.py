@@ -47,7 +47,9 @@ def test_gather_and_exchange_match_torch_indexing(ops, dtype, n, b, tail):
 
 
 def test_gather_rejects_out_of_range(ops, monkeypatch):
-    monkeypatch.setenv("PF_SYNC_CHECKS", "1")  # (the default check is torch's asynchronous device-side assert)
+    import pyfilter_amd.ops as ops_module
+
+    monkeypatch.setattr(ops_module, "SYNC_CHECKS", True)  # (the default check is torch's asynchronous device-side assert)
     t = torch.zeros(64, 4, device="cuda")
     with pytest.raises(IndexError):
         ops.gather_filters(t, torch.tensor([0, 1, 2, 4], device="cuda"))

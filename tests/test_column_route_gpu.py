@@ -51,7 +51,7 @@ def _model(kind, b, dtype):
     raise KeyError(kind)
 
 
-def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(), seed=7, ess=0.9):
+def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(), seed=7, ess=0.9, generic=False):
     from pyfilter_amd import ops, resampling
     from pyfilter_amd.filters.particle import APF, SISR, proposals
 
@@ -72,17 +72,17 @@ def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(),
     y = y.to(dtype)
     for k in nan_at:
         y[k] = float("nan")
-    os.environ.pop("PF_NO_COLUMN", None)
-    os.environ["PF_COLUMN_MAX_N"] = "4096"  # (the library hands columns beyond 2 048 particles to the per-step route: faster there)
-    if route == "per_step":
-        os.environ["PF_NO_COLUMN"] = "1"
+    from pyfilter_amd.hints import HINTS
+
+    saved = (HINTS.route, HINTS.column_max_n)
+    HINTS.column_max_n = 4096  # (the library hands columns beyond 2 048 particles to the per-step route: faster there)
+    HINTS.route = 1 if route == "per_step" else (2 if generic else 0)
     try:
         res = filt.batch_filter(y.to(DEV), bar=False)
         torch.cuda.synchronize()
         trace = ops.debug_launch_trace(4)
     finally:
-        os.environ.pop("PF_NO_COLUMN", None)
-        os.environ.pop("PF_COLUMN_MAX_N", None)
+        HINTS.route, HINTS.column_max_n = saved
     last = res.latest_state
     return dict(means=res.filter_means.cpu(), var=res.filter_variance.cpu(), ll=res.loglikelihood.cpu(),
                 x=last.timeseries_state.value.cpu(), w=last.weights.cpu(), idx=last.previous_indices.cpu(),
@@ -166,10 +166,10 @@ def test_column_route_float32_within_monte_carlo_error_of_float64(kind, filt_nam
 @pytest.mark.parametrize("prop", ["bootstrap", "lgo"])
 @pytest.mark.parametrize("filt_name", ["sisr", "apf"])
 @pytest.mark.parametrize("kind", ["lg", "sine", "ou", "sv", "lorenz"])
-def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, prop, resampler, n, monkeypatch):
+def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, prop, resampler, n):
     """float32 runs of the scalar closed-form models take instantiations of the column kernel with the model kind, filter
     and proposal as compile-time constants (``pf_column.hpp``: KIND / FILT / PROP).  Same draws, same arithmetic: they
-    must reproduce the run-time kernel (``PF_COLUMN_GENERIC=1``) - NaN observations included - and be the ones that ran."""
+    must reproduce the run-time kernel (``pf_run_hints.route = PF_ROUTE_COLUMN_GENERIC``) - NaN observations included - and be the ones that ran."""
     if kind == "sv" and prop == "lgo":
         pytest.skip("the stochastic-volatility observation has no linear-Gaussian proposal")
     if kind == "lorenz" and n % 4:
@@ -177,16 +177,14 @@ def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, p
     # (n = 333: the RAGGED instantiations - four particles per lane, N % 4 != 0; n = 1502: ragged AND the 1024-thread bound)
     b, t_len, nan_at = (5, 40, (3, 17)) if n < 1024 else (3, 12, (3,))
     spec = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
-    monkeypatch.setenv("PF_COLUMN_GENERIC", "1")
-    gen = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
+    gen = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at, generic=True)
     assert spec["SPEC"] == 9 and spec["FAST"] == 1 and gen["SPEC"] == 9 and gen["FAST"] == 0
     if kind == "lorenz" and prop == "bootstrap":
         # the Lorenz drift folds into different fused multiply-adds once its kind is a constant: an ulp in a chaotic state
         # moves an ancestor, after which the two are different - equally valid - Monte-Carlo runs.  What can be pinned: ONE
         # move from the same state (same ancestors, new particles and moments to float rounding), and that long runs stay finite.
         assert torch.isfinite(spec["ll"]).all() and torch.isfinite(spec["means"]).all()
-        one_s = _run("column", kind, filt_name, prop, resampler, n, b, 1, torch.float32)
-        monkeypatch.delenv("PF_COLUMN_GENERIC")
+        one_s = _run("column", kind, filt_name, prop, resampler, n, b, 1, torch.float32, generic=True)
         one_f = _run("column", kind, filt_name, prop, resampler, n, b, 1, torch.float32)
         assert one_s["FAST"] == 0 and one_f["FAST"] == 1
         assert torch.equal(one_s["idx"], one_f["idx"])

@@ -12,6 +12,7 @@ import torch
 
 from oracle import cpu_ref
 from oracle.cases import CASES, build_spec
+from pyfilter_amd.hints import HINTS
 from tests.conftest import both_routes
 from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
 
@@ -131,7 +132,7 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
 def test_step_by_step_route_matches_reference(name, dt, monkeypatch):
     """predict()/correct() through the stand-alone primitives (the fused single-step path of ``filter()`` switched off):
     every step's state, ancestors and ll."""
-    monkeypatch.setenv("PF_NO_FUSED_STEP", "1")
+    monkeypatch.setattr(HINTS, "fused_step", False)
     case = next(c for c in CASES if c["name"] == name)
     g = load_golden(name, dt)
     filt = build_filter_from_case(case, g, DT[dt], "cuda")
@@ -551,7 +552,7 @@ def test_weight_collapse_paths(filt_name, prop, kernel_route):
 def test_fused_single_step_filter_matches_reference(name, kernel_route):
     """``filter()`` one observation at a time (the online / SMC^2 entry point) through the fused single-step path:
     every step's particles, weights, log-likelihood and ancestors against the reference's golden run (float64,
-    identical draws) - and identical to what the step-by-step route (PF_NO_FUSED_STEP=1) produces."""
+    identical draws) - and identical to what the step-by-step route (``HINTS.fused_step = False``) produces."""
     from oracle.cases import CASE_BY_NAME
 
     if name not in CASE_BY_NAME:
@@ -561,7 +562,7 @@ def test_fused_single_step_filter_matches_reference(name, kernel_route):
     y = g["y"].cuda()
     outs = {}
     for route in ("fused", "steps"):
-        os.environ["PF_NO_FUSED_STEP"] = "1" if route == "steps" else "0"
+        HINTS.fused_step = route != "steps"
         try:
             filt = build_filter_from_case(case, g, torch.float64, "cuda")
             state = filt.initialize()
@@ -573,7 +574,7 @@ def test_fused_single_step_filter_matches_reference(name, kernel_route):
                              state.previous_indices.clone()))
             outs[route] = (rows, res)
         finally:
-            os.environ.pop("PF_NO_FUSED_STEP", None)
+            HINTS.fused_step = True
     rows, res = outs["fused"]
     tol = dict(rtol=1e-9, atol=1e-11)
     for t, (x, w, ll, idx) in enumerate(rows):
@@ -696,7 +697,7 @@ def test_parameters_are_read_live(route, monkeypatch):
     from pyfilter_amd.timeseries import models
 
     if route == "steps":
-        monkeypatch.setenv("PF_NO_FUSED_STEP", "1")
+        monkeypatch.setattr(HINTS, "fused_step", False)
     n, b, t_len = 4096, 3, 6
     gen = torch.Generator().manual_seed(2)
     z = torch.randn(t_len, n, b, generator=gen, dtype=torch.float64)
@@ -809,7 +810,7 @@ def test_repeated_runs_and_copies_draw_fresh_numbers(route, monkeypatch):
     global generator): log-likelihood estimates differ between calls, agree within Monte-Carlo error, and a filter
     rebuilt with the same seed reproduces the first call's numbers."""
     if route == "steps":
-        monkeypatch.setenv("PF_NO_FUSED_STEP", "1")
+        monkeypatch.setattr(HINTS, "fused_step", False)
     from pyfilter_amd.filters.particle import SISR, proposals
 
     case = dict(model="lg1d", B=4)
@@ -932,8 +933,8 @@ def test_randomised_parity_sweep(monkeypatch, kernel_route):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     monkeypatch.setattr("sys.argv", ["fuzz_parity.py", "30", "11"])
-    monkeypatch.delenv("PF_TARGET_WGS", raising=False)
+    saved = (HINTS.tile_target, HINTS.column_max_n)
     try:
         assert mod.main() == 0
     finally:
-        os.environ.pop("PF_TARGET_WGS", None)
+        HINTS.tile_target, HINTS.column_max_n = saved

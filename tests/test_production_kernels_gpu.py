@@ -30,7 +30,9 @@ def _per_step_route(monkeypatch):
     """These tests pin the STEP kernel's production instantiations (asserted through the launch trace), also at the golden
     cases' small particle counts - which the library would otherwise hand to the column-persistent kernel
     (tests/test_column_route_gpu.py covers that one)."""
-    monkeypatch.setenv("PF_NO_COLUMN", "1")
+    from pyfilter_amd.hints import HINTS
+
+    monkeypatch.setattr(HINTS, "route", 1)
 F32 = torch.float32
 
 

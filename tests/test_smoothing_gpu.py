@@ -88,11 +88,13 @@ def test_recorded_states_with_unobserved_substeps():
         f = SISR(ssm, n, proposal=proposals.Bootstrap(), ess_threshold=0.6, record_states=True, record_intermediary_states=inter)
         f.set_batch_shape(torch.Size([b]))
         f.set_tape(z=z, u=u, z0=z0)
-        os.environ["PF_NO_FUSED_BATCH"] = "0" if fused else "1"
+        from pyfilter_amd.hints import HINTS
+
+        HINTS.fused_batch = fused
         try:
             return f.batch_filter(y, bar=False)
         finally:
-            os.environ.pop("PF_NO_FUSED_BATCH")
+            HINTS.fused_batch = True
 
     for inter in (False, True):
         a, r = run(inter, True), run(inter, False)

@@ -66,7 +66,9 @@ def test_lambda_defined_models_reproduce_the_reference_fixtures(name, loop, kern
     """``loop``: "run" - ``batch_filter``'s own loop over the moves (callable -> planes -> one fused run per move, on the
     plan's buffers); "moves" - the reference's driver loop over ``filter()`` (one fused single-step move per call)."""
     if loop == "moves":
-        monkeypatch.setenv("PF_NO_FUSED_BATCH", "1")
+        from pyfilter_amd.hints import HINTS
+
+        monkeypatch.setattr(HINTS, "fused_batch", False)
     from pyfilter_amd import ops
     from pyfilter_amd.filters.particle import APF, SISR, proposals
     from pyfilter_amd.filters.particle.state import ParticleFilterCorrection

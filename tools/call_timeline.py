@@ -8,6 +8,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
+
+_env.setup()
 from tools.kbench import make  # noqa: E402
 from pyfilter_amd import _lib as L  # noqa: E402
 

@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     from oracle import cpu_ref
     from oracle.cases import build_spec, simulate
+    from pyfilter_amd.hints import HINTS
     from tests.helpers import build_filter_from_case
 
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
@@ -29,9 +30,9 @@ def main():
         b = rng.choice([1, 1, 2, 3, 5, 9, 17]) if n < 20000 else rng.choice([1, 2, 3])
         t_len = rng.randint(1, 9) if (n > 4096 or rng.random() < 0.5) else rng.randint(10, 40)  # (long runs: the column loop)
         if rng.random() < 0.3:  # columns of 2 049 .. 4 096 particles on the column-persistent route too (16-wave workgroups)
-            os.environ["PF_COLUMN_MAX_N"] = "4096"
+            HINTS.column_max_n = 4096
         else:
-            os.environ.pop("PF_COLUMN_MAX_N", None)
+            HINTS.column_max_n = 0
         ess = rng.choice([0.1, 0.5, 0.9, 0.97])  # (not 1.0: exactly uniform weights - after a NaN observation - sit ON that
         # threshold, and which side of it ESS = 1 / sum W^2 lands on is a rounding tie between any two implementations)
         target = rng.choice([None, None, 4, 64, 4096])  # geometry: few big tiles ... many small ones
@@ -49,10 +50,7 @@ def main():
                 y[s] = float("nan")
         if os.environ.get("FUZZ_TARGET"):  # (overrides for dissecting a single case: FUZZ_ONLY=<i> FUZZ_TARGET=<n|none> FUZZ_ROUTE=<route>)
             target = None if os.environ["FUZZ_TARGET"] == "none" else int(os.environ["FUZZ_TARGET"])
-        if target is None:
-            os.environ.pop("PF_TARGET_WGS", None)
-        else:
-            os.environ["PF_TARGET_WGS"] = str(target)
+        HINTS.tile_target = 0 if target is None else target
         only = os.environ.get("FUZZ_ONLY")  # e.g. "655": re-run single cases of a sweep (the random stream is consumed as usual)
         if only and str(i) not in only.split(","):
             rng.choice(["batch", "batch", "online", "recorded"])
@@ -132,4 +130,7 @@ def main():
 
 
 if __name__ == "__main__":
+    import _env
+
+    _env.setup()
     sys.exit(main())

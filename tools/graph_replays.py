@@ -12,6 +12,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
+
+_env.setup()
 
 
 def first_bad_replay(steps=2, b=256, n=2048, replays=600, seed=7):

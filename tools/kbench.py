@@ -9,6 +9,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
+
+_env.setup()
 
 from pyfilter_amd import resampling, timeseries as ts  # noqa: E402
 from pyfilter_amd.filters.particle import APF, SISR, proposals  # noqa: E402

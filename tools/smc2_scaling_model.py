@@ -17,6 +17,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
+
+_env.setup()
 
 ALL_GATHER_US = 25.0     # small-message RCCL all-gather over xGMI, latency-bound (8 ranks, a few KiB)
 XGMI_GBS = 153.0 * 0.8   # one point-to-point xGMI link at ~80 % of its 153 GB/s

@@ -11,6 +11,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
+
+_env.setup()
 
 
 def main():
@@ -38,9 +41,9 @@ def main():
         return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
 
     for route in ("column", "per_step"):
-        os.environ.pop("PF_NO_COLUMN", None)
-        if route == "per_step":
-            os.environ["PF_NO_COLUMN"] = "1"
+        from pyfilter_amd.hints import HINTS
+
+        HINTS.route = 1 if route == "per_step" else 0
         for mode in ("fit(block=16)", "step()"):
             best = None
             for rep in range(4):

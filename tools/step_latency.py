@@ -8,11 +8,14 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.kbench import make  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kbench import make  # noqa: E402
 
 
 def run(cfg, fused, reps=60):
-    os.environ["PF_NO_FUSED_STEP"] = "0" if fused else "1"
+    from pyfilter_amd.hints import HINTS
+
+    HINTS.fused_step = bool(fused)
     f, _ = make(*cfg)
     state = f.initialize()
     y = torch.tensor(0.1, device="cuda")
