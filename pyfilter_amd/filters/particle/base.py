@@ -363,7 +363,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             planes = (ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event).contiguous(),
                       ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event).contiguous())
             a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
-        a.y = y_dev.data_ptr()
+        a.y, a.y_rows = y_dev.data_ptr(), rows
+        a.observed, a.observed_dev, a.step_counter = None, None, None  # (the block route shares this argument block)
         a.seed = self._next_draw_seed()  # fresh Philox draws per move
         a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
         a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
@@ -428,12 +429,99 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if (not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1 or self._record_intermediary
                 or self._kernel_kind().is_user):
             return None
+        if (FilterResult.states_kept(self.record_states) == 1 and not getattr(self, "_time_kernels", False)
+                and not self._move_by_move and self._ctx_tapes_none()):
+            return self._filter_block_lean(y, state, observed, replay)
         res = self._batch_filter_fused(y, state._restarted(), observed=observed, replay=replay)
         run = self._last_run
         res.block_rows = (run["rows"][0][1:], run["rows"][1][1:])  # the moves' own moment rows (row 0 = the incoming state)
         ll = run["ll_steps"]
         u = run["u"]  # (a cached plan's buffer, redrawn by the next run: the token keeps a copy)
         return res, (ll if self._batched else ll[:, 0]), (run["seed_eff"], None if u is None else u.clone())
+
+    def _ctx_tapes_none(self) -> bool:
+        ctx = self._ensure_context()
+        return ctx.z_tape is None and ctx.u_tape is None
+
+    def _filter_block_lean(self, y: torch.Tensor, state: ParticleFilterCorrection, observed, replay):
+        """``filter_block`` for the caller it exists for - SMC^2, which issues a block of ~16 moves per host decision, a few
+        dozen blocks per fit: at 1 000 theta x 400 particles such a block is 90 us of kernel time, and the general fused
+        driver (persistent plan, staging copies in and out, a ``FilterResult`` with its moment log per call: ~25 small
+        torch ops, 0.25 ms of host time) was what a fit consisted of.  Here the run writes straight into the tensors that
+        become the new state and the block's rows (four allocations), reads the incoming state through one packed copy,
+        takes parameters / observations / flags where they are, draws its systematic offsets in the kernels (keyed by seed
+        and move, so a cut replay repeats them) - ten device operations and one ``pf_filter_run`` per block."""
+        ctx = self._ctx
+        kind = ctx.kind
+        ts_in = state.timeseries_state
+        x_in = ops.to_soa(ts_in.value, self._batched, self._has_event)
+        lw_in = ops.to_cols(state.weights)
+        device, dtype = x_in.device, x_in.dtype
+        d, b, n = x_in.shape
+        o = kind.obs_dim
+        steps = y.shape[0]
+        y_dev = y.to(device=device, dtype=dtype).reshape(steps, -1, o)
+        if not y_dev.is_contiguous():
+            y_dev = y_dev.contiguous()
+        rows = y_dev.shape[1]
+        if rows not in (1, b):
+            raise L.PfAmdError(f"observations of shape {tuple(y.shape)} do not broadcast against batch {b}")
+        flags = (observed if observed is not None else self._observed_flags(y, y_dev)).contiguous()
+        key = (n, b, d, o, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
+               self._resampler_kind(), float(self._resample_threshold))
+        plan = self._single_plans.get(key)
+        if plan is None:
+            plan = self._single_plans[key] = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
+        if plan.xl is None:  # the run's other state slot (the kernels alternate between two)
+            plan.xl = torch.empty((d + 1, b, n), device=device, dtype=dtype)
+        t_start = int(ts_in.time_index)
+
+        # what the run writes: the new state (particles + log-weights in one allocation, ancestors), the rows, the increments
+        xl_out = torch.empty((d + 1, b, n), device=device, dtype=dtype)
+        anc = torch.empty((b, n), device=device, dtype=torch.int32)
+        rows_buf = torch.empty((2, steps + 1, b, d), device=device, dtype=dtype)
+        ll = torch.zeros((steps + 1, b), device=device, dtype=dtype)  # per move | the run's total (accumulated in place)
+        # the incoming state goes to slot 0; the final state lands in slot steps & 1 - which must be the fresh allocation
+        first = xl_out if steps % 2 == 0 else plan.xl
+        other = plan.xl if steps % 2 == 0 else xl_out
+        xl_in = getattr(state, "_xl", None)
+        if (xl_in is not None and xl_in.shape == first.shape and xl_in.dtype == dtype and xl_in.data_ptr() == x_in.data_ptr()
+                and xl_in[d].data_ptr() == lw_in.data_ptr()):
+            first.copy_(xl_in)  # (a state this route produced and nobody replaced since: particles and log-weights sit in one buffer)
+        else:
+            first[:d].copy_(x_in)
+            first[d].copy_(lw_in)
+        anc.copy_(state.ancestors32().reshape(b, n))
+
+        a = plan.args
+        HINTS.fill(a)
+        a.model.params = ctx.params.data_ptr()
+        a.y, a.y_rows = y_dev.data_ptr(), rows
+        a.observed, a.observed_dev = flags.data_ptr(), None
+        seed_eff = self._next_draw_seed() if replay is None else replay[0]
+        a.seed, a.step_counter = seed_eff, None
+        u_tape = replay[1][:steps].contiguous() if (replay is not None and replay[1] is not None) else None
+        a.z_tape, a.u_tape = None, L.ptr(u_tape)
+        a.x[0], a.x[1] = first.data_ptr(), other.data_ptr()
+        a.logw[0], a.logw[1] = first[d].data_ptr(), other[d].data_ptr()
+        a.anc = anc.data_ptr()
+        a.means, a.vars = rows_buf[0].data_ptr(), rows_buf[1].data_ptr()
+        a.ll_steps, a.ll_total = ll.data_ptr(), ll[steps].data_ptr()
+        L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
+        self._last_run = dict(plan=plan, z=None, u=u_tape, ws=plan.ws, seed_eff=seed_eff, ll_steps=ll[:steps],
+                              keep=(x_in, lw_in, y_dev, flags, ctx.params))
+
+        md = (lambda t: t) if self._batched else (lambda t: t[:, 0])
+        means, variances = md(rows_buf[0]), md(rows_buf[1])
+        ll_steps = ll[:steps] if self._batched else ll[:steps, 0]
+        last = ParticleFilterCorrection(
+            TimeseriesState(t_start + steps, ops.from_soa(xl_out[:d], self._batched, self._has_event), self._model.hidden.event_shape),
+            ops.from_cols(xl_out[d], self._batched), ll_steps[steps - 1], None,
+            _moments=(means[steps], variances[steps]), _anc32=(anc, self._batched),
+        )
+        last._xl = xl_out
+        res = _BlockResult(means, variances, ll[steps] if self._batched else ll[steps, 0], last)
+        return res, ll_steps, (seed_eff, None)
 
     def _batch_filter_fused(self, y: torch.Tensor, init_state=None, observed=None, replay=None) -> FilterResult:
         state = init_state if init_state is not None else self.initialize()
@@ -678,6 +766,20 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         return torch.stack(res[::-1], dim=0)
 
 
+class _BlockResult:
+    """What ``filter_block`` hands back on its lean route: the run's rows (row 0 = the incoming state), its total
+    log-likelihood and final state behind ``FilterResult``'s read interface - no moment log, no state deque."""
+
+    def __init__(self, means, variances, loglikelihood, last_state):
+        self.filter_means, self.filter_variance = means, variances
+        self.loglikelihood, self.latest_state = loglikelihood, last_state
+        self.block_rows = (means[1:], variances[1:])  # the moves' own rows
+
+    @property
+    def states(self):
+        return [self.latest_state]
+
+
 class _SingleStepPlan:
     """Scratch + launch arguments of the fused *single-step* move behind ``filter()`` (the online / SMC^2 entry point):
     the kernels read the incoming state's own buffers and write freshly allocated ones that become the new state -
@@ -688,6 +790,7 @@ class _SingleStepPlan:
         self.pos = torch.empty((b, n), device=device, dtype=dtype)
         self.ws = L.new_workspace(n, b, device)
         self.rows = rows
+        self.xl = None  # (``_filter_block_lean``: the second state slot of a multi-move run, allocated on first use)
         a = L.PfFilterArgs()
         a.model = ops.make_model_struct(kind, filt._ctx.params)
         a.filter, a.proposal, a.resampler = filt._FILTER_KIND, filt._proposal._KERNEL_PROPOSAL, filt._resampler_kind()

@@ -23,7 +23,9 @@ def _on_device(d: Distribution, device, dtype) -> Distribution:
             continue
         args[name] = v.to(device=device, dtype=dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v
     try:
-        return type(d)(**args)
+        # (no argument validation: torch's ``_validate_sample`` / ``_validate_args`` end in ``if not valid.all(): raise`` - a
+        # device -> host round trip per ``log_prob``, i.e. per prior and PMMH move, while the re-filter is running)
+        return type(d)(**args, validate_args=False)
     except TypeError:
         return d
 
@@ -36,7 +38,7 @@ class Prior:
             distribution = _on_device(distribution, device, dtype)
         self.distribution = distribution
         self.bijection = biject_to(distribution.support)
-        self.unconstrained = TransformedDistribution(distribution, self.bijection.inv)
+        self.unconstrained = TransformedDistribution(distribution, self.bijection.inv, validate_args=False)
 
     @property
     def numel(self) -> int:

@@ -35,7 +35,7 @@ class RandomWalk:
     def build(self, theta, state, filter_, y) -> Distribution:
         loc = theta.stack_parameters(constrained=False)
         scale = torch.as_tensor(self._scale, device=loc.device, dtype=loc.dtype).expand_as(loc).clone()
-        return Independent(Normal(loc, scale), 1)
+        return Independent(Normal(loc, scale, validate_args=False), 1, validate_args=False)
 
     def exchange(self, latest, candidate, mask) -> None:
         m = mask.unsqueeze(-1)

@@ -261,39 +261,57 @@ class SMC2:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
         return state
 
-    def _steps_ahead(self, ys: torch.Tensor, flags: torch.Tensor, state: SMC2State):
-        """Up to ``len(ys)`` observations with ONE host decision point.  The reference tests the ESS of the theta-weights on
-        the host after every observation (``smc2.py:59-62``) - a device round trip per observation, which is what an
-        SMC^2 run on a GPU spends its time on.  Here the filters run the whole block as one fused sequence
-        (``filter_block``); the block's theta-weight paths ``w + cumsum(ll)`` (one all-gather per block when sharded) and
-        their ESS come back in one copy, and the test is applied to them in order.  No rejuvenation due (the rule, not the
-        exception): the block is committed.  Due at observation ``j``: the moves after it never happened - the block is
-        run again cut after ``j`` *on the same draws*, so state and weights belong to one particle system - and the
-        kernel takes over exactly where the reference's would.  Returns ``(observations consumed, state)``; 0 when the
-        filter has no fused block route."""
+    # ---- fit(): the filters run a block of observations ahead of the host's rejuvenation test ---------------------------
+    # The reference tests the ESS of the theta-weights on the host after every observation (``smc2.py:59-62``) - a device
+    # round trip per observation, which is what an SMC^2 run on a GPU spends its time on.  Here the filters run a whole
+    # block as one fused sequence (``filter_block``); the block's theta-weight paths ``w + cumsum(ll)`` (one all-gather per
+    # block when sharded) and their ESS come back in ONE small copy, and the test is applied to them in order.  No
+    # rejuvenation due (the rule, not the exception): the block is committed.  Due at observation ``j``: the moves after it
+    # never happened - the block is run again cut after ``j`` *on the same draws*, so state and weights belong to one
+    # particle system - and the kernel takes over exactly where the reference's would.
+    # Blocks are PIPELINED: block k + 1 is issued (from block k's final state, as if no rejuvenation were due) before the
+    # host waits for block k's statistics, so the device never idles while the host prepares launches; when block k does
+    # contain a rejuvenation, the speculative successor is simply dropped.
+    def _issue_block(self, ys: torch.Tensor, flags: torch.Tensor, latest, w: torch.Tensor, slot: int):
+        """Issues one block from (``latest`` state, theta-weights ``w``); nothing here waits for the device.  Returns None
+        when the filter has no fused block route."""
         filt, shard = self.filter, self.shard
-        sharded = shard.world > 1
-        latest = state.filter_state.latest_state
         out = filt.filter_block(ys, latest, observed=flags)
         if out is None:
-            return 0, state
-        thr = self._threshold * self.particles[0]
-
-        def paths(ll):
-            w_path = state.w + ll.cumsum(0)  # (n, B_local)
-            return w_path, _theta_stats(shard.all_gather(w_path, dim=1) if sharded else w_path)
-
+            return None
         res, ll, token = out
-        w_path, stats = paths(ll)
-        n = ys.shape[0]
-        hit = next((q for q, (ess, finite) in enumerate(stats.tolist()) if ess < thr or not finite), None)
-        take = n if hit is None else hit + 1
-        if take < n:
-            res, ll, _ = filt.filter_block(ys[:take], latest, observed=flags[:take], replay=token)
-            w_path, stats = paths(ll)
-        for q in range(take):
-            state.append_data(ys[q])
-        state.w.copy_(w_path[take - 1])
+        w_path = w + ll.cumsum(0)  # (n, B_local)
+        stats = _theta_stats(shard.all_gather(w_path, dim=1) if shard.world > 1 else w_path)  # (n, 2): ESS, all finite
+        event = None
+        if stats.is_cuda:  # one small asynchronous copy into pinned memory + an event: the host later waits for THIS block only
+            host = self._pinned(slot, stats)
+            host.copy_(stats, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        else:
+            host = stats
+        return dict(ys=ys, flags=flags, latest=latest, res=res, ll=ll, token=token, w_path=w_path, stats=stats, host=host, event=event)
+
+    def _pinned(self, slot: int, like: torch.Tensor) -> torch.Tensor:
+        bufs = self.__dict__.setdefault("_pinned_bufs", {})
+        key = (slot, like.dtype)
+        buf = bufs.get(key)
+        if buf is None or buf.shape[0] < like.shape[0]:
+            buf = bufs[key] = torch.empty((max(like.shape[0], self._block), 2), dtype=like.dtype, pin_memory=True)
+        return buf[: like.shape[0]]
+
+    def _first_hit(self, blk) -> Optional[int]:
+        """Waits for the block's statistics (only) and applies the reference's test to them in order."""
+        if blk["event"] is not None:
+            blk["event"].synchronize()
+        thr = self._threshold * self.particles[0]
+        return next((q for q, (ess, finite) in enumerate(blk["host"].tolist()) if ess < thr or not finite), None)
+
+    def _commit(self, blk, take: int, state: SMC2State) -> SMC2State:
+        """The first ``take`` observations of a block become part of the algorithm state."""
+        res, stats = blk["res"], blk["stats"]
+        state.parsed.extend(blk["ys"][:take].unbind(0))
+        state.w.copy_(blk["w_path"][take - 1])
         state.ess.extend(stats[:take, 0].unbind(0))
         state.stats = stats[take - 1]
         # the moves' moment rows as the run reported them - NOT a slice of the block result's series, whose window may be
@@ -301,9 +319,14 @@ class SMC2:
         rows = getattr(res, "block_rows", None) or (res.filter_means[1:], res.filter_variance[1:])
         state.filter_state._extend_fused(rows[0], rows[1], res.loglikelihood, res.latest_state)
         state.current_iteration += take
-        if hit is not None:
-            state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
-        return take, state
+        return state
+
+    def _cut(self, blk, take: int, state: SMC2State):
+        """The block again, cut after ``take`` observations, on the same draws."""
+        res, ll, _ = self.filter.filter_block(blk["ys"][:take], blk["latest"], observed=blk["flags"][:take], replay=blk["token"])
+        w_path = state.w + ll.cumsum(0)
+        stats = _theta_stats(self.shard.all_gather(w_path, dim=1) if self.shard.world > 1 else w_path)
+        return dict(blk, res=res, ll=ll, w_path=w_path, stats=stats)
 
     def fit(self, y: torch.Tensor, block: Optional[int] = None) -> SMC2State:
         """All observations of ``y``.  ``block`` (default: the constructor's) = how many observations the filters run
@@ -319,13 +342,35 @@ class SMC2:
             else:
                 flags = (~y.isnan().reshape(y.shape[0], -1).all(dim=1)).to(torch.uint8)
         t, total = 0, y.shape[0]
+        pending, slot = None, 0  # the block in flight: issued, not yet decided
         while t < total:
-            n, done = min(k, total - t), 0
-            if flags is not None and n > 1:
-                done, state = self._steps_ahead(y[t:t + n], flags[t:t + n], state)
-            if done == 0:
-                state, done = self.step(y[t], state), 1
-            t += done
+            n = min(k, total - t)
+            if flags is None or n < 2:
+                state, t = self.step(y[t], state), t + 1
+                continue
+            blk = pending if pending is not None else self._issue_block(y[t:t + n], flags[t:t + n], state.filter_state.latest_state, state.w, slot)
+            pending = None
+            if blk is None:  # no fused block route: the observation-by-observation loop
+                state, t = self.step(y[t], state), t + 1
+                continue
+            # speculate: the next block starts where this one ends - issued before the host looks at this one's statistics
+            t_next = t + n
+            n_next = min(k, total - t_next)
+            if n_next >= 2:
+                slot ^= 1
+                pending = self._issue_block(y[t_next:t_next + n_next], flags[t_next:t_next + n_next], blk["res"].latest_state,
+                                            blk["w_path"][n - 1], slot)
+            hit = self._first_hit(blk)
+            if hit is None:
+                state, t = self._commit(blk, n, state), t_next
+                continue
+            pending = None  # (the speculative successor started from a state that never was)
+            take = hit + 1
+            if take < n:
+                blk = self._cut(blk, take, state)
+            state = self._commit(blk, take, state)
+            t += take
+            state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
         return state
 
     def posterior_mean(self, state: SMC2State) -> torch.Tensor:

@@ -51,4 +51,4 @@ def calc_mean_chol(x: torch.Tensor, w: torch.Tensor) -> MeanChol:
 def construct_mvn(x: torch.Tensor, w: torch.Tensor, scale: float = 1.0) -> MultivariateNormal:
     """``MultivariateNormal(mean_w(x), scale_tril = scale * chol(cov_w(x)))`` (utils.py:60-76)."""
     mc = calc_mean_chol(x, w)
-    return MultivariateNormal(mc.mean, scale_tril=scale * mc.chol)
+    return MultivariateNormal(mc.mean, scale_tril=scale * mc.chol, validate_args=False)

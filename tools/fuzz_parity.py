@@ -130,6 +130,7 @@ def main():
 
 
 if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import _env
 
     _env.setup()

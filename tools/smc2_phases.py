@@ -4,6 +4,7 @@ state particles, T = 500, the OU model of tests/inference/models.py.  Wraps the 
 synchronisation added) and prints the totals per fit.  Usage: python tools/smc2_phases.py"""
 import os, sys, time, math, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
 
 _env.setup()

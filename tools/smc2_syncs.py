@@ -1,19 +1,18 @@
 #!/usr/bin/env python
-"""Where the HOST spends an SMC^2 fit (development tool): cProfile of one ``SMC2.fit`` at 128 theta-particles x 8 192 state
-particles, T = 500 - the per-rank job of an 8-GPU run, which is host-bound (tools/smc2_scaling_model.py).
-Usage: python tools/smc2_host_profile.py [n_theta] [n_state]"""
-import cProfile
+"""Every device -> host synchronisation of one ``SMC2.fit`` (development tool): torch's sync debug mode prints a warning with
+the Python stack of each; the count per call site is what is reported.  Usage: python tools/smc2_syncs.py [n_theta] [n_state]"""
+import collections
 import math
 import os
-import pstats
 import sys
-import time
+import traceback
+import warnings
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-import _env  # noqa: E402  (tools/_env.py: PF_AMD_LIB / PF_* of this process -> the package's explicit switches)
+import _env  # noqa: E402
 
 _env.setup()
 
@@ -26,9 +25,8 @@ def main():
     from pyfilter_amd.inference import SMC2
     from pyfilter_amd.timeseries import models
 
-    n_theta = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    n_state = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-    kw = {"block": int(os.environ["SMC2_BLOCK"])} if "SMC2_BLOCK" in os.environ else {}
+    n_theta = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    n_state = int(sys.argv[2]) if len(sys.argv) > 2 else 400
     device, dtype, t_len = torch.device("cuda"), torch.float32, 500
     g = torch.Generator().manual_seed(123)
     x, ys = 0.0, []
@@ -44,21 +42,30 @@ def main():
 
     def fit(seed):
         filt = APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=2024 + seed)
-        alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=seed, **kw)
+        alg = SMC2(filt, n_theta, priors, threshold=0.2, device=device, dtype=dtype, seed=seed)
         alg.fit(y)
         torch.cuda.synchronize()
         return alg
 
     fit(0)
-    t0 = time.perf_counter()
-    fit(1)
-    print(f"fit at {n_theta} theta x {n_state}: {1e3 * (time.perf_counter() - t0):.1f} ms")
-    pr = cProfile.Profile()
-    pr.enable()
-    fit(2)
-    pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
-    pstats.Stats(pr).sort_stats("tottime").print_stats(40)
+    sites = collections.Counter()
+
+    def showwarning(message, category, filename, lineno, file=None, line=None):
+        if "synchroniz" not in str(message):
+            return
+        stack = [f for f in traceback.extract_stack() if "/pyfilter_amd/" in f.filename]
+        where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}({f.name})" for f in reversed(stack[-3:]))
+        sites[where] += 1
+
+    warnings.showwarning = showwarning
+    warnings.simplefilter("always")
+    torch.cuda.set_sync_debug_mode("warn")
+    alg = fit(1)
+    torch.cuda.set_sync_debug_mode("default")
+    print(f"SMC2.fit {n_theta} theta x {n_state}, T = {t_len}: {sum(sites.values())} synchronising calls, "
+          f"{len(alg._kernel.acceptance_history)} PMMH moves")
+    for where, k in sites.most_common():
+        print(f"  {k:4d}  {where}")
 
 
 if __name__ == "__main__":
