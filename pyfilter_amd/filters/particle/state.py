@@ -16,6 +16,16 @@ from ..state import Correction, Prediction
 from .utils import get_filter_mean_and_variance
 
 
+def _masked_assign(dst: Tensor, src: Tensor, mask: Tensor):
+    """``dst[mask] = src[mask]`` along dim 0, in place.  A boolean mask of the right length goes through ``torch.where`` -
+    indexing with it would first count its set entries on the host (a device round trip per call; PMMH does this for every
+    per-filter quantity of every move)."""
+    if mask.dtype == torch.bool and mask.dim() == 1 and dst.shape == src.shape and dst.dim() >= 1 and mask.shape[0] == dst.shape[0]:
+        dst.copy_(torch.where(mask.reshape(mask.shape + (1,) * (dst.dim() - 1)), src, dst))
+    else:
+        dst[mask] = src[mask]
+
+
 class ParticleFilterPrediction(Prediction):
     def __init__(self, prev_x: TimeseriesState, weights: Tensor, normalized_weights: Tensor, indices: Tensor):
         self.prev_x = prev_x
@@ -175,15 +185,15 @@ class ParticleFilterCorrection(Correction):
         if new_x.data_ptr() != ts.value.data_ptr():
             self["_x"] = ts.copy(values=new_x)
         self["_w"] = ops.exchange_filters(self["_w"], other.weights, mask)
-        self["_ll"][mask] = other.get_loglikelihood()[mask]
+        _masked_assign(self["_ll"], other.get_loglikelihood(), mask)
         if self._anc32 is not None and self._anc32[1] and getattr(other, "_anc32", None) is not None and other._anc32[1] \
                 and mask.dtype == torch.bool:
             self._anc32 = (ops.to_cols(ops.exchange_filters(self._view32(), other._view32(), mask)), True)
             dict.pop(self, "_prev_inds", None)
         else:
             self["_prev_inds"] = ops.exchange_filters(self["_prev_inds"], other.previous_indices, mask)
-        self["_mean"][mask] = other["_mean"][mask]
-        self["_var"][mask] = other["_var"][mask]
+        _masked_assign(self["_mean"], other["_mean"], mask)
+        _masked_assign(self["_var"], other["_var"], mask)
 
     def state_dict(self) -> Dict[str, Any]:
         self._ensure_moments()

@@ -248,7 +248,9 @@ class FilterResult(dict, Generic[TCorrection]):
     # ---- whole-filter moves (SMC^2 / PMMH: result.py:76-117) ------------------------------------------------------
     def exchange(self, other: "FilterResult", mask: torch.Tensor):
         """Overwrites the filters selected by ``mask`` (batch dim) with those of ``other``."""
-        self._loglikelihood[mask] = other.loglikelihood[mask]
+        from .particle.state import _masked_assign
+
+        _masked_assign(self._loglikelihood, other.loglikelihood, mask)
         self._moments.exchange_filters(other._moments, mask)
         for mine, theirs in zip(self._states, other._states):
             mine.exchange(theirs, mask)

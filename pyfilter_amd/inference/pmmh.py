@@ -67,6 +67,17 @@ def as_draws(source):
     return ThetaDraws(source)
 
 
+def _to_device(host: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """Host draws -> the device of ``like`` without making the host wait: staged in pinned memory (torch's caching host
+    allocator), copied asynchronously on the current stream (a pageable source would be a synchronous copy)."""
+    host = host.to(like.dtype)
+    if like.is_cuda and not host.is_cuda:
+        staged = torch.empty(host.shape, dtype=host.dtype, pin_memory=True)
+        staged.copy_(host)
+        return staged.to(like.device, non_blocking=True)
+    return host.to(like.device)
+
+
 def _draw(kernel: Distribution, size, shard, draws):
     """theta* ~ kernel (``mcmc/utils.py:48``: ``proposal_kernel.sample(size)``): ``(B, P)`` for a kernel shared by all
     filters (``size = (B,)``: SMC^2's Gaussian fit) and for a per-filter kernel (``size = ()``, ``batch_shape = (B,)``:
@@ -80,7 +91,7 @@ def _draw(kernel: Distribution, size, shard, draws):
     if shard is not None:
         eps = shard.slice(eps)
     loc = kernel.mean if not hasattr(kernel, "loc") else kernel.loc
-    eps = eps.to(device=loc.device, dtype=loc.dtype)
+    eps = _to_device(eps, loc)
     if hasattr(kernel, "scale_tril"):
         rvs = loc + (kernel.scale_tril @ eps.unsqueeze(-1)).squeeze(-1)
     else:  # a diagonal kernel: Independent(Normal(loc, scale), 1) - the random walk
@@ -95,7 +106,7 @@ def _uniforms(like: torch.Tensor, shard, draws):
     u = draws.uniform((total,))
     if shard is not None:
         u = shard.slice(u)
-    return u.to(device=like.device, dtype=like.dtype)
+    return _to_device(u, like)
 
 
 def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_filter, proposal_theta, y: torch.Tensor,

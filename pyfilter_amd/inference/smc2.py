@@ -49,6 +49,7 @@ class SMC2State:
         self.ess = [self._ess()]
         self.parsed = []
         self.current_iteration = 0
+        self._series = None  # ``fit``: (the series being parsed, host flags "observation is not all-NaN") - see parsed_data
 
     def global_weights(self) -> torch.Tensor:
         return self.w if self.shard is None or self.shard.world == 1 else self.shard.all_gather(self.w)
@@ -67,9 +68,22 @@ class SMC2State:
     def append_data(self, y: torch.Tensor):
         self.parsed.append(y)
 
+    def attach_series(self, y: torch.Tensor, flags: Optional[torch.Tensor]):
+        """``fit`` knows the whole series up front: the observations parsed so far are a PREFIX of it - a view instead of a
+        stack of per-observation tensors rebuilt at every rejuvenation - and so are their host flags (which PMMH's
+        re-filter would otherwise fetch from the device once per rejuvenation)."""
+        self._series = (y, flags)
+
     @property
     def parsed_data(self) -> torch.Tensor:
+        series = getattr(self, "_series", None)
+        if series is not None:
+            return series[0][: len(self.parsed)]
         return torch.stack(self.parsed, dim=0)
+
+    def parsed_flags(self) -> Optional[torch.Tensor]:
+        series = getattr(self, "_series", None)
+        return None if series is None or series[1] is None else series[1][: len(self.parsed)]
 
     def normalized_weights(self) -> torch.Tensor:
         return theta_normalize(self.global_weights())
@@ -78,6 +92,7 @@ class SMC2State:
         other = SMC2State.__new__(SMC2State)
         other.w, other.filter_state, other.shard = torch.zeros_like(self.w), filter_state, self.shard
         other.ess, other.parsed, other.current_iteration, other.stats = [], self.parsed, self.current_iteration, None
+        other._series = getattr(self, "_series", None)
         return other
 
     def state_dict(self):
@@ -100,6 +115,7 @@ class SMC2State:
         self.parsed = list(parsed.to(self.w.device).unbind(0)) if parsed.numel() else []
         self.filter_state.load_state_dict(state_dict["filter_state"])
         self.w = state_dict["w"].to(self.w.device)
+        self._series = None
         self.current_iteration = int(state_dict["current_iteration"])
         self.stats = None
 
@@ -157,7 +173,8 @@ class ParticleMetropolisHastings:
         u = draws.uniform(()) if draws is not None else torch.rand(())
         indices = self._resampler(W, u)
         mine = shard.slice(indices) if sharded else indices
-        dist = self._proposal.build(theta, state, filter_, state.parsed_data)
+        data, data_flags = state.parsed_data, state.parsed_flags()
+        dist = self._proposal.build(theta, state, filter_, data)
 
         if self.trace is not None:
             self.trace.append(dict(kind="rejuvenate", indices=indices, kernel=dist))
@@ -170,10 +187,12 @@ class ParticleMetropolisHastings:
         proposal_theta = theta.like()
         proposal_filter = filter_.copy()
         proposal_filter.initialize_model(proposal_theta)
+        if data_flags is not None and hasattr(proposal_filter, "_obs_cache"):
+            proposal_filter._obs_cache = (data, data._version, data_flags)  # (known on the host: no device round trip)
 
         previous_distance, acceptance_rate = 0.0, 0.0
         for i in range(self._n_steps):
-            accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, state.parsed_data,
+            accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, data,
                                 shape, mutate_kernel=False, generator=draws, trace=self.trace)
             rate = accepted.float().sum()
             rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
@@ -204,10 +223,14 @@ class ParticleMetropolisHastings:
         filter_.initialize_model(theta)
         filter_.increase_particles(2.0)
         filter_.set_batch_shape(filter_.batch_shape)
-        new_filter_state = filter_.batch_filter(state.parsed_data, bar=False)
+        data, data_flags = state.parsed_data, state.parsed_flags()
+        if data_flags is not None and hasattr(filter_, "_obs_cache"):
+            filter_._obs_cache = (data, data._version, data_flags)
+        new_filter_state = filter_.batch_filter(data, bar=False)
         weight = new_filter_state.loglikelihood - state.filter_state.loglikelihood
         res = SMC2State(weight, new_filter_state, state.shard)
         res.ess, res.parsed, res.current_iteration = state.ess, state.parsed, state.current_iteration
+        res._series = getattr(state, "_series", None)
         return res
 
 
@@ -341,6 +364,7 @@ class SMC2:
                 flags = ops.observed_flags(y if y.dtype in (torch.float32, torch.float64) else y.float()).cpu()
             else:
                 flags = (~y.isnan().reshape(y.shape[0], -1).all(dim=1)).to(torch.uint8)
+        state.attach_series(y, flags)
         t, total = 0, y.shape[0]
         pending, slot = None, 0  # the block in flight: issued, not yet decided
         while t < total:

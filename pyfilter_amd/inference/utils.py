@@ -26,8 +26,11 @@ def theta_systematic(W: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     on every rank that holds the same ``W`` and ``u``."""
     b = W.shape[0]
     cdf = W.cumsum(0)
-    cdf[-1] = 1.0
-    probs = (torch.arange(b, device=W.device, dtype=W.dtype) + u.to(W)) / b
+    cdf[-1:].fill_(1.0)  # (fill_: the scalar travels as a kernel argument; ``cdf[-1] = 1.0`` stages it through a host tensor)
+    # (``u`` is a host scalar - the lock-step CPU stream: as a Python float it rides in the kernel arguments instead of a
+    # pageable host -> device copy the host would wait for)
+    u = float(u) if not (isinstance(u, torch.Tensor) and u.device == W.device) else u
+    probs = (torch.arange(b, device=W.device, dtype=W.dtype) + u) / b
     return torch.searchsorted(cdf, probs).clamp_max(b - 1)
 
 

@@ -35,9 +35,12 @@ def main():
     y = torch.tensor(ys, dtype=dtype, device=device)
     priors = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
 
+    # the observation constants live on the device ONCE: created inside the builder they would be two pageable host -> device
+    # copies - two waits for the device - per model build, and PMMH rebuilds the model at every move
+    obs_a, obs_s = torch.tensor(1.0, dtype=dtype, device=device), torch.tensor(0.05, dtype=dtype, device=device)
+
     def build(theta):
-        t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
-        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (obs_a, obs_s))
 
     for rep in range(3):
         filt = APF(build, 8192, proposal=proposals.LinearGaussianObservations(), seed=2024 + rep)
