@@ -56,6 +56,12 @@ class Prior:
         return self.unconstrained.log_prob(self.get_unconstrained(x))
 
 
+def _sum_event(ladj: torch.Tensor, prior: "Prior") -> torch.Tensor:
+    """``log |det J|`` of the bijection summed over the prior's event dimensions the transform treats elementwise."""
+    extra = len(prior.distribution.event_shape) - prior.bijection.codomain.event_dim
+    return ladj.sum(tuple(range(-extra, 0))) if extra > 0 else ladj
+
+
 class ThetaParticles:
     """Named parameters of ``batch`` parallel filters.  ``self[name]`` is the tensor to hand to the model."""
 
@@ -65,6 +71,13 @@ class ThetaParticles:
         self.batch_shape = torch.Size([batch])
         self.shard = shard  # pyfilter_amd.distributed.Shard or None: `batch` is this rank's block of the theta-particles
         self._values: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        # Derived quantities of the CURRENT values, kept across calls: "u" the stacked unconstrained parameters (B, P), "prior_u"
+        # the summed log priors in unconstrained space (B,).  A rejuvenation asks for each of them several times (the proposal
+        # fit, the reverse kernel, the acceptance ratio) and every evaluation is ~10 / ~45 small launches through
+        # torch.distributions' transform machinery; the whole-filter moves below carry them along (an index / a select)
+        # instead of dropping them.  Every method that writes the values maintains or clears the cache - the tensors are
+        # handed to the model by reference, but nothing outside this class writes them.
+        self._cache: Dict[str, torch.Tensor] = {}
 
     # ---- values ---------------------------------------------------------------------------------------------------
     def initialize_parameters(self, generator: Optional[torch.Generator] = None):
@@ -99,6 +112,7 @@ class ThetaParticles:
                 self._values[name].copy_(v)
             else:
                 self._values[name] = v.contiguous()
+        self._cache.clear()
         return self
 
     def __getitem__(self, name: str) -> torch.Tensor:
@@ -112,16 +126,22 @@ class ThetaParticles:
         other = ThetaParticles(self.priors, self.batch_shape[0], self.device, self.dtype, self.shard)
         for k, v in self._values.items():
             other._values[k] = v.clone()
+        other._cache = dict(self._cache)  # (same values: the derived quantities hold - tensors nobody writes in place)
         return other
 
     # ---- stacked views (context.py:193-243) -----------------------------------------------------------------------
     def stack_parameters(self, constrained: bool = True) -> torch.Tensor:
         """``(B, P)``: the parameters side by side, flattened per filter."""
+        if not constrained and "u" in self._cache:
+            return self._cache["u"]
         cols = []
         for name, prior in self.priors.items():
             v = self._values[name]
             cols.append((v if constrained else prior.get_unconstrained(v)).reshape(self.batch_shape[0], -1))
-        return torch.cat(cols, dim=-1)
+        out = torch.cat(cols, dim=-1)
+        if not constrained:
+            self._cache["u"] = out
+        return out
 
     def unstack_parameters(self, x: torch.Tensor, constrained: bool = True):
         """Writes ``x (B, P)`` back into the parameter tensors - in place."""
@@ -132,16 +152,43 @@ class ThetaParticles:
             part = x[..., at:at + k].reshape(v.shape)
             v.copy_(part if constrained else prior.get_constrained(part))
             at += k
+        self._cache.clear()
+        if not constrained and x.dim() == 2 and x.shape[0] == self.batch_shape[0]:
+            self._cache["u"] = x  # (the caller's own unconstrained values: what a later stack / prior evaluation starts from)
 
     def eval_priors(self, constrained: bool = True) -> torch.Tensor:
-        """``(B,)`` sum of the log priors (``context.py:245-253``)."""
-        return sum(p.eval_prior(self._values[n], constrained) for n, p in self.priors.items())
+        """``(B,)`` sum of the log priors (``context.py:245-253``).  Unconstrained: the density of ``u = bijection^-1(x)``,
+        ``log p(x) + log |dx / du|`` - evaluated from the stacked ``u`` when it is at hand (no inverse transforms), kept
+        until the values change."""
+        if constrained:
+            return sum(p.eval_prior(self._values[n], True) for n, p in self.priors.items())
+        if "prior_u" in self._cache:
+            return self._cache["prior_u"]
+        u_all, at, total = self._cache.get("u"), 0, 0.0
+        for name, prior in self.priors.items():
+            v = self._values[name]
+            k = max(1, v[0].numel())
+            if u_all is None:
+                lp = prior.eval_prior(v, False)
+            else:
+                u = u_all[..., at:at + k].reshape(v.shape)
+                lp = prior.distribution.log_prob(v) + _sum_event(prior.bijection.log_abs_det_jacobian(u, v), prior)
+            total = total + lp
+            at += k
+        self._cache["prior_u"] = total
+        return total
 
     # ---- whole-filter moves ---------------------------------------------------------------------------------------
     def exchange(self, other: "ThetaParticles", mask: torch.Tensor):
         for name, v in self._values.items():
             m = mask.reshape(mask.shape + (1,) * (v.dim() - 1))
             v.copy_(torch.where(m, other._values[name], v))
+        kept = {}
+        for key in ("u", "prior_u"):  # the derived quantities move with the values
+            if key in self._cache and key in other._cache:
+                mine = self._cache[key]
+                kept[key] = torch.where(mask.reshape(mask.shape + (1,) * (mine.dim() - 1)), other._cache[key], mine)
+        self._cache = kept
 
     def resample(self, indices: torch.Tensor, route=None):
         """``theta <- theta[indices]`` in place.  Sharded: ``indices`` are GLOBAL ancestors of this rank's positions
@@ -150,6 +197,7 @@ class ThetaParticles:
             route = self.shard.route(indices)
         for name, v in self._values.items():
             v.copy_(v[indices] if route is None else route.take(v))
+        self._cache = {k: (c[indices] if route is None else route.take(c)) for k, c in self._cache.items()}
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._values.items())
@@ -157,3 +205,4 @@ class ThetaParticles:
     def load_state_dict(self, sd):
         for k, v in sd.items():
             self._values[k].copy_(v)
+        self._cache.clear()

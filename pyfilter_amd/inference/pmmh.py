@@ -33,7 +33,7 @@ class RandomWalk:
         self._scale = scale
 
     def build(self, theta, state, filter_, y) -> Distribution:
-        loc = theta.stack_parameters(constrained=False)
+        loc = theta.stack_parameters(constrained=False).clone()  # (re-centred in place after accepted moves: a tensor of its own)
         scale = torch.as_tensor(self._scale, device=loc.device, dtype=loc.dtype).expand_as(loc).clone()
         return Independent(Normal(loc, scale, validate_args=False), 1, validate_args=False)
 

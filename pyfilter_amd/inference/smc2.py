@@ -240,14 +240,19 @@ class SMC2:
     ``particles`` is the TOTAL number of theta-particles; under a process group each rank holds its block."""
 
     def __init__(self, filter_, particles: int, priors, threshold: float = 0.2, kernel=None, max_increases: int = 5,
-                 device="cuda", dtype=torch.float32, seed: int = 0, group=None, block: int = 16, **kwargs):
+                 device="cuda", dtype=torch.float32, seed: int = 0, group=None, block: Optional[int] = None, **kwargs):
         self.filter = filter_
         self.shard = Shard(particles, group)
         self.particles = torch.Size([particles])
         self.theta = ThetaParticles(priors, self.shard.local, device, dtype, self.shard)
         self.filter.set_batch_shape(torch.Size([self.shard.local]))
         self._threshold = threshold
-        self._block = max(1, int(block))  # observations ``fit`` runs ahead of its rejuvenation test (see ``_steps_ahead``)
+        # observations ``fit`` runs ahead of its rejuvenation test.  A block costs the host ~0.25 ms whatever its length, so it
+        # should hold about that much device time: 32 moves of a few hundred thousand particles (1 000 theta x 400: 5 us per
+        # move), 16 of more (128 x 8 192: 12 us per move; profiles/r04_smc2_block_sweep.txt)
+        if block is None:
+            block = 32 if self.shard.local * int(filter_.particles[0]) < (3 << 18) else 16
+        self._block = max(1, int(block))
         self._kernel = ParticleMetropolisHastings(proposal=kernel, max_increases=max_increases, **kwargs)
         self._gen = torch.Generator().manual_seed(seed)  # CPU: the same stream on every rank (theta-level draws)
         self._seed = seed

@@ -472,3 +472,38 @@ def test_optimal_proposal_innovation_form_equals_the_precision_form():
         for vy in (False, True):
             for batched_a in (False, True):
                 check(vx, vy, batched_a)
+
+
+def test_theta_particles_carry_their_derived_quantities_through_every_move():
+    """``ThetaParticles`` keeps the stacked unconstrained values and the summed unconstrained log priors of its current
+    values and carries them through ``unstack_parameters`` / ``exchange`` / ``resample`` / ``like`` (SMC^2's rejuvenation
+    asks for them several times per move): at every point they equal a fresh evaluation through torch.distributions."""
+    from torch.distributions import Beta, Exponential, LogNormal, Normal, Uniform
+
+    from pyfilter_amd.inference.parameters import ThetaParticles
+
+    f64 = torch.float64
+    th = ThetaParticles({"a": Exponential(10.0), "b": Normal(0.0, 1.0), "c": LogNormal(-2.0, 1.0), "d": Beta(2.0, 3.0),
+                         "e": Uniform(0.2, 0.9)}, 17, "cpu", f64)
+    th.initialize_parameters(torch.Generator().manual_seed(1))
+    fresh = lambda t: sum(p.eval_prior(t[n], False) for n, p in t.priors.items())  # noqa: E731
+    fresh_u = lambda t: torch.cat([p.get_unconstrained(t[n]).reshape(17, -1) for n, p in t.priors.items()], dim=-1)  # noqa: E731
+    tol = dict(rtol=1e-10, atol=1e-10)
+    torch.testing.assert_close(th.eval_priors(False), fresh(th), **tol)          # (no stack at hand: the plain evaluation)
+    u = th.stack_parameters(False)
+    th._cache.pop("prior_u")
+    torch.testing.assert_close(th.eval_priors(False), fresh(th), **tol)          # (from the stacked values)
+    other = th.like()
+    g = torch.Generator().manual_seed(2)
+    rv = u + 0.1 * torch.randn(u.shape, generator=g, dtype=f64)
+    other.unstack_parameters(rv, constrained=False)
+    torch.testing.assert_close(other.eval_priors(False), fresh(other), **tol)
+    torch.testing.assert_close(other.stack_parameters(False), fresh_u(other), **tol)
+    th.exchange(other, torch.rand(17, generator=g) < 0.5)
+    torch.testing.assert_close(th.eval_priors(False), fresh(th), **tol)
+    torch.testing.assert_close(th.stack_parameters(False), fresh_u(th), **tol)
+    th.resample(torch.randint(0, 17, (17,), generator=g))
+    torch.testing.assert_close(th.eval_priors(False), fresh(th), **tol)
+    torch.testing.assert_close(th.stack_parameters(False), fresh_u(th), **tol)
+    th.initialize_parameters(torch.Generator().manual_seed(3))
+    assert not th._cache
