@@ -399,7 +399,26 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                 or (self._kernel_kind().is_user and FilterResult.states_kept(self.record_states) != 1)):
             # (a user-defined affine process with recorded states: the driver's loop over fused single steps)
             return super().batch_filter(y, bar=bar, init_state=init_state)
+        if self._single_launch_run(y):
+            return self._batch_filter_lean(y, init_state)
         return self._batch_filter_fused(y, init_state)
+
+    def _single_launch_run(self, y) -> bool:
+        """A run the library issues as ONE launch of the column-persistent kernel (filters of <= 2 048 particles) with nothing
+        recorded but the moments: there is no launch sequence for a hipGraph to replay, so the persistent plan of the general
+        driver (its buffers, staging copies and per-shape cache - PMMH re-filters a data set of another length at every
+        rejuvenation) only costs host time."""
+        return (y.shape[0] > 0 and FilterResult.states_kept(self.record_states) == 1 and not getattr(self, "_time_kernels", False)
+                and not self._move_by_move and not self._kernel_kind().is_user and int(self._model.observe_every_step) == 1
+                and HINTS.route != 1 and self._base_particles[0] <= (HINTS.column_max_n or 2048) and self._ctx_tapes_none())
+
+    def _batch_filter_lean(self, y: torch.Tensor, init_state=None) -> FilterResult:
+        state = init_state if init_state is not None else self.initialize()
+        result = FilterResult(state, self.record_states, self.record_moments, _defer_moments=True)
+        blk, _, _ = self._filter_block_lean(y, state, None, None)
+        result._extend_fused(blk.filter_means, blk.filter_variance, blk.loglikelihood, blk.latest_state)
+        self._last_run["rows"] = (blk.filter_means, blk.filter_variance)
+        return result
 
     def _observed_flags(self, y: torch.Tensor, y_dev: torch.Tensor) -> torch.Tensor:
         """Host copy of "observation k carries information" (not all-NaN), one byte per observation.  The launch loop

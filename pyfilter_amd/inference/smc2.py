@@ -11,6 +11,7 @@ same theta-weights and take the same ESS decision; a rejuvenation performs the s
 theta-particles on every rank (same weights, same uniform), takes the surviving filters' states from their owners
 (``FilterResult`` blocks via ``Shard.take``), fits the proposal to all theta-particles and averages the acceptance rate
 over all of them."""
+import time
 from typing import Callable, Optional
 
 import torch
@@ -162,10 +163,13 @@ class ParticleMetropolisHastings:
         self._resampler = resampler
         self.acceptance_history = []
         self.trace = None  # set to a list to collect every update's intermediate quantities (see ``run_pmmh``)
+        self.timeline = None  # set to a list: host wall-clock marks (label, seconds) of every update (tools/smc2_small.py)
 
     def update(self, theta: ThetaParticles, filter_, state: SMC2State, generator=None) -> SMC2State:
         shard = state.shard
         sharded = shard is not None and shard.world > 1
+        mark = (lambda label: self.timeline.append((label, time.perf_counter()))) if self.timeline is not None else (lambda label: None)
+        mark("start")
         # the same resampling on every rank: same (gathered) weights, same uniform (the generator is a CPU stream seeded
         # identically everywhere and advanced in lock step - no broadcast needed)
         draws = as_draws(generator)
@@ -178,15 +182,16 @@ class ParticleMetropolisHastings:
 
         if self.trace is not None:
             self.trace.append(dict(kind="rejuvenate", indices=indices, kernel=dist))
+        mark("resampled + proposal fitted")
         route = shard.route(mine) if sharded else None  # one exchange plan for the parameters and the filters' states
         theta.resample(mine, route)
         _take_filters(state.filter_state, shard, mine, route)
+        mark("filters moved")
         shape = torch.Size([]) if any(dist.batch_shape) else filter_.batch_shape
 
         old = theta.stack_parameters(constrained=False)
         proposal_theta = theta.like()
-        proposal_filter = filter_.copy()
-        proposal_filter.initialize_model(proposal_theta)
+        proposal_filter = filter_.copy()  # (``run_pmmh`` builds its model from theta* before it filters)
         if data_flags is not None and hasattr(proposal_filter, "_obs_cache"):
             proposal_filter._obs_cache = (data, data._version, data_flags)  # (known on the host: no device round trip)
 
@@ -196,7 +201,9 @@ class ParticleMetropolisHastings:
                                 shape, mutate_kernel=False, generator=draws, trace=self.trace)
             rate = accepted.float().sum()
             rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
+            mark("move issued")
             acceptance_rate = (float(rate) + i * acceptance_rate) / (i + 1)  # the kernel's one host decision per move
+            mark("move done on the device")
             self.acceptance_history.append(acceptance_rate)
             if acceptance_rate < self._acceptance_threshold:  # abort early: more state particles are needed
                 return self._increase_states(filter_, state, theta)
@@ -213,6 +220,7 @@ class ParticleMetropolisHastings:
 
         filter_.initialize_model(theta)
         state.w.fill_(0.0)
+        mark("end")
         return state
 
     def _increase_states(self, filter_, state: SMC2State, theta: ThetaParticles) -> SMC2State:

@@ -67,6 +67,7 @@ def main():
                                 phases[key] += time.perf_counter() - t1
                         setattr(obj, name, g)
                     timed(alg._kernel, "update", "update")
+                    alg._kernel.timeline = []
                     timed(filt, "filter_block", "filter_block")
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -78,6 +79,13 @@ def main():
                         state = alg.step(yt, state)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
+                if os.environ.get("SMC2_PHASES") and rep == 3 and alg._kernel.timeline:
+                    tl = alg._kernel.timeline
+                    spans = {}
+                    for (la, ta), (lb, tb) in zip(tl[:-1], tl[1:]):
+                        if lb != "start":
+                            spans[lb] = spans.get(lb, 0.0) + 1e3 * (tb - ta)
+                    print("   host ms per stage, summed over the rejuvenations:", {k: round(v, 2) for k, v in spans.items()})
                 if rep and (best is None or dt < best[0]):
                     best = (dt, len(alg._kernel.acceptance_history), int(filt.particles[0]), alg.posterior_mean(state).tolist(), dict(phases))
             print(f"{route:9s} {mode:14s}: {1e3 * best[0]:8.1f} ms  ({n_theta * n_state * t_len / best[0]:.3e} particle-steps/s)  PMMH moves {best[1]}, "
