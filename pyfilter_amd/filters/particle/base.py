@@ -415,7 +415,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
     def _batch_filter_lean(self, y: torch.Tensor, init_state=None) -> FilterResult:
         state = init_state if init_state is not None else self.initialize()
         result = FilterResult(state, self.record_states, self.record_moments, _defer_moments=True)
-        blk, _, _ = self._filter_block_lean(y, state, None, None)
+        blk, _, _ = self._filter_block_lean(y, state, None, None, host_u=True)
         result._extend_fused(blk.filter_means, blk.filter_variance, blk.loglikelihood, blk.latest_state)
         self._last_run["rows"] = (blk.filter_means, blk.filter_variance)
         return result
@@ -462,7 +462,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ctx = self._ensure_context()
         return ctx.z_tape is None and ctx.u_tape is None
 
-    def _filter_block_lean(self, y: torch.Tensor, state: ParticleFilterCorrection, observed, replay):
+    def _filter_block_lean(self, y: torch.Tensor, state: ParticleFilterCorrection, observed, replay, host_u: bool = False):
         """``filter_block`` for the caller it exists for - SMC^2, which issues a block of ~16 moves per host decision, a few
         dozen blocks per fit: at 1 000 theta x 400 particles such a block is 90 us of kernel time, and the general fused
         driver (persistent plan, staging copies in and out, a ``FilterResult`` with its moment log per call: ~25 small
@@ -520,6 +520,13 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         seed_eff = self._next_draw_seed() if replay is None else replay[0]
         a.seed, a.step_counter = seed_eff, None
         u_tape = replay[1][:steps].contiguous() if (replay is not None and replay[1] is not None) else None
+        if host_u and u_tape is None and self._resampler_kind() == L.RESAMPLE_SYSTEMATIC:
+            # ``batch_filter``: the offsets of the general driver (a device generator seeded by the run's seed), so that a
+            # run draws the same numbers whichever driver - and kernel route - carries it
+            if plan.u_gen is None:
+                plan.u_gen = torch.Generator(device=device)
+            plan.u_gen.manual_seed(seed_eff & 0x7FFFFFFFFFFFFFFF)
+            u_tape = torch.empty((steps, b), device=device, dtype=dtype).uniform_(generator=plan.u_gen)
         a.z_tape, a.u_tape = None, L.ptr(u_tape)
         a.x[0], a.x[1] = first.data_ptr(), other.data_ptr()
         a.logw[0], a.logw[1] = first[d].data_ptr(), other[d].data_ptr()
@@ -810,6 +817,7 @@ class _SingleStepPlan:
         self.ws = L.new_workspace(n, b, device)
         self.rows = rows
         self.xl = None  # (``_filter_block_lean``: the second state slot of a multi-move run, allocated on first use)
+        self.u_gen = None
         a = L.PfFilterArgs()
         a.model = ops.make_model_struct(kind, filt._ctx.params)
         a.filter, a.proposal, a.resampler = filt._FILTER_KIND, filt._proposal._KERNEL_PROPOSAL, filt._resampler_kind()
