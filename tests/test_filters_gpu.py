@@ -788,9 +788,11 @@ def test_copy_and_increase_particles():
     assert ((r3.filter_means[1:] - r1.filter_means[1:]).abs() <= 10.0 * se + 1e-3).all()
 
 
-def test_plan_caches_survive_eviction_and_online_moves():
+def test_plan_caches_survive_eviction_and_online_moves(monkeypatch):
     """One ``filter()`` move followed by more ``batch_filter`` shapes than the graph cache holds: the oldest fused plan is
-    evicted (its graph destroyed), the online move's scratch is kept, everything still filters."""
+    evicted (its graph destroyed), the online move's scratch is kept, everything still filters.  (On the per-step route: a
+    filter this small would otherwise be one column launch per run, which keeps no plan at all.)"""
+    monkeypatch.setattr(HINTS, "route", 1)
     case = next(c for c in CASES if c["name"] == "sine_apf_lgo")
     g = load_golden("sine_apf_lgo", "f32")
     filt = build_filter_from_case(case, g, torch.float32, "cuda", tape=False)
@@ -802,6 +804,11 @@ def test_plan_caches_survive_eviction_and_online_moves():
     assert len(filt._fused_plans) == 4 and len(filt._single_plans) == 1
     state = filt.filter(y[1], state)
     assert torch.isfinite(state.get_mean()).all()
+    monkeypatch.setattr(HINTS, "route", 0)  # single-launch runs keep no persistent plan; they share the online move's scratch
+    for t_len in (3, 9):
+        res = filt.batch_filter(y[:t_len], bar=False)
+        assert torch.isfinite(res.loglikelihood).all() and res.filter_means.shape[0] == t_len + 1
+    assert len(filt._fused_plans) == 4 and len(filt._single_plans) == 1
 
 
 @pytest.mark.parametrize("route", ["fused", "steps"])
