@@ -192,6 +192,13 @@ typedef struct pf_run_hints {
     int32_t tile_target;     /* workgroups per launch the tile size aims at; 0 = the default (1024 = 4 per CU) */
     int32_t ancestor_search; /* != 0: systematic ancestors by searching the staged window at any size (default: only float
                               * grids beyond 2^22 positions, where the inverted grid's closed form is not exact) */
+    int32_t resume;          /* != 0 (t0 > 0, SISR): the incoming state of step t0 is the one the PREVIOUS pf_filter_run call on
+                              * this argument block wrote - its per-tile partials and local scans are still in the workspace
+                              * (a SISR step leaves them for its successor), so the pass that re-reduces the incoming state
+                              * is skipped.  A run issued move by move (user-defined models: one call per move) pays one
+                              * launch per move less.  Ignored for an APF, whose first-stage weights need the new
+                              * observation, and on the column route (which has no such pass) */
+    int32_t reserved;
 } pf_run_hints;
 
 typedef struct pf_filter_args {
@@ -248,6 +255,9 @@ typedef struct pf_filter_args {
                    * reference carries prev_inds (sisr.py:25-26). */
     const void* user_loc;   /* PF_HID_USER_AFFINE only: (D, B, N) one-step mean of every particle of the INCOMING state ... */
     const void* user_scale; /* ... and its transition scale, both in the state's layout and dtype (else NULL) */
+    int64_t user_scale_per_column; /* 0: user_scale is a (D, B, N) plane like user_loc; 1: a (D, B) array - ONE transition scale
+                                    * per filter and state component (a diffusion that does not depend on the state: the common
+                                    * case, and no plane to fill per move) */
     pf_run_hints hints;     /* all zero = the library's own choices */
 } pf_filter_args;
 

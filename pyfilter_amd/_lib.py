@@ -43,7 +43,8 @@ ABI_VERSION = 2  # include/pf_amd.h: PF_ABI_VERSION
 
 
 class PfRunHints(C.Structure):
-    _fields_ = [("route", C.c_int32), ("column_max_n", C.c_int32), ("tile_target", C.c_int32), ("ancestor_search", C.c_int32)]
+    _fields_ = [("route", C.c_int32), ("column_max_n", C.c_int32), ("tile_target", C.c_int32), ("ancestor_search", C.c_int32),
+                ("resume", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PfFilterArgs(C.Structure):
@@ -65,7 +66,7 @@ class PfFilterArgs(C.Structure):
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("observed_dev", C.c_void_p),
         ("ring", C.c_int64),
-        ("user_loc", C.c_void_p), ("user_scale", C.c_void_p),
+        ("user_loc", C.c_void_p), ("user_scale", C.c_void_p), ("user_scale_per_column", C.c_int64),
         ("hints", PfRunHints),
     ]
 

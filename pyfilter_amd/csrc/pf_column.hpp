@@ -343,7 +343,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = x[d][j];
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if constexpr (user) { if (ok[j]) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j); }
+                if constexpr (user) { if (ok[j]) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j, a.user_scale_percol != 0, b, g.B); }
                 const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj, false, um);
                 if (ok[j] && is_nan_or_posinf(pre)) poison = true;
                 rw[j] = ok[j] ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
         for (int j = 0; j < VEC; ++j) {
             T xn[D], w_new;
             UserMS<T, D> um = UserMS<T, D>::none();
-            if constexpr (user) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j]);  // the parent's
+            if constexpr (user) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j], a.user_scale_percol != 0, b, g.B);  // the parent's
             if (obs) {
                 const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn, um);
                 if (apf) {

@@ -68,6 +68,7 @@ template <typename T> struct FusedArgs {
     const T* u_tape;
     const T* user_loc;    // PF_HID_USER_AFFINE: (D, B, N) one-step means / transition scales of the incoming particles, evaluated
     const T* user_scale;  // by the caller's callable (pf_filter_args.user_loc / user_scale)
+    int user_scale_percol;  // user_scale is a (D, B) array: one scale per column and component
     T* means;
     T* vars;
     T* ll_steps;
@@ -243,6 +244,29 @@ template <typename T, int D, bool WQ = true> struct PartialAcc {
         }
         if (poison) atomicOr(poison_slot, 1);
         __syncthreads();
+#ifndef PF_NO_LANE_TAIL
+        // the tile's record: lane q of wave 0 adds the four waves' sums of quantity q (same order as a single thread would:
+        // identical values) and stores it to its row - one pass of ~10 instructions instead of thread 0 walking NS + 1
+        // quantities and 6 + 2 D stores one after the other at the very end of the workgroup's critical path
+        if (threadIdx.x < NS + 1) {
+            const int q = threadIdx.x;
+            double r = 0.0;
+            if (q < NS || WITH_ES) {
+                r = red[q * PF_NWAVES];
+#pragma unroll
+                for (int w = 1; w < PF_NWAVES; ++w) r += red[q * PF_NWAVES + w];
+            }
+            // quantity q -> partial row: 0 sum e, 1 sum e^2, 2 sum e_rw, 3 .. 3 + 2 D - 1 the moments, NS the spacings
+            const int row = q == 0 ? PQ_S1 : q == 1 ? PQ_Q1 : q == 2 ? PQ_S2 : q == NS ? PQ_E : PQ_MX + (q - 3);
+            const int64_t stride = (int64_t)B * tiles;
+            const int64_t o = (int64_t)b * tiles + k;
+            part[row * stride + o] = r;
+            if (q == 0) {
+                part[PQ_M1 * stride + o] = (double)M1;
+                part[PQ_M2 * stride + o] = pre_on ? (double)M2 : -__builtin_huge_val();
+            }
+        }
+#else
         if (threadIdx.x == 0) {
             double tot[NS + 1];
 #pragma unroll
@@ -269,6 +293,7 @@ template <typename T, int D, bool WQ = true> struct PartialAcc {
                 part[(PQ_MX + D + d) * stride + o] = tot[3 + D + d];
             }
         }
+#endif
     }
 };
 
@@ -496,7 +521,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
                 for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
                 UserMS<T, D> um = UserMS<T, D>::none();
                 if (user && pre_on)  // the particle's own one-step mean / scale (the caller's planes)
-                    um.gather(a.user_loc, a.user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, i0 + j);
+                    um.gather(a.user_loc, a.user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, i0 + j, a.user_scale_percol != 0, b, g.B);
                 pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, false, um) : T(0);
                 if (pre_on && is_nan_or_posinf(pre[j])) acc.poison = true;
                 rw[j] = pre_on ? sanitize_logw(pre[j] + lw[j]) : lw[j];
@@ -582,6 +607,36 @@ template <bool WITH_Q, int NX = 0>
 __device__ __forceinline__ void load_col_partials(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
                                                   int slot_s, int slot_x, ColPartials<WITH_Q, NX>& r) {
     const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
+#ifndef PF_NO_VEC_PARTIALS
+    if constexpr (PF_COMBINE_ITERS == 4 && NX == 0) {
+        // a full table (IT = 4, tiles a multiple of four: 2^20 x 1 and every column of >= 769 tiles): a thread's four records
+        // are 32 contiguous, 32-byte aligned bytes of each row - two 16-byte loads per row instead of four 8-byte ones with
+        // their 64-bit address arithmetic (the rows start 256-byte aligned: make_ws; stride and cb are multiples of tiles)
+        if (IT == 4 && (tiles & 3) == 0) {  // (uniform)
+            const int t0 = threadIdx.x * 4;
+            if (t0 < tiles) {
+                double a2[2], b2[2];
+                const double* pm = part + slot_m * stride + cb + t0;
+                load_vec<double, 2>(pm, a2); load_vec<double, 2>(pm + 2, b2);
+                r.m[0] = a2[0]; r.m[1] = a2[1]; r.m[2] = b2[0]; r.m[3] = b2[1];
+                const double* ps = part + slot_s * stride + cb + t0;
+                load_vec<double, 2>(ps, a2); load_vec<double, 2>(ps + 2, b2);
+                r.s[0] = a2[0]; r.s[1] = a2[1]; r.s[2] = b2[0]; r.s[3] = b2[1];
+                if constexpr (WITH_Q) {
+                    const double* pq = part + PQ_Q1 * stride + cb + t0;
+                    load_vec<double, 2>(pq, a2); load_vec<double, 2>(pq + 2, b2);
+                    r.q[0] = a2[0]; r.q[1] = a2[1]; r.q[2] = b2[0]; r.q[3] = b2[1];
+                } else {
+                    r.q[0] = r.q[1] = r.q[2] = r.q[3] = 0.0;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { r.m[q] = -__builtin_huge_val(); r.s[q] = 0.0; r.q[q] = 0.0; }
+            }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         const int t = threadIdx.x * IT + q;
@@ -1430,7 +1485,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 T w_new;
                 // user-defined affine models (MK = 3): the parent's one-step mean / scale from the caller's planes
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if constexpr (USER) um.gather(la->user_loc, la->user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, idx[j]);
+                if constexpr (USER) um.gather(la->user_loc, la->user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, idx[j], la->user_scale_percol != 0, b, g.B);
                 if (obs) {
                     T wi, pre_anc = T(0);
                     if constexpr (FAST) {

@@ -1506,6 +1506,7 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
     a.u_tape = (const T*)A->u_tape;
     a.user_loc = (const T*)A->user_loc;
     a.user_scale = (const T*)A->user_scale;
+    a.user_scale_percol = A->user_scale_per_column != 0 ? 1 : 0;
     a.means = (T*)A->means;
     a.vars = (T*)A->vars;
     a.ll_steps = (T*)A->ll_steps;
@@ -1579,7 +1580,10 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     }
     a.obs = n_steps > 0 ? (dev_flags ? -1 : (observed[t0] != 0)) : 0;
     a.obs_next = 0;
-    hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid_tiles, block, 0, st, a);
+    // (pf_run_hints.resume: the previous call on this argument block ended with a SISR step that left the partials and local
+    // scans of exactly this state in the workspace - the pass is redundant)
+    const bool resumed = A->hints.resume != 0 && t0 > 0 && A->filter == PF_FILTER_SISR && A->ring < 3;
+    if (!resumed) hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid_tiles, block, 0, st, a);
 
     // ancestor stage of the step kernel: 0 inverted grid (systematic), 1 multinomial, 2 systematic by search - float
     // grids beyond 2^22 positions, where the closed form is not exact (PF_FORCE_SEARCH=1 selects it for testing)

@@ -443,12 +443,14 @@ template <typename T, int D> struct UserMS {
         return u;
     }
     // planes (D, B, N): `col0` = index of (component 0, this column, particle 0), `plane` = B * N, `i` = the particle
-    __device__ __forceinline__ void gather(const T* __restrict__ ploc, const T* __restrict__ pscale, int64_t col0, int64_t plane, int64_t i) {
+    // `percol` (pf_filter_args.user_scale_per_column): pscale is a (D, B) array, `b` the column, `nb` = B
+    __device__ __forceinline__ void gather(const T* __restrict__ ploc, const T* __restrict__ pscale, int64_t col0, int64_t plane, int64_t i,
+                                           bool percol = false, int b = 0, int nb = 0) {
         on = true;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             loc[d] = ploc[col0 + d * plane + i];
-            scale[d] = pscale[col0 + d * plane + i];
+            scale[d] = percol ? pscale[d * nb + b] : pscale[col0 + d * plane + i];
         }
     }
 };

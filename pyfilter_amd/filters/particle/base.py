@@ -360,9 +360,11 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             # evaluating a built-in closed form.  Everything else of the step stays in the fused kernels.
             loc, scale = self._model.hidden.mean_scale(ts_in)
             full = ts_in.value.shape
+            percol = self._scale_per_column(scale, full, dtype)
             planes = (ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event).contiguous(),
-                      ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event).contiguous())
+                      percol if percol is not None else ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event).contiguous())
             a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
+            a.user_scale_per_column = 0 if percol is None else 1
         a.y, a.y_rows = y_dev.data_ptr(), rows
         a.observed, a.observed_dev, a.step_counter = None, None, None  # (the block route shares this argument block)
         a.seed = self._next_draw_seed()  # fresh Philox draws per move
@@ -457,6 +459,18 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ll = run["ll_steps"]
         u = run["u"]  # (a cached plan's buffer, redrawn by the next run: the token keeps a copy)
         return res, (ll if self._batched else ll[:, 0]), (run["seed_eff"], None if u is None else u.clone())
+
+    def _scale_per_column(self, scale: torch.Tensor, full, dtype) -> Optional[torch.Tensor]:
+        """The user's transition scale as a ``(D, B)`` array when it does not vary along the particle dimension (a broadcast
+        scalar / per-filter / per-component value: stride 0 along dim 0 of the broadcast ``mean_scale`` returns) - what
+        ``pf_filter_args.user_scale_per_column`` takes instead of a ``(D, B, N)`` plane filled per move.  None otherwise."""
+        if scale.dim() != len(full) or scale.shape != full or scale.stride(0) != 0:
+            return None
+        row = scale[0].to(dtype)                                   # ([B], [D])
+        if not self._batched:
+            row = row.unsqueeze(0)                                 # (1, [D])
+        row = row.reshape(row.shape[0], -1)                        # (B, D)
+        return row.t().contiguous()                                # (D, B)
 
     def _ctx_tapes_none(self) -> bool:
         ctx = self._ensure_context()
@@ -648,21 +662,38 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             # copies (the driver's loop over filter() spends ~2x the time of the kernels on those).
             hidden, full = self._model.hidden, x0.shape
             es_u = hidden.event_shape
+            # Between the moves of a per-step-route run nothing needs flushing (the next move's launch keeps the books of
+            # the state it reads), and a SISR move leaves the partials / scans its successor starts from: intermediate
+            # moves run without the bookkeeping launch and - SISR - the successor without the reduce launch
+            # (pf_run_hints.resume).  Filters small enough for the column kernel keep self-contained moves (finalize = 1
+            # is what makes a call eligible for that one-launch route).
+            chained = kind.is_user and (HINTS.route == 1 or n > (HINTS.column_max_n or 2048))
+            keep = []
             for s_ in range(steps):
                 if not kind.is_user:  # (``_move_by_move``: a built-in model issued the same way - the pieces of one run)
                     L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
                     continue
                 ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
                 loc, scale = hidden.mean_scale(ts)
-                planes = []
-                for val, buf in ((loc, plan.user_loc), (scale, plan.user_scale)):
-                    v = ops.to_soa(val.to(dtype).expand(full), self._batched, self._has_event)
-                    # (already a (D, B, N) plane - an unbatched scalar state's loc: read in place, kept alive past the launch)
-                    planes.append(v if v.is_contiguous() else buf.copy_(v))
-                a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
-                L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
+                v = ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event)
+                # (already a (D, B, N) plane - an unbatched scalar state's loc: read in place, kept alive past the launch)
+                loc_p = v if v.is_contiguous() else plan.user_loc.copy_(v)
+                percol = self._scale_per_column(scale, full, dtype)
+                if percol is not None:  # a state-independent diffusion: one scale per filter and component, no plane to fill
+                    scale_p = percol
+                else:
+                    v = ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event)
+                    scale_p = v if v.is_contiguous() else plan.user_scale.copy_(v)
+                keep = [loc_p, scale_p]
+                a.user_loc, a.user_scale = loc_p.data_ptr(), scale_p.data_ptr()
+                a.user_scale_per_column = 0 if percol is None else 1
+                a.hints.resume = 1 if (chained and s_ > 0 and self._FILTER_KIND == L.FILTER_SISR) else 0
+                last_move = s_ == steps - 1
+                L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1 if (last_move or not chained) else 0, L.stream_ptr()), "pf_filter_run")
             if kind.is_user:
                 a.user_loc, a.user_scale = plan.user_loc.data_ptr(), plan.user_scale.data_ptr()
+                a.user_scale_per_column, a.hints.resume = 0, 0
+                self._keep_planes = keep
         elif getattr(self, "_time_kernels", False):
             kms = (C.c_float * 3)()
             L.check(lib.pf_filter_run_timed(C.byref(a), 0, steps, 1, L.stream_ptr(), kms), "pf_filter_run_timed")

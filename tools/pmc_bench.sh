@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ counters of the step kernel on the bench workload (per-wave averages): tools/pmc_bench.sh <workload> <counter...>
 W=${1:-apf_lgo_1m}; shift
-export TMPDIR=/tmp PF_NO_GRAPH=1
+export TMPDIR=/tmp
 OUT=/tmp/pmcb_$$
 (cd /tmp && rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT -o p -- python $OLDPWD/bench.py --_inner --workload $W --T 40 --steps 1 --warmup 1 --no-cpu-baseline --no-traffic > /dev/null 2>&1)
 python - <<PY
