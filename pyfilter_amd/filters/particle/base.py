@@ -466,6 +466,17 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ``pf_filter_args.user_scale_per_column`` takes instead of a ``(D, B, N)`` plane filled per move.  None otherwise."""
         if scale.dim() != len(full) or scale.shape != full or scale.stride(0) != 0:
             return None
+        # (a callable typically hands back the same parameter tensor move after move: the small array is built once per
+        # storage / in-place version, not per move - four tiny launches a host-bound small filter would feel)
+        key = (scale.data_ptr(), scale._version, tuple(scale.stride()), dtype)
+        cached = getattr(self, "_percol_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        out = self._scale_rows(scale, dtype)
+        self._percol_cache = (key, out)
+        return out
+
+    def _scale_rows(self, scale: torch.Tensor, dtype) -> torch.Tensor:
         row = scale[0].to(dtype)                                   # ([B], [D])
         if not self._batched:
             row = row.unsqueeze(0)                                 # (1, [D])
