@@ -77,6 +77,8 @@ class Shard:
             self.group, self.rank, self.world = None, 0, 1
         elif group is not None and dist.is_available() and dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)  # a sub-group: ITS ranks, not the world's
+            if self.rank < 0:  # (torch's answer for a non-member: spans[-1] would silently hand out the LAST rank's block)
+                raise ValueError("Shard: this process is not a member of the process group it was given")
         else:
             self.rank, self.world = world()
         self.spans: List[Tuple[int, int]] = [shard_bounds(self.total, r, self.world) for r in range(self.world)]
@@ -126,11 +128,12 @@ class Shard:
         dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)
         return out
 
-    def route(self, global_index: torch.Tensor) -> "Route":
+    def route(self, global_index: torch.Tensor, full_index: Optional[torch.Tensor] = None) -> "Route":
         """The exchange plan of a global gather along the filter dimension (see ``Route``); ``global_index`` = the global
         ancestors of THIS rank's positions.  One small all-gather of the index vectors + a host copy: build it once per
-        resampling and move every buffer through it."""
-        return Route(self, global_index)
+        resampling and move every buffer through it.  ``full_index``: the ancestors of ALL positions when the caller holds
+        them anyway (SMC^2's rejuvenation resamples the theta-particles identically on every rank) - no all-gather then."""
+        return Route(self, global_index, full_index)
 
     def take(self, local: torch.Tensor, global_index: torch.Tensor, dim: int = 0) -> torch.Tensor:
         """``concat(all blocks)[global_index]`` along ``dim`` - this rank's new block after a global gather (resampling of
@@ -147,14 +150,17 @@ class Route:
     never leave it) and a local gather that puts the received columns in place.  SURVEY.md section 8(e): <= N (4 D + 12)
     bytes per MOVED column, against world x that for an all-gather of everything."""
 
-    def __init__(self, shard: "Shard", global_index: torch.Tensor):
+    def __init__(self, shard: "Shard", global_index: torch.Tensor, full_index: Optional[torch.Tensor] = None):
         self.shard = shard
         self.device = global_index.device
         mine = global_index.to(torch.int64).reshape(-1)
         if shard.world == 1:
             self.local_index = mine
             return
-        full = shard.all_gather(mine).cpu()  # (total,) in global position order: rank r's wants = full[lo_r:hi_r]
+        if full_index is not None and full_index.numel() == shard.total:
+            full = full_index.to(torch.int64).reshape(-1).cpu()  # every rank already holds every rank's wants
+        else:
+            full = shard.all_gather(mine).cpu()  # (total,) in global position order: rank r's wants = full[lo_r:hi_r]
         me = shard.rank
         lo, hi = shard.spans[me]
         wants = full[lo:hi]

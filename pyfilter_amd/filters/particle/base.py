@@ -455,7 +455,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             return self._filter_block_lean(y, state, observed, replay)
         res = self._batch_filter_fused(y, state._restarted(), observed=observed, replay=replay)
         run = self._last_run
-        res.block_rows = (run["rows"][0][1:], run["rows"][1][1:])  # the moves' own moment rows (row 0 = the incoming state)
+        # the moves' own moment rows (row 0 = the incoming state) - copies: a cached plan's buffers are rewritten by its next run
+        res.block_rows = (run["rows"][0][1:].clone(), run["rows"][1][1:].clone())
         ll = run["ll_steps"]
         u = run["u"]  # (a cached plan's buffer, redrawn by the next run: the token keeps a copy)
         return res, (ll if self._batched else ll[:, 0]), (run["seed_eff"], None if u is None else u.clone())
@@ -680,7 +681,17 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             # is what makes a call eligible for that one-launch route).
             chained = kind.is_user and (HINTS.route == 1 or n > (HINTS.column_max_n or 2048))
             keep = []
-            for s_ in range(steps):
+            if not kind.is_user and isinstance(self._move_by_move, (list, tuple)):
+                # (testing knob, general form: the run as explicit pieces ``(n_steps, finalize)`` on one argument block - a
+                # piece without ``finalize`` takes the per-step kernels, a self-contained one of a small filter the column
+                # kernel: the workspace's per-filter bookkeeping is what carries a run across the two)
+                t_piece = 0
+                for n_piece, fin in self._move_by_move:
+                    n_piece = steps - t_piece if n_piece is None else n_piece
+                    L.check(lib.pf_filter_run(C.byref(a), t_piece, n_piece, fin, L.stream_ptr()), "pf_filter_run")
+                    t_piece += n_piece
+                assert t_piece == steps, "the pieces do not cover the run"
+            for s_ in range(steps if (kind.is_user or not isinstance(self._move_by_move, (list, tuple))) else 0):
                 if not kind.is_user:  # (``_move_by_move``: a built-in model issued the same way - the pieces of one run)
                     L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
                     continue

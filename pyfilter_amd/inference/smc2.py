@@ -183,7 +183,8 @@ class ParticleMetropolisHastings:
         if self.trace is not None:
             self.trace.append(dict(kind="rejuvenate", indices=indices, kernel=dist))
         mark("resampled + proposal fitted")
-        route = shard.route(mine) if sharded else None  # one exchange plan for the parameters and the filters' states
+        # one exchange plan for the parameters and the filters' states (every rank holds ALL ancestors: no all-gather)
+        route = shard.route(mine, full_index=indices) if sharded else None
         theta.resample(mine, route)
         _take_filters(state.filter_state, shard, mine, route)
         mark("filters moved")

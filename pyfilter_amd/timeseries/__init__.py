@@ -176,17 +176,34 @@ def _user_affine_kind(hidden: "AffineProcess") -> Optional[KernelKind]:
     scale), parameters, increment_distribution, ...)``, README.md:44-67) - available when its increments are centred
     Gaussians of one common scale (``Normal(0, s)``, possibly ``.to_event(1)``): then ``x' = loc(x) + scale(x) s e`` is what
     the fused kernels compute from the (loc, scale) planes.  Anything else stays on the step-by-step route."""
+    # exactly these two classes: a subclass may override ``build_density`` / ``propagate`` (other dynamics than loc + scale * e),
+    # which the kernels would silently ignore - such a process keeps the step-by-step route unless it says otherwise
+    # (``fused_affine = True`` on the instance / class)
+    if type(hidden) not in (AffineProcess, AffineEulerMaruyama) and not getattr(hidden, "fused_affine", False):
+        return None
     inc = hidden.increment_distribution
     base = inc.base_dist if isinstance(inc, Independent) else inc
     if not isinstance(base, Normal):
         return None
-    loc, scale = base.loc.reshape(-1), base.scale.reshape(-1)
-    if loc.numel() == 0 or bool((loc != 0).any()) or bool((scale != scale[0]).any()):
+    # the Normal(0, s) test needs the VALUES of the increment parameters: one host copy per increment distribution (PMMH
+    # rebuilds the model around the same increments at every move; a device round trip there would make the host wait for
+    # the running re-filter), remembered by the tensors' identity and in-place version
+    key = (id(base.loc), base.loc._version, id(base.scale), base.scale._version)
+    cached = getattr(base, "_pf_user_kind", None)
+    if cached is None or cached[0] != key:
+        loc, scale = base.loc.detach().reshape(-1).cpu(), base.scale.detach().reshape(-1).cpu()
+        ok = loc.numel() > 0 and not bool((loc != 0).any()) and not bool((scale != scale[0]).any())
+        cached = (key, float(scale[0]) if ok else None)
+        try:
+            base._pf_user_kind = cached
+        except AttributeError:
+            pass
+    if cached[1] is None:
         return None
     dim = hidden.n_dim and hidden.event_shape.numel()
     if dim > L.MAX_D:
         return None
-    return KernelKind(L.HID_USER_AFFINE, dim, 1.0, float(scale[0]))
+    return KernelKind(L.HID_USER_AFFINE, dim, 1.0, cached[1])
 
 
 class StateSpacePath:

@@ -86,6 +86,34 @@ def test_a_run_issued_move_by_move_equals_the_run(name, kernel_route):
     torch.testing.assert_close(last.weights.cpu(), g["step_w"][-1], equal_nan=True, **tol)
 
 
+@pytest.mark.parametrize("pieces", [[(3, 0), (2, 1), (1, 0), (None, 1)], [(1, 1), (4, 0), (None, 1)], [(5, 0), (None, 1)]])
+@pytest.mark.parametrize("name", ["sine_apf_lgo", "lg1d_sisr_boot", "sine_sisr_boot_nan", "sv_apf_boot", "rw2d_apf_lgo", "lorenz_sisr_boot"])
+def test_a_run_issued_in_pieces_that_alternate_between_the_kernel_routes(name, pieces):
+    """``pf_filter_run`` pieces on ONE argument block with mixed ``finalize``: a piece that is not self-contained
+    (``finalize = 0``) runs on the per-step kernels, a self-contained piece of a filter this small (N <= 2048) on the
+    column-persistent kernel - the run changes route from piece to piece and only the workspace's per-filter records
+    (``ColStat``: log-likelihood bases, what has been flushed) connect them.  Same numbers as the reference (float64,
+    identical draws)."""
+    case = next(c for c in CASES if c["name"] == name)
+    g = load_golden(name, "f64")
+    filt = build_filter_from_case(case, g, DT["f64"], "cuda")
+    filt._move_by_move = pieces
+    res = filt.batch_filter(g["y"].cuda(), bar=False)
+    torch.cuda.synchronize()
+    from pyfilter_amd import ops
+
+    specs = {r["SPEC"] for r in ops.debug_launch_trace(64)[-g["y"].shape[0]:]}
+    assert 9 in specs and len(specs) > 1, f"both routes should have run: {specs}"
+    tol = _tols("f64")
+    torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
+    torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=tol["rtol"] * 10, atol=tol["atol"])
+    torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], **tol)
+    last = res.latest_state
+    assert torch.equal(last.previous_indices.cpu(), g["step_idx"][-1]), "final ancestors differ"
+    torch.testing.assert_close(last.timeseries_state.value.cpu(), g["step_x"][-1], **tol)
+    torch.testing.assert_close(last.weights.cpu(), g["step_w"][-1], equal_nan=True, **tol)
+
+
 @both_routes
 @pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f32"])
 def test_float32_teacher_forced_steps(name, dt, kernel_route):
