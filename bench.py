@@ -407,7 +407,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--_inner", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--direct", action="store_true", help=argparse.SUPPRESS)  # (A/B: every run through the direct driver)
     args = ap.parse_args()
+    if args.direct:
+        from pyfilter_amd.hints import HINTS
+
+        HINTS.direct = True
     if args._inner:  # profiled child of pmc_traffic(): no hipGraph replays (per-dispatch counter rows)
         from pyfilter_amd.hints import HINTS
 
@@ -533,6 +538,10 @@ def main():
     value = units_per_pass * args.steps / elapsed
     ll_check = check_loglikelihood(args.workload, w, ll_all)  # (raises: no throughput line for a wrong answer)
 
+    if args.direct:
+        from pyfilter_amd.hints import HINTS
+
+        HINTS.direct = True
     if args._inner:  # profiled child of pmc_traffic(): the timed passes above are all it needs
         return
 
@@ -547,8 +556,12 @@ def main():
     units = w["N"] * w["B"]  # particles one launch processes
     gbs = {k: v * units / (step_ms * 1e-3) / 1e9 for k, v in bm.items()}
     roofline = {
-        "bound": "hbm",  # the roofline this kernel class is priced against (no dense contraction: MFMA does not apply) ...
-        # ... what actually limits it at this shape (rocprofv3 --pmc SQ_INSTS_VALU per wave, dev-tools stamps)
+        # what limits the kernel at this shape by the counters (rocprofv3 --pmc SQ_INSTS_VALU per stage, profiles/r04_step_kernel_
+        # pmc_stages.txt: 1 519 VALU instructions per wave at four waves per SIMD - issue-bound in every stage) ...
+        "bound": "valu" if gbs["as_built"] / HBM_PEAK_GBS < 0.30 else "hbm",
+        # ... while `achieved` / `peak` / `frac` stay what the bench contract defines: algorithmic bytes against the HBM peak
+        # (no dense contraction on this path: MFMA does not apply)
+        "priced_against": "hbm",
         "limited_by": "VALU issue + dependent-load latency inside one resident wave of workgroups, and the launch boundary - "
                       "not HBM bandwidth (the as_built bytes would take 3.1 us at peak)",
         "kernel": "k_fused_step", "achieved": gbs["survey_8d"],

@@ -301,6 +301,24 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     }
     T ll_tot = (tid == 0) ? a.ll_total[b] : T(0);
     double lse_w = M1 + log_sum<T>(S1);
+    if (run.t0 > 0 && tid == 0) {
+        // A run issued in pieces: the piece before this one may have been a per-step piece WITHOUT finalize, whose last
+        // move's log-likelihood increment is still pending - the per-step route flushes it one launch later, from the
+        // column record it keeps in the workspace (column_bookkeeping).  That launch is this one: ll = lse(logw) - base,
+        // NaN when the move's weights were poisoned, 0 for an unweighted move.  (A finalised predecessor - either route -
+        // left ll_done = 1.)
+        const ColStat st = a.stat[b];
+        if (!st.ll_done) {
+            const int pslot = (run.t0 - 1) & 3;
+            double ll = 0.0;
+            if (st.prev_observed) {
+                ll = lse_w - st.base_lse;
+                if (a.poison[pslot * g.B + b]) ll = __builtin_nan("");
+            }
+            a.ll_steps[(int64_t)(run.t0 - 1) * g.B + b] = (T)ll;
+            ll_tot = (T)((double)ll_tot + ll);
+        }
+    }
 
     // the first step's observation and offset; every later step's are requested one step ahead
     // Requested a step ahead and consumed RAW one iteration later (nothing in the requesting iteration touches the values,

@@ -412,7 +412,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         rejuvenation) only costs host time."""
         return (y.shape[0] > 0 and FilterResult.states_kept(self.record_states) == 1 and not getattr(self, "_time_kernels", False)
                 and not self._move_by_move and not self._kernel_kind().is_user and int(self._model.observe_every_step) == 1
-                and HINTS.route != 1 and self._base_particles[0] <= (HINTS.column_max_n or 2048) and self._ctx_tapes_none())
+                and (HINTS.direct or (HINTS.route != 1 and self._base_particles[0] <= (HINTS.column_max_n or 2048)))
+                and self._ctx_tapes_none())
 
     def _batch_filter_lean(self, y: torch.Tensor, init_state=None) -> FilterResult:
         state = init_state if init_state is not None else self.initialize()

@@ -10,7 +10,7 @@ ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC = 0, 1, 2
 
 
 class RunHints:
-    __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph")
+    __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph", "direct")
 
     def __init__(self):
         self.reset()
@@ -23,6 +23,7 @@ class RunHints:
         self.fused_step = True       # ``filter()`` of a built-in model takes the fused single-step move
         self.fused_batch = True      # ``batch_filter()`` of a built-in model takes the fused run
         self.graph = True            # repeated fused runs of one configuration replay a captured hipGraph
+        self.direct = False          # every plain fused run takes the direct driver (no persistent plan, no graph), not only single-launch runs
 
     def key(self):
         """What a cached launch plan depends on."""
@@ -43,6 +44,7 @@ class RunHints:
         self.tile_target = int(m.get("PF_TARGET_WGS", 0) or 0)
         self.ancestor_search = 1 if on("PF_FORCE_SEARCH") else 0
         self.fused_step, self.fused_batch, self.graph = not on("PF_NO_FUSED_STEP"), not on("PF_NO_FUSED_BATCH"), not on("PF_NO_GRAPH")
+        self.direct = on("PF_DIRECT")
         return self
 
 
