@@ -101,7 +101,7 @@ template <typename T> __device__ __forceinline__ double inv_sum(double s) {
 // run-time branch the ragged paths cost the aligned shapes 3 - 6 % per step (same-box A/B, profiles/r03_column_ragged.txt).
 template <typename T, int D, int VEC, int TPB, bool USER, int KIND = -1, int FILT = -1, int PROP = -1, bool RAGGED = false>
 __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun run) {
-    static_assert(!RAGGED || (D == 1 && VEC > 1), "ragged columns: scalar states, several particles per lane");
+    static_assert(!RAGGED || VEC > 1, "ragged columns: several particles per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char pfc_lds[];
     const Geom& g = a.g;
     const int N = (int)g.N;
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     // N % VEC != 0: the last lane holds fewer than VEC particles and a column starts at no vector boundary of the (B, N)
     // planes - the state is then loaded / stored element by element and the per-particle validity `ok[j]` stands in for
     // `on` (an invalid slot carries log-weight -inf, i.e. weight 0, through every sum and scan)
-    // (scalar states only: for D > 1 the extra paths cost the kernels registers - D = 2: 164 -> 241 VGPRs - and such columns
-    // keep one particle per lane when N % 4 != 0)
+    // (as a RUN-TIME branch these paths had cost the D > 1 kernels registers - D = 2: 164 -> 241 VGPRs; as instantiations of
+    // their own - round 4: for every state dimension - they cost the aligned kernels nothing)
     constexpr bool RAG = RAGGED;
     constexpr bool ragged = RAGGED;  // (the host launches the RAGGED instantiations for exactly the N % VEC != 0 columns)
     bool ok[VEC];

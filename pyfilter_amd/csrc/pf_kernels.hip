@@ -1721,7 +1721,7 @@ static inline int column_threads(int64_t N, int vec) {
 // (pf_column.hpp: `ragged`).  D > 1 keeps the geometry's width.  The state's layout in HBM and the Philox addressing do not
 // depend on it.  (One particle per lane for ALIGNED columns measured <= 16 % faster below 512 filters x 256 particles and
 // up to 3x slower above: profiles/r03_column_vec1_vs_vec4.txt - not adopted.)
-static inline int column_vec(const pf_filter_args* A, const Geom& g) { return A->model.dim == 1 ? 4 : g.vec; }
+static inline int column_vec(const pf_filter_args* /*A*/, const Geom& /*g*/) { return 4; }
 static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize, int vec) {
     int64_t np2 = 64;
     while (np2 < N) np2 <<= 1;
@@ -1785,7 +1785,7 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
             spec_ok = !A->z_tape && !generic_only && (closed || sv);  // (any workgroup size: the 256- or the 1024-thread bound)
         }
         if constexpr (sizeof(T) == 4 && D == 3 && VEC == 4) {  // Lorenz-63
-            spec_ok = nt <= 256 && !A->z_tape && A->hints.route != PF_ROUTE_COLUMN_GENERIC && A->model.obs_kind == PF_OBS_LINEAR &&
+            spec_ok = A->N % VEC == 0 && !A->z_tape && A->hints.route != PF_ROUTE_COLUMN_GENERIC && A->model.obs_kind == PF_OBS_LINEAR &&
                       A->model.hid_kind == PF_HID_LORENZ63_EM && (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
         }
         trace_launch(r.t0, (int)sizeof(T), D, VEC, A->resampler == PF_RESAMPLE_MULTINOMIAL ? 1 : 0, A->proposal, spec_ok ? 1 : 0,
@@ -1793,7 +1793,7 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         const bool user = A->model.hid_kind == PF_HID_USER_AFFINE;
         // columns of N % 4 != 0 particles (scalar states): the RAGGED instantiations
         auto with_rag = [&](auto&& f) {
-            if constexpr (D == 1 && VEC == 4) {
+            if constexpr (VEC == 4) {
                 if (A->N % VEC != 0) return f(std::true_type{});
             }
             f(std::false_type{});
@@ -1845,9 +1845,13 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         if constexpr (sizeof(T) == 4 && D == 3 && VEC == 4) {
             if (spec_ok) {
                 specialised = true;
-                auto go3 = [&](auto filt_c, auto prop_c) {
-                    hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, PF_HID_LORENZ63_EM, decltype(filt_c)::value,
-                                                       decltype(prop_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                auto go3 = [&](auto filt_c, auto prop_c) {  // (the 256- or - 1 024 < N <= 2 048 - the 1024-thread bound)
+                    if (nt <= 256)
+                        hipLaunchKernelGGL((k_fused_column<T, D, VEC, 256, false, PF_HID_LORENZ63_EM, decltype(filt_c)::value,
+                                                           decltype(prop_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
+                    else
+                        hipLaunchKernelGGL((k_fused_column<T, D, VEC, 1024, false, PF_HID_LORENZ63_EM, decltype(filt_c)::value,
+                                                           decltype(prop_c)::value>), dim3(g.B), dim3(nt), lds, st, a, r);
                 };
                 auto with_prop3 = [&](auto filt_c) {
                     if (A->proposal == PF_PROP_LGO) go3(filt_c, std::integral_constant<int, PF_PROP_LGO>{});
@@ -1881,13 +1885,10 @@ int pf_run_column_f64(PF_COL_ARGS);
 #define PF_DEFINE_COLUMN(NAME, T)                                                                     \
     int NAME(PF_COL_ARGS) {                                                                           \
         const int D = A->model.dim;                                                                   \
+        /* four particles per lane whatever N: columns of N % 4 != 0 take the RAGGED instantiations */  \
         if (D == 1) return column_run_impl<T, 1, 4>(A, g, wl, t0, n_steps, st, kernel_ms);            \
-        if (g.vec == 4) {                                                                             \
-            if (D == 2) return column_run_impl<T, 2, 4>(A, g, wl, t0, n_steps, st, kernel_ms);        \
-            return column_run_impl<T, 3, 4>(A, g, wl, t0, n_steps, st, kernel_ms);                    \
-        }                                                                                             \
-        if (D == 2) return column_run_impl<T, 2, 1>(A, g, wl, t0, n_steps, st, kernel_ms);            \
-        return column_run_impl<T, 3, 1>(A, g, wl, t0, n_steps, st, kernel_ms);                        \
+        if (D == 2) return column_run_impl<T, 2, 4>(A, g, wl, t0, n_steps, st, kernel_ms);            \
+        return column_run_impl<T, 3, 4>(A, g, wl, t0, n_steps, st, kernel_ms);                        \
     }
 #if defined(PF_TU_COLUMN_F32) || !defined(PF_TU_SPLIT)
 PF_DEFINE_COLUMN(pf_run_column_f32, float)

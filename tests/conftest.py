@@ -9,6 +9,10 @@ from pyfilter_amd.hints import HINTS
 # tiles at test sizes; PF_FORCE_SEARCH: the searching ancestor stage): the test infrastructure translates them - the package
 # itself never reads the environment (pyfilter_amd/hints.py)
 HINTS.apply_mapping(os.environ)
+if os.environ.get("PF_AMD_LIB"):  # (an A/B build of the library under test: tools/build_variant.sh)
+    from pyfilter_amd import _lib as _pf_lib
+
+    _pf_lib.LIB_PATH = os.environ["PF_AMD_LIB"]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

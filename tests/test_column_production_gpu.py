@@ -38,7 +38,7 @@ def _specialised(kind, n):
     if kind in ("lg", "sine", "ou", "sv"):
         return True  # scalar kinds: aligned or RAGGED, the 256- or the 1024-thread bound
     if kind == "lorenz":
-        return n % 4 == 0 and n // 4 <= 256
+        return n % 4 == 0  # (the 256- or the 1024-thread bound; N % 4 != 0: the run-time kernel's RAGGED instantiation)
     return False  # D = 2: the run-time kernel
 
 
@@ -53,9 +53,11 @@ def _cases():
                     if kind == "lorenz" and n != 512:
                         continue
                     out.append((kind, filt_name, prop, n))
-    # not specialised, float32 all the same: Lorenz beyond 1 024 particles / of N % 4 != 0, and the D = 2 run-time kernels
-    out += [("lorenz", "apf", "lgo", 1536), ("lorenz", "sisr", "bootstrap", 333),
-            ("rw2d", "apf", "lgo", 512), ("rw2d", "sisr", "bootstrap", 1000), ("rw2d", "sisr", "lgo", 333)]
+    # Lorenz under the 1024-thread bound (specialised since round 4); not specialised, float32 all the same: Lorenz of
+    # N % 4 != 0 and the D = 2 kernels - for N % 4 != 0 their RAGGED instantiations (four particles per lane for every D)
+    out += [("lorenz", "apf", "lgo", 1536), ("lorenz", "sisr", "bootstrap", 1536), ("lorenz", "sisr", "bootstrap", 333),
+            ("lorenz", "apf", "lgo", 1502),
+            ("rw2d", "apf", "lgo", 512), ("rw2d", "sisr", "bootstrap", 1000), ("rw2d", "sisr", "lgo", 333), ("rw2d", "apf", "bootstrap", 1502)]
     return out
 
 

@@ -99,7 +99,7 @@ CASES = [
     ("lg", "apf", "lgo", "systematic", 2048, 2, 25, ()),
     ("lg", "apf", "lgo", "systematic", 3072, 3, 25, (0,)),    # 12 waves; (float64: 4096 particles exceed the 64 KB of LDS)
     ("ou", "apf", "lgo", "systematic", 1024, 7, 30, ()),
-    ("ou", "sisr", "lgo", "systematic", 100, 3, 30, ()),       # N % 4 != 0: one particle per thread
+    ("ou", "sisr", "lgo", "systematic", 100, 3, 30, ()),       # N % 4 != 0: the RAGGED instantiation
     ("ou", "apf", "bootstrap", "systematic", 333, 2, 20, (3,)),
     ("sv", "apf", "bootstrap", "systematic", 512, 6, 40, ()),
     ("sv", "sisr", "bootstrap", "systematic", 256, 4, 40, ()),
@@ -108,7 +108,7 @@ CASES = [
     ("lorenz", "apf", "bootstrap", "systematic", 1536, 1, 10, ()),
     ("rw2d", "sisr", "bootstrap", "systematic", 512, 3, 40, ()),
     ("rw2d", "apf", "lgo", "systematic", 1024, 2, 30, (3, 4)),
-    ("rw2d", "sisr", "lgo", "systematic", 333, 2, 30, ()),     # D = 2, N % 4 != 0: one particle per thread
+    ("rw2d", "sisr", "lgo", "systematic", 333, 2, 30, ()),     # D = 2, N % 4 != 0: the RAGGED instantiation
     ("rw2d", "apf", "bootstrap", "systematic", 2048, 1, 20, (0,)),
     ("rw2d", "apf", "lgo", "multinomial", 256, 3, 25, ()),
     ("sine", "sisr", "bootstrap", "multinomial", 512, 3, 30, ()),
@@ -173,7 +173,7 @@ def test_specialised_column_kernels_equal_the_run_time_kernel(kind, filt_name, p
     if kind == "sv" and prop == "lgo":
         pytest.skip("the stochastic-volatility observation has no linear-Gaussian proposal")
     if kind == "lorenz" and n % 4:
-        pytest.skip("D > 1: columns of N % 4 != 0 particles keep one particle per lane and the run-time kernel")
+        pytest.skip("Lorenz columns of N % 4 != 0 particles: the run-time kernel's RAGGED instantiation (no specialised twin)")
     # (n = 333: the RAGGED instantiations - four particles per lane, N % 4 != 0; n = 1502: ragged AND the 1024-thread bound)
     b, t_len, nan_at = (5, 40, (3, 17)) if n < 1024 else (3, 12, (3,))
     spec = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float32, nan_at)
@@ -264,8 +264,6 @@ def test_random_cross_route_sweep():
         prop = "bootstrap" if kind == "sv" else rng.choice(["bootstrap", "lgo"])
         resampler = rng.choice(["systematic", "systematic", "multinomial"])
         n = rng.choice([rng.randint(1, 70), rng.randint(71, 700), rng.randint(701, 2048), rng.choice([64, 256, 1024, 2048])])
-        if n > 1024:
-            n -= n % 4  # (one particle per thread - N % 4 != 0 - fits a workgroup up to 1 024 particles only)
         if kind == "lorenz":
             n = min(n, 1536)  # (float64, D = 3: the cdf + three particle planes of 2 048 particles exceed the 64 KB of LDS)
         b = rng.choice([1, 2, 3, 7, 33])
