@@ -373,12 +373,13 @@ __device__ __forceinline__ void systematic_round(const T* __restrict__ cdf_col, 
 // ---------------------------------------------------------------------------------------------------------------
 
 // per-tile online (max, sum exp, sum exp^2) of log-weights; optional in-place sanitise
+// (the primitives' bodies are device functions of (column b, tile k): the kernels below run one per workgroup; the one-launch
+// variants for columns of ONE tile - k_resample_one_tile / k_normalize_one_tile - run them back to back in one workgroup)
 template <typename T, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_reduce_logw(T* __restrict__ logw, int sanitize, const uint8_t* colmask,
-                                                          double* __restrict__ part, Geom g) {
+__device__ __forceinline__ void reduce_logw_body(T* __restrict__ logw, int sanitize, const uint8_t* colmask,
+                                                 double* __restrict__ part, const Geom& g, int b, int k) {
     __shared__ double red[4 * PF_NWAVES];
     __shared__ T redm[PF_NWAVES];
-    const int b = blockIdx.y, k = blockIdx.x;
     if (colmask && !colmask[b]) return;
     T* col = logw + (int64_t)b * g.N;
     OnlineLse<T> acc;
@@ -415,6 +416,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_reduce_logw(T* __restrict__ logw, 
         part[PQ_Q1 * stride + o] = sums[1];
     }
 }
+template <typename T, int VEC>
+__global__ __launch_bounds__(PF_BLOCK) void k_reduce_logw(T* __restrict__ logw, int sanitize, const uint8_t* colmask,
+                                                          double* __restrict__ part, Geom g) {
+    reduce_logw_body<T, VEC>(logw, sanitize, colmask, part, g, blockIdx.y, blockIdx.x);
+}
 
 // combine the (m, s[, q]) partials of one column; every thread gets the results
 struct ColLse {
@@ -448,12 +454,10 @@ __device__ __forceinline__ ColLse combine_partials(const double* __restrict__ pa
 }
 
 template <typename T, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_normalize_write(const T* __restrict__ logw, T* __restrict__ W,
-                                                              T* __restrict__ lse, T* __restrict__ ess,
-                                                              const double* __restrict__ part, Geom g) {
+__device__ __forceinline__ void normalize_write_body(const T* __restrict__ logw, T* __restrict__ W, T* __restrict__ lse,
+                                                     T* __restrict__ ess, const double* __restrict__ part, const Geom& g, int b, int k) {
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
-    const int b = blockIdx.y, k = blockIdx.x;
     const ColLse c = combine_partials(part, PQ_M1, PQ_S1, PQ_Q1, b, k, g.B, g.tiles, red, redm);
     if (k == 0 && threadIdx.x == 0) {
         if (lse) lse[b] = (T)(c.M + log(c.S));
@@ -475,13 +479,27 @@ __global__ __launch_bounds__(PF_BLOCK) void k_normalize_write(const T* __restric
         if (VEC == 1) out[i0] = v[0]; else store_vec<T, VEC>(out + i0, v);
     }
 }
+template <typename T, int VEC>
+__global__ __launch_bounds__(PF_BLOCK) void k_normalize_write(const T* __restrict__ logw, T* __restrict__ W,
+                                                              T* __restrict__ lse, T* __restrict__ ess,
+                                                              const double* __restrict__ part, Geom g) {
+    normalize_write_body<T, VEC>(logw, W, lse, ess, part, g, blockIdx.y, blockIdx.x);
+}
+// pf_normalize for columns of ONE tile: both passes in one launch (same arithmetic, same values)
+template <typename T, int VEC>
+__global__ __launch_bounds__(PF_BLOCK) void k_normalize_one_tile(T* __restrict__ logw, T* __restrict__ W, T* __restrict__ lse,
+                                                                 T* __restrict__ ess, double* __restrict__ part, Geom g) {
+    reduce_logw_body<T, VEC>(logw, 1, nullptr, part, g, blockIdx.y, 0);
+    __threadfence_block();
+    __syncthreads();  // the tile's record and the sanitised log-weights (this workgroup's own writes) are visible
+    normalize_write_body<T, VEC>(logw, W, lse, ess, part, g, blockIdx.y, 0);
+}
 
 // per-tile fp64 sums of already-normalised weights (systematic, normalized=True path)
 template <typename T, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_tile_sum(const T* __restrict__ W, const uint8_t* colmask,
-                                                       double* __restrict__ part, Geom g) {
+__device__ __forceinline__ void tile_sum_body(const T* __restrict__ W, const uint8_t* colmask, double* __restrict__ part,
+                                              const Geom& g, int b, int k) {
     __shared__ double red[PF_NWAVES];
-    const int b = blockIdx.y, k = blockIdx.x;
     if (colmask && !colmask[b]) return;
     const T* col = W + (int64_t)b * g.N;
     double s[1] = {0.0};
@@ -500,6 +518,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_tile_sum(const T* __restrict__ W, 
         part[PQ_M1 * stride + (int64_t)b * g.tiles + k] = 0.0;  // "max" 0 -> exp_diff = 1
         part[PQ_S1 * stride + (int64_t)b * g.tiles + k] = s[0];
     }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(PF_BLOCK) void k_tile_sum(const T* __restrict__ W, const uint8_t* colmask,
+                                                       double* __restrict__ part, Geom g) {
+    tile_sum_body<T, VEC>(W, colmask, part, g, blockIdx.y, blockIdx.x);
 }
 
 // Scan of one tile: cdf_i = T( P_k + f_k * sum_{j <= i in tile} e_j ), carried in fp64 and rounded per element -
@@ -546,11 +569,10 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
 }
 
 template <typename T, int VEC, bool FROM_W>
-__global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T* __restrict__ cdf,
-                                                   const uint8_t* colmask, const double* __restrict__ part, Geom g) {
+__device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restrict__ cdf, const uint8_t* colmask,
+                                          const double* __restrict__ part, const Geom& g, int b, int k) {
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
-    const int b = blockIdx.y, k = blockIdx.x;
     if (colmask && !colmask[b]) return;
     const ColLse c = combine_partials(part, PQ_M1, PQ_S1, -1, b, k, g.B, g.tiles, red, redm);
     const int64_t stride = (int64_t)g.B * g.tiles;
@@ -568,16 +590,20 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T*
     }
     scan_tile<T, VEC, FROM_W>(src + (int64_t)b * g.N, cdf + (int64_t)b * g.N, g, k, (T)mk, Pk, fk, Pnext, red);
 }
+template <typename T, int VEC, bool FROM_W>
+__global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T* __restrict__ cdf,
+                                                   const uint8_t* colmask, const double* __restrict__ part, Geom g) {
+    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, blockIdx.y, blockIdx.x);
+}
 
 // ancestors from the cdf: systematic grid (u per column) or iid uniforms (multinomial)
 template <typename T, int VEC>
-__global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, const T* __restrict__ u,
-                                                     int u_per_elem, const T* __restrict__ v, int multinomial, uint64_t seed,
-                                                     uint32_t step, const uint8_t* colmask, int32_t* __restrict__ idx,
-                                                     Geom g, int force_search) {
+__device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* __restrict__ u, int u_per_elem,
+                                            const T* __restrict__ v, int multinomial, uint64_t seed, uint32_t step,
+                                            const uint8_t* colmask, int32_t* __restrict__ idx, const Geom& g, int force_search,
+                                            int b, int k) {
     __shared__ __attribute__((aligned(32))) T win[SearchWin<T, VEC>::WIN];
     __shared__ int sh_j0;
-    const int b = blockIdx.y, k = blockIdx.x;
     if (colmask && !colmask[b]) return;
     const T* col = cdf + (int64_t)b * g.N;
     int32_t* out = idx + (int64_t)b * g.N;
@@ -669,6 +695,32 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
             if (VEC == 1) out[i0] = res[0]; else store_vec<int, VEC>(out + i0, res);
         }
     }
+}
+template <typename T, int VEC>
+__global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, const T* __restrict__ u,
+                                                     int u_per_elem, const T* __restrict__ v, int multinomial, uint64_t seed,
+                                                     uint32_t step, const uint8_t* colmask, int32_t* __restrict__ idx,
+                                                     Geom g, int force_search) {
+    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, force_search, blockIdx.y, blockIdx.x);
+}
+// systematic / multinomial resampling of columns of ONE tile (filters of up to a few thousand particles, or many filters:
+// 1 024 x 8 192 is one 8-round tile per column) in ONE launch: tile record -> scan -> ancestors, the three kernels' bodies back
+// to back in the column's workgroup (same arithmetic: identical cdf and ancestors; the cdf goes through memory between
+// the stages exactly as between the launches, it is just never re-read from another CU)
+template <typename T, int VEC, bool FROM_W>
+__global__ __launch_bounds__(PF_BLOCK) void k_resample_one_tile(T* __restrict__ src, const T* __restrict__ u, int u_per_elem,
+                                                                const T* __restrict__ v, int multinomial, uint64_t seed,
+                                                                uint32_t step, const uint8_t* colmask, T* __restrict__ cdf,
+                                                                int32_t* __restrict__ idx, double* __restrict__ part, Geom g) {
+    const int b = blockIdx.y;
+    if (FROM_W) tile_sum_body<T, VEC>(src, colmask, part, g, b, 0);
+    else reduce_logw_body<T, VEC>(src, 1, colmask, part, g, b, 0);
+    __threadfence_block();
+    __syncthreads();
+    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, b, 0);
+    __threadfence_block();
+    __syncthreads();
+    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, 0, b, 0);
 }
 
 template <typename T>
@@ -1157,10 +1209,15 @@ extern "C" int pf_normalize(void* logw, void* W, void* lse, void* ess, int64_t N
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(g.tiles, g.B);
 #define CALL(T, V)                                                                                                   \
-    hipLaunchKernelGGL((k_reduce_logw<T, V>), grid, dim3(PF_BLOCK), 0, st, (T*)logw, 1, (const uint8_t*)nullptr,     \
-                       part, g);                                                                                     \
-    hipLaunchKernelGGL((k_normalize_write<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)logw, (T*)W, (T*)lse,       \
-                       (T*)ess, (const double*)part, g);
+    if (g.tiles == 1) { /* one tile per column: both passes in one launch */                                          \
+        hipLaunchKernelGGL((k_normalize_one_tile<T, V>), grid, dim3(PF_BLOCK), 0, st, (T*)logw, (T*)W, (T*)lse,      \
+                           (T*)ess, part, g);                                                                        \
+    } else {                                                                                                         \
+        hipLaunchKernelGGL((k_reduce_logw<T, V>), grid, dim3(PF_BLOCK), 0, st, (T*)logw, 1, (const uint8_t*)nullptr, \
+                           part, g);                                                                                 \
+        hipLaunchKernelGGL((k_normalize_write<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)logw, (T*)W, (T*)lse,   \
+                           (T*)ess, (const double*)part, g);                                                         \
+    }
     PF_DISPATCH_T_VEC(dtype, g.vec, CALL)
 #undef CALL
     PF_CHECK_LAUNCH();
@@ -1178,7 +1235,14 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(g.tiles, g.B);
 #define CALL(T, V)                                                                                                   \
-    if (from_w) {                                                                                                    \
+    if (g.tiles == 1) { /* one tile per column: record -> scan -> ancestors in one launch */                          \
+        if (from_w)                                                                                                  \
+            hipLaunchKernelGGL((k_resample_one_tile<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (T*)src, (const T*)u, \
+                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g);    \
+        else                                                                                                         \
+            hipLaunchKernelGGL((k_resample_one_tile<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (T*)src, (const T*)u,\
+                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g);    \
+    } else if (from_w) {                                                                                             \
         hipLaunchKernelGGL((k_tile_sum<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, colmask, part, g);        \
         hipLaunchKernelGGL((k_scan<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,       \
                            (const double*)part, g);                                                                  \
@@ -1187,8 +1251,9 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
         hipLaunchKernelGGL((k_scan<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,      \
                            (const double*)part, g);                                                                  \
     }                                                                                                                \
-    hipLaunchKernelGGL((k_search<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u, u_per_elem,        \
-                       (const T*)v, multinomial, seed, step, colmask, idx, g, /*force_search*/ 0);
+    if (g.tiles != 1)                                                                                                \
+        hipLaunchKernelGGL((k_search<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u, u_per_elem,    \
+                           (const T*)v, multinomial, seed, step, colmask, idx, g, /*force_search*/ 0);
     PF_DISPATCH_T_VEC(dtype, g.vec, CALL)
 #undef CALL
     PF_CHECK_LAUNCH();
