@@ -177,6 +177,43 @@ int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems, int dtype
  * `out`: (rows, 2) device values of `dtype`. */
 int pf_theta_ess(const void* logw, int64_t rows, int64_t B, int dtype, void* out, void* stream);
 
+/* theta-level arithmetic of one SMC^2 / PMMH move on B theta-particles of P <= PF_THETA_MAXP scalar parameters, in
+ * unconstrained space (pyfilter/inference/utils.py:42-76 construct_mvn; batch/mcmc/utils.py:48-70 run_pmmh; prior.py:47-123
+ * the priors' bijections) - three small kernels instead of ~130 torch launches per move.  All arithmetic in double; arrays
+ * are of `dtype`.  Prior families: parameters (a, b) as torch.distributions names them. */
+#define PF_THETA_MAXP 8
+#define PF_PRIOR_NORMAL 0      /* Normal(loc a, scale b)               real support:        x = u                       */
+#define PF_PRIOR_LOGNORMAL 1   /* LogNormal(loc a, scale b)            positive:            x = exp(u)                  */
+#define PF_PRIOR_EXPONENTIAL 2 /* Exponential(rate a)                                                                   */
+#define PF_PRIOR_GAMMA 3       /* Gamma(concentration a, rate b)                                                        */
+#define PF_PRIOR_HALFNORMAL 4  /* HalfNormal(scale a)                                                                   */
+#define PF_PRIOR_BETA 5        /* Beta(concentration1 a, concentration0 b)   unit interval: x = sigmoid(u)              */
+#define PF_PRIOR_UNIFORM 6     /* Uniform(low a, high b)               interval:            x = a + (b - a) sigmoid(u)  */
+typedef struct pf_theta_priors {
+    int32_t P;
+    int32_t kind[PF_THETA_MAXP];
+    double a[PF_THETA_MAXP], b[PF_THETA_MAXP];
+} pf_theta_priors;
+
+/* calc_mean_chol / construct_mvn (inference/utils.py:42-76): normalised weights of `logw` (B) as pyfilter.utils.normalize
+ * defines them (NULL: equal weights), mean (P) <- weighted mean of values (B, P), chol (P, P) <- scale * lower Cholesky factor
+ * of the weighted covariance - its diagonal's square root when the covariance is not positive definite. */
+int pf_theta_fit(const void* values, const void* logw, int64_t B, int32_t P, double scale, int dtype, void* mean, void* chol,
+                 void* stream);
+
+/* theta* ~ N(mean, chol chol^T) from the standard normals eps (B, P) (mcmc/utils.py:48): u_out (B, P) <- mean + chol eps;
+ * x_out[p] (B) <- the constrained value of parameter p (its prior's bijection; parameter.py:79-107); prior_out (B) <- the
+ * summed log priors of u (TransformedDistribution(prior, bijection^-1).log_prob, prior.py:98-123). */
+int pf_theta_propose(const pf_theta_priors* priors, const void* mean, const void* chol, const void* eps, int64_t B, int dtype,
+                     void* u_out, void* const* x_out, void* prior_out, void* stream);
+
+/* The acceptance step (mcmc/utils.py:57-70): log_acc (B) <- [log q_r(u_cur) - log q_f(u_star)] + [prior_star - prior_cur] +
+ * [ll_star - ll_cur] with q_f = N(mean_f, chol_f chol_f^T) the kernel theta* was drawn from and q_r the one fitted to
+ * theta*; accepted (B, uint8) <- log(unif) < log_acc (NaN: rejected); rate (1) <- the share accepted. */
+int pf_theta_accept(const void* u_cur, const void* u_star, const void* mean_f, const void* chol_f, const void* mean_r,
+                    const void* chol_r, const void* prior_cur, const void* prior_star, const void* ll_cur, const void* ll_star,
+                    const void* unif, int64_t B, int32_t P, int dtype, void* log_acc, uint8_t* accepted, void* rate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------ *
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and
  * APF (apf.py:16-46) with Bootstrap / LinearGaussianObservations on a built-in model; one kernel per step.

@@ -1442,6 +1442,68 @@ extern "C" int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems
     return PF_OK;
 }
 
+// ---- theta-level kernels (pf_theta.hpp) ---------------------------------------------------------------------------------
+#include "pf_theta.hpp"
+extern "C" int pf_theta_fit(const void* values, const void* logw, int64_t B, int32_t P, double scale, int dtype, void* mean,
+                            void* chol, void* stream) {
+    if (!values || !mean || !chol || B < 1 || P < 1 || P > PF_THETA_MAXP) return PF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_theta_fit<float>), dim3(1), dim3(PF_BLOCK), 0, st, (const float*)values, (const float*)logw, B, (int)P, scale,
+                           (float*)mean, (float*)chol);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_theta_fit<double>), dim3(1), dim3(PF_BLOCK), 0, st, (const double*)values, (const double*)logw, B, (int)P,
+                           scale, (double*)mean, (double*)chol);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_theta_propose(const pf_theta_priors* priors, const void* mean, const void* chol, const void* eps, int64_t B,
+                                int dtype, void* u_out, void* const* x_out, void* prior_out, void* stream) {
+    if (!priors || !mean || !chol || !eps || !u_out || !x_out || !prior_out || B < 1 || priors->P < 1 || priors->P > PF_THETA_MAXP)
+        return PF_EINVAL;
+    ThetaPriors pr;
+    ThetaOut out;
+    pr.P = priors->P;
+    for (int p = 0; p < PF_THETA_MAXP; ++p) {
+        pr.kind[p] = p < pr.P ? priors->kind[p] : 0;
+        pr.a[p] = p < pr.P ? priors->a[p] : 0.0;
+        pr.b[p] = p < pr.P ? priors->b[p] : 1.0;
+        out.x[p] = p < pr.P ? x_out[p] : nullptr;
+        if (p < pr.P && (!x_out[p] || pr.kind[p] < 0 || pr.kind[p] > PF_PRIOR_UNIFORM)) return PF_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((B + PF_BLOCK - 1) / PF_BLOCK));
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_theta_propose<float>), grid, dim3(PF_BLOCK), 0, st, pr, (const float*)mean, (const float*)chol,
+                           (const float*)eps, B, (float*)u_out, out, (float*)prior_out);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_theta_propose<double>), grid, dim3(PF_BLOCK), 0, st, pr, (const double*)mean, (const double*)chol,
+                           (const double*)eps, B, (double*)u_out, out, (double*)prior_out);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_theta_accept(const void* u_cur, const void* u_star, const void* mean_f, const void* chol_f, const void* mean_r,
+                               const void* chol_r, const void* prior_cur, const void* prior_star, const void* ll_cur,
+                               const void* ll_star, const void* unif, int64_t B, int32_t P, int dtype, void* log_acc,
+                               uint8_t* accepted, void* rate, void* stream) {
+    if (!u_cur || !u_star || !mean_f || !chol_f || !mean_r || !chol_r || !prior_cur || !prior_star || !ll_cur || !ll_star || !unif ||
+        !log_acc || !accepted || !rate || B < 1 || P < 1 || P > PF_THETA_MAXP)
+        return PF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define CALL(T)                                                                                                               \
+    hipLaunchKernelGGL((k_theta_accept<T>), dim3(1), dim3(PF_BLOCK), 0, st, (const T*)u_cur, (const T*)u_star, (const T*)mean_f, \
+                       (const T*)chol_f, (const T*)mean_r, (const T*)chol_r, (const T*)prior_cur, (const T*)prior_star,         \
+                       (const T*)ll_cur, (const T*)ll_star, (const T*)unif, B, (int)P, (T*)log_acc, accepted, (T*)rate);
+    if (dtype == PF_F32) { CALL(float) } else if (dtype == PF_F64) { CALL(double) } else return PF_EINVAL;
+#undef CALL
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
 extern "C" int pf_theta_ess(const void* logw, int64_t rows, int64_t B, int dtype, void* out, void* stream) {
     if (!logw || !out || B < 1 || rows < 0 || rows > 0x7fffffff) return PF_EINVAL;
     if (rows == 0) return PF_OK;

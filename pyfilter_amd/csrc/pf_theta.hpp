@@ -1,0 +1,245 @@
+// pf_theta.hpp - the theta-level arithmetic of an SMC^2 / PMMH move as three small kernels.
+//
+// A rejuvenation moves B theta-particles (10^2 .. 10^4) of P parameters (<= 8): it fits a Gaussian to the weighted particles
+// (pyfilter/inference/utils.py:42-76 `construct_mvn`), proposes theta* = mean + L eps in unconstrained space and maps it back
+// through the priors' bijections (mcmc/utils.py:48-50, prior.py:47-123), evaluates log prior(theta*) - log prior(theta), fits
+// the reverse kernel to theta*, and accepts per particle (mcmc/utils.py:57-70).  As torch operations that is ~130 launches
+// of a few microseconds each per move - the host time of a rejuvenation, with the re-filter (1 ms of kernels) waiting
+// behind them.  Here: pf_theta_fit (one workgroup: weights, mean, covariance, Cholesky), pf_theta_propose (one thread per
+// theta-particle), pf_theta_accept (one workgroup: both kernels' log-densities, the acceptance test, the acceptance rate).
+// All arithmetic in double whatever the tensors' type (B x P numbers); values are read and written in the caller's type.
+#pragma once
+
+namespace pf {
+
+#define PF_THETA_PAIRS (PF_THETA_MAXP * (PF_THETA_MAXP + 1) / 2)
+
+struct ThetaPriors {  // device-side copy of pf_theta_priors (kernel argument)
+    int P;
+    int kind[PF_THETA_MAXP];
+    double a[PF_THETA_MAXP], b[PF_THETA_MAXP];
+};
+struct ThetaOut {  // the P parameter tensors (B,) theta* is written to
+    void* x[PF_THETA_MAXP];
+};
+
+__device__ __forceinline__ double th_softplus(double v) { return v > 0.0 ? v + log1p(exp(-v)) : log1p(exp(v)); }
+__device__ __forceinline__ double th_xlogy(double x, double y) { return x == 0.0 ? 0.0 : x * log(y); }
+
+// constrained value x = bijection(u) of prior `kind` and log p(x) + log |dx / du|: the density of u (prior.py:98-123 -
+// `TransformedDistribution(prior, biject_to(support).inv).log_prob(u)` with torch's own formulas per family)
+__device__ __forceinline__ void theta_prior(int kind, double a, double b, double u, double& x, double& lp) {
+    const double half_log_2pi = 0.91893853320467274178;
+    switch (kind) {
+        case PF_PRIOR_NORMAL: {  // real support: identity
+            x = u;
+            const double z = (x - a) / b;
+            lp = -0.5 * z * z - log(b) - half_log_2pi;
+            break;
+        }
+        case PF_PRIOR_LOGNORMAL: {  // positive support: x = exp(u)
+            x = exp(u);
+            const double lx = log(x), z = (lx - a) / b;
+            lp = (-0.5 * z * z - log(b) - half_log_2pi) - lx + u;
+            break;
+        }
+        case PF_PRIOR_EXPONENTIAL: {  // rate a
+            x = exp(u);
+            lp = log(a) - a * x + u;
+            break;
+        }
+        case PF_PRIOR_GAMMA: {  // concentration a, rate b
+            x = exp(u);
+            lp = th_xlogy(a, b) + th_xlogy(a - 1.0, x) - b * x - lgamma(a) + u;
+            break;
+        }
+        case PF_PRIOR_HALFNORMAL: {  // scale a
+            x = exp(u);
+            const double z = x / a;
+            lp = (-0.5 * z * z - log(a) - half_log_2pi) + 0.69314718055994530942 + u;
+            break;
+        }
+        case PF_PRIOR_BETA: {  // concentration1 a, concentration0 b; unit interval: x = sigmoid(u) (clamped as torch clamps it)
+            double s = 1.0 / (1.0 + exp(-u));
+            s = s < 2.2250738585072014e-308 ? 2.2250738585072014e-308 : (s > 1.0 - 2.220446049250313e-16 ? 1.0 - 2.220446049250313e-16 : s);
+            x = s;
+            lp = th_xlogy(a - 1.0, x) + th_xlogy(b - 1.0, 1.0 - x) + lgamma(a + b) - lgamma(a) - lgamma(b) - th_softplus(-u) - th_softplus(u);
+            break;
+        }
+        default: {  // PF_PRIOR_UNIFORM: low a, high b; x = a + (b - a) sigmoid(u)
+            double s = 1.0 / (1.0 + exp(-u));
+            s = s < 2.2250738585072014e-308 ? 2.2250738585072014e-308 : (s > 1.0 - 2.220446049250313e-16 ? 1.0 - 2.220446049250313e-16 : s);
+            x = a + (b - a) * s;
+            lp = -log(b - a) - th_softplus(-u) - th_softplus(u) + log(fabs(b - a));
+            break;
+        }
+    }
+}
+
+// lower Cholesky factor of the P x P matrix c (row-major, PF_THETA_MAXP stride); false when it is not positive definite
+__device__ __forceinline__ bool theta_cholesky(const double (&c)[PF_THETA_MAXP][PF_THETA_MAXP], int P, double (&l)[PF_THETA_MAXP][PF_THETA_MAXP]) {
+    bool ok = true;
+    for (int i = 0; i < P; ++i)
+        for (int j = 0; j < P; ++j) l[i][j] = 0.0;
+    for (int j = 0; j < P; ++j) {
+        double d = c[j][j];
+        for (int k = 0; k < j; ++k) d -= l[j][k] * l[j][k];
+        if (!(d > 0.0)) ok = false;
+        const double dj = sqrt(d);
+        l[j][j] = dj;
+        for (int i = j + 1; i < P; ++i) {
+            double v = c[i][j];
+            for (int k = 0; k < j; ++k) v -= l[i][k] * l[j][k];
+            l[i][j] = v / dj;
+        }
+    }
+    return ok;
+}
+
+// One workgroup: normalised weights of the B log-weights (pyfilter.utils.normalize: NaN / +inf count as -inf; NULL = equal
+// weights), weighted mean (P), weighted covariance about it, mean <- mean, chol <- scale * lower Cholesky factor of the
+// covariance - or, when that is not positive definite, scale * sqrt(diag) (inference/utils.py:42-57).
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_fit(const T* __restrict__ values, const T* __restrict__ logw, int64_t B, int P,
+                                                        double scale, T* __restrict__ mean_out, T* __restrict__ chol_out) {
+    __shared__ double red[PF_THETA_PAIRS * PF_NWAVES];
+    __shared__ double redm[PF_NWAVES];
+    double mx = -__builtin_huge_val();
+    if (logw) {
+        for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+            const double v = (double)logw[i];
+            const double s = (v != v || v == __builtin_huge_val()) ? -__builtin_huge_val() : v;
+            mx = s > mx ? s : mx;
+        }
+        mx = block_max<double>(mx, redm);
+    }
+    const bool uniform = !logw || !(mx > -__builtin_huge_val());
+    auto weight = [&](int64_t i) -> double {
+        if (uniform) return 1.0;
+        const double v = (double)logw[i];
+        return (v != v || v == __builtin_huge_val()) ? 0.0 : exp(v - mx);
+    };
+    // sum of the weights and the weighted sums of the values
+    double acc[PF_THETA_MAXP + 1];
+#pragma unroll
+    for (int p = 0; p <= PF_THETA_MAXP; ++p) acc[p] = 0.0;
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        const double w = weight(i);
+        acc[PF_THETA_MAXP] += w;
+#pragma unroll
+        for (int p = 0; p < PF_THETA_MAXP; ++p)
+            if (p < P) acc[p] += w * (double)values[i * P + p];
+    }
+    block_sum<PF_THETA_MAXP + 1>(acc, red);
+    const double wsum = acc[PF_THETA_MAXP];
+    double m[PF_THETA_MAXP];
+#pragma unroll
+    for (int p = 0; p < PF_THETA_MAXP; ++p) m[p] = p < P ? acc[p] / wsum : 0.0;
+    // weighted covariance about the mean (lower triangle, pair (p, q <= p) at p (p + 1) / 2 + q)
+    double cv[PF_THETA_PAIRS];
+#pragma unroll
+    for (int k = 0; k < PF_THETA_PAIRS; ++k) cv[k] = 0.0;
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        const double w = weight(i) / wsum;
+        double c[PF_THETA_MAXP];
+#pragma unroll
+        for (int p = 0; p < PF_THETA_MAXP; ++p) c[p] = p < P ? (double)values[i * P + p] - m[p] : 0.0;
+#pragma unroll
+        for (int p = 0; p < PF_THETA_MAXP; ++p)
+#pragma unroll
+            for (int q = 0; q <= p; ++q) cv[p * (p + 1) / 2 + q] += w * c[p] * c[q];
+    }
+    __syncthreads();
+    block_sum<PF_THETA_PAIRS>(cv, red);
+    if (threadIdx.x == 0) {
+        double c[PF_THETA_MAXP][PF_THETA_MAXP], l[PF_THETA_MAXP][PF_THETA_MAXP];
+        for (int p = 0; p < PF_THETA_MAXP; ++p)
+            for (int q = 0; q < PF_THETA_MAXP; ++q) c[p][q] = cv[(p >= q ? p * (p + 1) / 2 + q : q * (q + 1) / 2 + p)];
+        if (!theta_cholesky(c, P, l)) {  // not positive definite: the diagonal alone
+            for (int p = 0; p < P; ++p)
+                for (int q = 0; q < P; ++q) l[p][q] = (p == q) ? sqrt(c[p][p] > 0.0 ? c[p][p] : 0.0) : 0.0;
+        }
+        for (int p = 0; p < P; ++p) {
+            mean_out[p] = (T)m[p];
+            for (int q = 0; q < P; ++q) chol_out[p * P + q] = (T)(scale * l[p][q]);
+        }
+    }
+}
+
+// One thread per theta-particle: u* = mean + L eps; x* = bijection(u*) into the P parameter tensors; the summed log prior
+// of u* (unconstrained space).
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_propose(ThetaPriors pr, const T* __restrict__ mean, const T* __restrict__ chol,
+                                                            const T* __restrict__ eps, int64_t B, T* __restrict__ u_out, ThetaOut out,
+                                                            T* __restrict__ prior_out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= B) return;
+    const int P = pr.P;
+    double e[PF_THETA_MAXP], lp = 0.0;
+#pragma unroll
+    for (int p = 0; p < PF_THETA_MAXP; ++p) e[p] = p < P ? (double)eps[i * P + p] : 0.0;
+#pragma unroll
+    for (int p = 0; p < PF_THETA_MAXP; ++p) {
+        if (p < P) {
+            double u = (double)mean[p];
+            for (int q = 0; q <= p; ++q) u += (double)chol[p * P + q] * e[q];
+            u = (double)(T)u;  // (the value the caller keeps - and every later evaluation starts from - is the stored one)
+            double x, l1;
+            theta_prior(pr.kind[p], pr.a[p], pr.b[p], u, x, l1);
+            lp += l1;
+            u_out[i * P + p] = (T)u;
+            reinterpret_cast<T*>(out.x[p])[i] = (T)x;
+        }
+    }
+    prior_out[i] = (T)lp;
+}
+
+// One workgroup: log_acc = [log q_r(u) - log q_f(u*)] + [prior* - prior] + [ll* - ll]; accepted = log(unif) < log_acc (NaN:
+// rejected); rate = mean(accepted).  q_f = N(mean_f, L_f L_f^T) the forward kernel, q_r the reverse one (fit to theta*).
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_accept(const T* __restrict__ u_cur, const T* __restrict__ u_star,
+                                                           const T* __restrict__ mean_f, const T* __restrict__ chol_f,
+                                                           const T* __restrict__ mean_r, const T* __restrict__ chol_r,
+                                                           const T* __restrict__ prior_cur, const T* __restrict__ prior_star,
+                                                           const T* __restrict__ ll_cur, const T* __restrict__ ll_star,
+                                                           const T* __restrict__ unif, int64_t B, int P, T* __restrict__ log_acc,
+                                                           uint8_t* __restrict__ accepted, T* __restrict__ rate) {
+    __shared__ double red[PF_NWAVES];
+    double mf[PF_THETA_MAXP], mr[PF_THETA_MAXP], lf[PF_THETA_MAXP][PF_THETA_MAXP], lr[PF_THETA_MAXP][PF_THETA_MAXP];
+    double hf = 0.0, hr = 0.0;  // sum of the log diagonals
+    for (int p = 0; p < P; ++p) {
+        mf[p] = (double)mean_f[p];
+        mr[p] = (double)mean_r[p];
+        for (int q = 0; q <= p; ++q) {
+            lf[p][q] = (double)chol_f[p * P + q];
+            lr[p][q] = (double)chol_r[p * P + q];
+        }
+        hf += log(lf[p][p]);
+        hr += log(lr[p][p]);
+    }
+    const double cst = 0.5 * P * 1.83787706640934548356;  // P / 2 log(2 pi)
+    auto log_q = [&](const T* x, const double (&m)[PF_THETA_MAXP], const double (&l)[PF_THETA_MAXP][PF_THETA_MAXP], double h) {
+        double z[PF_THETA_MAXP], ss = 0.0;
+        for (int p = 0; p < P; ++p) {  // forward substitution: z = L^-1 (x - m)
+            double v = (double)x[p] - m[p];
+            for (int q = 0; q < p; ++q) v -= l[p][q] * z[q];
+            z[p] = v / l[p][p];
+            ss += z[p] * z[p];
+        }
+        return -0.5 * ss - h - cst;
+    };
+    double cnt[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        const double la = (log_q(u_cur + i * P, mr, lr, hr) - log_q(u_star + i * P, mf, lf, hf)) +
+                          ((double)prior_star[i] - (double)prior_cur[i]) + ((double)ll_star[i] - (double)ll_cur[i]);
+        const T la_t = (T)la;
+        log_acc[i] = la_t;
+        const bool acc = log((double)unif[i]) < (double)la_t;  // (NaN compares false: a failed proposal is rejected)
+        accepted[i] = acc ? 1 : 0;
+        cnt[0] += acc ? 1.0 : 0.0;
+    }
+    block_sum<1>(cnt, red);
+    if (threadIdx.x == 0) rate[0] = (T)(cnt[0] / (double)B);
+}
+
+}  // namespace pf

@@ -10,7 +10,8 @@ ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC = 0, 1, 2
 
 
 class RunHints:
-    __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph", "direct")
+    __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph", "direct",
+                 "theta_kernels")
 
     def __init__(self):
         self.reset()
@@ -23,6 +24,7 @@ class RunHints:
         self.fused_step = True       # ``filter()`` of a built-in model takes the fused single-step move
         self.fused_batch = True      # ``batch_filter()`` of a built-in model takes the fused run
         self.graph = True            # repeated fused runs of one configuration replay a captured hipGraph
+        self.theta_kernels = True    # SMC^2 / PMMH moves of scalar standard-family priors: theta arithmetic in pf_theta_* (else torch)
         self.direct = False          # every plain fused run takes the direct driver (no persistent plan, no graph), not only single-launch runs
 
     def key(self):
@@ -37,7 +39,7 @@ class RunHints:
 
     def apply_mapping(self, m):
         """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
-        PF_NO_FUSED_BATCH / PF_NO_GRAPH`` of a mapping the CALLER owns -> attributes (absent keys: the defaults)."""
+        PF_NO_FUSED_BATCH / PF_NO_GRAPH / PF_DIRECT / PF_NO_THETA_KERNELS`` of a mapping the CALLER owns -> attributes (absent keys: the defaults)."""
         on = lambda k: str(m.get(k, "0")) not in ("", "0")  # noqa: E731
         self.route = ROUTE_PER_STEP if on("PF_NO_COLUMN") else (ROUTE_COLUMN_GENERIC if on("PF_COLUMN_GENERIC") else ROUTE_AUTO)
         self.column_max_n = int(m.get("PF_COLUMN_MAX_N", 0) or 0)
@@ -45,6 +47,7 @@ class RunHints:
         self.ancestor_search = 1 if on("PF_FORCE_SEARCH") else 0
         self.fused_step, self.fused_batch, self.graph = not on("PF_NO_FUSED_STEP"), not on("PF_NO_FUSED_BATCH"), not on("PF_NO_GRAPH")
         self.direct = on("PF_DIRECT")
+        self.theta_kernels = not on("PF_NO_THETA_KERNELS")
         return self
 
 

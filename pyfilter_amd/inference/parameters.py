@@ -5,20 +5,25 @@
 Every parameter is ONE tensor of shape ``(B, *event)`` that the model holds by reference: the filters of this library
 read parameter tensors live (in-place updates re-pack the kernels' parameter rows), so ``unstack_parameters`` /
 ``exchange`` / ``resample`` write in place and the next filter move sees the new values - nothing is rebuilt."""
+import inspect
 from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
-from torch.distributions import Distribution, TransformedDistribution
+from torch.distributions import Distribution, Independent, TransformedDistribution
 from torch.distributions.constraint_registry import biject_to
 
 
 def _on_device(d: Distribution, device, dtype) -> Distribution:
     """The same distribution with its parameter tensors on ``device`` (rebuilt from ``arg_constraints``, which names the
     constructor arguments of every standard torch distribution)."""
+    if isinstance(d, Independent):  # (its one argument is a distribution)
+        return Independent(_on_device(d.base_dist, device, dtype), d.reinterpreted_batch_ndims, validate_args=False)
     args = {}
     for name in d.arg_constraints:
         v = d.__dict__.get(name)
+        if v is None and isinstance(inspect.getattr_static(type(d), name, None), property):
+            v = getattr(d, name)  # an argument kept in another form (Beta's concentrations live in its Dirichlet)
         if v is None:  # lazily derived alternatives (e.g. MultivariateNormal's precision / covariance forms)
             continue
         args[name] = v.to(device=device, dtype=dtype) if isinstance(v, torch.Tensor) and v.is_floating_point() else v
@@ -30,6 +35,25 @@ def _on_device(d: Distribution, device, dtype) -> Distribution:
         return d
 
 
+def _native_family(d: Distribution):
+    """``(PF_PRIOR_* code, a, b)`` when ``d`` is a scalar prior of a family the theta kernels evaluate (``include/pf_amd.h``:
+    the family's density and the bijection ``biject_to(d.support)`` that goes with it), else ``None``.  Exact types only: a
+    subclass may override ``log_prob`` or ``support``."""
+    from torch.distributions import Beta, Exponential, Gamma, HalfNormal, LogNormal, Normal, Uniform
+
+    table = {Normal: (0, "loc", "scale"), LogNormal: (1, "loc", "scale"), Exponential: (2, "rate", None),
+             Gamma: (3, "concentration", "rate"), HalfNormal: (4, "scale", None), Beta: (5, "concentration1", "concentration0"),
+             Uniform: (6, "low", "high")}
+    row = table.get(type(d))
+    if row is None or d.event_shape.numel() != 1 or len(d.event_shape) or d.batch_shape.numel() != 1:
+        return None
+    vals = []
+    for name in row[1:]:
+        v = getattr(d, name) if name is not None else 1.0
+        vals.append(float(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v))
+    return (row[0], vals[0], vals[1])
+
+
 class Prior:
     """A prior with its bijection to unconstrained space (``prior.py:47-123``)."""
 
@@ -39,6 +63,7 @@ class Prior:
         self.distribution = distribution
         self.bijection = biject_to(distribution.support)
         self.unconstrained = TransformedDistribution(distribution, self.bijection.inv, validate_args=False)
+        self.native = _native_family(distribution)  # (parameters as the device copy holds them, read once - here)
 
     @property
     def numel(self) -> int:
@@ -118,6 +143,35 @@ class ThetaParticles:
     def __getitem__(self, name: str) -> torch.Tensor:
         return self._values[name]
 
+    def native_priors(self):
+        """The priors as the theta kernels take them (``_lib.PfThetaPriors``; ``ops.theta_propose``) - or ``None``: a prior
+        of another family / with an event shape, more than ``PF_THETA_MAXP`` parameters, a CPU run, or theta-particles
+        sharded over several ranks (their Gaussian fit needs every rank's particles: the torch path all-gathers them)."""
+        from ..hints import HINTS
+
+        if not HINTS.theta_kernels or len(self._values) != len(self.priors):
+            return None
+        if "native" not in self.__dict__:
+            from .. import _lib
+
+            ok = (self.device.type == "cuda" and (self.shard is None or self.shard.world == 1) and
+                  0 < len(self.priors) <= _lib.THETA_MAXP and all(p.native is not None for p in self.priors.values()) and
+                  all(v.dim() == 1 and v.is_contiguous() for v in self._values.values()) and
+                  self.dtype in (torch.float32, torch.float64))
+            packed = None
+            if ok:
+                packed = _lib.PfThetaPriors()
+                packed.P = len(self.priors)
+                for i, p in enumerate(self.priors.values()):
+                    packed.kind[i], packed.a[i], packed.b[i] = p.native
+            self.native = packed
+        return self.native
+
+    def adopt_proposal(self, u: torch.Tensor, prior_u: torch.Tensor):
+        """The value tensors were just written by ``ops.theta_propose`` from the unconstrained ``u (B, P)``: what is known
+        about them (``u`` itself, their summed log prior) replaces whatever was known about the old values."""
+        self._cache = {"u": u, "prior_u": prior_u}
+
     def names(self):
         return list(self.priors)
 
@@ -126,6 +180,8 @@ class ThetaParticles:
         other = ThetaParticles(self.priors, self.batch_shape[0], self.device, self.dtype, self.shard)
         for k, v in self._values.items():
             other._values[k] = v.clone()
+        if "native" in self.__dict__:
+            other.native = self.native
         other._cache = dict(self._cache)  # (same values: the derived quantities hold - tensors nobody writes in place)
         return other
 

@@ -8,18 +8,50 @@ from torch.distributions import Distribution, Independent, Normal
 from .utils import construct_mvn, theta_normalize
 
 
+class GaussianKernel:
+    """``N(loc, scale_tril scale_tril^T)`` shared by all theta-particles, as ``ops.theta_fit`` produced it: the two tensors,
+    read by the theta kernels (``ops.theta_propose`` / ``theta_accept``).  The ``torch.distributions`` surface the callers of
+    ``SymmetricMH.build`` use (``loc / mean / scale_tril / batch_shape / event_shape / log_prob / sample``) goes through a
+    ``MultivariateNormal`` built on demand."""
+
+    def __init__(self, loc: torch.Tensor, scale_tril: torch.Tensor):
+        self.loc, self.scale_tril = loc, scale_tril
+        self.batch_shape, self.event_shape = torch.Size([]), torch.Size([loc.shape[0]])
+
+    mean = property(lambda self: self.loc)
+
+    def as_torch(self) -> Distribution:
+        from torch.distributions import MultivariateNormal
+
+        return MultivariateNormal(self.loc, scale_tril=self.scale_tril, validate_args=False)
+
+    def log_prob(self, x):
+        return self.as_torch().log_prob(x)
+
+    def sample(self, size=torch.Size([])):
+        return self.as_torch().sample(size)
+
+
 class SymmetricMH:
     """The proposal of the SMC^2 paper (``proposals/symmetric_mh.py``): a Gaussian fitted to the weighted theta-particles
     (unconstrained space), Cholesky factor scaled by 1.1.  Sharded runs fit it to ALL theta-particles (all-gather of
-    ``(B, P)`` values and weights), so every rank holds the same kernel."""
+    ``(B, P)`` values and weights), so every rank holds the same kernel.  Scalar priors of the standard families on one
+    GPU (``ThetaParticles.native_priors``): the fit is ONE launch (``ops.theta_fit``) and the move's theta arithmetic two
+    more (``run_pmmh``)."""
+
+    SCALE = 1.1
 
     def build(self, theta, state, filter_, y) -> Distribution:
         values = theta.stack_parameters(constrained=False)
         weights_log = state.w
+        if theta.native_priors() is not None and weights_log.dtype == values.dtype:
+            from .. import ops
+
+            return GaussianKernel(*ops.theta_fit(values, weights_log, self.SCALE))
         shard = getattr(theta, "shard", None)
         if shard is not None and shard.world > 1:
             values, weights_log = shard.all_gather(values), shard.all_gather(weights_log)
-        return construct_mvn(values, theta_normalize(weights_log), scale=1.1)
+        return construct_mvn(values, theta_normalize(weights_log), scale=self.SCALE)
 
     def exchange(self, latest, candidate, mask) -> None:
         return
@@ -109,15 +141,49 @@ def _uniforms(like: torch.Tensor, shard, draws):
     return _to_device(u, like)
 
 
+def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_filter, proposal_theta, y, draws, trace, stats):
+    """``run_pmmh`` for a Gaussian kernel shared by all theta-particles and scalar priors of the standard families: the
+    same move with its theta arithmetic in three launches (``csrc/pf_theta.hpp``) - theta* with its constrained values and
+    log prior, the reverse kernel's fit, the acceptance step - instead of ~130 small torch launches the re-filter waits
+    behind."""
+    from .. import ops
+
+    priors = theta.native_priors()
+    b, p = theta.batch_shape[0], priors.P
+    like = kernel.loc
+    eps = _to_device(draws.normal((b, p)), like) if draws is not None else torch.randn((b, p), device=like.device, dtype=like.dtype)
+    rvs, prior_star = ops.theta_propose(priors, kernel.loc, kernel.scale_tril, eps, [proposal_theta[n] for n in proposal_theta.names()])
+    proposal_theta.adopt_proposal(rvs, prior_star)
+    proposal_filter.initialize_model(proposal_theta)  # (rebuilt from theta*: see run_pmmh)
+    new_res = proposal_filter.batch_filter(y, bar=False)
+    new_kernel = proposal.build(proposal_theta, state.replicate(new_res), proposal_filter, y)
+    log_acc, accepted, rate = ops.theta_accept(
+        theta.stack_parameters(constrained=False), rvs, (kernel.loc, kernel.scale_tril), (new_kernel.loc, new_kernel.scale_tril),
+        theta.eval_priors(constrained=False), prior_star, state.filter_state.loglikelihood, new_res.loglikelihood,
+        _uniforms(prior_star, None, draws))
+    if stats is not None:
+        stats["rate"] = rate
+    if trace is not None:
+        trace.append(dict(kind="pmmh", rvs=rvs, proposed_ll=new_res.loglikelihood.clone(), log_acc=log_acc, accepted=accepted,
+                          new_kernel=new_kernel))
+    state.filter_state.exchange(new_res, accepted)
+    theta.exchange(proposal_theta, accepted)
+    return accepted
+
+
 def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_filter, proposal_theta, y: torch.Tensor,
-             size=torch.Size([]), mutate_kernel: bool = False, generator=None, trace=None) -> torch.Tensor:
+             size=torch.Size([]), mutate_kernel: bool = False, generator=None, trace=None, stats=None) -> torch.Tensor:
     """One PMMH iteration (``mcmc/utils.py:14-77``).  ``theta`` / ``state``: the chains' parameters and algorithm state
     (``state.filter_state`` a ``FilterResult``); ``proposal_filter`` reads ``proposal_theta``.  Returns the ``(B,)``
     boolean mask of accepted proposals; ``state`` and ``theta`` are updated in place.  ``trace``: an optional list that
     receives the move's intermediate quantities (references, no copies, no synchronisation) - diagnostics, and what the
-    parity tests compare with the reference's own values."""
+    parity tests compare with the reference's own values.  ``stats``: an optional dict; the native route leaves the
+    move's acceptance rate (a device scalar) under ``"rate"``."""
     shard = getattr(theta, "shard", None)
     draws = as_draws(generator)
+    if (isinstance(proposal_kernel, GaussianKernel) and isinstance(proposal, SymmetricMH) and not mutate_kernel and
+            theta.native_priors() is not None and proposal_theta.native_priors() is not None):
+        return _run_pmmh_native(theta, state, proposal, proposal_kernel, proposal_filter, proposal_theta, y, draws, trace, stats)
     rvs = _draw(proposal_kernel, size, shard, draws)
     proposal_theta.unstack_parameters(rvs, constrained=False)
     # the model is REBUILT from theta* (mcmc/utils.py:52-53): whatever the builder derives from the parameters - e.g. the

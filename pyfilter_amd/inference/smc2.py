@@ -198,10 +198,14 @@ class ParticleMetropolisHastings:
 
         previous_distance, acceptance_rate = 0.0, 0.0
         for i in range(self._n_steps):
+            stats = {}
             accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, data,
-                                shape, mutate_kernel=False, generator=draws, trace=self.trace)
-            rate = accepted.float().sum()
-            rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
+                                shape, mutate_kernel=False, generator=draws, trace=self.trace, stats=stats)
+            if "rate" in stats:  # (the native theta route: the acceptance kernel counted - one GPU by construction)
+                rate = stats["rate"]
+            else:
+                rate = accepted.float().sum()
+                rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
             mark("move issued")
             acceptance_rate = (float(rate) + i * acceptance_rate) / (i + 1)  # the kernel's one host decision per move
             mark("move done on the device")

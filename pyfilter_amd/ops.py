@@ -351,6 +351,55 @@ def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def theta_fit(values: torch.Tensor, log_w, scale: float = 1.0):
+    """``values (B, P)``, ``log_w (B,)`` or ``None`` (equal weights) -> ``(mean (P,), scale * chol (P, P))`` of the weighted
+    Gaussian fit (pf_theta_fit; ``inference/utils.py:42-76``).  One launch."""
+    L.require_gpu(values)
+    values = values.contiguous()
+    b, p = values.shape
+    out = torch.empty(p + p * p, dtype=values.dtype, device=values.device)
+    if log_w is not None:
+        log_w = log_w.contiguous()
+        assert log_w.shape == (b,) and log_w.dtype == values.dtype and log_w.device == values.device
+    L.check(L.load().pf_theta_fit(values.data_ptr(), None if log_w is None else log_w.data_ptr(), b, p, float(scale),
+                                  L.dtype_code(values.dtype), out.data_ptr(), out[p:].data_ptr(), L.stream_ptr()), "pf_theta_fit")
+    return out[:p], out[p:].view(p, p)
+
+
+def theta_propose(priors, mean: torch.Tensor, chol: torch.Tensor, eps: torch.Tensor, x_out):
+    """theta* = mean + chol eps -> ``(u* (B, P), log prior of u* (B,))``; the constrained values are written into the ``P``
+    tensors ``x_out`` (pf_theta_propose; ``mcmc/utils.py:48-50``, ``prior.py:98-123``).  ``priors``: a ``PfThetaPriors``."""
+    L.require_gpu(eps, mean, chol)
+    eps = eps.contiguous()
+    b, p = eps.shape
+    assert p == priors.P == len(x_out) and mean.is_contiguous() and chol.is_contiguous() and mean.dtype == chol.dtype == eps.dtype
+    for x in x_out:
+        assert x.is_contiguous() and x.numel() == b and x.dtype == eps.dtype and x.device == eps.device
+    ptrs = (C.c_void_p * p)(*[x.data_ptr() for x in x_out])
+    u = torch.empty_like(eps)
+    lp = torch.empty(b, dtype=eps.dtype, device=eps.device)
+    L.check(L.load().pf_theta_propose(C.byref(priors), mean.data_ptr(), chol.data_ptr(), eps.data_ptr(), b, L.dtype_code(eps.dtype),
+                                      u.data_ptr(), ptrs, lp.data_ptr(), L.stream_ptr()), "pf_theta_propose")
+    return u, lp
+
+
+def theta_accept(u_cur, u_star, fwd, rev, prior_cur, prior_star, ll_cur, ll_star, unif):
+    """The acceptance step of one PMMH move (pf_theta_accept; ``mcmc/utils.py:57-70``): ``fwd`` / ``rev`` = ``(mean, chol)`` of
+    the forward / reverse Gaussian kernels.  Returns ``(log_acc (B,), accepted (B,) bool, rate ())``."""
+    L.require_gpu(u_cur, u_star, unif)
+    b, p = u_cur.shape
+    dt = u_cur.dtype
+    args = [u_cur, u_star, fwd[0], fwd[1], rev[0], rev[1], prior_cur, prior_star, ll_cur, ll_star, unif]
+    args = [a.contiguous() for a in args]
+    assert all(a.dtype == dt and a.device == u_cur.device for a in args), "theta_accept: one dtype / device"
+    assert all(a.numel() == b for a in args[6:]) and u_star.shape == (b, p)
+    log_acc = torch.empty(b + 1, dtype=dt, device=u_cur.device)
+    accepted = torch.empty(b, dtype=torch.bool, device=u_cur.device)
+    L.check(L.load().pf_theta_accept(*[a.data_ptr() for a in args], b, p, L.dtype_code(dt), log_acc.data_ptr(), accepted.data_ptr(),
+                                     log_acc[b:].data_ptr(), L.stream_ptr()), "pf_theta_accept")
+    return log_acc[:b], accepted, log_acc[b]
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # smoothing over a recorded state history
 # ----------------------------------------------------------------------------------------------------------------

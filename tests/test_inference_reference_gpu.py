@@ -14,6 +14,18 @@ from tests.test_inference_reference_cpu import SMC2_CASES, replay_pmmh, replay_s
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["theta_kernels", "theta_torch"], autouse=True)
+def theta_route(request):
+    """Every replay runs on both theta routes: the move's theta arithmetic in ``pf_theta_fit / _propose / _accept``
+    (``csrc/pf_theta.hpp`` - taken for the scalar Exponential / Normal / LogNormal priors of these cases) and in
+    ``torch.distributions``."""
+    from pyfilter_amd.hints import HINTS
+
+    HINTS.theta_kernels = request.param == "theta_kernels"
+    yield request.param
+    HINTS.theta_kernels = True
+
+
 def _hip_filter(cursor, n):
     from pyfilter_amd import timeseries as ts
     from pyfilter_amd.filters.particle import APF, proposals

@@ -1,0 +1,181 @@
+"""The theta-level kernels of an SMC^2 / PMMH move (``pyfilter_amd/csrc/pf_theta.hpp``: ``pf_theta_fit / _propose / _accept``)
+against the ``torch.distributions`` arithmetic they replace - the product's own general route (``inference/utils.py``,
+``parameters.py``, ``pmmh.py::run_pmmh``), which restates ``pyfilter/inference/utils.py:42-76`` (``construct_mvn``),
+``prior.py:47-123`` (the priors' bijections) and ``batch/mcmc/utils.py:48-70`` (the acceptance step) and is itself pinned to
+the reference's event logs (``tests/test_inference_reference_*.py`` - which run on BOTH routes, see ``theta_route`` there).
+
+float64: 1e-11 relative (the kernels and torch evaluate the same formulas in double, in a different order); float32
+tensors: the kernels still compute in double, so they sit within float32 rounding of the float64 answer."""
+import math
+
+import pytest
+import torch
+from torch.distributions import Beta, Exponential, Gamma, HalfNormal, LogNormal, MultivariateNormal, Normal, Uniform
+
+from pyfilter_amd import ops
+from pyfilter_amd.hints import HINTS
+from pyfilter_amd.inference import ThetaParticles
+from pyfilter_amd.inference.utils import construct_mvn, theta_normalize
+
+pytestmark = pytest.mark.gpu
+
+PRIORS = {"a": Normal(0.3, 1.7), "b": LogNormal(-2.0, 0.8), "c": Exponential(4.0), "d": Gamma(2.5, 3.0), "e": HalfNormal(0.7),
+          "f": Beta(2.0, 5.0), "g": Uniform(-0.4, 1.3)}
+
+
+def _tol(dtype):
+    return dict(rtol=1e-11, atol=1e-12) if dtype == torch.float64 else dict(rtol=3e-6, atol=3e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("b,p", [(1000, 3), (77, 1), (4096, 8)])
+def test_theta_fit_is_construct_mvn(dtype, b, p):
+    g = torch.Generator().manual_seed(b + p)
+    mix = torch.randn(p, p, generator=g, dtype=torch.float64)
+    x = (torch.randn(b, p, generator=g, dtype=torch.float64) @ mix + torch.randn(p, generator=g, dtype=torch.float64)).to(dtype).cuda()
+    lw = (3.0 * torch.randn(b, generator=g, dtype=torch.float64)).to(dtype).cuda()
+    lw[5], lw[11], lw[17] = float("nan"), -math.inf, math.inf  # (normalize: NaN and +inf carry no weight)
+    for weights in (lw, torch.zeros_like(lw), None):
+        mean, chol = ops.theta_fit(x, weights, 1.1)
+        # (the reference weights from the host: torch's float64 softmax over more than 1 024 entries on the device is only good
+        # to ~1e-6 relative on this stack - measured 1.7e-6 on the mean at B = 4 096 - the kernel agrees with the host to 1e-14)
+        w = theta_normalize(lw.double().cpu() if weights is lw else torch.zeros(b, dtype=torch.float64)).cuda()
+        want = construct_mvn(x.double(), w, 1.1)
+        torch.testing.assert_close(mean.double(), want.loc, **_tol(dtype))
+        torch.testing.assert_close(chol.double(), want.scale_tril, **_tol(dtype))
+        assert torch.equal(chol, chol.tril())
+
+
+def test_theta_fit_of_a_degenerate_cloud_keeps_the_diagonal():
+    """A covariance that is not positive definite -> its diagonal's square root (inference/utils.py:50-55)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(500, 3, generator=g, dtype=torch.float64).cuda()
+    x[:, 2] = 0.0  # a parameter every theta-particle agrees on (zero: its row of the covariance is exactly 0 in any order)
+    mean, chol = ops.theta_fit(x, None, 1.0)
+    want = construct_mvn(x, torch.full((500,), 1 / 500, dtype=torch.float64, device="cuda"), 1.0)
+    torch.testing.assert_close(chol, want.scale_tril, rtol=1e-11, atol=1e-12)
+    assert float(chol[2, 2]) == 0.0 and float(chol[1, 0]) == 0.0 and float(mean[2]) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_theta_propose_is_the_priors_bijections_and_densities(dtype):
+    b = 777
+    theta = ThetaParticles(PRIORS, b, "cuda", dtype).initialize_parameters(torch.Generator().manual_seed(1))
+    packed = theta.native_priors()
+    assert packed is not None and packed.P == 7 and list(packed.kind)[:7] == [0, 1, 2, 3, 4, 5, 6]
+    p = packed.P
+    g = torch.Generator().manual_seed(2)
+    mean = torch.randn(p, generator=g, dtype=torch.float64).mul(0.5).to(dtype).cuda()
+    chol = (torch.randn(p, p, generator=g, dtype=torch.float64).tril() * 0.6).to(dtype).cuda().contiguous()
+    eps = torch.randn(b, p, generator=g, dtype=torch.float64).to(dtype).cuda()
+    eps[0] = 12.0   # far tails: sigmoid / exp saturate the way torch's transforms do
+    eps[1] = -12.0
+    u, lp = ops.theta_propose(packed, mean, chol, eps, [theta[n] for n in theta.names()])
+    want_u = mean.double() + (chol.double() @ eps.double().unsqueeze(-1)).squeeze(-1)
+    torch.testing.assert_close(u.double(), want_u, **_tol(dtype))
+    # the constrained values and the log prior of the u the kernel stored (what every later evaluation starts from)
+    ref = ThetaParticles(PRIORS, b, "cuda", torch.float64).initialize_parameters(torch.Generator().manual_seed(1))
+    total = 0.0
+    for i, (name, prior) in enumerate(ref.priors.items()):
+        ui = u[:, i].double()
+        torch.testing.assert_close(theta[name].double(), prior.get_constrained(ui), **_tol(dtype))
+        total = total + prior.unconstrained.log_prob(ui)
+    ok = torch.isfinite(total)
+    assert ok.sum() >= b - 2
+    tol = _tol(dtype) if dtype == torch.float64 else dict(rtol=2e-6, atol=2e-5)
+    torch.testing.assert_close(lp.double()[ok], total[ok], **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_theta_accept_is_the_metropolis_hastings_ratio(dtype):
+    b, p = 1500, 4
+    g = torch.Generator().manual_seed(9)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    fwd = (r(p).to(dtype).cuda(), (r(p, p).tril() * 0.3 + torch.eye(p, dtype=torch.float64)).to(dtype).cuda())
+    rev = (r(p).to(dtype).cuda(), (r(p, p).tril() * 0.3 + torch.eye(p, dtype=torch.float64)).to(dtype).cuda())
+    u_cur, u_star = r(b, p).to(dtype).cuda(), r(b, p).to(dtype).cuda()
+    pr_cur, pr_star, ll_cur, ll_star = (r(b).to(dtype).cuda() for _ in range(4))
+    ll_star[3] = float("nan")   # a failed re-filter: rejected
+    ll_star[4] = -math.inf
+    unif = torch.rand(b, generator=g, dtype=torch.float64).to(dtype).cuda()
+    log_acc, accepted, rate = ops.theta_accept(u_cur, u_star, fwd, rev, pr_cur, pr_star, ll_cur, ll_star, unif)
+    q = lambda k: MultivariateNormal(k[0].double(), scale_tril=k[1].double(), validate_args=False)  # noqa: E731
+    want = (q(rev).log_prob(u_cur.double()) - q(fwd).log_prob(u_star.double())) + (pr_star.double() - pr_cur.double()) + (
+        ll_star.double() - ll_cur.double())
+    tol = _tol(dtype) if dtype == torch.float64 else dict(rtol=2e-6, atol=2e-5)
+    torch.testing.assert_close(log_acc.double(), want, equal_nan=True, **tol)
+    assert accepted.dtype == torch.bool and torch.equal(accepted, unif.log() < log_acc)  # on the kernel's own log_acc
+    assert not bool(accepted[3]) and not bool(accepted[4])
+    assert abs(float(rate) - float(accepted.double().mean())) < 1e-6
+
+
+def _smc2_run(dtype, native):
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    HINTS.theta_kernels = native
+    try:
+        def build(theta):
+            t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+            return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (t(1.0), t(0.05)))
+
+        g = torch.Generator().manual_seed(5)
+        x, ys = 0.0, []
+        for _ in range(120):
+            x = x * math.exp(-0.05) + 0.15 * math.sqrt((1 - math.exp(-0.1)) / 0.1) * float(torch.randn((), generator=g))
+            ys.append(x + 0.05 * float(torch.randn((), generator=g)))
+        y = torch.tensor(ys, dtype=dtype, device="cuda")
+        pri = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+        filt = APF(build, 200, proposal=proposals.LinearGaussianObservations(), seed=11)
+        alg = SMC2(filt, 256, pri, threshold=0.5, device="cuda", dtype=dtype, seed=3)
+        alg._kernel.trace = []
+        state = alg.fit(y)
+        moves = [t for t in alg._kernel.trace if t["kind"] == "pmmh"]
+        fits = [t for t in alg._kernel.trace if t["kind"] == "rejuvenate"]
+        return alg, state, moves, fits
+    finally:
+        HINTS.theta_kernels = True
+
+
+def test_a_fit_on_the_theta_kernels_is_the_fit_on_torch():
+    """One SMC^2 run (float64, same seeds) on both theta routes: the same rejuvenations at the same observations, the same
+    proposals, acceptance probabilities and accepted theta-particles, the same posterior."""
+    from pyfilter_amd.inference.pmmh import GaussianKernel
+
+    a1, s1, m1, f1 = _smc2_run(torch.float64, True)
+    a0, s0, m0, f0 = _smc2_run(torch.float64, False)
+    assert len(m1) == len(m0) >= 2 and len(f1) == len(f0)
+    assert all(isinstance(f["kernel"], GaussianKernel) for f in f1) and not any(isinstance(f["kernel"], GaussianKernel) for f in f0)
+    for k, (x, y) in enumerate(zip(f1, f0)):
+        assert torch.equal(x["indices"], y["indices"])
+        torch.testing.assert_close(x["kernel"].loc, y["kernel"].loc, rtol=1e-9, atol=1e-11)
+        torch.testing.assert_close(x["kernel"].scale_tril, y["kernel"].scale_tril, rtol=1e-9, atol=1e-11)
+    for k, (x, y) in enumerate(zip(m1, m0)):
+        torch.testing.assert_close(x["rvs"], y["rvs"], rtol=1e-9, atol=1e-11)
+        torch.testing.assert_close(x["proposed_ll"], y["proposed_ll"], rtol=1e-8, atol=1e-8, equal_nan=True)
+        torch.testing.assert_close(x["log_acc"], y["log_acc"], rtol=1e-7, atol=1e-7, equal_nan=True)
+        assert torch.equal(x["accepted"], y["accepted"]), f"move {k}"
+    torch.testing.assert_close(a1.posterior_mean(s1), a0.posterior_mean(s0), rtol=1e-8, atol=1e-10)
+    assert a1._kernel.acceptance_history == pytest.approx(a0._kernel.acceptance_history, abs=1e-12)
+
+
+def test_a_float32_fit_takes_the_theta_kernels_and_finds_the_posterior():
+    alg, state, moves, fits = _smc2_run(torch.float32, True)
+    from pyfilter_amd.inference.pmmh import GaussianKernel
+
+    assert len(moves) >= 2 and all(isinstance(f["kernel"], GaussianKernel) for f in fits)
+    post = alg.posterior_mean(state)
+    assert torch.isfinite(post).all() and 0.0 < float(post[0]) < 0.5 and 0.0 < float(post[2]) < 0.5
+
+
+def test_priors_outside_the_kernels_families_take_the_torch_route():
+    from torch.distributions import Independent, StudentT
+
+    theta = ThetaParticles({"a": Normal(0.0, 1.0), "b": StudentT(3.0)}, 16, "cuda", torch.float64).initialize_parameters()
+    assert theta.native_priors() is None
+    theta = ThetaParticles({"a": Independent(Normal(torch.zeros(2), torch.ones(2)), 1)}, 16, "cuda", torch.float64).initialize_parameters()
+    assert theta.native_priors() is None  # (an event-shaped prior)
+    assert ThetaParticles({"a": Normal(0.0, 1.0)}, 16, "cuda", torch.float64).native_priors() is None  # (no values yet)
+    assert ThetaParticles({"a": Normal(0.0, 1.0)}, 16, "cuda", torch.float64).initialize_parameters().native_priors() is not None
