@@ -141,26 +141,34 @@ def _uniforms(like: torch.Tensor, shard, draws):
     return _to_device(u, like)
 
 
-def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_filter, proposal_theta, y, draws, trace, stats):
+def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_filter, proposal_theta, y, draws, trace, stats,
+                     overlap=None):
     """``run_pmmh`` for a Gaussian kernel shared by all theta-particles and scalar priors of the standard families: the
     same move with its theta arithmetic in three launches (``csrc/pf_theta.hpp``) - theta* with its constrained values and
     log prior, the reverse kernel's fit, the acceptance step - instead of ~130 small torch launches the re-filter waits
     behind."""
     from .. import ops
 
+    mark = (stats or {}).get("mark") or (lambda label: None)
     priors = theta.native_priors()
     b, p = theta.batch_shape[0], priors.P
     like = kernel.loc
     eps = _to_device(draws.normal((b, p)), like) if draws is not None else torch.randn((b, p), device=like.device, dtype=like.dtype)
     rvs, prior_star = ops.theta_propose(priors, kernel.loc, kernel.scale_tril, eps, [proposal_theta[n] for n in proposal_theta.names()])
     proposal_theta.adopt_proposal(rvs, prior_star)
+    mark("  theta* proposed")
     proposal_filter.initialize_model(proposal_theta)  # (rebuilt from theta*: see run_pmmh)
+    mark("  model rebuilt")
     new_res = proposal_filter.batch_filter(y, bar=False)
+    mark("  re-filter issued")
+    if overlap is not None:
+        overlap()
     new_kernel = proposal.build(proposal_theta, state.replicate(new_res), proposal_filter, y)
     log_acc, accepted, rate = ops.theta_accept(
         theta.stack_parameters(constrained=False), rvs, (kernel.loc, kernel.scale_tril), (new_kernel.loc, new_kernel.scale_tril),
         theta.eval_priors(constrained=False), prior_star, state.filter_state.loglikelihood, new_res.loglikelihood,
         _uniforms(prior_star, None, draws))
+    mark("  acceptance issued")
     if stats is not None:
         stats["rate"] = rate
     if trace is not None:
@@ -168,28 +176,34 @@ def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_
                           new_kernel=new_kernel))
     state.filter_state.exchange(new_res, accepted)
     theta.exchange(proposal_theta, accepted)
+    mark("  accepted filters swapped in")
     return accepted
 
 
 def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_filter, proposal_theta, y: torch.Tensor,
-             size=torch.Size([]), mutate_kernel: bool = False, generator=None, trace=None, stats=None) -> torch.Tensor:
+             size=torch.Size([]), mutate_kernel: bool = False, generator=None, trace=None, stats=None, overlap=None) -> torch.Tensor:
     """One PMMH iteration (``mcmc/utils.py:14-77``).  ``theta`` / ``state``: the chains' parameters and algorithm state
     (``state.filter_state`` a ``FilterResult``); ``proposal_filter`` reads ``proposal_theta``.  Returns the ``(B,)``
     boolean mask of accepted proposals; ``state`` and ``theta`` are updated in place.  ``trace``: an optional list that
     receives the move's intermediate quantities (references, no copies, no synchronisation) - diagnostics, and what the
     parity tests compare with the reference's own values.  ``stats``: an optional dict; the native route leaves the
-    move's acceptance rate (a device scalar) under ``"rate"``."""
+    move's acceptance rate (a device scalar) under ``"rate"``.  ``overlap``: called once the re-filter has been issued -
+    host work of the caller that the move's outcome does not depend on until the filters are compared (SMC^2 moves the
+    resampled filters' states there: the device is busy with the re-filter meanwhile)."""
     shard = getattr(theta, "shard", None)
     draws = as_draws(generator)
     if (isinstance(proposal_kernel, GaussianKernel) and isinstance(proposal, SymmetricMH) and not mutate_kernel and
             theta.native_priors() is not None and proposal_theta.native_priors() is not None):
-        return _run_pmmh_native(theta, state, proposal, proposal_kernel, proposal_filter, proposal_theta, y, draws, trace, stats)
+        return _run_pmmh_native(theta, state, proposal, proposal_kernel, proposal_filter, proposal_theta, y, draws, trace, stats,
+                                overlap)
     rvs = _draw(proposal_kernel, size, shard, draws)
     proposal_theta.unstack_parameters(rvs, constrained=False)
     # the model is REBUILT from theta* (mcmc/utils.py:52-53): whatever the builder derives from the parameters - e.g. the
     # stationary initial distribution of an Ornstein-Uhlenbeck process - belongs to the proposed values, not the old ones
     proposal_filter.initialize_model(proposal_theta)
     new_res = proposal_filter.batch_filter(y, bar=False)
+    if overlap is not None:
+        overlap()
 
     diff_logl = new_res.loglikelihood - state.filter_state.loglikelihood
     diff_prior = proposal_theta.eval_priors(constrained=False) - theta.eval_priors(constrained=False)

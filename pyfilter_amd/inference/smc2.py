@@ -151,6 +151,8 @@ def _take_filters(result: FilterResult, shard: Optional[Shard], mine: torch.Tens
 class ParticleMetropolisHastings:
     """The rejuvenation kernel (``kernels/mh.py:15-140``)."""
 
+    OVERLAP_FILTER_MOVE = True  # (development switch: False moves the resampled filters before the first move, like the reference)
+
     def __init__(self, num_steps: int = 1, proposal=None, distance_threshold: Optional[float] = None,
                  acceptance_threshold: float = 0.2, max_increases: int = 5, resampler: Callable = theta_systematic):
         self._n_steps = num_steps
@@ -186,8 +188,18 @@ class ParticleMetropolisHastings:
         # one exchange plan for the parameters and the filters' states (every rank holds ALL ancestors: no all-gather)
         route = shard.route(mine, full_index=indices) if sharded else None
         theta.resample(mine, route)
-        _take_filters(state.filter_state, shard, mine, route)
-        mark("filters moved")
+        # the surviving filters' states are not read before the first move compares log-likelihoods: they move while the
+        # device runs that move's re-filter (``run_pmmh(overlap=...)``) - 0.4 ms of host work off the serial path
+        unmoved = [True]
+
+        def move_filters():
+            if unmoved[0]:
+                unmoved[0] = False
+                _take_filters(state.filter_state, shard, mine, route)
+                mark("filters moved")
+
+        if not self.OVERLAP_FILTER_MOVE:
+            move_filters()
         shape = torch.Size([]) if any(dist.batch_shape) else filter_.batch_shape
 
         old = theta.stack_parameters(constrained=False)
@@ -198,9 +210,9 @@ class ParticleMetropolisHastings:
 
         previous_distance, acceptance_rate = 0.0, 0.0
         for i in range(self._n_steps):
-            stats = {}
+            stats = {"mark": mark} if self.timeline is not None else {}
             accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, data,
-                                shape, mutate_kernel=False, generator=draws, trace=self.trace, stats=stats)
+                                shape, mutate_kernel=False, generator=draws, trace=self.trace, stats=stats, overlap=move_filters)
             if "rate" in stats:  # (the native theta route: the acceptance kernel counted - one GPU by construction)
                 rate = stats["rate"]
             else:
@@ -223,6 +235,7 @@ class ParticleMetropolisHastings:
                 break
             previous_distance = distance
 
+        move_filters()  # (num_steps = 0: a pure resampling)
         filter_.initialize_model(theta)
         state.w.fill_(0.0)
         mark("end")

@@ -44,6 +44,10 @@ def main():
     def build(theta):
         return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (obs_a, obs_s))
 
+    if os.environ.get("SMC2_NO_OVERLAP"):
+        from pyfilter_amd.inference.smc2 import ParticleMetropolisHastings
+
+        ParticleMetropolisHastings.OVERLAP_FILTER_MOVE = False
     for route in ("column", "per_step"):
         from pyfilter_amd.hints import HINTS
 
