@@ -165,6 +165,13 @@ int pf_sample_and_weight(const pf_model* model, int proposal, int weigh, const v
 int pf_initial_sample(const double* m0, const double* s0, const void* z, uint64_t seed, void* x, int64_t N,
                       int64_t B, int64_t D, int dtype, void* stream);
 
+/* ... with one initial mean / scale per filter (theta-particles on the batch dimension: the stationary law of an
+ * Ornstein-Uhlenbeck process depends on theta): element (b, d) of m0 / s0 at [b * stride_b + d * stride_d], strides in
+ * elements, 0 = broadcast; device arrays of `dtype`.  x <- m0 + s0 * z. */
+int pf_initial_sample_cols(const void* m0, int64_t m0_stride_b, int64_t m0_stride_d, const void* s0, int64_t s0_stride_b,
+                           int64_t s0_stride_d, const void* z, uint64_t seed, void* x, int64_t N, int64_t B, int64_t D,
+                           int dtype, void* stream);
+
 /* "Observation k carries information": out[k] = 1 unless every element of y[k] ((steps, row_elems), row_elems =
  * y_rows * O) is NaN - the reference's host test `y.isnan().all()` that turns a move into propagate-only
  * (filters/base.py:212), for all steps of a series in one launch.  `out`: device bytes (steps). */
@@ -213,6 +220,15 @@ int pf_theta_propose(const pf_theta_priors* priors, const void* mean, const void
 int pf_theta_accept(const void* u_cur, const void* u_star, const void* mean_f, const void* chol_f, const void* mean_r,
                     const void* chol_r, const void* prior_cur, const void* prior_star, const void* ll_cur, const void* ll_star,
                     const void* unif, int64_t B, int32_t P, int dtype, void* log_acc, uint8_t* accepted, void* rate, void* stream);
+
+/* The theta-weights along a block of n observations (sequential/state.py:35-44, n times): w_path (n, B) <- w0 (B) + the
+ * running sum of the log-likelihood increments ll (n, B); stats (n, 2) <- (ESS, 1 if every weight is finite) per row, as
+ * pf_theta_ess reports them. */
+int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats, void* stream);
+
+/* Systematic resampling of B theta-particles from their log-weights (kernels/mh.py:52-56: pyfilter.utils.normalize, then
+ * resampling.py:24-52 with the uniform u in [0, 1]): ancestors (B, int64).  cdf_scratch: B values of `dtype`. */
+int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t* ancestors, void* cdf_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------ *
  * fused filter loop: BaseFilter.batch_filter / filter (filters/base.py:140-221) for SISR (sisr.py:14-56) and

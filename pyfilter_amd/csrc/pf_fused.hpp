@@ -1670,11 +1670,7 @@ __global__ __launch_bounds__(PF_WAVE) void k_observed_flags(const T* __restrict_
 // finite.  One workgroup per row of B weights (B = the number of theta-particles, 10^2 .. 10^5; rows = the observations of
 // a speculative block).  out[r][0] = ESS, out[r][1] = 1 if all finite.
 template <typename T>
-__global__ __launch_bounds__(PF_BLOCK) void k_theta_ess(const T* __restrict__ w, int64_t B, T* __restrict__ out) {
-    __shared__ T redm[PF_NWAVES];
-    __shared__ double red[3 * PF_NWAVES];
-    w += (int64_t)blockIdx.x * B;
-    out += 2 * (int64_t)blockIdx.x;
+__device__ __forceinline__ void theta_ess_row(const T* w, int64_t B, T* out, T* redm, double* red) {
     T m = -Lim<T>::inf();
     bool finite = true;
     for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
@@ -1698,6 +1694,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_ess(const T* __restrict__ w,
         out[0] = (T)(acc[1] > 0.0 ? acc[0] * acc[0] / acc[1] : (double)B);
         out[1] = acc[2] == 0.0 ? T(1) : T(0);
     }
+}
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_ess(const T* __restrict__ w, int64_t B, T* __restrict__ out) {
+    __shared__ T redm[PF_NWAVES];
+    __shared__ double red[3 * PF_NWAVES];
+    theta_ess_row<T>(w + (int64_t)blockIdx.x * B, B, out + 2 * (int64_t)blockIdx.x, redm, red);
 }
 
 }  // namespace pf

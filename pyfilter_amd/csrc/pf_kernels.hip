@@ -947,6 +947,32 @@ __global__ __launch_bounds__(PF_BLOCK) void k_initial_sample(double m0a, double 
     }
 }
 
+// ... with one initial mean / scale per filter: element (b, d) at m0[b * mb + d * md] (strides in elements, 0 = broadcast)
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_initial_sample_cols(const T* __restrict__ m0, int64_t mb, int64_t md, const T* __restrict__ s0,
+                                                                  int64_t sb, int64_t sd, const T* __restrict__ z, uint64_t seed,
+                                                                  T* __restrict__ x, int64_t N, int B, int D) {
+    const int b = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < N; i += (int64_t)gridDim.x * PF_BLOCK) {
+        T zv[4] = {T(0), T(0), T(0), T(0)};
+        if (!z) NormalDraw<T, 4>::draw(seed, PF_STREAM_INIT, 0u, (uint64_t)((int64_t)b * N + i), zv);
+#pragma unroll
+        for (int d = 0; d < PF_MAXD; ++d) {
+            if (d < D) {
+                const int64_t o = ((int64_t)d * B + b) * N + i;
+                const T zz = z ? z[o] : zv[d];
+                // (two roundings - product, then sum; not contracted into an fma - the torch expression `m + s * z` this
+                // replaces, to the last bit)
+                {
+#pragma clang fp contract(off)
+                    const T sz = s0[b * sb + d * sd] * zz;
+                    x[o] = m0[b * mb + d * md] + sz;
+                }
+            }
+        }
+    }
+}
+
 // Test support (pf_debug_draw_normals): the standard normals the fused step kernel draws for steps step0 .. - the same
 // draw_normals<T, D, VEC> call, addressed as the step kernel addresses it (thread = VEC consecutive particles).
 template <typename T, int D, int VEC>
@@ -1431,6 +1457,25 @@ extern "C" int pf_initial_sample(const double* m0, const double* s0, const void*
 }
 
 
+extern "C" int pf_initial_sample_cols(const void* m0, int64_t m0_stride_b, int64_t m0_stride_d, const void* s0, int64_t s0_stride_b,
+                                      int64_t s0_stride_d, const void* z, uint64_t seed, void* x, int64_t N, int64_t B, int64_t D,
+                                      int dtype, void* stream) {
+    if (!m0 || !s0 || !x || bad_shape(N, B) || D < 1 || D > PF_MAXD || m0_stride_b < 0 || m0_stride_d < 0 || s0_stride_b < 0 ||
+        s0_stride_d < 0)
+        return PF_EINVAL;
+    const dim3 grid(ew_blocks(N), (int)B);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_initial_sample_cols<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)m0, m0_stride_b, m0_stride_d,
+                           (const float*)s0, s0_stride_b, s0_stride_d, (const float*)z, seed, (float*)x, N, (int)B, (int)D);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_initial_sample_cols<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)m0, m0_stride_b, m0_stride_d,
+                           (const double*)s0, s0_stride_b, s0_stride_d, (const double*)z, seed, (double*)x, N, (int)B, (int)D);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
 extern "C" int pf_observed_flags(const void* y, int64_t steps, int64_t row_elems, int dtype, uint8_t* out, void* stream) {
     if (!y || !out || steps < 0 || row_elems < 1 || steps > 0x7fffffff) return PF_EINVAL;
     if (steps == 0) return PF_OK;
@@ -1500,6 +1545,35 @@ extern "C" int pf_theta_accept(const void* u_cur, const void* u_star, const void
                        (const T*)ll_cur, (const T*)ll_star, (const T*)unif, B, (int)P, (T*)log_acc, accepted, (T*)rate);
     if (dtype == PF_F32) { CALL(float) } else if (dtype == PF_F64) { CALL(double) } else return PF_EINVAL;
 #undef CALL
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats,
+                             void* stream) {
+    if (!w0 || !ll || !w_path || !stats || B < 1 || n < 0 || n > 65535) return PF_EINVAL;
+    if (n == 0) return PF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_theta_path<float>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const float*)w0, (const float*)ll, B,
+                           (float*)w_path, (float*)stats);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_theta_path<double>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const double*)w0, (const double*)ll, B,
+                           (double*)w_path, (double*)stats);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t* ancestors, void* cdf_scratch,
+                                 void* stream) {
+    if (!logw || !ancestors || !cdf_scratch || B < 1 || !(u >= 0.0 && u <= 1.0)) return PF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_theta_resample<float>), dim3(1), dim3(PF_BLOCK), 0, st, (const float*)logw, B, u, ancestors, (float*)cdf_scratch);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_theta_resample<double>), dim3(1), dim3(PF_BLOCK), 0, st, (const double*)logw, B, u, ancestors, (double*)cdf_scratch);
+    else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;
 }

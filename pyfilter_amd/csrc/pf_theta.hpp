@@ -242,4 +242,77 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_accept(const T* __restrict__
     if (threadIdx.x == 0) rate[0] = (T)(cnt[0] / (double)B);
 }
 
+// The theta-weights along a block of n observations and their statistics in one launch (sequential/state.py:35-44 applied
+// n times): w_path[r] = w0 + (ll[0] + .. + ll[r]) - the running sum accumulated in the tensors' type, observation by
+// observation, as `w0 + ll.cumsum(0)` does - and stats[r] = (ESS, every weight finite) of row r (k_theta_ess).  One
+// workgroup per row; row r re-adds its r + 1 increments (n <= a few dozen).
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* __restrict__ w0, const T* __restrict__ ll, int64_t B,
+                                                         T* __restrict__ w_path, T* __restrict__ stats) {
+    __shared__ T redm[PF_NWAVES];
+    __shared__ double red[3 * PF_NWAVES];
+    const int r = blockIdx.x;
+    T* row = w_path + (int64_t)r * B;
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        T c = ll[i];
+        for (int k0 = 1; k0 <= r; k0 += 8) {  // (eight independent loads in flight, then the additions in order)
+            T v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (k0 + j <= r) ? ll[(int64_t)(k0 + j) * B + i] : T(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k0 + j <= r) c = c + v[j];
+        }
+        row[i] = w0[i] + c;
+    }
+    // (every thread reads back the entries it wrote itself)
+    theta_ess_row<T>(row, B, stats + 2 * (int64_t)r, redm, red);
+}
+
+// Systematic resampling of the B theta-particles from their log-weights in one launch (kernels/mh.py:52-56 ->
+// pyfilter.utils.normalize, resampling.py:24-52): W = softmax of the sanitised weights (NaN / +inf carry none; nothing
+// finite: equal weights), cdf = its running sum - accumulated in double, rounded once to the tensors' type, last entry 1 -,
+// ancestor of position i = the first j with cdf[j] >= (i + u) / B, at most B - 1.  One workgroup; `cdf` is B scratch values.
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_resample(const T* __restrict__ logw, int64_t B, double u, int64_t* __restrict__ idx,
+                                                             T* __restrict__ cdf) {
+    __shared__ double redm[PF_NWAVES];
+    __shared__ double red[PF_NWAVES];
+    auto clean = [](T v) -> double { return is_nan_or_posinf(v) ? -__builtin_huge_val() : (double)v; };
+    double mx = -__builtin_huge_val();
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        const double s = clean(logw[i]);
+        mx = s > mx ? s : mx;
+    }
+    mx = block_max<double>(mx, redm);
+    const bool uniform = !(mx > -__builtin_huge_val());
+    // contiguous chunks per thread: local sums -> exclusive offsets -> the running sum
+    const int64_t chunk = (B + PF_BLOCK - 1) / PF_BLOCK;
+    const int64_t lo = (int64_t)threadIdx.x * chunk, hi = lo + chunk < B ? lo + chunk : B;
+    double local = 0.0;
+    for (int64_t i = lo; i < hi; ++i) local += uniform ? 1.0 : exp(clean(logw[i]) - mx);
+    double total;
+    double run = block_scan_excl(local, red, total);
+    for (int64_t i = lo; i < hi; ++i) {
+        run += uniform ? 1.0 : exp(clean(logw[i]) - mx);
+        cdf[i] = i == B - 1 ? T(1) : (T)(run / total);
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
+        const T p = ((T)i + (T)u) / (T)B;
+        int64_t a = 0, n = B;  // lower_bound: the first j with cdf[j] >= p
+        while (n > 0) {
+            const int64_t h = n >> 1;
+            if (cdf[a + h] < p) {
+                a += h + 1;
+                n -= h + 1;
+            } else {
+                n = h;
+            }
+        }
+        idx[i] = a < B - 1 ? a : B - 1;
+    }
+}
+
 }  // namespace pf

@@ -205,13 +205,10 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                 soa = ops.initial_sample_soa(ctx.init_host[0], ctx.init_host[1], n, b, d, dtype, device, seed, z0)
             else:
                 im, isd = im.to(device=device, dtype=dtype), isd.to(device=device, dtype=dtype)
-                # per-filter initial parameters (theta on the batch dim): standard draws from the kernel, then the
-                # column-wise affine map (once per run)
-                soa = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, device, seed, z0)
+                # per-filter initial parameters (theta on the batch dim): m + s z inside the sampling kernel - the parameters
+                # are read through the strides of their broadcast views
                 from ...timeseries.models import _expand
-                mb = _expand(im, b, (d,), dtype, device).t().unsqueeze(-1)  # (D, B, 1)
-                sb = _expand(isd, b, (d,), dtype, device).t().unsqueeze(-1)
-                soa = mb + sb * soa
+                soa = ops.initial_sample_cols(_expand(im, b, (d,), dtype, device), _expand(isd, b, (d,), dtype, device), n, b, d, seed, z0)
             x = TimeseriesState(0, ops.from_soa(soa, self._batched, self._has_event), hidden.event_shape)
         else:
             x = hidden.initial_sample(self.particles)

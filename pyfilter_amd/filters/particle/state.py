@@ -147,6 +147,26 @@ class ParticleFilterCorrection(Correction):
     def get_timeseries_state(self) -> TimeseriesState:
         return self.timeseries_state
 
+    def _packed(self):
+        """The ``(D + 1, B, N)`` buffer a fused run left particles AND log-weights in (``ParticleFilter._filter_block_lean``) -
+        while the state still shows exactly that buffer: whole-filter moves then take both in one launch."""
+        xl = getattr(self, "_xl", None)
+        if xl is None or not xl.is_cuda or "_x" not in self or "_w" not in self:
+            return None
+        d = xl.shape[0] - 1
+        if self["_x"].value.data_ptr() != xl.data_ptr() or self["_w"].data_ptr() != xl[d].data_ptr() or self["_w"].dim() != 2:
+            return None
+        return xl
+
+    def _adopt_packed(self, xl: Tensor):
+        from ... import ops
+
+        d = xl.shape[0] - 1
+        ts = self.timeseries_state
+        self["_x"] = ts.copy(values=ops.from_soa(xl[:d], True, len(ts.event_shape) > 0))
+        self["_w"] = ops.from_cols(xl[d], True)
+        self._xl = xl
+
     def resample(self, indices: Tensor):
         """Gather whole filters along the batch dim (``:150-158``): the particle planes, weights
         and ancestors move with ``pf_columns_gather`` (whole contiguous columns in the library layout)."""
@@ -154,8 +174,12 @@ class ParticleFilterCorrection(Correction):
 
         self._ensure_moments()
         ts = self.timeseries_state
-        self["_x"] = ts.copy(values=ops.gather_filters(ts.value, indices))
-        self["_w"] = ops.gather_filters(self.weights, indices)
+        xl = self._packed()
+        if xl is not None and indices.dtype == torch.int64 and indices.is_contiguous() and indices.numel() == xl.shape[1]:
+            self._adopt_packed(ops.gather_columns(xl, indices))
+        else:
+            self["_x"] = ts.copy(values=ops.gather_filters(ts.value, indices))
+            self["_w"] = ops.gather_filters(self.weights, indices)
         self["_ll"][indices] = self["_ll"][indices]
         if self._anc32 is not None and self._anc32[1]:  # the int32 buffer moves; the int64 view is rebuilt on demand
             self._anc32 = (ops.to_cols(ops.gather_filters(self._view32(), indices)), True)
@@ -181,10 +205,15 @@ class ParticleFilterCorrection(Correction):
         self._ensure_moments()
         other._ensure_moments()
         ts = self.timeseries_state
-        new_x = ops.exchange_filters(ts.value, other.timeseries_state.value, mask)
-        if new_x.data_ptr() != ts.value.data_ptr():
-            self["_x"] = ts.copy(values=new_x)
-        self["_w"] = ops.exchange_filters(self["_w"], other.weights, mask)
+        xl, xl_other = self._packed(), other._packed()
+        if (xl is not None and xl_other is not None and xl.shape == xl_other.shape and xl.dtype == xl_other.dtype
+                and mask.dtype == torch.bool and mask.is_contiguous() and mask.numel() == xl.shape[1]):
+            ops.exchange_columns(xl, xl_other, mask)  # (in place: the state's views keep showing the buffer)
+        else:
+            new_x = ops.exchange_filters(ts.value, other.timeseries_state.value, mask)
+            if new_x.data_ptr() != ts.value.data_ptr():
+                self["_x"] = ts.copy(values=new_x)
+            self["_w"] = ops.exchange_filters(self["_w"], other.weights, mask)
         _masked_assign(self["_ll"], other.get_loglikelihood(), mask)
         if self._anc32 is not None and self._anc32[1] and getattr(other, "_anc32", None) is not None and other._anc32[1] \
                 and mask.dtype == torch.bool:

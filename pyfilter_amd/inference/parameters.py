@@ -103,6 +103,27 @@ class ThetaParticles:
         # instead of dropping them.  Every method that writes the values maintains or clears the cache - the tensors are
         # handed to the model by reference, but nothing outside this class writes them.
         self._cache: Dict[str, torch.Tensor] = {}
+        # Scalar parameters (every prior without an event shape - the usual case) live side by side in ONE ``(P + 1, B)``
+        # buffer: ``self[name]`` is row k (a contiguous ``(B,)`` tensor), the last row carries ``_cache["prior_u"]``.  A whole-
+        # filter move (``resample`` / ``exchange``) of a rejuvenation is then two launches / one instead of two per parameter
+        # and cached quantity (3 parameters: 8 -> 3 and 8 -> 2) - and one collective instead of P + 2 when sharded.
+        self._buf: Optional[torch.Tensor] = None
+
+    def _store(self, fresh: "OrderedDict[str, torch.Tensor]"):
+        """First values: allocates the storage (``_buf`` rows when every parameter is a scalar per filter)."""
+        b = self.batch_shape[0]
+        if all(v.dim() == 1 and v.shape[0] == b for v in fresh.values()) and len(fresh) > 0:
+            self._buf = torch.empty((len(fresh) + 1, b), device=self.device, dtype=self.dtype)
+            for k, (name, v) in enumerate(fresh.items()):
+                self._buf[k].copy_(v)
+                self._values[name] = self._buf[k]
+        else:
+            for name, v in fresh.items():
+                self._values[name] = v.contiguous()
+
+    def _prior_row(self) -> Optional[torch.Tensor]:
+        """Where the summed log prior of the unconstrained values lives when the parameters are packed (else ``None``)."""
+        return None if self._buf is None else self._buf[-1]
 
     # ---- values ---------------------------------------------------------------------------------------------------
     def initialize_parameters(self, generator: Optional[torch.Generator] = None):
@@ -110,6 +131,7 @@ class ThetaParticles:
         ``generator`` the draws are reproducible - inverse CDF of its uniforms where the prior has one - and, sharded, every
         rank draws the same global set and keeps its block."""
         total = self.shard.total if self.shard is not None else self.batch_shape[0]
+        fresh = OrderedDict()
         for name, prior in self.priors.items():
             d = prior.distribution
             shape = torch.Size([total])
@@ -132,11 +154,12 @@ class ThetaParticles:
                 v = d.sample(shape)
             if self.shard is not None:
                 v = self.shard.slice(v)
-            v = v.to(device=self.device, dtype=self.dtype).clone()
-            if name in self._values:
+            fresh[name] = v.to(device=self.device, dtype=self.dtype)
+        if self._values:
+            for name, v in fresh.items():
                 self._values[name].copy_(v)
-            else:
-                self._values[name] = v.contiguous()
+        else:
+            self._store(fresh)
         self._cache.clear()
         return self
 
@@ -145,8 +168,7 @@ class ThetaParticles:
 
     def native_priors(self):
         """The priors as the theta kernels take them (``_lib.PfThetaPriors``; ``ops.theta_propose``) - or ``None``: a prior
-        of another family / with an event shape, more than ``PF_THETA_MAXP`` parameters, a CPU run, or theta-particles
-        sharded over several ranks (their Gaussian fit needs every rank's particles: the torch path all-gathers them)."""
+        of another family / with an event shape, more than ``PF_THETA_MAXP`` parameters, a CPU run."""
         from ..hints import HINTS
 
         if not HINTS.theta_kernels or len(self._values) != len(self.priors):
@@ -154,8 +176,7 @@ class ThetaParticles:
         if "native" not in self.__dict__:
             from .. import _lib
 
-            ok = (self.device.type == "cuda" and (self.shard is None or self.shard.world == 1) and
-                  0 < len(self.priors) <= _lib.THETA_MAXP and all(p.native is not None for p in self.priors.values()) and
+            ok = (self.device.type == "cuda" and 0 < len(self.priors) <= _lib.THETA_MAXP and all(p.native is not None for p in self.priors.values()) and
                   all(v.dim() == 1 and v.is_contiguous() for v in self._values.values()) and
                   self.dtype in (torch.float32, torch.float64))
             packed = None
@@ -170,7 +191,14 @@ class ThetaParticles:
     def adopt_proposal(self, u: torch.Tensor, prior_u: torch.Tensor):
         """The value tensors were just written by ``ops.theta_propose`` from the unconstrained ``u (B, P)``: what is known
         about them (``u`` itself, their summed log prior) replaces whatever was known about the old values."""
-        self._cache = {"u": u, "prior_u": prior_u}
+        self._cache = {"u": u}
+        self._keep_prior(prior_u)
+
+    def _keep_prior(self, prior_u: torch.Tensor):
+        row = self._prior_row()
+        if row is not None and prior_u.data_ptr() != row.data_ptr():
+            row.copy_(prior_u)
+        self._cache["prior_u"] = prior_u if row is None else row
 
     def names(self):
         return list(self.priors)
@@ -178,11 +206,18 @@ class ThetaParticles:
     def like(self) -> "ThetaParticles":
         """An independent set with the same priors / shape (the proposal's parameters: ``context.make_new``)."""
         other = ThetaParticles(self.priors, self.batch_shape[0], self.device, self.dtype, self.shard)
-        for k, v in self._values.items():
-            other._values[k] = v.clone()
+        if self._buf is not None:
+            other._buf = self._buf.clone()
+            for k, name in enumerate(self._values):
+                other._values[name] = other._buf[k]
+        else:
+            for k, v in self._values.items():
+                other._values[k] = v.clone()
         if "native" in self.__dict__:
             other.native = self.native
-        other._cache = dict(self._cache)  # (same values: the derived quantities hold - tensors nobody writes in place)
+        other._cache = dict(self._cache)  # (same values: the derived quantities hold - "u" is a tensor nobody writes in place,
+        if "prior_u" in other._cache and other._buf is not None:  # the log prior travels in the buffer's last row)
+            other._cache["prior_u"] = other._buf[-1]
         return other
 
     # ---- stacked views (context.py:193-243) -----------------------------------------------------------------------
@@ -231,29 +266,49 @@ class ThetaParticles:
                 lp = prior.distribution.log_prob(v) + _sum_event(prior.bijection.log_abs_det_jacobian(u, v), prior)
             total = total + lp
             at += k
-        self._cache["prior_u"] = total
-        return total
+        self._keep_prior(total)
+        return self._cache["prior_u"]
 
     # ---- whole-filter moves ---------------------------------------------------------------------------------------
     def exchange(self, other: "ThetaParticles", mask: torch.Tensor):
-        for name, v in self._values.items():
-            m = mask.reshape(mask.shape + (1,) * (v.dim() - 1))
-            v.copy_(torch.where(m, other._values[name], v))
+        packed = self._buf is not None and other._buf is not None and other._buf.shape == self._buf.shape
+        if packed:
+            torch.where(mask, other._buf, self._buf, out=self._buf)  # (every parameter and the log-prior row: one launch)
+        else:
+            for name, v in self._values.items():
+                m = mask.reshape(mask.shape + (1,) * (v.dim() - 1))
+                v.copy_(torch.where(m, other._values[name], v))
         kept = {}
         for key in ("u", "prior_u"):  # the derived quantities move with the values
             if key in self._cache and key in other._cache:
                 mine = self._cache[key]
-                kept[key] = torch.where(mask.reshape(mask.shape + (1,) * (mine.dim() - 1)), other._cache[key], mine)
-        self._cache = kept
+                if key == "prior_u" and packed:
+                    kept[key] = mine  # (the buffer's last row: moved above)
+                else:
+                    kept[key] = torch.where(mask.reshape(mask.shape + (1,) * (mine.dim() - 1)), other._cache[key], mine)
+        self._cache = {}
+        if "u" in kept:
+            self._cache["u"] = kept["u"]
+        if "prior_u" in kept:
+            self._keep_prior(kept["prior_u"])
 
     def resample(self, indices: torch.Tensor, route=None):
         """``theta <- theta[indices]`` in place.  Sharded: ``indices`` are GLOBAL ancestors of this rank's positions
         (``route``: the exchange plan of that gather when the caller already built it, ``distributed.Route``)."""
         if self.shard is not None and self.shard.world > 1 and route is None:
             route = self.shard.route(indices)
-        for name, v in self._values.items():
-            v.copy_(v[indices] if route is None else route.take(v))
-        self._cache = {k: (c[indices] if route is None else route.take(c)) for k, c in self._cache.items()}
+        moved = (lambda c: c[indices]) if route is None else route.take
+        if self._buf is not None:
+            self._buf.copy_(self._buf.index_select(1, indices) if route is None else route.take(self._buf, dim=1))
+        else:
+            for name, v in self._values.items():
+                v.copy_(moved(v))
+        kept = dict(self._cache)
+        self._cache = {}
+        if "u" in kept:
+            self._cache["u"] = moved(kept["u"])
+        if "prior_u" in kept:
+            self._keep_prior(kept["prior_u"] if self._buf is not None else moved(kept["prior_u"]))
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._values.items())

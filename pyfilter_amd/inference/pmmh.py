@@ -44,13 +44,13 @@ class SymmetricMH:
     def build(self, theta, state, filter_, y) -> Distribution:
         values = theta.stack_parameters(constrained=False)
         weights_log = state.w
+        shard = getattr(theta, "shard", None)
+        if shard is not None and shard.world > 1:
+            values, weights_log = shard.all_gather(values), shard.all_gather(weights_log)
         if theta.native_priors() is not None and weights_log.dtype == values.dtype:
             from .. import ops
 
             return GaussianKernel(*ops.theta_fit(values, weights_log, self.SCALE))
-        shard = getattr(theta, "shard", None)
-        if shard is not None and shard.world > 1:
-            values, weights_log = shard.all_gather(values), shard.all_gather(weights_log)
         return construct_mvn(values, theta_normalize(weights_log), scale=self.SCALE)
 
     def exchange(self, latest, candidate, mask) -> None:
@@ -153,8 +153,14 @@ def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_
     priors = theta.native_priors()
     b, p = theta.batch_shape[0], priors.P
     like = kernel.loc
-    eps = _to_device(draws.normal((b, p)), like) if draws is not None else torch.randn((b, p), device=like.device, dtype=like.dtype)
-    rvs, prior_star = ops.theta_propose(priors, kernel.loc, kernel.scale_tril, eps, [proposal_theta[n] for n in proposal_theta.names()])
+    shard = getattr(theta, "shard", None)
+    if draws is not None:  # (every rank draws the numbers of ALL theta-particles and keeps its block: see ThetaDraws)
+        eps = draws.normal((shard.total if shard is not None else b, p))
+        eps = _to_device(shard.slice(eps) if shard is not None else eps, like)
+    else:
+        eps = torch.randn((b, p), device=like.device, dtype=like.dtype)
+    rvs, prior_star = ops.theta_propose(priors, kernel.loc, kernel.scale_tril, eps, [proposal_theta[n] for n in proposal_theta.names()],
+                                        prior_out=proposal_theta._prior_row())
     proposal_theta.adopt_proposal(rvs, prior_star)
     mark("  theta* proposed")
     proposal_filter.initialize_model(proposal_theta)  # (rebuilt from theta*: see run_pmmh)
@@ -167,7 +173,7 @@ def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_
     log_acc, accepted, rate = ops.theta_accept(
         theta.stack_parameters(constrained=False), rvs, (kernel.loc, kernel.scale_tril), (new_kernel.loc, new_kernel.scale_tril),
         theta.eval_priors(constrained=False), prior_star, state.filter_state.loglikelihood, new_res.loglikelihood,
-        _uniforms(prior_star, None, draws))
+        _uniforms(prior_star, shard, draws))
     mark("  acceptance issued")
     if stats is not None:
         stats["rate"] = rate

@@ -20,6 +20,7 @@ from ..distributed import Shard
 from ..filters.result import FilterResult
 from .parameters import ThetaParticles
 from .pmmh import SymmetricMH, as_draws, run_pmmh
+from ..hints import HINTS
 from .utils import theta_ess, theta_normalize, theta_systematic
 
 
@@ -37,6 +38,19 @@ def _theta_stats(gw: torch.Tensor) -> torch.Tensor:
     rows = gw.reshape(-1, gw.shape[-1])
     out = torch.stack([torch.stack([theta_ess(r), r.isfinite().all().to(r.dtype)]) for r in rows])
     return out.reshape(gw.shape[:-1] + (2,))
+
+
+def _theta_path(w: torch.Tensor, ll: torch.Tensor, shard):
+    """The theta log-weights after each of a block's ``n`` observations, ``w + ll.cumsum(0)``, and their ``(n, 2)`` statistics
+    (``_theta_stats``) - one launch on one GPU (``pf_theta_path``); sharded, the rows are all-gathered in between."""
+    from ..hints import HINTS
+
+    if ll.is_cuda and (shard is None or shard.world == 1) and HINTS.theta_kernels and ll.dim() == 2 and ll.dtype == w.dtype:
+        from .. import ops
+
+        return ops.theta_path(w.contiguous(), ll.contiguous())
+    w_path = w + ll.cumsum(0)
+    return w_path, _theta_stats(shard.all_gather(w_path, dim=1) if shard is not None and shard.world > 1 else w_path)
 
 
 class SMC2State:
@@ -175,9 +189,14 @@ class ParticleMetropolisHastings:
         # the same resampling on every rank: same (gathered) weights, same uniform (the generator is a CPU stream seeded
         # identically everywhere and advanced in lock step - no broadcast needed)
         draws = as_draws(generator)
-        W = state.normalized_weights()
         u = draws.uniform(()) if draws is not None else torch.rand(())
-        indices = self._resampler(W, u)
+        gw = state.global_weights()
+        if self._resampler is theta_systematic and gw.is_cuda and HINTS.theta_kernels:
+            from .. import ops
+
+            indices = ops.theta_resample(gw, float(u))  # (normalisation, cdf and search in one launch)
+        else:
+            indices = self._resampler(theta_normalize(gw), u)
         mine = shard.slice(indices) if sharded else indices
         data, data_flags = state.parsed_data, state.parsed_flags()
         dist = self._proposal.build(theta, state, filter_, data)
@@ -213,8 +232,10 @@ class ParticleMetropolisHastings:
             stats = {"mark": mark} if self.timeline is not None else {}
             accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, data,
                                 shape, mutate_kernel=False, generator=draws, trace=self.trace, stats=stats, overlap=move_filters)
-            if "rate" in stats:  # (the native theta route: the acceptance kernel counted - one GPU by construction)
+            if "rate" in stats:  # (the native theta route: the acceptance kernel counted this rank's share)
                 rate = stats["rate"]
+                if sharded:
+                    rate = shard.all_mean(rate * accepted.numel(), accepted.numel())
             else:
                 rate = accepted.float().sum()
                 rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
@@ -334,8 +355,7 @@ class SMC2:
         if out is None:
             return None
         res, ll, token = out
-        w_path = w + ll.cumsum(0)  # (n, B_local)
-        stats = _theta_stats(shard.all_gather(w_path, dim=1) if shard.world > 1 else w_path)  # (n, 2): ESS, all finite
+        w_path, stats = _theta_path(w, ll, shard)  # (n, B_local) theta-weights after each observation; (n, 2): ESS, all finite
         event = None
         if stats.is_cuda:  # one small asynchronous copy into pinned memory + an event: the host later waits for THIS block only
             host = self._pinned(slot, stats)
@@ -378,8 +398,7 @@ class SMC2:
     def _cut(self, blk, take: int, state: SMC2State):
         """The block again, cut after ``take`` observations, on the same draws."""
         res, ll, _ = self.filter.filter_block(blk["ys"][:take], blk["latest"], observed=blk["flags"][:take], replay=blk["token"])
-        w_path = state.w + ll.cumsum(0)
-        stats = _theta_stats(self.shard.all_gather(w_path, dim=1) if self.shard.world > 1 else w_path)
+        w_path, stats = _theta_path(state.w, ll, self.shard)
         return dict(blk, res=res, ll=ll, w_path=w_path, stats=stats)
 
     def fit(self, y: torch.Tensor, block: Optional[int] = None) -> SMC2State:

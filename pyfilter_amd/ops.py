@@ -80,6 +80,47 @@ def _batch_view(t: torch.Tensor):
     return buf, rebuild
 
 
+_checked_index = None  # (tensor, its in-place version, bound): the last ancestor vector that passed the bounds check
+
+
+def _check_filter_index(idx: torch.Tensor, b: int):
+    """Bounds check of a vector of filter ancestors without a host round trip where torch offers the asynchronous assert
+    (as torch's own CUDA indexing does).  A resampling moves every buffer of a filter set with the SAME vector (three to
+    six gathers per rejuvenation): it is checked once - five small launches - not once per buffer."""
+    global _checked_index
+    c = _checked_index
+    if c is not None and c[0] is idx and c[1] == idx._version and c[2] == b:
+        return
+    ok = ((idx >= -b) & (idx < b)).all()
+    if hasattr(torch, "_assert_async") and not SYNC_CHECKS:
+        torch._assert_async(ok)
+    elif not bool(ok):
+        raise IndexError(f"index out of bounds for dimension 1 with size {b}")
+    _checked_index = (idx, idx._version, b)
+
+
+def gather_columns(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """``src[:, idx]`` for a library buffer ``(planes, B, N)`` and ``B`` int64 ancestors: a fresh buffer (pf_columns_gather)."""
+    L.require_gpu(src, idx)
+    planes, b, n = src.shape
+    assert src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() == b
+    _check_filter_index(idx, b)
+    dst = torch.empty_like(src)
+    L.check(L.load().pf_columns_gather(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), n, b, planes, src.element_size(),
+                                       L.stream_ptr()), "pf_columns_gather")
+    return dst
+
+
+def exchange_columns(dst: torch.Tensor, src: torch.Tensor, mask: torch.Tensor):
+    """``dst[:, mask] = src[:, mask]`` in place for library buffers ``(planes, B, N)`` (pf_columns_exchange)."""
+    L.require_gpu(dst, src, mask)
+    planes, b, n = dst.shape
+    assert dst.is_contiguous() and src.is_contiguous() and src.shape == dst.shape and src.dtype == dst.dtype
+    assert mask.dtype == torch.bool and mask.is_contiguous() and mask.numel() == b
+    L.check(L.load().pf_columns_exchange(dst.data_ptr(), src.data_ptr(), mask.data_ptr(), n, b, planes, dst.element_size(),
+                                         L.stream_ptr()), "pf_columns_exchange")
+
+
 def gather_filters(t: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
     """``t[:, indices]`` for an ``(N, B, ...)`` tensor, as a view of a freshly gathered ``(planes, B, N)`` buffer
     (pf_columns_gather; ParticleFilterCorrection.resample, particle/state.py:150-158)."""
@@ -90,12 +131,7 @@ def gather_filters(t: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
     b = t.shape[1]
     if idx.numel() != b:
         return t[:, indices]  # a different number of filters out than in: not the in-place resample of the reference
-    # bounds check without a host round trip where torch offers the asynchronous assert (as torch's own CUDA indexing does)
-    ok = ((idx >= -b) & (idx < b)).all()
-    if hasattr(torch, "_assert_async") and not SYNC_CHECKS:
-        torch._assert_async(ok)
-    elif not bool(ok):
-        raise IndexError(f"index out of bounds for dimension 1 with size {b}")
+    _check_filter_index(idx, b)
     src, rebuild = _batch_view(t)
     dst = torch.empty_like(src)
     planes, _, n = src.shape
@@ -293,6 +329,18 @@ def initial_sample_soa(m0, s0, n: int, b: int, d: int, dtype, device, seed: int,
     return x
 
 
+def initial_sample_cols(m0: torch.Tensor, s0: torch.Tensor, n: int, b: int, d: int, seed: int, z: Optional[torch.Tensor] = None):
+    """``(D, B, N)`` initial particles ``m0 + s0 * z`` for per-filter initial parameters: ``m0`` / ``s0`` are ``(B, D)``
+    tensors or broadcast views of that shape (their strides travel, nothing is materialised) - pf_initial_sample_cols."""
+    assert tuple(m0.shape) == (b, d) and tuple(s0.shape) == (b, d) and m0.dtype == s0.dtype and m0.device == s0.device
+    x = torch.empty((d, b, n), dtype=m0.dtype, device=m0.device)
+    L.require_gpu(x, z, m0, s0)
+    (mb, md), (sb, sd) = m0.stride(), s0.stride()
+    L.check(L.load().pf_initial_sample_cols(m0.data_ptr(), mb, md, s0.data_ptr(), sb, sd, L.ptr(z), seed, x.data_ptr(), n, b, d,
+                                            L.dtype_code(x.dtype), L.stream_ptr()), "pf_initial_sample_cols")
+    return x
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # test support
 # ----------------------------------------------------------------------------------------------------------------
@@ -351,6 +399,32 @@ def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def theta_path(w0: torch.Tensor, ll: torch.Tensor):
+    """``w0 (B,)``, ``ll (n, B)`` -> ``(w0 + ll.cumsum(0) (n, B), (n, 2) ESS / all-finite rows)`` in one launch
+    (pf_theta_path; ``sequential/state.py:35-44`` for the n observations of a block)."""
+    L.require_gpu(w0, ll)
+    n, b = ll.shape
+    assert w0.shape == (b,) and w0.dtype == ll.dtype and w0.is_contiguous() and ll.is_contiguous()
+    w_path = torch.empty_like(ll)
+    stats = torch.empty((n, 2), dtype=ll.dtype, device=ll.device)
+    L.check(L.load().pf_theta_path(w0.data_ptr(), ll.data_ptr(), n, b, L.dtype_code(ll.dtype), w_path.data_ptr(), stats.data_ptr(),
+                                   L.stream_ptr()), "pf_theta_path")
+    return w_path, stats
+
+
+def theta_resample(log_w: torch.Tensor, u: float) -> torch.Tensor:
+    """Systematic resampling of the theta-particles from their log-weights: ``(B,)`` int64 ancestors, one launch
+    (pf_theta_resample; ``kernels/mh.py:52-56``)."""
+    L.require_gpu(log_w)
+    log_w = log_w.contiguous()
+    b = log_w.shape[0]
+    idx = torch.empty(b, dtype=torch.int64, device=log_w.device)
+    scratch = torch.empty_like(log_w)
+    L.check(L.load().pf_theta_resample(log_w.data_ptr(), b, float(u), L.dtype_code(log_w.dtype), idx.data_ptr(), scratch.data_ptr(),
+                                       L.stream_ptr()), "pf_theta_resample")
+    return idx
+
+
 def theta_fit(values: torch.Tensor, log_w, scale: float = 1.0):
     """``values (B, P)``, ``log_w (B,)`` or ``None`` (equal weights) -> ``(mean (P,), scale * chol (P, P))`` of the weighted
     Gaussian fit (pf_theta_fit; ``inference/utils.py:42-76``).  One launch."""
@@ -366,7 +440,7 @@ def theta_fit(values: torch.Tensor, log_w, scale: float = 1.0):
     return out[:p], out[p:].view(p, p)
 
 
-def theta_propose(priors, mean: torch.Tensor, chol: torch.Tensor, eps: torch.Tensor, x_out):
+def theta_propose(priors, mean: torch.Tensor, chol: torch.Tensor, eps: torch.Tensor, x_out, prior_out: Optional[torch.Tensor] = None):
     """theta* = mean + chol eps -> ``(u* (B, P), log prior of u* (B,))``; the constrained values are written into the ``P``
     tensors ``x_out`` (pf_theta_propose; ``mcmc/utils.py:48-50``, ``prior.py:98-123``).  ``priors``: a ``PfThetaPriors``."""
     L.require_gpu(eps, mean, chol)
@@ -377,7 +451,8 @@ def theta_propose(priors, mean: torch.Tensor, chol: torch.Tensor, eps: torch.Ten
         assert x.is_contiguous() and x.numel() == b and x.dtype == eps.dtype and x.device == eps.device
     ptrs = (C.c_void_p * p)(*[x.data_ptr() for x in x_out])
     u = torch.empty_like(eps)
-    lp = torch.empty(b, dtype=eps.dtype, device=eps.device)
+    lp = prior_out if prior_out is not None else torch.empty(b, dtype=eps.dtype, device=eps.device)
+    assert lp.shape == (b,) and lp.dtype == eps.dtype and lp.is_contiguous()
     L.check(L.load().pf_theta_propose(C.byref(priors), mean.data_ptr(), chol.data_ptr(), eps.data_ptr(), b, L.dtype_code(eps.dtype),
                                       u.data_ptr(), ptrs, lp.data_ptr(), L.stream_ptr()), "pf_theta_propose")
     return u, lp

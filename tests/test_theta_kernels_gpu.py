@@ -179,3 +179,76 @@ def test_priors_outside_the_kernels_families_take_the_torch_route():
     assert theta.native_priors() is None  # (an event-shaped prior)
     assert ThetaParticles({"a": Normal(0.0, 1.0)}, 16, "cuda", torch.float64).native_priors() is None  # (no values yet)
     assert ThetaParticles({"a": Normal(0.0, 1.0)}, 16, "cuda", torch.float64).initialize_parameters().native_priors() is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("n,b", [(16, 1000), (1, 37), (32, 4097)])
+def test_theta_path_is_the_running_weights_and_their_ess(dtype, n, b):
+    """``pf_theta_path`` against ``w + ll.cumsum(0)`` (the same additions in the same order: equal to the last bit) and
+    ``pf_theta_ess`` of its rows."""
+    g = torch.Generator().manual_seed(n * b)
+    w = torch.randn(b, generator=g, dtype=torch.float64).to(dtype).cuda()
+    ll = torch.randn(n, b, generator=g, dtype=torch.float64).mul(2.0).to(dtype).cuda()
+    if n > 4:
+        ll[3, 7] = float("nan")
+        ll[2, 5] = -math.inf
+    w_path, stats = ops.theta_path(w, ll)
+    want = w + ll.cumsum(0)
+    assert torch.equal(torch.nan_to_num(w_path, nan=123.0), torch.nan_to_num(want, nan=123.0))
+    assert torch.equal(stats, ops.theta_ess(want))
+    if n > 4:
+        assert stats[1, 1] == 1 and stats[2, 1] == 0 and stats[3, 1] == 0  # "every weight finite" from the -inf on
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("b", [1000, 37, 5000])
+def test_theta_resample_is_normalize_then_systematic(dtype, b):
+    from pyfilter_amd.inference.utils import theta_systematic
+
+    g = torch.Generator().manual_seed(b)
+    for case in range(4):
+        lw = (4.0 * torch.randn(b, generator=g, dtype=torch.float64)).to(dtype)
+        if case == 1:
+            lw[3], lw[b // 2], lw[b - 1] = float("nan"), math.inf, -math.inf
+        if case == 2:
+            lw[:] = -math.inf
+            lw[b // 3] = 0.5  # all the weight on one theta-particle
+        if case == 3:
+            lw[:] = -math.inf  # nothing finite: equal weights
+        for u in (0.0, 0.3718, 0.999999):
+            got = ops.theta_resample(lw.cuda(), u).cpu()
+            assert got.dtype == torch.int64 and int(got.min()) >= 0 and int(got.max()) <= b - 1
+            assert bool((got[1:] >= got[:-1]).all())
+            if case == 3:
+                want = torch.arange(b) if u > 0 else torch.arange(b).sub(1).clamp_min(0)
+                # (i + u) / B against cdf[j] = (j + 1) / B: ancestor i for u > 0 (u = 0: ties resolve to i - 1, as searchsorted does)
+                assert int((got - want).abs().max()) <= 1
+                continue
+            # the reference arithmetic on the host in float64 (torch's float64 softmax on this device is 1e-6 off beyond 1 024 entries)
+            want = theta_systematic(theta_normalize(lw.double()), u)
+            if dtype == torch.float64:
+                assert torch.equal(got, want), (case, u, int((got != want).sum()))
+            else:  # float32 cdf and grid: a position within rounding of a cdf step may land on the neighbour
+                assert int((got - want).abs().max()) <= 1 and int((got != want).sum()) <= max(2, b // 200)
+            if case == 2 and u > 0:  # (u = 0: position 0 sits AT cdf[0] = 0 and takes ancestor 0, as searchsorted has it)
+                assert bool((got == b // 3).all())
+
+
+def test_initial_sample_with_per_filter_parameters_is_m_plus_s_z():
+    from pyfilter_amd.timeseries.models import _expand
+
+    n, b, d = 300, 7, 3
+    g = torch.Generator().manual_seed(4)
+    for dtype in (torch.float64, torch.float32):
+        z = torch.randn(d, b, n, generator=g, dtype=torch.float64).to(dtype).cuda()
+        for m_shape, s_shape in (((b,), (b,)), ((b, d), ()), ((d,), (b, 1)), ((), (b, d))):
+            m = torch.randn(m_shape, generator=g, dtype=torch.float64).to(dtype).cuda()
+            s = torch.rand(s_shape, generator=g, dtype=torch.float64).add(0.1).to(dtype).cuda()
+            me, se = _expand(m, b, (d,), dtype, "cuda"), _expand(s, b, (d,), dtype, "cuda")
+            got = ops.initial_sample_cols(me, se, n, b, d, 17, z)
+            want = me.t().unsqueeze(-1) + se.t().unsqueeze(-1) * z
+            assert torch.equal(got, want)
+        # Philox draws: the standard normals of pf_initial_sample, mapped
+        std = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, torch.device("cuda"), 99)
+        got = ops.initial_sample_cols(me, se, n, b, d, 99)
+        assert torch.equal(got, me.t().unsqueeze(-1) + se.t().unsqueeze(-1) * std)

@@ -80,8 +80,30 @@ def read(path):
         print(f"   {gap / 1e3:8.1f}  at {(rows[i][0] - rows[0][0]) / 1e6:6.2f} ms  {rows[i - 1][2].split('(')[0][:48]}  ->  {rows[i][2].split('(')[0][:48]}")
 
 
+def sequence(path, out):
+    """The last fit's kernels in launch order, one line per kernel: start (us from the fit's first kernel), duration, name."""
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    cut = 0
+    for i in range(1, len(rows)):
+        if rows[i][0] - rows[i - 1][1] > 30_000_000:
+            cut = i
+    rows = rows[cut:]
+    with open(out, "w") as f:
+        for s0, e0, n in rows:
+            short = n.split("(")[0]
+            for junk in ("void at::native::", "void pf::", "at::native::"):
+                short = short.replace(junk, "")
+            f.write(f"{(s0 - rows[0][0]) / 1e3:10.1f} {(e0 - s0) / 1e3:7.1f}  {short[:110]}\n")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]) if len(sys.argv) > 2 else 1000, int(sys.argv[3]) if len(sys.argv) > 3 else 400)
+    elif sys.argv[1] == "sequence":
+        sequence(sys.argv[2], sys.argv[3])
     else:
         read(sys.argv[2])
