@@ -35,10 +35,11 @@ def _on_device(d: Distribution, device, dtype) -> Distribution:
         return d
 
 
-def _native_family(d: Distribution):
+def _native_family(d: Distribution, dtype=None):
     """``(PF_PRIOR_* code, a, b)`` when ``d`` is a scalar prior of a family the theta kernels evaluate (``include/pf_amd.h``:
     the family's density and the bijection ``biject_to(d.support)`` that goes with it), else ``None``.  Exact types only: a
-    subclass may override ``log_prob`` or ``support``."""
+    subclass may override ``log_prob`` or ``support``.  ``dtype``: the parameters are rounded to it first - the values the
+    device copy of the prior holds (read from the caller's distribution: no device round trip)."""
     from torch.distributions import Beta, Exponential, Gamma, HalfNormal, LogNormal, Normal, Uniform
 
     table = {Normal: (0, "loc", "scale"), LogNormal: (1, "loc", "scale"), Exponential: (2, "rate", None),
@@ -50,7 +51,8 @@ def _native_family(d: Distribution):
     vals = []
     for name in row[1:]:
         v = getattr(d, name) if name is not None else 1.0
-        vals.append(float(v.reshape(-1)[0]) if isinstance(v, torch.Tensor) else float(v))
+        v = v.reshape(-1)[0] if isinstance(v, torch.Tensor) else torch.tensor(float(v))
+        vals.append(float(v.to(dtype) if dtype is not None and v.is_floating_point() else v))
     return (row[0], vals[0], vals[1])
 
 
@@ -58,12 +60,12 @@ class Prior:
     """A prior with its bijection to unconstrained space (``prior.py:47-123``)."""
 
     def __init__(self, distribution: Distribution, device=None, dtype=None):
+        self.native = _native_family(distribution, dtype if device is not None else None)
         if device is not None:
             distribution = _on_device(distribution, device, dtype)
         self.distribution = distribution
         self.bijection = biject_to(distribution.support)
         self.unconstrained = TransformedDistribution(distribution, self.bijection.inv, validate_args=False)
-        self.native = _native_family(distribution)  # (parameters as the device copy holds them, read once - here)
 
     @property
     def numel(self) -> int:
