@@ -93,8 +93,13 @@ template <typename T> struct FusedArgs {
     __device__ __forceinline__ bool is_obs_next() const { return obs_next >= 0 ? obs_next != 0 : obs_dev[step + 1] != 0; }
     int finalize_only;
     int book_inline;  // the column's bookkeeping is done by its last step workgroup (after its own work) instead of an
-                      // extra workgroup per column: columns of few tiles, where the extra workgroups would be a large
-                      // share of the grid (1024 x 8192: every second one)
+                      // extra workgroup per column (development / A-B only since the bookkeepers are dispatched last)
+    int book_rows;    // where the extra workgroups sit in the grid: 0 = block (tiles, b) - one column only: the grid's last
+                      // block -, 1 = rows b >= B of a (tiles, B + ceil(B / tiles)) grid, block (k, B + r) keeping the books of
+                      // column r tiles + k.  Blocks are dispatched in linear order and the 1 024 resident slots (4 per CU)
+                      // are all taken by a 2^20-particle step: with the bookkeepers LAST the step workgroups all start at
+                      // once and the short bookkeepers fill slots as they free up; interleaved per column (block x = tiles
+                      // of every column) they took slots first and the last columns' step workgroups started 2 - 3 us late
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
     __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
@@ -1626,9 +1631,17 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC, 
     __shared__ int sh_plan[2];
     __shared__ double crec[MULTI ? 2 * PF_LDS_CHUNKS : 2];
     __shared__ double redb[PF_NWAVES];
-    if (!a.book_inline && blockIdx.x == (unsigned)a.g.tiles) {  // the column's bookkeeper (scratch: 2 + 2 D rows of `red`)
-        column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
-        return;
+    if (!a.book_inline) {  // the columns' bookkeepers (scratch: 2 + 2 D rows of `red`)
+        if (a.book_rows) {
+            if (blockIdx.y >= (unsigned)a.g.B) {
+                const int bc = (int)(blockIdx.y - (unsigned)a.g.B) * (int)a.g.tiles + (int)blockIdx.x;
+                if (bc < (int)a.g.B) column_bookkeeping<T, D>(a, bc, red, redb);
+                return;
+            }
+        } else if (blockIdx.x == (unsigned)a.g.tiles) {
+            column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
+            return;
+        }
     }
     const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan, crec};
     T z0[VEC][D];

@@ -1731,6 +1731,13 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
     return a;
 }
 
+// Columns of fewer tiles than this keep their books inline (the column's last step workgroup, after its own work).  Since
+// the bookkeepers are dispatched LAST (FusedArgs::book_rows) they cost nothing on the critical path and inline lost at every
+// shape measured, single-tile columns included (1 024 x 8 192: 65.5 -> 59.1 us per step; 256 x 8 192 27.3 -> 22.1;
+// profiles/r04c_step_kernel_book_inline_threshold_ab.txt): 1 = never.  (Round 2's rule was 8.)
+#ifndef PF_BOOK_INLINE_TILES
+#define PF_BOOK_INLINE_TILES 1
+#endif
 template <typename T, int D, int VEC, bool MULTI>
 static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
                            int finalize, hipStream_t st, float* kernel_ms) {
@@ -1738,13 +1745,18 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const uint8_t* observed = A->observed;  // host array
 
     const dim3 grid_tiles(g.tiles, g.B), block(PF_BLOCK);
-    // the step kernel: one workgroup per tile + the column's bookkeeper - an extra workgroup when the column has many
-    // tiles, else its last step workgroup (PF_BOOK_INLINE=0/1 overrides: development)
-    a.book_inline = g.tiles < 8 ? 1 : 0;
+    // the step kernel: one workgroup per tile + one bookkeeper per column, dispatched after all step workgroups
+    // (PF_BOOK_INLINE=0/1 overrides in the development build: 1 = the column's last step workgroup keeps the books)
+    a.book_inline = g.tiles < PF_BOOK_INLINE_TILES ? 1 : 0;
 #ifdef PF_DEVTOOLS
     if (const char* bi = getenv("PF_BOOK_INLINE")) a.book_inline = atoi(bi);  // (2: nobody keeps the books - timing experiments)
 #endif
-    const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
+#ifndef PF_NO_BOOK_ROWS
+    a.book_rows = (!a.book_inline && g.B > 1) ? 1 : 0;
+#else
+    a.book_rows = 0;
+#endif
+    const dim3 grid(g.tiles + ((a.book_inline || a.book_rows) ? 0 : 1), g.B + (a.book_rows ? (g.B + g.tiles - 1) / g.tiles : 0));
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
         // (a kernel, not hipMemsetAsync: captured as a memset node the fill stopped clearing these records after ~195
