@@ -245,13 +245,19 @@ typedef struct pf_run_hints {
     int32_t tile_target;     /* workgroups per launch the tile size aims at; 0 = the default (1024 = 4 per CU) */
     int32_t ancestor_search; /* != 0: systematic ancestors by searching the staged window at any size (default: only float
                               * grids beyond 2^22 positions, where the inverted grid's closed form is not exact) */
-    int32_t resume;          /* != 0 (t0 > 0, SISR): the incoming state of step t0 is the one the PREVIOUS pf_filter_run call on
+    int32_t resume;          /* != 0 (t0 > 0): the incoming state of step t0 is the one the PREVIOUS pf_filter_run call on
                               * this argument block wrote - its per-tile partials and local scans are still in the workspace
-                              * (a SISR step leaves them for its successor), so the pass that re-reduces the incoming state
-                              * is skipped.  A run issued move by move (user-defined models: one call per move) pays one
-                              * launch per move less.  Ignored for an APF, whose first-stage weights need the new
-                              * observation, and on the column route (which has no such pass) */
-    int32_t reserved;
+                              * (a SISR step leaves them for its successor; an APF step does when that call ran with
+                              * prepare_next), so the pass that re-reduces the incoming state is skipped.  A run issued
+                              * move by move (user-defined models: one call per move) pays one launch per move less.
+                              * Ignored on the column route (which has no such pass) */
+    int32_t prepare_next;    /* != 0 (APF, finalize == 0): the run's LAST step also prepares the first-stage weights of the
+                              * step after it, as every earlier step of a run does for its successor - the caller promises
+                              * that y holds row t0 + n_steps, that it carries information, and that the next call on this
+                              * block starts there with `resume`.  Built-in models; PF_HID_USER_AFFINE only with PF_PROP_LGO
+                              * and user_scale_per_column: the optimal proposal's first-stage weight (linear.py:57-86) needs
+                              * the particle and its transition scale - not the caller's one-step mean, which does not exist
+                              * yet for the new particles */
 } pf_run_hints;
 
 typedef struct pf_filter_args {

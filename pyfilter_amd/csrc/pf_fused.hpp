@@ -1519,7 +1519,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 for (int d = 0; d < D; ++d) xo[d][j] = xn[d];
                 // first-stage weight of the next step, while the new particle is still in registers
                 if constexpr (FAST) pre_n[j] = pre_next ? fc.template pre_weight<FAST ? MK : 0>(proposal, xn[0], true) : T(0);
-                else pre_n[j] = pre_next ? pre_weight<T, D>(md, proposal, cp, cc, xn, true) : T(0);
+                else if constexpr (USER) {
+                    // (pf_run_hints.prepare_next: the optimal proposal with one transition scale per column - the new particle
+                    // and the column's scale are all its first-stage weight reads; `um.scale` IS the column's scale)
+                    pre_n[j] = pre_next ? pre_weight<T, D>(md, proposal, cp, cc, xn, true, um) : T(0);
+                } else pre_n[j] = pre_next ? pre_weight<T, D>(md, proposal, cp, cc, xn, true) : T(0);
                 // keep the scheduler from interleaving all VEC particles' arithmetic: that is what pushes the kernel
                 // over its register budget (spills cost real HBM traffic: PMC WRITE_SIZE)
                 if (j & 1) __builtin_amdgcn_sched_barrier(0);

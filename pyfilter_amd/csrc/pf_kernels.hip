@@ -1795,7 +1795,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.obs_next = 0;
     // (pf_run_hints.resume: the previous call on this argument block ended with a SISR step that left the partials and local
     // scans of exactly this state in the workspace - the pass is redundant)
-    const bool resumed = A->hints.resume != 0 && t0 > 0 && A->filter == PF_FILTER_SISR && A->ring < 3;
+    // (an APF leaves them when its last step ran with pf_run_hints.prepare_next: the caller's promise)
+    const bool resumed = A->hints.resume != 0 && t0 > 0 && A->ring < 3;
+    const bool prepare_next = A->hints.prepare_next != 0 && A->filter == PF_FILTER_APF && !finalize && n_steps > 0;
     if (!resumed) hipLaunchKernelGGL((k_fused_reduce<T, D, VEC>), grid_tiles, block, 0, st, a);
 
     // ancestor stage of the step kernel: 0 inverted grid (systematic), 1 multinomial, 2 systematic by search - float
@@ -1807,6 +1809,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     // steady-state specialisation of this launch (float only: the double kernels are the parity path): see SPEC
     auto spec_of = [&]() -> int {
         if (sizeof(T) != 4 || a.z_tape || a.obs != 1) return 0;
+        if (a.md.hid_kind == PF_HID_USER_AFFINE && a.filter == PF_FILTER_APF) return 0;  // (its steady state is not instantiated)
         if (a.filter == PF_FILTER_APF) return a.obs_next == 1 ? 1 : 0;
         return 2;
     };
@@ -1886,7 +1889,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         a.step = (int)t;
         place(t);
         a.obs = dev_flags ? -1 : (observed[t] != 0);
-        a.obs_next = (s + 1 < n_steps) ? (dev_flags ? -1 : (observed[t + 1] != 0)) : 0;
+        a.obs_next = (s + 1 < n_steps) ? (dev_flags ? -1 : (observed[t + 1] != 0)) : (prepare_next ? 1 : 0);
 #ifdef PF_DEVTOOLS
         // stage cuts on ONE launch (the last but one step) when PF_DEBUG_CUT_AT_END is set: the state entering it is
         // valid, so per-dispatch PMC rows of that launch profile the stages on real data
@@ -2263,6 +2266,10 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (rc) return rc;
     if (bad_shape(A->N, A->B) || t0 < 0 || n_steps < 0) return PF_EINVAL;
     if (A->ring < 0 || A->ring == 1) return PF_EINVAL;
+    if (A->hints.prepare_next != 0) {  // (see pf_run_hints: what the last step would have to evaluate must be in the kernels' reach)
+        if (A->filter != PF_FILTER_APF || finalize || n_steps < 1) return PF_EINVAL;
+        if (A->model.hid_kind == PF_HID_USER_AFFINE && (A->proposal != PF_PROP_LGO || !A->user_scale_per_column)) return PF_EINVAL;
+    }
     if (!A->x[0] || !A->logw[0] || (A->ring < 3 && (!A->x[1] || !A->logw[1])) || !A->anc || !A->cdf || !A->means || !A->vars ||
         !A->ll_steps || !A->ll_total || !A->ws)
         return PF_EINVAL;

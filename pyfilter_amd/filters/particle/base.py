@@ -472,7 +472,9 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if cached is not None and cached[0] == key:
             return cached[1]
         out = self._scale_rows(scale, dtype)
-        self._percol_cache = (key, out)
+        # (the view is kept with the entry: while it lives its storage cannot be handed to another tensor, so an equal
+        # address + version really is the same data - a callable that computes a fresh scale per move misses, as it must)
+        self._percol_cache = (key, out, scale)
         return out
 
     def _scale_rows(self, scale: torch.Tensor, dtype) -> torch.Tensor:
@@ -679,6 +681,11 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             # is what makes a call eligible for that one-launch route).
             chained = kind.is_user and (HINTS.route == 1 or n > (HINTS.column_max_n or 2048))
             keep = []
+            # An APF move with the optimal proposal and ONE transition scale per filter can prepare its successor's first-stage
+            # weights itself, like every step of a built-in model's run (pf_run_hints.prepare_next: they read the new particle
+            # and that scale, not the callable's mean) - the successor then starts without the reduce launch as well
+            apf_lgo = self._FILTER_KIND == L.FILTER_APF and self._proposal._KERNEL_PROPOSAL == L.PROP_LGO
+            prepared_with = None  # the per-column scale the previous move prepared this move's first-stage weights with
             if not kind.is_user and isinstance(self._move_by_move, (list, tuple)):
                 # (testing knob, general form: the run as explicit pieces ``(n_steps, finalize)`` on one argument block - a
                 # piece without ``finalize`` takes the per-step kernels, a self-contained one of a small filter the column
@@ -707,12 +714,18 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                 keep = [loc_p, scale_p]
                 a.user_loc, a.user_scale = loc_p.data_ptr(), scale_p.data_ptr()
                 a.user_scale_per_column = 0 if percol is None else 1
-                a.hints.resume = 1 if (chained and s_ > 0 and self._FILTER_KIND == L.FILTER_SISR) else 0
                 last_move = s_ == steps - 1
+                # (prepared first-stage weights are only taken when this move's scale IS the one they were computed with - a
+                # time-dependent diffusion hands over another tensor, and the move re-reduces like any other)
+                a.hints.resume = 1 if (chained and s_ > 0 and (self._FILTER_KIND == L.FILTER_SISR or
+                                                               (prepared_with is not None and percol is prepared_with))) else 0
+                prepare = bool(chained and apf_lgo and percol is not None and not last_move and observed_host[s_ + 1])
+                a.hints.prepare_next = 1 if prepare else 0
+                prepared_with = percol if prepare else None
                 L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1 if (last_move or not chained) else 0, L.stream_ptr()), "pf_filter_run")
             if kind.is_user:
                 a.user_loc, a.user_scale = plan.user_loc.data_ptr(), plan.user_scale.data_ptr()
-                a.user_scale_per_column, a.hints.resume = 0, 0
+                a.user_scale_per_column, a.hints.resume, a.hints.prepare_next = 0, 0, 0
                 self._keep_planes = keep
         elif getattr(self, "_time_kernels", False):
             kms = (C.c_float * 3)()

@@ -35,7 +35,7 @@ class RunHints:
         """Writes the kernel-side choices into a ``PfFilterArgs``."""
         h = args.hints
         h.route, h.column_max_n, h.tile_target, h.ancestor_search = self.route, self.column_max_n, self.tile_target, self.ancestor_search
-        h.resume = 0  # (a per-call fact, set by the move loops that know it)
+        h.resume = h.prepare_next = 0  # (per-call facts, set by the move loops that know them)
 
     def apply_mapping(self, m):
         """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
