@@ -135,6 +135,64 @@ int main() {
             if (!(std::fabs(h_ll[c] - kll) < 0.25) || !(std::fabs(last - km) < 0.01)) ++failures;
         }
     }
+    // ---- the theta-level entry points (what an SMC^2 driver in any host language does with the filters' log-likelihoods):
+    // ESS of B_t log-weights, their systematic resampling, the Gaussian fit of the proposal - against the same arithmetic on
+    // the host in double
+    {
+        const int64_t BT = 1000;
+        const int P = 2;
+        std::vector<float> lw(BT), vals(BT * P);
+        for (int64_t i = 0; i < BT; ++i) {
+            lw[i] = (float)(2.0 * gauss());
+            vals[i * P] = (float)gauss();
+            vals[i * P + 1] = (float)(0.5 * vals[i * P] + 0.3 * gauss());
+        }
+        double mx = -1e300, sw = 0.0, sw2 = 0.0, m[2] = {0.0, 0.0}, c[3] = {0.0, 0.0, 0.0};
+        for (float v : lw) mx = v > mx ? v : mx;
+        for (int64_t i = 0; i < BT; ++i) { const double e = std::exp(lw[i] - mx); sw += e; sw2 += e * e; }
+        for (int64_t i = 0; i < BT; ++i) { const double w = std::exp(lw[i] - mx) / sw; m[0] += w * vals[i * P]; m[1] += w * vals[i * P + 1]; }
+        for (int64_t i = 0; i < BT; ++i) {
+            const double w = std::exp(lw[i] - mx) / sw, d0 = vals[i * P] - m[0], d1 = vals[i * P + 1] - m[1];
+            c[0] += w * d0 * d0; c[1] += w * d0 * d1; c[2] += w * d1 * d1;
+        }
+        const double l00 = std::sqrt(c[0]), l10 = c[1] / l00, l11 = std::sqrt(c[2] - l10 * l10);
+        float *d_lw, *d_vals, *d_stats, *d_scratch, *d_mean, *d_chol;
+        int64_t* d_idx;
+        HIP_OK(hipMalloc((void**)&d_lw, sizeof(float) * BT));
+        HIP_OK(hipMalloc((void**)&d_vals, sizeof(float) * BT * P));
+        HIP_OK(hipMalloc((void**)&d_stats, sizeof(float) * 2));
+        HIP_OK(hipMalloc((void**)&d_scratch, sizeof(float) * BT));
+        HIP_OK(hipMalloc((void**)&d_mean, sizeof(float) * P));
+        HIP_OK(hipMalloc((void**)&d_chol, sizeof(float) * P * P));
+        HIP_OK(hipMalloc((void**)&d_idx, sizeof(int64_t) * BT));
+        HIP_OK(hipMemcpy(d_lw, lw.data(), sizeof(float) * BT, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(d_vals, vals.data(), sizeof(float) * BT * P, hipMemcpyHostToDevice));
+        PF_CALL(pf_theta_ess(d_lw, 1, BT, PF_F32, d_stats, nullptr));
+        PF_CALL(pf_theta_resample(d_lw, BT, 0.37, PF_F32, d_idx, d_scratch, nullptr));
+        PF_CALL(pf_theta_fit(d_vals, d_lw, BT, P, 1.1, PF_F32, d_mean, d_chol, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        float stats[2], mean[2], chol[4];
+        std::vector<int64_t> idx(BT);
+        HIP_OK(hipMemcpy(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(mean, d_mean, sizeof(mean), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(chol, d_chol, sizeof(chol), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(idx.data(), d_idx, sizeof(int64_t) * BT, hipMemcpyDeviceToHost));
+        // the host's systematic resampling of the same weights (resampling.py:24-52)
+        int64_t wrong = 0, j = 0;
+        double run = std::exp(lw[0] - mx) / sw;
+        for (int64_t i = 0; i < BT; ++i) {
+            const double p = ((double)i + 0.37) / (double)BT;
+            while (j < BT - 1 && run < p) { ++j; run += std::exp(lw[j] - mx) / sw; }
+            if (std::llabs(idx[i] - j) > 1) ++wrong;  // (float cdf on the device: a position within rounding of a step may take the neighbour)
+        }
+        const double ess = sw * sw / sw2;
+        std::printf("theta level: ESS %.3f (host %.3f)  mean (%.5f, %.5f) (host %.5f, %.5f)  1.1 L = [%.5f; %.5f %.5f] (host [%.5f; %.5f %.5f])  ancestors off by more than one: %lld\n",
+                    stats[0], ess, mean[0], mean[1], m[0], m[1], chol[0], chol[2], chol[3], 1.1 * l00, 1.1 * l10, 1.1 * l11, (long long)wrong);
+        if (!(std::fabs(stats[0] - ess) < 1e-3 * ess) || stats[1] != 1.0f || wrong != 0 || !(std::fabs(mean[0] - m[0]) < 1e-5) ||
+            !(std::fabs(mean[1] - m[1]) < 1e-5) || !(std::fabs(chol[0] - 1.1 * l00) < 1e-5) || !(std::fabs(chol[2] - 1.1 * l10) < 1e-5) ||
+            !(std::fabs(chol[3] - 1.1 * l11) < 1e-5) || chol[1] != 0.0f)
+            ++failures;
+    }
     std::printf("%s (%s)\n", failures ? "c-abi FAILED" : "c-abi ok", pf_version());
     return failures ? 1 : 0;
 }

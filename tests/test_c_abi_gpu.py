@@ -1,7 +1,8 @@
 """The C ABI without Python: ``tests/c_abi/standalone.cpp`` includes ``include/pf_amd.h``, links ``libpfamd.so`` and the
 HIP runtime, allocates device memory itself and runs SISR + Bootstrap and APF + LinearGaussianObservations on the
 reference's AR(1) test model - the whole time loop behind one ``pf_filter_run`` call - against an exact Kalman filter
-computed on the host (log-likelihood within 0.25, final mean within 0.01 at 65 536 particles)."""
+computed on the host (log-likelihood within 0.25, final mean within 0.01 at 65 536 particles) - and the theta-level entry
+points (``pf_theta_ess / _resample / _fit``) against the same arithmetic on the host."""
 import os
 import subprocess
 
@@ -27,3 +28,4 @@ def test_standalone_program_against_kalman(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
     assert "c-abi ok" in run.stdout and run.stdout.count("Kalman") == 8  # 2 variants x 2 columns x (ll, mean)
+    assert "theta level: ESS" in run.stdout
