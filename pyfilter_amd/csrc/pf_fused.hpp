@@ -27,14 +27,23 @@
 
 namespace pf {
 
+// the step kernel's grid axes: x = column, y = tile (bookkeepers last in dispatch order); A/B builds can restore (tiles + 1, B)
+#ifdef PF_STEP_GRID_TILES_FIRST
+#define PF_STEP_B blockIdx.y
+#define PF_STEP_K blockIdx.x
+#else
+#define PF_STEP_B blockIdx.x
+#define PF_STEP_K blockIdx.y
+#endif
+
 // Development instrumentation (cycle stamps, early-exit cuts for per-stage PMC profiles) is compiled in only with
 // -DPF_DEVTOOLS (tools/pmc_stages.py builds that variant); the production kernels carry none of it.
 #ifdef PF_DEVTOOLS
 #define PF_CUT(a, n) ((a).debug_cut == (n))
 #define PF_STAMP(a, slot)                                                                       \
     do {                                                                                        \
-        if ((a).debug_cut < 0 && !(a).finalize_only && blockIdx.x == (unsigned)(-(a).debug_cut - 1) &&  \
-            blockIdx.y == 0 && threadIdx.x == 0)                                                \
+        if ((a).debug_cut < 0 && !(a).finalize_only && PF_STEP_K == (unsigned)(-(a).debug_cut - 1) &&  \
+            PF_STEP_B == 0 && threadIdx.x == 0)                                                 \
             (a).dbg[slot] = (unsigned long long)clock64();                                      \
     } while (0)
 #else
@@ -94,12 +103,6 @@ template <typename T> struct FusedArgs {
     int finalize_only;
     int book_inline;  // the column's bookkeeping is done by its last step workgroup (after its own work) instead of an
                       // extra workgroup per column (development / A-B only since the bookkeepers are dispatched last)
-    int book_rows;    // where the extra workgroups sit in the grid: 0 = block (tiles, b) - one column only: the grid's last
-                      // block -, 1 = rows b >= B of a (tiles, B + ceil(B / tiles)) grid, block (k, B + r) keeping the books of
-                      // column r tiles + k.  Blocks are dispatched in linear order and the 1 024 resident slots (4 per CU)
-                      // are all taken by a 2^20-particle step: with the bookkeepers LAST the step workgroups all start at
-                      // once and the short bookkeepers fill slots as they free up; interleaved per column (block x = tiles
-                      // of every column) they took slots first and the last columns' step workgroups started 2 - 3 us late
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
     __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
@@ -947,7 +950,7 @@ template <typename T> struct StepPlan {
 template <typename T, int D, int VEC, int MODE, int SPEC, bool EARLY_Z, bool MULTI>
 __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, T (&z0)[VEC][D]) {
     const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
+    const int b = PF_STEP_B, k = PF_STEP_K;
     const int step = a.step;
     const bool obs = SPEC ? true : a.is_obs();
     const bool apf = SPEC ? (SPEC == 1) : (a.filter == PF_FILTER_APF);
@@ -1161,7 +1164,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     T* const redm = sh.redm;
     int* hd = reinterpret_cast<int*>(win);  // systematic route: heads of the offspring ranges (the cdf window is not staged)
     const Geom& g = a.g;
-    const int b = blockIdx.y, k = blockIdx.x;
+    const int b = PF_STEP_B, k = PF_STEP_K;
     const int tid = threadIdx.x;
     const int step = a.step;
     const int slot = step & 1;
@@ -1635,17 +1638,12 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC, 
     __shared__ int sh_plan[2];
     __shared__ double crec[MULTI ? 2 * PF_LDS_CHUNKS : 2];
     __shared__ double redb[PF_NWAVES];
-    if (!a.book_inline) {  // the columns' bookkeepers (scratch: 2 + 2 D rows of `red`)
-        if (a.book_rows) {
-            if (blockIdx.y >= (unsigned)a.g.B) {
-                const int bc = (int)(blockIdx.y - (unsigned)a.g.B) * (int)a.g.tiles + (int)blockIdx.x;
-                if (bc < (int)a.g.B) column_bookkeeping<T, D>(a, bc, red, redb);
-                return;
-            }
-        } else if (blockIdx.x == (unsigned)a.g.tiles) {
-            column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
-            return;
-        }
+    // Grid (B, tiles + 1): x = the column, y = the tile - and y == tiles the column's bookkeeper (scratch: 2 + 2 D rows of `red`).
+    // Workgroups are dispatched in linear order (x fastest), so every column's bookkeeper comes AFTER all step workgroups: see
+    // filter_run_impl.  PF_STEP_GRID_TILES_FIRST (A/B builds): the round-2 layout (tiles + 1, B) with its interleaved bookkeepers.
+    if (!a.book_inline && PF_STEP_K == (unsigned)a.g.tiles) {
+        column_bookkeeping<T, D>(a, PF_STEP_B, red, redb);
+        return;
     }
     const SH sh{win, xwin, &sh_j0, sh_cl, sh_wm, red, reds, redm, ptl, ftl, sh_plan, crec};
     T z0[VEC][D];
@@ -1660,8 +1658,8 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC, 
         if (pl.resample) step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, true, MULTI>(a, sh, pl, z0);
         else step_body<T, D, VEC, MODE, PROP, FAST, SPEC, MK, false, MULTI>(a, sh, pl, z0);
     }
-    if (a.book_inline == 1 && blockIdx.x == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
-        column_bookkeeping<T, D>(a, blockIdx.y, red, redb);
+    if (a.book_inline == 1 && PF_STEP_K == (unsigned)a.g.tiles - 1u)  // (reads the partials of the incoming state only)
+        column_bookkeeping<T, D>(a, PF_STEP_B, red, redb);
 }
 
 // clears the per-column records of a fresh run (see filter_run_impl)

@@ -1732,7 +1732,7 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
 }
 
 // Columns of fewer tiles than this keep their books inline (the column's last step workgroup, after its own work).  Since
-// the bookkeepers are dispatched LAST (FusedArgs::book_rows) they cost nothing on the critical path and inline lost at every
+// the bookkeepers are dispatched LAST (the grid's slowest axis is the tile index, see below) they cost nothing on the critical path and inline lost at every
 // shape measured, single-tile columns included (1 024 x 8 192: 65.5 -> 59.1 us per step; 256 x 8 192 27.3 -> 22.1;
 // profiles/r04c_step_kernel_book_inline_threshold_ab.txt): 1 = never.  (Round 2's rule was 8.)
 #ifndef PF_BOOK_INLINE_TILES
@@ -1751,12 +1751,16 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
 #ifdef PF_DEVTOOLS
     if (const char* bi = getenv("PF_BOOK_INLINE")) a.book_inline = atoi(bi);  // (2: nobody keeps the books - timing experiments)
 #endif
-#ifndef PF_NO_BOOK_ROWS
-    a.book_rows = (!a.book_inline && g.B > 1) ? 1 : 0;
+    // Grid (B, tiles + 1), x = the column: blocks are dispatched in linear order and a 2^20-particle step fills every
+    // resident slot of the chip (1 024 = 4 per CU: 33 KB of LDS, 113 VGPRs) - with the tile index slowest the bookkeepers
+    // (y == tiles) come after ALL step workgroups and fill slots as they free up; as block (tiles, b) of a (tiles + 1, B) grid
+    // they sat between the columns, took slots first, and the last columns' step workgroups started 2 - 3 us late
+    // (profiles/r04c_step_kernel_bookkeepers_last_ab.txt).  B = 1 is the same linear order either way.
+#ifdef PF_STEP_GRID_TILES_FIRST
+    const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
 #else
-    a.book_rows = 0;
+    const dim3 grid(g.B, g.tiles + (a.book_inline ? 0 : 1));
 #endif
-    const dim3 grid(g.tiles + ((a.book_inline || a.book_rows) ? 0 : 1), g.B + (a.book_rows ? (g.B + g.tiles - 1) / g.tiles : 0));
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
         // (a kernel, not hipMemsetAsync: captured as a memset node the fill stopped clearing these records after ~195
