@@ -103,6 +103,15 @@ template <typename T> struct FusedArgs {
     int finalize_only;
     int book_inline;  // the column's bookkeeping is done by its last step workgroup (after its own work) instead of an
                       // extra workgroup per column (development / A-B only since the bookkeepers are dispatched last)
+    unsigned kmap;    // block row y -> tile k = ((y & m) << s) + (y >> r), (m, s, r) = bytes 0, 1, 2; 0 = identity.  Workgroups go
+                      // to the 8 XCDs round robin by linear id; a single column of 2^q tiles maps row y to tile
+                      // (y % 8) (tiles / 8) + y / 8 (m = 7, s = q - 3, r = 3): every XCD works on a CONTIGUOUS eighth of the
+                      // column, so the neighbouring tiles whose scans / particles a tile gathers from were written - and are
+                      // still cached - by its own XCD's L2 (many columns with B % 8 == 0 have that property by construction:
+                      // linear id = b + B k)
+    __device__ __forceinline__ int tile_of_row(unsigned y) const {
+        return (int)(((y & (kmap & 0xffu)) << ((kmap >> 8) & 0xffu)) + (y >> ((kmap >> 16) & 0xffu)));
+    }
     unsigned long long* dbg;
     __device__ __forceinline__ const double* part_r() const { return part + (int64_t)(step & 1) * part_stride; }
     __device__ __forceinline__ double* part_w(int state) const { return part + (int64_t)(state & 1) * part_stride; }
@@ -950,7 +959,7 @@ template <typename T> struct StepPlan {
 template <typename T, int D, int VEC, int MODE, int SPEC, bool EARLY_Z, bool MULTI>
 __device__ __forceinline__ StepPlan<T> step_prologue(const FusedArgs<T>& a, const StepShared<T, D, VEC>& sh, T (&z0)[VEC][D]) {
     const Geom& g = a.g;
-    const int b = PF_STEP_B, k = PF_STEP_K;
+    const int b = PF_STEP_B, k = a.tile_of_row(PF_STEP_K);
     const int step = a.step;
     const bool obs = SPEC ? true : a.is_obs();
     const bool apf = SPEC ? (SPEC == 1) : (a.filter == PF_FILTER_APF);
@@ -1164,7 +1173,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     T* const redm = sh.redm;
     int* hd = reinterpret_cast<int*>(win);  // systematic route: heads of the offspring ranges (the cdf window is not staged)
     const Geom& g = a.g;
-    const int b = PF_STEP_B, k = PF_STEP_K;
+    const int b = PF_STEP_B, k = a.tile_of_row(PF_STEP_K);
     const int tid = threadIdx.x;
     const int step = a.step;
     const int slot = step & 1;

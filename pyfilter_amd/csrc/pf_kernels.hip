@@ -1756,6 +1756,14 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     // (y == tiles) come after ALL step workgroups and fill slots as they free up; as block (tiles, b) of a (tiles + 1, B) grid
     // they sat between the columns, took slots first, and the last columns' step workgroups started 2 - 3 us late
     // (profiles/r04c_step_kernel_bookkeepers_last_ab.txt).  B = 1 is the same linear order either way.
+    a.kmap = 0u;
+#ifndef PF_NO_XCD_TILE_MAP
+    if (g.B == 1 && g.tiles >= 16 && (g.tiles & (g.tiles - 1)) == 0) {  // one column of 2^q tiles: an eighth of it per XCD
+        unsigned q = 0;
+        while ((1 << q) < g.tiles) ++q;
+        a.kmap = 7u | ((q - 3u) << 8) | (3u << 16);
+    }
+#endif
 #ifdef PF_STEP_GRID_TILES_FIRST
     const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
 #else
