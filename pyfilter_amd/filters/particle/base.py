@@ -536,7 +536,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         else:
             first[:d].copy_(x_in)
             first[d].copy_(lw_in)
-        anc.copy_(state.ancestors32().reshape(b, n))
+        if self._FILTER_KIND != L.FILTER_APF:  # (an APF names new ancestors at every move: it never reads the incoming ones)
+            anc.copy_(state.ancestors32().reshape(b, n))
 
         a = plan.args
         HINTS.fill(a)
