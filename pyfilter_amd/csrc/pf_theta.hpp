@@ -76,21 +76,22 @@ __device__ __forceinline__ void theta_prior(int kind, double a, double b, double
     }
 }
 
-// lower Cholesky factor of the P x P matrix c (row-major, PF_THETA_MAXP stride); false when it is not positive definite
-__device__ __forceinline__ bool theta_cholesky(const double (&c)[PF_THETA_MAXP][PF_THETA_MAXP], int P, double (&l)[PF_THETA_MAXP][PF_THETA_MAXP]) {
+// lower Cholesky factor of the P x P matrix c (row-major, PF_THETA_MAXP stride; both in LDS: run-time indices into a thread's
+// own arrays would live in scratch); false when it is not positive definite
+__device__ __forceinline__ bool theta_cholesky(const double* c, int P, double* l) {
     bool ok = true;
     for (int i = 0; i < P; ++i)
-        for (int j = 0; j < P; ++j) l[i][j] = 0.0;
+        for (int j = 0; j < P; ++j) l[i * PF_THETA_MAXP + j] = 0.0;
     for (int j = 0; j < P; ++j) {
-        double d = c[j][j];
-        for (int k = 0; k < j; ++k) d -= l[j][k] * l[j][k];
+        double d = c[j * PF_THETA_MAXP + j];
+        for (int k = 0; k < j; ++k) d -= l[j * PF_THETA_MAXP + k] * l[j * PF_THETA_MAXP + k];
         if (!(d > 0.0)) ok = false;
         const double dj = sqrt(d);
-        l[j][j] = dj;
+        l[j * PF_THETA_MAXP + j] = dj;
         for (int i = j + 1; i < P; ++i) {
-            double v = c[i][j];
-            for (int k = 0; k < j; ++k) v -= l[i][k] * l[j][k];
-            l[i][j] = v / dj;
+            double v = c[i * PF_THETA_MAXP + j];
+            for (int k = 0; k < j; ++k) v -= l[i * PF_THETA_MAXP + k] * l[j * PF_THETA_MAXP + k];
+            l[i * PF_THETA_MAXP + j] = v / dj;
         }
     }
     return ok;
@@ -151,17 +152,24 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_fit(const T* __restrict__ va
     }
     __syncthreads();
     block_sum<PF_THETA_PAIRS>(cv, red);
+    __shared__ double sc[PF_THETA_MAXP * PF_THETA_MAXP], sl[PF_THETA_MAXP * PF_THETA_MAXP], sm[PF_THETA_MAXP];
     if (threadIdx.x == 0) {
-        double c[PF_THETA_MAXP][PF_THETA_MAXP], l[PF_THETA_MAXP][PF_THETA_MAXP];
-        for (int p = 0; p < PF_THETA_MAXP; ++p)
-            for (int q = 0; q < PF_THETA_MAXP; ++q) c[p][q] = cv[(p >= q ? p * (p + 1) / 2 + q : q * (q + 1) / 2 + p)];
-        if (!theta_cholesky(c, P, l)) {  // not positive definite: the diagonal alone
+#pragma unroll
+        for (int p = 0; p < PF_THETA_MAXP; ++p) {
+            sm[p] = m[p];
+#pragma unroll
+            for (int q = 0; q <= p; ++q) sc[p * PF_THETA_MAXP + q] = sc[q * PF_THETA_MAXP + p] = cv[p * (p + 1) / 2 + q];
+        }
+        if (!theta_cholesky(sc, P, sl)) {  // not positive definite: the diagonal alone
             for (int p = 0; p < P; ++p)
-                for (int q = 0; q < P; ++q) l[p][q] = (p == q) ? sqrt(c[p][p] > 0.0 ? c[p][p] : 0.0) : 0.0;
+                for (int q = 0; q < P; ++q) {
+                    const double d = sc[p * PF_THETA_MAXP + p];
+                    sl[p * PF_THETA_MAXP + q] = (p == q) ? sqrt(d > 0.0 ? d : 0.0) : 0.0;
+                }
         }
         for (int p = 0; p < P; ++p) {
-            mean_out[p] = (T)m[p];
-            for (int q = 0; q < P; ++q) chol_out[p * P + q] = (T)(scale * l[p][q]);
+            mean_out[p] = (T)sm[p];
+            for (int q = 0; q < P; ++q) chol_out[p * P + q] = (T)(scale * sl[p * PF_THETA_MAXP + q]);
         }
     }
 }
@@ -205,32 +213,46 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_accept(const T* __restrict__
                                                            const T* __restrict__ unif, int64_t B, int P, T* __restrict__ log_acc,
                                                            uint8_t* __restrict__ accepted, T* __restrict__ rate) {
     __shared__ double red[PF_NWAVES];
-    double mf[PF_THETA_MAXP], mr[PF_THETA_MAXP], lf[PF_THETA_MAXP][PF_THETA_MAXP], lr[PF_THETA_MAXP][PF_THETA_MAXP];
-    double hf = 0.0, hr = 0.0;  // sum of the log diagonals
-    for (int p = 0; p < P; ++p) {
-        mf[p] = (double)mean_f[p];
-        mr[p] = (double)mean_r[p];
-        for (int q = 0; q <= p; ++q) {
-            lf[p][q] = (double)chol_f[p * P + q];
-            lr[p][q] = (double)chol_r[p * P + q];
+    // the two kernels' means and factors in LDS (run-time indices into per-thread arrays would live in scratch)
+    __shared__ double smf[PF_THETA_MAXP], smr[PF_THETA_MAXP], slf[PF_THETA_MAXP * PF_THETA_MAXP], slr[PF_THETA_MAXP * PF_THETA_MAXP], sh[2];
+    if (threadIdx.x < PF_THETA_MAXP * PF_THETA_MAXP) {
+        const int p = threadIdx.x / PF_THETA_MAXP, q = threadIdx.x % PF_THETA_MAXP;
+        const bool in = p < P && q <= p;
+        slf[threadIdx.x] = in ? (double)chol_f[p * P + q] : (p == q ? 1.0 : 0.0);
+        slr[threadIdx.x] = in ? (double)chol_r[p * P + q] : (p == q ? 1.0 : 0.0);
+        if (q == 0) {
+            smf[p] = p < P ? (double)mean_f[p] : 0.0;
+            smr[p] = p < P ? (double)mean_r[p] : 0.0;
         }
-        hf += log(lf[p][p]);
-        hr += log(lr[p][p]);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double hf0 = 0.0, hr0 = 0.0;  // sum of the log diagonals
+        for (int p = 0; p < P; ++p) {
+            hf0 += log(slf[p * PF_THETA_MAXP + p]);
+            hr0 += log(slr[p * PF_THETA_MAXP + p]);
+        }
+        sh[0] = hf0;
+        sh[1] = hr0;
+    }
+    __syncthreads();
+    const double hf = sh[0], hr = sh[1];
     const double cst = 0.5 * P * 1.83787706640934548356;  // P / 2 log(2 pi)
-    auto log_q = [&](const T* x, const double (&m)[PF_THETA_MAXP], const double (&l)[PF_THETA_MAXP][PF_THETA_MAXP], double h) {
+    auto log_q = [&](const T* x, const double* m, const double* l, double h) {
         double z[PF_THETA_MAXP], ss = 0.0;
-        for (int p = 0; p < P; ++p) {  // forward substitution: z = L^-1 (x - m)
-            double v = (double)x[p] - m[p];
-            for (int q = 0; q < p; ++q) v -= l[p][q] * z[q];
-            z[p] = v / l[p][p];
+#pragma unroll
+        for (int p = 0; p < PF_THETA_MAXP; ++p) {  // forward substitution: z = L^-1 (x - m)  (rows beyond P: identity, z = 0)
+            double v = p < P ? (double)x[p] - m[p] : 0.0;
+#pragma unroll
+            for (int q = 0; q < p; ++q) v -= l[p * PF_THETA_MAXP + q] * z[q];
+            z[p] = v / l[p * PF_THETA_MAXP + p];
             ss += z[p] * z[p];
         }
         return -0.5 * ss - h - cst;
     };
     double cnt[1] = {0.0};
     for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
-        const double la = (log_q(u_cur + i * P, mr, lr, hr) - log_q(u_star + i * P, mf, lf, hf)) +
+        const double la = (log_q(u_cur + i * P, smr, slr, hr) - log_q(u_star + i * P, smf, slf, hf)) +
                           ((double)prior_star[i] - (double)prior_cur[i]) + ((double)ll_star[i] - (double)ll_cur[i]);
         const T la_t = (T)la;
         log_acc[i] = la_t;
