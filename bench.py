@@ -81,7 +81,8 @@ def check_loglikelihood(workload, w, ll_all):
 
 def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None, solo=False):
     """BASELINE configs[4] as the algorithm; returns (elapsed seconds for `steps` full fits, info).  ``solo``: the whole
-    job on this rank alone, no sharding, no collectives (the single-GPU reference leg of a multi-GPU line)."""
+    job (``w["B"]`` theta-particles) on this rank alone, no sharding, no collectives (the single-GPU reference leg of a
+    multi-GPU line).  ``w["B"]`` is the TOTAL number of theta-particles: 1 024 (strong scaling) or 1 024 per GPU (weak)."""
     import torch.distributed as dist
     from torch.distributions import Exponential, LogNormal, Normal
 
@@ -133,6 +134,141 @@ def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None, solo
             "theta_per_rank": alg.shard.local, "T": t_len}
     return elapsed, info, state.global_weights()
 
+
+
+def smc2_step_kernel_roofline(w, b_local, dtype, device, t_len=64):
+    """The dominant kernel of the SMC^2 job - ``k_fused_step`` at the PER-RANK shape (``b_local`` filters x 8 192 particles,
+    APF + optimal proposal on the OU model: what every online move and every PMMH re-filter launches) - timed with HIP events
+    on the launch stream (``pf_filter_run_timed``) on a filter of exactly that shape, priced on SURVEY 8(d)'s APF bytes."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.timeseries import models
+
+    gen = torch.Generator().manual_seed(77)
+    t = lambda v: torch.tensor(v, dtype=dtype, device=device)  # noqa: E731
+    kappa = (0.01 + 0.05 * torch.rand(b_local, generator=gen)).to(dtype).to(device)
+    gamma = (0.2 * torch.randn(b_local, generator=gen)).to(dtype).to(device)
+    sigma = (0.03 + 0.04 * torch.rand(b_local, generator=gen)).to(dtype).to(device)
+    ssm = ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(kappa, gamma, sigma, dt=1.0), (t(1.0), t(0.05)))
+    filt = APF(ssm, w["N"], proposal=proposals.LinearGaussianObservations(), seed=9)
+    filt.set_batch_shape(torch.Size([b_local]))
+    y = (0.1 * torch.randn(t_len, generator=gen)).to(dtype).to(device)
+    filt.batch_filter(y, bar=False)
+    filt._time_kernels = True
+    filt.batch_filter(y, bar=False)
+    torch.cuda.synchronize()
+    filt._time_kernels = False
+    step_ms = filt.kernel_ms[2]
+    esz = 8 if dtype == torch.float64 else 4
+    bm = byte_models(dict(w, D=1, filter="apf"), esz)
+    units = w["N"] * b_local
+    gbs = {k: v * units / (step_ms * 1e-3) / 1e9 for k, v in bm.items()}
+    return {
+        "bound": "valu" if gbs["as_built"] / HBM_PEAK_GBS < 0.30 else "hbm", "priced_against": "hbm",
+        "kernel": "k_fused_step", "achieved": gbs["survey_8d"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": gbs["survey_8d"] / HBM_PEAK_GBS, "traffic": None,
+        "shape": f"{b_local} filters x {w['N']} particles per launch (this rank's theta-block), APF + lgo, OU",
+        "byte_model": "survey_8d: SURVEY.md 8(d) APF bytes (32 + 16 D) x particles per launch / the step kernel's in-sequence duration",
+        "bytes_per_particle": bm, "bytes_per_launch": {k: v * units for k, v in bm.items()},
+        "kernel_us": {"k_fused_step": 1e3 * step_ms},
+        "duration_source": "HIP events on the launch stream around the step launches of a 64-move run at this shape (pf_filter_run_timed)",
+        "as_built": {"achieved": gbs["as_built"], "frac": gbs["as_built"] / HBM_PEAK_GBS},
+    }
+
+
+def smc2_cpu_baseline(w, seconds_budget=12.0, b_sample=8):
+    """The oracle on the host cores for the FILTERING moves of the SMC^2 job (what ``value`` counts): APF + optimal proposal on
+    the OU model, ``b_sample`` theta-particles x 8 192 state particles, as many observations as fit the budget - the
+    rejuvenations (re-filtering all parsed data per PMMH move) would come on top, so this flatters the CPU."""
+    from oracle import cpu_ref
+    from oracle import models as M
+
+    g = torch.Generator().manual_seed(1)
+    n, b = w["N"], b_sample
+    kappa, gamma = 0.01 + 0.05 * torch.rand(b, generator=g), 0.2 * torch.randn(b, generator=g)
+    sigma = 0.03 + 0.04 * torch.rand(b, generator=g)
+    spec = M.ModelSpec(M.HID_OU, (kappa, gamma, sigma), 0, 1.0, (0.0, 0.1), M.OBS_LINEAR, (1.0, 0.0, 0.05), 0)
+    y, x0 = 0.1 * torch.randn(4096, generator=g), 0.1 * torch.randn(n, b, generator=g)
+
+    def run(steps):
+        t0 = time.perf_counter()
+        cpu_ref.batch_filter(spec, "apf", "lgo", y[:steps], x0, None, None)
+        return time.perf_counter() - t0
+
+    cores = os.cpu_count() or 1
+    best = None
+    for th in sorted({c for c in (1, 8, 16, 32) if c <= cores}):
+        torch.set_num_threads(th)
+        run(1)
+        dt = min(run(2) for _ in range(2)) / 2
+        if best is None or dt < best[1]:
+            best = (th, dt)
+    torch.set_num_threads(best[0])
+    steps = int(max(3, min(400, seconds_budget / best[1])))
+    dt = run(steps)
+    return {"value": n * b * steps / dt, "unit": "particle-steps/s", "cores": best[0], "kind": "port",
+            "sample": f"smc2: the filtering moves only - APF + lgo on the OU model, {b} theta-particles x {n} state particles, {steps} "
+                      f"observations ({dt:.1f} s) of T={w['T']}, fp32, oracle/cpu_ref.py on {best[0]} threads (best of 1/8/16/32); no "
+                      f"rejuvenation work (the GPU figure includes it as overhead)",
+            "host": host_info()}
+
+
+def smc2_line(args, dtype, device, world, rank, scaling, attach=False):
+    """One JSON-able record of the SMC^2 job (BASELINE configs[4]).  ``scaling``: ``"strong"`` - 1 024 theta-particles split over
+    the ranks; ``"weak"`` - 1 024 per GPU.  At N = 1 both are the same job: the N = 1 point of either curve."""
+    import torch.distributed as dist
+
+    w = dict(WORKLOADS["smc2"])
+    per_gpu = w["B"]
+    if scaling == "weak":
+        w["B"] = per_gpu * world
+    elapsed, info, _ = run_smc2(w, dtype, device, world, rank, args.steps, args.warmup, args.T)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    solo = None
+    if world > 1:  # the one-GPU job of the same curve on ONE of these GPUs (rank 0 alone, the others wait)
+        if rank == 0:
+            try:  # (rank 0 alone: whatever happens here it must reach the barrier the others wait at)
+                k = max(1, min(2, args.steps))
+                w1 = dict(w, B=per_gpu)
+                e1, _, _ = run_smc2(w1, dtype, device, world, rank, k, 1, args.T, solo=True)
+                solo = {"value": w1["N"] * w1["B"] * info["T"] * k / e1, "unit": "particle-steps/s", "ms_per_step": 1e3 * e1 / k,
+                        "what": f"{per_gpu} theta-particles on rank 0's GPU alone (no sharding, no collectives), timed after the "
+                                f"N-GPU region: the N = 1 point of this curve"}
+            except Exception as exc:
+                solo = {"error": f"{type(exc).__name__}: {exc}"}
+        dist.barrier()
+    roof = None
+    if rank == 0:
+        try:
+            roof = smc2_step_kernel_roofline(w, info["theta_per_rank"], dtype, device)
+        except Exception as exc:
+            roof = {"error": f"{type(exc).__name__}: {exc}"}
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        return None
+    value = w["N"] * w["B"] * info["T"] * args.steps / elapsed
+    if solo and "value" in solo:
+        solo["speedup_over_it"] = value / solo["value"]
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not attach:
+        cpu = smc2_cpu_baseline(dict(w, T=info["T"]))
+    out = {
+        "metric": f"particle-steps/sec (batch x particles x T), SMC^2 {w['B']} theta x {w['N']} particles", "value": value,
+        "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic", "world_size": world,
+        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+        "config": {"workload": f"smc2: SMC^2, APF + lgo, {w['B']} theta-particles (sharded {info['theta_per_rank']} per GPU) x "
+                               f"{w['N']} state particles, T={info['T']}, theta-weights all-gathered per block of 16 observations",
+                   "parallelism": f"theta-particles block-sharded over {world} GPU(s)", **info},
+        "single_gpu_same_workload": solo, "roofline": roof, "cpu_baseline": cpu}
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+    return out
 
 
 def build_problem(name, dtype, device, world, rank, t_override=None, n_override=None):
@@ -400,7 +536,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="default: apf_lgo_1m on one GPU (BASELINE configs[1]), smc2 on several (configs[4], strong scaling)")
+                    help="default: apf_lgo_1m (BASELINE configs[1]) - with N > 1 one replica per GPU (weak scaling: the N = 1 "
+                         "job on every GPU) and the SMC^2 job (configs[4]) attached to the same line, strong and weak")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="--workload smc2: 1 024 theta-particles split over the GPUs (strong, default) or 1 024 per GPU (weak)")
+    ap.add_argument("--no-smc2", action="store_true", help="N > 1 default workload: skip the attached SMC^2 records")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--T", type=int, default=None, help="override the number of observations")
     ap.add_argument("--N", type=int, default=None, help="override the number of particles (development: shape studies)")
@@ -452,8 +592,13 @@ def main():
     dtype = {"f32": torch.float32, "f64": torch.float64}[args.dtype]
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
-    if args.workload is None:
-        args.workload = "apf_lgo_1m" if world == 1 else "smc2"
+    default_job = args.workload is None
+    if default_job:
+        # ONE workload at every N, so that value(N) / (N value(1)) is a scaling curve: BASELINE configs[1], whose single
+        # filter does not shard (replicas only) - one replica per GPU, log-likelihoods all-gathered.  The
+        # job that DOES shard - SMC^2, configs[4] - rides on the same line at N > 1 (``smc2_scaling``: strong and weak, each
+        # with its own one-GPU point measured in the same process).
+        args.workload = "apf_lgo_1m"
 
     import __graft_entry__ as ge
 
@@ -463,35 +608,9 @@ def main():
         dist.barrier()
 
     if args.workload == "smc2":
-        w = dict(WORKLOADS["smc2"])
-        elapsed, info, ll_all = run_smc2(w, dtype, device, world, rank, args.steps, args.warmup, args.T)
-        if world > 1:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            elapsed = tmax.item()
-        solo = None
-        if world > 1:  # the same job on ONE of these GPUs (rank 0 alone, the others wait): the strong-scaling reference
-            if rank == 0:
-                e1, _, _ = run_smc2(w, dtype, device, world, rank, max(1, min(2, args.steps)), 1, args.T, solo=True)
-                solo = {"value": w["N"] * w["B"] * info["T"] * max(1, min(2, args.steps)) / e1, "unit": "particle-steps/s",
-                        "what": "the whole 1024-theta job on rank 0's GPU alone (no sharding, no collectives), timed after the "
-                                "N-GPU region"}
-            dist.barrier()
+        out = smc2_line(args, dtype, device, world, rank, args.scaling or "strong")
         if rank == 0:
-            value = w["N"] * w["B"] * info["T"] * args.steps / elapsed
-            if solo:
-                solo["speedup_over_it"] = value / solo["value"]
-            print(json.dumps({
-                "metric": "particle-steps/sec (batch x particles x T), SMC^2 1024 theta x 8192 particles", "value": value,
-                "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": args.dtype, "data": "synthetic", "world_size": world,
-                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
-                "config": {"workload": f"smc2: SMC^2, APF + lgo, {w['B']} theta-particles (sharded {info['theta_per_rank']} per GPU) x "
-                                       f"{w['N']} state particles, T={info['T']}, theta-weights all-gathered per block of 16 observations",
-                           "parallelism": f"theta-particles block-sharded over {world} GPU(s)", **info},
-                "single_gpu_same_workload": solo,
-                "roofline": None, "cpu_baseline": None}))
+            print(json.dumps(out))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -623,6 +742,18 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
+    if world > 1 and default_job and not args.no_smc2:
+        # the sharded job of BASELINE configs[4] on the same ranks (every rank takes part; rank 0 keeps the records)
+        attached = {}
+        for scaling in ("strong", "weak"):
+            try:
+                rec = smc2_line(args, dtype, device, world, rank, scaling, attach=True)
+            except Exception as exc:  # (a failure here must not cost the line its measured headline)
+                rec = {"error": f"{type(exc).__name__}: {exc}"}
+            attached[scaling] = rec
+        if rank == 0:
+            out["smc2_scaling"] = attached
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -7,6 +7,14 @@ the Verhulst SV model of examples/stochastic-volatility.ipynb, Lorenz-63 of exam
 of tests/inference/models.py:12-19, and the reference's own 2-D acceptance model - the random walk with sigma = (0.05, 0.1),
 A = I2, s = 0.15 of tests/filters/models.py:28-52 (``rw2d``; B in {1, 3} and 10 % NaN rows as tests/filters/test_particle.py:44-63
 runs it).
+
+Round 5 - the observation shapes and schedules the kernels accept beyond those: a SCALAR observation of a vector state
+(``event_shape = Size([])`` with ``a`` of shape ``(D,)``: the ``obs_is_1d`` branch of proposals/utils.py:243-260; ``lorenz_s``,
+``rw2d_s``) and the same observation declared as a vector of length one (``event_shape = Size([1])``, ``a`` of shape ``(1, D)``:
+``lorenz_o1``, ``rw2d_o1`` - the only way the reference's APF + LinearGaussianObservations runs on such a model: its
+``pre_weight`` mixes ``(N, B, D)`` and ``(N, B)`` tensors for ``obs_is_1d`` and D > 1, proposals/linear.py:79-81), D = 3 / O = 3
+with a dense ``A``, a non-zero offset and three distinct noise scales (``lorenz_o3``), per-filter ``sigma / A / b / s`` rows on a
+vector model (``rw2d_theta``), and ``observe_every_step > 1`` (filters/base.py:196-221; ``*_oes3``).
 """
 import math
 
@@ -52,12 +60,61 @@ CASES = [
          ess_threshold=0.5, seed=115, dtypes=("f64",)),
     dict(name="rw2d_apf_boot", model="rw2d", filter="apf", proposal="bootstrap", N=333, B=2, T=20,
          ess_threshold=0.9, seed=116, nan_steps=(7,), dtypes=("f64",)),
+    # ---- round 5 ---------------------------------------------------------------------------------------------------
+    # D = 3 / scalar observation (event_shape = Size([])): y = 0.8 x1 + 0.3 x3 + s v
+    dict(name="lorenz_s_sisr_lgo", model="lorenz_s", filter="sisr", proposal="lgo", N=256, B=2, T=15,
+         ess_threshold=0.9, seed=117, dtypes=("f64", "f32")),
+    dict(name="lorenz_s_apf_boot", model="lorenz_s", filter="apf", proposal="bootstrap", N=200, B=3, T=15,
+         ess_threshold=0.9, seed=118, nan_steps=(6,), dtypes=("f64",)),
+    # ... the same observation as a vector of length one (event_shape = Size([1])): the APF + optimal proposal
+    dict(name="lorenz_o1_apf_lgo", model="lorenz_o1", filter="apf", proposal="lgo", N=128, B=2, T=15,
+         ess_threshold=0.9, seed=119, dtypes=("f64", "f32")),
+    # D = 2 / scalar observation: y = x1 + 0.5 x2 + s v
+    dict(name="rw2d_s_sisr_lgo", model="rw2d_s", filter="sisr", proposal="lgo", N=300, B=3, T=20,
+         ess_threshold=0.6, seed=120, nan_steps=(5,), dtypes=("f64",)),
+    dict(name="rw2d_o1_apf_lgo", model="rw2d_o1", filter="apf", proposal="lgo", N=256, B=1, T=20,
+         ess_threshold=0.9, seed=121, nan_steps=(4, 12), dtypes=("f64", "f32")),
+    dict(name="rw2d_s_sisr_boot", model="rw2d_s", filter="sisr", proposal="bootstrap", N=333, B=2, T=20,
+         ess_threshold=0.9, seed=122, dtypes=("f64",)),
+    # D = 3 / O = 3: dense A, offset, three noise scales - the full 3x3 algebra of the optimal proposal
+    dict(name="lorenz_o3_apf_lgo", model="lorenz_o3", filter="apf", proposal="lgo", N=128, B=2, T=15,
+         ess_threshold=0.9, seed=123, dtypes=("f64", "f32")),
+    dict(name="lorenz_o3_sisr_lgo", model="lorenz_o3", filter="sisr", proposal="lgo", N=200, B=1, T=15,
+         ess_threshold=0.7, seed=124, nan_steps=(9,), dtypes=("f64",)),
+    dict(name="lorenz_o3_sisr_boot", model="lorenz_o3", filter="sisr", proposal="bootstrap", N=256, B=2, T=15,
+         ess_threshold=0.9, seed=125, dtypes=("f64",)),
+    # per-filter (theta on the batch dim) sigma / A / b / s rows of a VECTOR model: B = 3 distinct parameter sets
+    dict(name="rw2d_theta_apf_lgo", model="rw2d_theta", filter="apf", proposal="lgo", N=256, B=3, T=20,
+         ess_threshold=0.9, seed=126, nan_steps=(8,), dtypes=("f64", "f32")),
+    dict(name="rw2d_theta_sisr_boot", model="rw2d_theta_b", filter="sisr", proposal="bootstrap", N=300, B=3, T=20,
+         ess_threshold=0.8, seed=127, dtypes=("f64",)),
+    dict(name="rw2d_theta_sisr_lgo", model="rw2d_theta", filter="sisr", proposal="lgo", N=128, B=3, T=20,
+         ess_threshold=0.5, seed=128, dtypes=("f64",)),
+    # observe_every_step = 3 (filters/base.py:204-210): two propagate-only moves before every weighted one, NaN rows too
+    dict(name="lg1d_sisr_boot_oes3", model="lg1d", filter="sisr", proposal="bootstrap", N=500, B=2, T=12,
+         ess_threshold=0.9, seed=129, observe_every_step=3, nan_steps=(4, 5), dtypes=("f64", "f32")),
+    dict(name="sine_apf_lgo_oes3", model="sine", filter="apf", proposal="lgo", N=256, B=3, T=12,
+         ess_threshold=0.9, seed=130, observe_every_step=3, nan_steps=(7,), dtypes=("f64", "f32")),
+    dict(name="lorenz_sisr_boot_oes2", model="lorenz", filter="sisr", proposal="bootstrap", N=256, B=2, T=10,
+         ess_threshold=0.5, seed=131, observe_every_step=2, dtypes=("f64",)),
+    dict(name="sv_apf_boot_oes5", model="sv_batched", filter="apf", proposal="bootstrap", N=256, B=4, T=8,
+         ess_threshold=0.9, seed=132, observe_every_step=5, dtypes=("f64",)),  # the SV notebook's own setting (:83)
 ]
+
+_LORENZ_A_S = [0.8, 0.0, 0.3]
+_LORENZ_A_O3 = [[0.8, 0.1, 0.0], [-0.2, 0.9, 0.05], [0.0, 0.3, 0.7]]
+_RW2D_A_S = [1.0, 0.5]
 
 CASE_BY_NAME = {c["name"]: c for c in CASES}
 
 
 def build_spec(case, dtype=torch.float64) -> M.ModelSpec:
+    spec = _build_spec(case, dtype)
+    spec.observe_every_step = int(case.get("observe_every_step", 1))
+    return spec
+
+
+def _build_spec(case, dtype=torch.float64) -> M.ModelSpec:
     m, b = case["model"], case["B"]
     t = lambda v: torch.tensor(v, dtype=dtype)  # noqa: E731
 
@@ -76,6 +133,31 @@ def build_spec(case, dtype=torch.float64) -> M.ModelSpec:
         return M.ModelSpec(
             M.HID_LORENZ63_EM, (10.0, 28.0, 8.0 / 3.0, 1.0), 3, 0.01, (t(_LORENZ_INIT[0]), t(_LORENZ_INIT[1])),
             M.OBS_LINEAR, (t(_LORENZ_A), t([0.0]), t([math.sqrt(0.1)])), 2,
+        )
+    if m in ("lorenz_s", "lorenz_o1", "lorenz_o3"):  # lorenz.ipynb's process under other linear observations
+        hid = (M.HID_LORENZ63_EM, (10.0, 28.0, 8.0 / 3.0, 1.0), 3, 0.01, (t(_LORENZ_INIT[0]), t(_LORENZ_INIT[1])))
+        if m == "lorenz_s":  # scalar observation: event_shape = Size([]), a of shape (D,)
+            return M.ModelSpec(*hid, M.OBS_LINEAR, (t(_LORENZ_A_S), t(0.0), t(math.sqrt(0.1))), 0)
+        if m == "lorenz_o1":  # the same observation as a vector of length one
+            return M.ModelSpec(*hid, M.OBS_LINEAR, (t([_LORENZ_A_S]), t([0.0]), t([math.sqrt(0.1)])), 1)
+        return M.ModelSpec(*hid, M.OBS_LINEAR, (t(_LORENZ_A_O3), t([0.1, -0.2, 0.3]), t([0.3, 0.4, 0.5])), 3)
+    if m in ("rw2d_s", "rw2d_o1"):
+        sig = t([0.05, 0.1])
+        hid = (M.HID_LINEAR, (torch.zeros_like(sig), torch.ones_like(sig), sig), 2, 1.0, (torch.zeros_like(sig), sig))
+        if m == "rw2d_s":
+            return M.ModelSpec(*hid, M.OBS_LINEAR, (t(_RW2D_A_S), t(0.05), t(0.15)), 0)
+        return M.ModelSpec(*hid, M.OBS_LINEAR, (t([_RW2D_A_S]), t([0.05]), t([0.15])), 1)
+    if m in ("rw2d_theta", "rw2d_theta_b"):
+        # B distinct (sigma, A, s) rows: theta on the batch dim of a vector model.  The offset b is shared by the filters
+        # under the optimal proposal - the reference's find_optimal_density takes ``y - b`` of shape (B, O) for a MATRIX
+        # (proposals/utils.py:260 ``o_inv_cov.matmul(y)``) and raises - and per filter in the ``_b`` variant (Bootstrap)
+        sig = torch.stack([t([0.05 + 0.02 * i, 0.1 - 0.02 * i]) for i in range(b)])               # (B, 2)
+        a = torch.stack([(1.0 + 0.25 * i) * t([[1.0, 0.2 * i], [-0.1 * i, 1.0]]) for i in range(b)])  # (B, 2, 2)
+        off = torch.stack([t([0.02 * i, -0.03 * i]) for i in range(b)]) if m == "rw2d_theta_b" else t([0.02, -0.03])
+        s = torch.stack([t([0.15 + 0.05 * i, 0.2 - 0.03 * i]) for i in range(b)])                  # (B, 2)
+        return M.ModelSpec(
+            M.HID_LINEAR, (torch.zeros_like(sig), torch.ones_like(sig), sig), 2, 1.0, (torch.zeros_like(sig), sig),
+            M.OBS_LINEAR, (a, off, s), 2,
         )
     if m == "rw2d":  # tests/filters/models.py:28-52: x' = I2 x + (0.05, 0.1) e, x0 ~ N(0, sigma), y ~ N(I2 x, 0.15)
         sig = t([0.05, 0.1])
@@ -98,13 +180,14 @@ def simulate(case, spec: M.ModelSpec, dtype=torch.float64) -> torch.Tensor:
     t_len = case["T"]
     b = case["B"]
     per_series = case["model"] == "sv_batched"
-    shape = (1, b) if (per_series or case["model"] == "ou_batched") else (1, 1)
+    shape = (1, b) if (per_series or case["model"] in ("ou_batched", "rw2d_theta", "rw2d_theta_b")) else (1, 1)
     if spec.dim > 0:
         shape = shape + (spec.dim,)
     x = M.initial_sample(spec, torch.randn(shape, generator=g, dtype=dtype))
     ys = []
     for _ in range(t_len):
-        x = M.propagate(spec, x, torch.randn(shape, generator=g, dtype=dtype))
+        for _ in range(spec.observe_every_step):  # (observed at every observe_every_step-th move of the process)
+            x = M.propagate(spec, x, torch.randn(shape, generator=g, dtype=dtype))
         loc, scale = M.obs_loc_scale(spec, x)
         scale = M._t(scale, loc)
         yv = loc + scale * torch.randn(loc.shape, generator=g, dtype=dtype)

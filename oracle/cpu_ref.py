@@ -271,14 +271,17 @@ def batch_filter(
     ess_threshold: float = 0.9,
     resampler: str = "systematic",
     record_steps: bool = False,
+    observe_every_step: Optional[int] = None,
+    time_index: int = 0,
 ):
-    """BaseFilter.batch_filter / filter (filters/base.py:140-221) + FilterResult.append (filters/result.py:119-133)
-    for ``observe_every_step == 1``.
+    """BaseFilter.batch_filter / filter (filters/base.py:140-221) + FilterResult.append (filters/result.py:119-133);
+    ``observe_every_step`` defaults to the spec's, ``time_index`` is the incoming state's.
 
     Args:
         y: ``(T,[O])`` or - for B independent scalar series - ``(T,B)``.
         x0: ``(N,[B],[D])`` initial particles.
-        z_tape: ``(T,N,[B],[D])`` standard normals;  u_tape: ``(T,B)`` uniforms (``B=1`` when unbatched) or None.
+        z_tape: ``(T,N,[B],[D])`` standard normals;  u_tape: ``(T,B)`` uniforms (``B=1`` when unbatched) or None - one
+            row per MOVE (= per observation when ``observe_every_step == 1``).
             Either may be None: the draws then come from torch's global CPU generator, as in the reference (this is
             the mode ``bench.py`` times as the CPU baseline).
 
@@ -299,19 +302,36 @@ def batch_filter(
     steps = {"x": [], "w": [], "ll": [], "idx": []}
     thr = ess_threshold * n
 
+    # observe_every_step > 1 (filters/base.py:204-210): before the weighted move of an observation the filter makes
+    # ``(-time_index) % observe_every_step`` propagate-only moves, each preceded by its own ``predict`` (a SISR may resample
+    # there).  The tapes are per MOVE; only the state after an observation's weighted move is reported (the reference's
+    # default ``record_intermediary_states=False``), its log-likelihood increment being that move's (the sub-steps add 0).
+    oes = int(getattr(spec, "observe_every_step", 1) if observe_every_step is None else observe_every_step)
+    time_index, move = int(time_index), 0
+
+    def sub_step(x, w, prev, u, z):
+        if filt == "sisr":  # predict still runs (and may resample) before the propagate-only move
+            x, w, _, idx, _ = sisr_predict(spec, x, w, prev, u, thr, resampler)
+        else:  # APF.predict hands out identity ancestors (apf.py:18-23)
+            idx = torch.arange(n)
+            if w.dim() > 1:
+                idx = idx.unsqueeze(-1).expand(w.shape)
+        x, w, ll = propagate_only_step(spec, x, w, z)
+        return x, w, ll, idx
+
     for t in range(y.shape[0]):
         y_t = y[t]
+        for _ in range((-time_index) % oes):
+            u = None if u_tape is None else u_tape[move]
+            z = z_tape[move] if z_tape is not None else torch.randn(x.shape, dtype=x.dtype)
+            x, w, _, prev = sub_step(x, w, prev, u, z)
+            move, time_index = move + 1, time_index + 1
         # no tape: draw like the reference does (torch's global CPU generator), u first then z (Appendix A)
-        u = None if u_tape is None else u_tape[t]
-        z = z_tape[t] if z_tape is not None else torch.randn(x.shape, dtype=x.dtype)
+        u = None if u_tape is None else u_tape[move]
+        z = z_tape[move] if z_tape is not None else torch.randn(x.shape, dtype=x.dtype)
+        move, time_index = move + 1, time_index + 1
         if bool(y_t.isnan().all()):
-            if filt == "sisr":  # predict still runs (and may resample) before the propagate-only move
-                x, w, _, idx, _ = sisr_predict(spec, x, w, prev, u, thr, resampler)
-            else:  # APF.predict hands out identity ancestors (apf.py:18-23)
-                idx = torch.arange(n)
-                if w.dim() > 1:
-                    idx = idx.unsqueeze(-1).expand(w.shape)
-            x, w, ll = propagate_only_step(spec, x, w, z)
+            x, w, ll, idx = sub_step(x, w, prev, u, z)
         elif filt == "sisr":
             x, w, ll, idx, _ = sisr_step(spec, proposal, y_t, x, w, prev, z, u, thr, resampler)
         elif filt == "apf":

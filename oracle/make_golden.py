@@ -18,6 +18,12 @@ Tape injection (the reference's arithmetic is untouched):
 * the ``resampling=`` ctor argument receives a callable that draws ``u`` (float32), records it and calls the
   reference's ``systematic(w, normalized=..., u=u)``.  ``batch_shape=[B>=1]`` always: the reference drops ``u``
   for 1-D weights (resampling.py:14).
+* ``observe_every_step > 1`` (round 5): one ``filter()`` call is several moves (filters/base.py:204-210); the tapes are then
+  PER MOVE - ``u_tape (moves, B)`` drawn at the top of every ``predict`` (the only place a SISR resamples; the APF's
+  resampling in ``correct`` follows the call's last ``predict``), ``z_tape (moves, N, B, [D])`` one lazily drawn transition
+  per move, in order - and ``move_of_obs (T,)`` names the move that consumed each observation.
+
+    python oracle/make_golden.py --only lorenz_s_sisr_lgo,...   # (re)generates the named cases only
 
 The fixtures are data only.  The reference source never leaves this container.
 """
@@ -33,7 +39,7 @@ STATE_DICT_CASES = ("lg1d_apf_lgo", "lorenz_sisr_boot", "sv_sisr_boot", "rw2d_ap
 STATE_DICT_AT = 12  # observations consumed when the checkpoint is taken
 
 
-def _main_child(dtype_name: str):
+def _main_child(dtype_name: str, only=None):
     import math
 
     import numpy as np
@@ -138,9 +144,9 @@ def _main_child(dtype_name: str):
         op = tuple(torch.as_tensor(p, dtype=dtype) for p in spec.obs_params)
         if spec.obs == M.OBS_LINEAR:
             es = torch.Size([spec.obs_dim]) if spec.obs_dim > 0 else torch.Size([])
-            return ts.LinearStateSpaceModel(hidden, op, es)
+            return ts.LinearStateSpaceModel(hidden, op, es, observe_every_step=spec.observe_every_step)
         if spec.obs == M.OBS_SV:
-            return ts.StateSpaceModel(hidden, lambda x, mu: Normal(mu, x.value), op)
+            return ts.StateSpaceModel(hidden, lambda x, mu: Normal(mu, x.value), op, observe_every_step=spec.observe_every_step)
         raise NotImplementedError(spec.obs)
 
     def flatten_state_dict(sd, prefix="sd"):
@@ -158,8 +164,9 @@ def _main_child(dtype_name: str):
     os.makedirs(GOLDEN, exist_ok=True)
 
     for case in CASES:
-        if dtype_name not in case["dtypes"]:
+        if dtype_name not in case["dtypes"] or (only is not None and case["name"] not in only):
             continue
+        oes = int(case.get("observe_every_step", 1))
         torch.manual_seed(case["seed"])
         spec = build_spec(case, dtype)
         ssm = build_reference_model(spec)
@@ -171,6 +178,9 @@ def _main_child(dtype_name: str):
 
         class Taped(filt_cls):
             def predict(self, state):
+                if oes > 1:  # per-move tapes: a fresh u at the top of every predict
+                    tape.cur_u = torch.rand(b, dtype=torch.float32)
+                    u_tape.append(tape.cur_u)
                 if case["filter"] == "sisr":
                     w_ = ref_normalize(state.weights.clone())
                     tape.mask = ref_get_ess(w_, normalized=True) < self._resample_threshold
@@ -195,17 +205,22 @@ def _main_child(dtype_name: str):
         result = filt.initialize_with_result(state)
 
         steps = {k: [] for k in ("x", "w", "ll", "idx")}
-        u_tape, z_tape = [], []
+        u_tape, z_tape, move_of_obs = [], [], []
         all_states, checkpoint = [state], None
         for t in range(t_len):
             if t == STATE_DICT_AT and case["name"] in STATE_DICT_CASES:
                 checkpoint = flatten_state_dict(result.state_dict())
-            tape.cur_u = torch.rand(b, dtype=torch.float32)
-            u_tape.append(tape.cur_u)
+            if oes == 1:
+                tape.cur_u = torch.rand(b, dtype=torch.float32)
+                u_tape.append(tape.cur_u)
+            t_before = int(state.timeseries_state.time_index)
             state = filt.filter(y[t], state, result=result)
             _ = state.timeseries_state.value  # force the lazy sample
-            assert len(tape.z) == 1, len(tape.z)
-            z_tape.append(tape.z.pop())
+            moves = int(state.timeseries_state.time_index) - t_before
+            assert len(tape.z) == moves and (oes > 1 or moves == 1), (len(tape.z), moves)
+            z_tape.extend(tape.z)
+            tape.z.clear()
+            move_of_obs.append(len(z_tape) - 1)
             steps["x"].append(state.timeseries_state.value.clone())
             steps["w"].append(state.weights.clone())
             steps["ll"].append(state.get_loglikelihood().clone())
@@ -222,11 +237,15 @@ def _main_child(dtype_name: str):
             "filter_variance": result.filter_variance.numpy(),
             "loglikelihood": result.loglikelihood.numpy(),
         }
+        if oes > 1:
+            assert len(u_tape) == len(z_tape)
+            out["move_of_obs"] = np.asarray(move_of_obs, dtype=np.int64)
         for k, v in steps.items():
             out[f"step_{k}"] = torch.stack(v).numpy()
         # smoothing over the recorded states (particle/base.py:105-157); everything the filtering part of the fixture
         # holds was produced above - the calls below only consume further random numbers
-        out["smooth_fl"] = filt.smooth(all_states, "fl").numpy()
+        if oes == 1:  # (recorded states of a thinned run skip moves: their ancestors do not chain)
+            out["smooth_fl"] = filt.smooth(all_states, "fl").numpy()
         if case["name"] in FFBS_CASES and dtype_name == "f64":
             tape.mask = torch.ones(b, dtype=torch.bool)
             tape.cur_u = torch.rand(b, dtype=torch.float32)
@@ -242,6 +261,8 @@ def _main_child(dtype_name: str):
         print(f"wrote {path}: ll={result.loglikelihood.tolist()}")
 
     # ---------------------------------------------------------------------------------------------------------
+    if only is not None:
+        return
     # primitives: the reference's own known-answer arrangement for systematic() (tests/test_resampling.py:31-47)
     # plus correctly-normalised rows, normalize()/get_ess()/log_likelihood() edge cases.
     # ---------------------------------------------------------------------------------------------------------
@@ -278,7 +299,8 @@ def _main_child(dtype_name: str):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child":
-        _main_child(sys.argv[2])
+        _main_child(sys.argv[2], set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None)
     else:
+        extra = [sys.argv[2]] if len(sys.argv) > 2 and sys.argv[1] == "--only" else []
         for dt in ("f64", "f32"):
-            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", dt], cwd=ROOT)
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--child", dt] + extra, cwd=ROOT)

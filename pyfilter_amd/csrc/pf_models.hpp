@@ -555,12 +555,17 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
 
     // optimal proposal for linear-Gaussian observations (find_optimal_density, proposals/utils.py:219-267):
     //   precision = diag(g^-2) + A^T diag(s^-2) A ; cov = precision^-1 ; mean = cov (g^-2 m + A^T s^-2 (y - b))
+    // Vector states take the mean in INNOVATION form, mean = m + cov A^T s^-2 (y - b - A m): algebraically the line above
+    // (cov (g^-2 m + A^T s^-2 A m) = m), but without its cancellation - with |m| ~ 25 and a posterior spread of ~ 1
+    // (Lorenz-63) the precision form loses 4 - 5 float32 ulps of the new particle, which the transition density's
+    // 1 / (2 inc^2 g^2) = 50 turns into 3e-3 of log-weight (measured, round 5: the reference's own float32 run is 1.5e-3
+    // from exact arithmetic there; this form stays within the particle's own rounding).  float64 results agree to 1e-13.
     constexpr int MO = ColParams<T, D>::MAXO;
     T hvi[D], prec[D][D], rhs[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         hvi[d] = pf_div(T(1), scale[d] * scale[d]);
-        rhs[d] = hvi[d] * loc[d];
+        rhs[d] = (D == 1) ? hvi[d] * loc[d] : T(0);
     }
 #pragma unroll
     for (int i = 0; i < D; ++i)
@@ -570,7 +575,12 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
     for (int o = 0; o < MO; ++o) {
         if (o < cp.O) {
             const T ovi = pf_div(T(1), cp.os[o] * cp.os[o]);
-            const T ry = ovi * (cp.y[o] - cp.ob[o]);
+            T innov = cp.y[o] - cp.ob[o];
+            if constexpr (D > 1) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) innov -= cp.A[o][d] * loc[d];
+            }
+            const T ry = ovi * innov;
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 rhs[i] += cp.A[o][i] * ry;
@@ -590,7 +600,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
         T t = T(0);
 #pragma unroll
         for (int j = 0; j < D; ++j) t += cov[i][j] * rhs[j];
-        km[i] = t;
+        km[i] = t;  // (D > 1: the mean's offset from m)
     }
     chol_lower<T, D>(cov, l);
     T logq = T(0);
@@ -599,7 +609,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
         T t = km[i];
 #pragma unroll
         for (int j = 0; j <= i; ++j) t += l[i][j] * z[j];
-        xn[i] = t;
+        xn[i] = (D == 1) ? t : loc[i] + t;  // (one rounding at the particle's magnitude)
         logq += -T(0.5) * z[i] * z[i] - pf_log_g(l[i][i]) - T(PF_LOG_SQRT_2PI);
     }
     return obs_logpdf<T, D>(md, cp, xn) + transition_logpdf<T, D>(md, xn, loc, scale) - logq;

@@ -65,6 +65,17 @@ def theta_ess(log_weights: torch.Tensor) -> torch.Tensor:
 
 SOLO = "solo"  # Shard(total, SOLO): this process alone holds every filter, whatever process group exists
 
+# Testing switch: with a process group of ONE rank every exchange below is the identity and ``Shard`` / ``Route`` skip the
+# collective.  ``force_collectives(True)`` makes a one-rank group issue them anyway - ``all_gather_into_tensor`` /
+# ``all_gather`` / ``all_reduce`` / ``all_to_all_single`` with this rank as the only peer - so that a one-GPU box runs the
+# very RCCL calls of an N-GPU job (tests/test_distributed_gpu.py::test_rccl_world_of_one_*).  Never set by the library.
+_FORCE_COLLECTIVES = False
+
+
+def force_collectives(on: bool = True) -> None:
+    global _FORCE_COLLECTIVES
+    _FORCE_COLLECTIVES = bool(on)
+
 
 class Shard:
     """This rank's block of ``total`` filters and the collectives over the filter dimension.  With one process (no
@@ -83,6 +94,8 @@ class Shard:
             self.rank, self.world = world()
         self.spans: List[Tuple[int, int]] = [shard_bounds(self.total, r, self.world) for r in range(self.world)]
         self.lo, self.hi = self.spans[self.rank]
+        # does an exchange go through torch.distributed?  (more than one rank - or a forced one-rank group, see above)
+        self.collective = self.world > 1 or (_FORCE_COLLECTIVES and group is not SOLO and dist.is_available() and dist.is_initialized())
 
     @property
     def local(self) -> int:
@@ -94,7 +107,7 @@ class Shard:
 
     def all_gather(self, local: torch.Tensor, dim: int = 0) -> torch.Tensor:
         """Concatenation of every rank's block along ``dim``, in global order, identical on every rank."""
-        if self.world == 1:
+        if not self.collective:
             return local
         dim = dim % local.dim()
         moved = local.movedim(dim, 0).contiguous()
@@ -114,7 +127,7 @@ class Shard:
 
     def all_mean(self, local_sum: torch.Tensor, local_count: int) -> torch.Tensor:
         """Mean over all filters of a quantity summed locally (e.g. an acceptance rate)."""
-        if self.world == 1:
+        if not self.collective:
             return local_sum / max(1, local_count)
         v = torch.stack([local_sum.to(torch.float64).reshape(()), torch.tensor(float(local_count), device=local_sum.device, dtype=torch.float64)])
         dist.all_reduce(v, group=self.group)
@@ -122,7 +135,7 @@ class Shard:
 
     def all_max(self, local: torch.Tensor) -> torch.Tensor:
         """Element-wise maximum over the ranks."""
-        if self.world == 1:
+        if not self.collective:
             return local
         out = local.clone()
         dist.all_reduce(out, op=dist.ReduceOp.MAX, group=self.group)
@@ -154,7 +167,7 @@ class Route:
         self.shard = shard
         self.device = global_index.device
         mine = global_index.to(torch.int64).reshape(-1)
-        if shard.world == 1:
+        if not shard.collective:
             self.local_index = mine
             return
         if full_index is not None and full_index.numel() == shard.total:
@@ -194,7 +207,7 @@ class Route:
 
     def take(self, local: torch.Tensor, dim: int = 0) -> torch.Tensor:
         dim = dim % local.dim()
-        if self.shard.world == 1:
+        if not self.shard.collective:
             return local.index_select(dim, self.local_index.to(local.device))
         moved = local.movedim(dim, 0)
         rest = tuple(moved.shape[1:])

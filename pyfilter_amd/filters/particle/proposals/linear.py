@@ -44,7 +44,7 @@ class _ObservationUpdate:
         self.P = self.A * h2.unsqueeze(-2)                                         # (..., O, D) = A diag(h^2)
         o = self.P.shape[-2]
         self.S = self.P @ self.A.transpose(-2, -1) + torch.diag_embed(s2.expand(self.P.shape[:-2] + (o,)))
-        self.S_chol = torch.linalg.cholesky(self.S)
+        self.S_chol = torch.linalg.cholesky_ex(self.S)[0]  # (no info check: that is a host sync per move; proposals/linear.py:84)
 
     def _vec_y(self, y):
         return y if self.vec_y else y.unsqueeze(-1)
@@ -71,7 +71,7 @@ class _ObservationUpdate:
         if not self.vec_x:
             return Normal(mean.squeeze(-1), cov[..., 0, 0].sqrt(), validate_args=False)
         cov = 0.5 * (cov + cov.transpose(-2, -1))
-        return MultivariateNormal(mean, scale_tril=torch.linalg.cholesky(cov), validate_args=False)
+        return MultivariateNormal(mean, scale_tril=torch.linalg.cholesky_ex(cov)[0], validate_args=False)  # proposals/utils.py:267
 
 
 class LinearGaussianObservations(Proposal):

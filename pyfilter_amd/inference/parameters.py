@@ -297,7 +297,7 @@ class ThetaParticles:
     def resample(self, indices: torch.Tensor, route=None):
         """``theta <- theta[indices]`` in place.  Sharded: ``indices`` are GLOBAL ancestors of this rank's positions
         (``route``: the exchange plan of that gather when the caller already built it, ``distributed.Route``)."""
-        if self.shard is not None and self.shard.world > 1 and route is None:
+        if self.shard is not None and self.shard.collective and route is None:
             route = self.shard.route(indices)
         moved = (lambda c: c[indices]) if route is None else route.take
         if self._buf is not None:

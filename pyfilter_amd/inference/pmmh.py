@@ -45,7 +45,7 @@ class SymmetricMH:
         values = theta.stack_parameters(constrained=False)
         weights_log = state.w
         shard = getattr(theta, "shard", None)
-        if shard is not None and shard.world > 1:
+        if shard is not None and shard.collective:
             values, weights_log = shard.all_gather(values), shard.all_gather(weights_log)
         if theta.native_priors() is not None and weights_log.dtype == values.dtype:
             from .. import ops

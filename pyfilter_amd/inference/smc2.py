@@ -45,12 +45,12 @@ def _theta_path(w: torch.Tensor, ll: torch.Tensor, shard):
     (``_theta_stats``) - one launch on one GPU (``pf_theta_path``); sharded, the rows are all-gathered in between."""
     from ..hints import HINTS
 
-    if ll.is_cuda and (shard is None or shard.world == 1) and HINTS.theta_kernels and ll.dim() == 2 and ll.dtype == w.dtype:
+    if ll.is_cuda and (shard is None or not shard.collective) and HINTS.theta_kernels and ll.dim() == 2 and ll.dtype == w.dtype:
         from .. import ops
 
         return ops.theta_path(w.contiguous(), ll.contiguous())
     w_path = w + ll.cumsum(0)
-    return w_path, _theta_stats(shard.all_gather(w_path, dim=1) if shard is not None and shard.world > 1 else w_path)
+    return w_path, _theta_stats(shard.all_gather(w_path, dim=1) if shard is not None and shard.collective else w_path)
 
 
 class SMC2State:
@@ -67,7 +67,7 @@ class SMC2State:
         self._series = None  # ``fit``: (the series being parsed, host flags "observation is not all-NaN") - see parsed_data
 
     def global_weights(self) -> torch.Tensor:
-        return self.w if self.shard is None or self.shard.world == 1 else self.shard.all_gather(self.w)
+        return self.w if self.shard is None or not self.shard.collective else self.shard.all_gather(self.w)
 
     def _ess(self) -> torch.Tensor:
         """ESS of ALL theta-weights; ``self.stats`` keeps it together with the "every weight finite" flag - on the GPU both
@@ -138,7 +138,7 @@ class SMC2State:
 def _take_filters(result: FilterResult, shard: Optional[Shard], mine: torch.Tensor, route=None):
     """``FilterResult.resample`` for a sharded set of filters: ``mine`` = the GLOBAL ancestors of this rank's positions
     (single process: all of them, and the reference's in-place gather - one ``pf_columns_gather`` per buffer)."""
-    if shard is None or shard.world == 1:
+    if shard is None or not shard.collective:
         result.resample(mine)
         return
     route = route or shard.route(mine)  # who sends which columns to whom: built once, every buffer moves through it
@@ -183,7 +183,7 @@ class ParticleMetropolisHastings:
 
     def update(self, theta: ThetaParticles, filter_, state: SMC2State, generator=None) -> SMC2State:
         shard = state.shard
-        sharded = shard is not None and shard.world > 1
+        sharded = shard is not None and shard.collective
         mark = (lambda label: self.timeline.append((label, time.perf_counter()))) if self.timeline is not None else (lambda label: None)
         mark("start")
         # the same resampling on every rank: same (gathered) weights, same uniform (the generator is a CPU stream seeded
@@ -313,7 +313,7 @@ class SMC2:
         g = torch.Generator().manual_seed(self._seed * 7919 + 13)  # every rank draws all B and keeps its block
         self.theta.initialize_parameters(g)
         if theta0 is not None:
-            mine = self.shard.slice(theta0) if self.shard.world > 1 else theta0
+            mine = self.shard.slice(theta0) if self.shard.collective else theta0
             self.theta.unstack_parameters(mine.to(device=self.theta.device, dtype=self.theta.dtype), constrained=True)
         self.filter.initialize_model(self.theta)
         init_state = self.filter.initialize()
@@ -450,6 +450,6 @@ class SMC2:
     def posterior_mean(self, state: SMC2State) -> torch.Tensor:
         """Weighted mean of the stacked (constrained) parameters over ALL theta-particles."""
         vals, w = self.theta.stack_parameters(True), state.w
-        if self.shard.world > 1:
+        if self.shard.collective:
             vals, w = self.shard.all_gather(vals), self.shard.all_gather(w)
         return theta_normalize(w) @ vals

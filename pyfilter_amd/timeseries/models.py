@@ -201,6 +201,10 @@ def pack_params(ssm: StateSpaceModel, b: int, dtype, device) -> torch.Tensor:
             cols.append(torch.zeros((b, d), dtype=dtype, device=device))
     if kind.obs_kind == L.OBS_LINEAR:
         a, ob, os_ = ssm.parameters
+        if d > 1 and ssm.n_dim == 0 and a.dim() >= 1:
+            # a SCALAR observation of a vector state (event_shape = Size([])): ``a`` is the (D,) row - or (B, D), one row per
+            # filter - that the reference unsqueezes to (1, D) (proposals/utils.py:248 ``c.unsqueeze(-2)``)
+            a = a.unsqueeze(-2)
         cols.append(_expand(a, b, (o, d), dtype, device).reshape(b, o * d))
         cols.append(_expand(ob, b, (o,), dtype, device))
         cols.append(_expand(os_, b, (o,), dtype, device))

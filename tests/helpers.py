@@ -14,6 +14,14 @@ def load_golden(name, dt):
         return {k: torch.from_numpy(f[k]) for k in f.files}
 
 
+def moves_after(g, t):
+    """Moves a filter has made once it has consumed ``t`` observations of fixture ``g`` (= the time index of that state):
+    ``t`` unless the model is observed every k-th step only (``move_of_obs``, oracle/make_golden.py)."""
+    if t == 0 or "move_of_obs" not in g:
+        return t
+    return int(g["move_of_obs"][t - 1]) + 1
+
+
 def build_ssm_from_case(case, dtype, device):
     from pyfilter_amd import timeseries as ts
     from pyfilter_amd.timeseries import models
@@ -40,6 +48,34 @@ def build_ssm_from_case(case, dtype, device):
                                  initial_mean=t([-5.91652, -5.52332, 24.5723]), initial_scale=t([math.sqrt(10.0)] * 3))
         a = t([[0.8, 0.0, 0.0], [0.0, 0.0, 0.8]])
         ssm = ts.LinearStateSpaceModel(hidden, (a, t([0.0]), t([math.sqrt(0.1)])), torch.Size([2]))
+    elif m in ("lorenz_s", "lorenz_o1", "lorenz_o3"):  # the lorenz.ipynb process under other linear observations (oracle/cases.py)
+        from oracle.cases import _LORENZ_A_O3, _LORENZ_A_S
+
+        hidden = models.Lorenz63(t(10.0), t(28.0), t(8.0 / 3.0), t(1.0), dt=0.01,
+                                 initial_mean=t([-5.91652, -5.52332, 24.5723]), initial_scale=t([math.sqrt(10.0)] * 3))
+        if m == "lorenz_s":
+            ssm = ts.LinearStateSpaceModel(hidden, (t(_LORENZ_A_S), t(0.0), t(math.sqrt(0.1))), torch.Size([]))
+        elif m == "lorenz_o1":
+            ssm = ts.LinearStateSpaceModel(hidden, (t([_LORENZ_A_S]), t([0.0]), t([math.sqrt(0.1)])), torch.Size([1]))
+        else:
+            ssm = ts.LinearStateSpaceModel(hidden, (t(_LORENZ_A_O3), t([0.1, -0.2, 0.3]), t([0.3, 0.4, 0.5])), torch.Size([3]))
+    elif m in ("rw2d_s", "rw2d_o1"):
+        from oracle.cases import _RW2D_A_S
+
+        sig = t([0.05, 0.1])
+        hidden = models.RandomWalk(sig, initial_mean=t([0.0, 0.0]), initial_scale=sig, dim=2)
+        if m == "rw2d_s":
+            ssm = ts.LinearStateSpaceModel(hidden, (t(_RW2D_A_S), t(0.05), t(0.15)), torch.Size([]))
+        else:
+            ssm = ts.LinearStateSpaceModel(hidden, (t([_RW2D_A_S]), t([0.05]), t([0.15])), torch.Size([1]))
+    elif m in ("rw2d_theta", "rw2d_theta_b"):  # B distinct (sigma, A, [b], s) rows - the very tensors of the oracle's spec
+        from oracle.cases import build_spec
+
+        spec = build_spec(case, dtype)
+        sig = spec.hidden_params[2].to(device)
+        a, off, s = (p.to(device) for p in spec.obs_params)
+        hidden = models.RandomWalk(sig, initial_mean=torch.zeros_like(sig), initial_scale=sig, dim=2)
+        ssm = ts.LinearStateSpaceModel(hidden, (a, off, s), torch.Size([2]))
     elif m == "rw2d":  # the reference's own 2-D model (tests/filters/models.py:28-52)
         sig = t([0.05, 0.1])
         hidden = models.RandomWalk(sig, initial_mean=t([0.0, 0.0]), initial_scale=sig, dim=2)
@@ -52,6 +88,7 @@ def build_ssm_from_case(case, dtype, device):
         ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.05)))
     else:
         raise KeyError(m)
+    ssm.observe_every_step = int(case.get("observe_every_step", 1))
     return ssm.to(device)
 
 

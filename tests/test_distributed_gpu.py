@@ -91,10 +91,11 @@ def test_bench_under_torchrun_with_two_ranks(workload, extra):
     assert rec["scaling"] == ("strong" if workload == "smc2" else "weak")
 
 
-def test_bench_spawns_its_own_ranks_and_defaults_to_smc2():
+def test_bench_spawns_its_own_ranks_one_workload_at_every_n():
     """``python bench.py --gpus 2`` with no launcher around it (the shape of the driver's N = 1 command): the script
-    re-executes itself under ``torch.distributed.run`` with two ranks, picks the sharded SMC^2 workload (BASELINE
-    configs[4], strong scaling) and reports ``n_gpus = world_size = 2`` plus the same job on one GPU."""
+    re-executes itself under ``torch.distributed.run`` with two ranks.  The default workload is the N = 1 one (BASELINE
+    configs[1], one replica per GPU: weak scaling - ``value(N) / (N value(1))`` is a scaling curve), and the job that shards -
+    SMC^2, configs[4] - rides on the same line, strong and weak, each with its own one-GPU point and a roofline object."""
     import json
     import subprocess
     import sys
@@ -102,15 +103,38 @@ def test_bench_spawns_its_own_ranks_and_defaults_to_smc2():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(PF_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "24"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--T", "24", "--N", "65536"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "strong"
-    assert rec["config"]["workload"].startswith("smc2") and rec["config"]["theta_per_rank"] == 512
-    assert rec["value"] > 0 and rec["single_gpu_same_workload"]["value"] > 0
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["scaling"] == "weak"
+    assert rec["config"]["workload"].startswith("apf_lgo_1m") and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+    strong, weak = rec["smc2_scaling"]["strong"], rec["smc2_scaling"]["weak"]
+    assert "error" not in strong and "error" not in weak, (strong, weak)
+    assert strong["scaling"] == "strong" and strong["config"]["theta_per_rank"] == 512 and strong["value"] > 0
+    assert weak["scaling"] == "weak" and weak["config"]["theta_per_rank"] == 1024 and weak["value"] > 0
+    for r in (strong, weak):
+        assert r["single_gpu_same_workload"]["value"] > 0 and r["roofline"]["kernel"] == "k_fused_step" and r["roofline"]["frac"] > 0
+
+
+def test_bench_smc2_is_one_workload_from_one_gpu_on():
+    """``bench.py --gpus 1 --workload smc2`` is the N = 1 point of the SMC^2 curves (strong == weak there) and carries the
+    ``roofline`` of its dominant kernel at the per-rank shape and a ``cpu_baseline`` like every N = 1 line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "smc2", "--steps", "1", "--warmup", "1", "--T", "40"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "strong" and rec["config"]["theta_per_rank"] == 1024
+    assert rec["roofline"]["kernel"] == "k_fused_step" and 0 < rec["roofline"]["frac"] < 1.5
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0 and rec["speedup_vs_cpu_baseline"] > 1
 
 
 def _rccl_worker(rank, world, port, out):
@@ -173,4 +197,63 @@ def test_bench_smc2_over_rccl():
                          cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert rec["n_gpus"] == n and rec["rccl_version"] and rec["config"]["theta_per_rank"] == 1024 // n
+    assert rec["n_gpus"] == n and rec["rccl_version"]
+    assert rec["smc2_scaling"]["strong"]["config"]["theta_per_rank"] == 1024 // n and rec["smc2_scaling"]["weak"]["config"]["theta_per_rank"] == 1024
+
+
+def _rccl_world_of_one(_rank, port, out):
+    """RCCL with ONE rank on the box's one GPU, every exchange of the sharded driver FORCED through its collective branch
+    (``distributed.force_collectives``): the exact ``torch.distributed`` calls of an N-GPU job - ``all_gather_into_tensor``
+    (even blocks on nccl), ``all_to_all_single`` with split lists, the small all-reduces - issued on RCCL, and a whole SMC^2
+    fit through them, against the same fit with no process group in the way (``SOLO``)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)  # "nccl" is RCCL on ROCm
+    try:
+        from pyfilter_amd import distributed as D
+
+        D.force_collectives(True)
+        sh = D.Shard(96)
+        assert sh.collective and sh.world == 1 and dist.get_backend() == "nccl"
+        g = torch.Generator().manual_seed(5)
+        full = torch.randn(96, 2048, generator=g).to(device)
+        planes = torch.randn(3, 96, 512, generator=g).to(device)
+        idx = torch.randint(0, 96, (96,), generator=g).to(device)
+        ok = torch.equal(sh.all_gather(full), full)                       # all_gather_into_tensor
+        ok &= torch.equal(sh.all_gather(planes, dim=1), planes)
+        route = sh.route(idx)                                             # all-gather of the wants + host plan
+        ok &= torch.equal(route.take(full), full[idx])                    # all_to_all_single (empty splits: nothing changes owner)
+        ok &= torch.equal(route.take(planes, dim=1), planes[:, idx])
+        ok &= sh.all_max(torch.tensor([3.0], device=device)).item() == 3.0    # all_reduce MAX
+        ok &= abs(sh.all_mean(torch.tensor(6.0, device=device), 4).item() - 1.5) < 1e-6   # all_reduce SUM
+        # the algorithm through the same calls: theta-weights all-gathered per block, a rejuvenation's routed redistribution
+        import importlib.util
+
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("smc2_example", os.path.join(root, "examples", "smc2_linear_gaussian.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        y = _data(60).cuda()
+        forced = mod.smc2(y, n_theta=64, n_state=512, ess_frac=0.5, seed=3, block=8)
+        D.force_collectives(False)
+        plain = mod.smc2(y, n_theta=64, n_state=512, ess_frac=0.5, seed=3, block=8)
+        torch.save({"ok": bool(ok), "rccl": torch.cuda.nccl.version(), "moves": (forced["moves"], plain["moves"]),
+                    "w": (forced["weights"].cpu(), plain["weights"].cpu()), "mean": (forced["mean"].cpu(), plain["mean"].cpu()),
+                    "ll": (forced["loglikelihood"].cpu(), plain["loglikelihood"].cpu())}, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_of_one_runs_every_exchange_of_the_sharded_driver(tmp_path):
+    """Runs on the one-GPU test box: the RCCL library is loaded, a communicator is built and the driver's collectives execute
+    on it (a world of one - what a one-GPU box can offer); the forced fit must land on the plain one's numbers (a one-rank
+    all-gather / all-to-all returns its input)."""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_rccl_world_of_one, args=(_free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["ok"], got
+    assert got["moves"][0] == got["moves"][1] and got["moves"][0] >= 1, got["moves"]
+    for k in ("w", "mean", "ll"):  # (the sharded branches evaluate the theta-level arithmetic with torch ops where the one-rank
+        # route takes one kernel: same numbers to rounding)
+        torch.testing.assert_close(got[k][0], got[k][1], rtol=1e-5, atol=1e-6, msg=k)

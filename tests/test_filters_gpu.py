@@ -14,7 +14,7 @@ from oracle import cpu_ref
 from oracle.cases import CASES, build_spec
 from pyfilter_amd.hints import HINTS
 from tests.conftest import both_routes
-from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
+from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden, moves_after
 
 pytestmark = pytest.mark.gpu
 
@@ -136,7 +136,7 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
             prev = init
         else:
             prev = ParticleFilterCorrection(
-                TimeseriesState(t, g["step_x"][t - 1].cuda(), es), g["step_w"][t - 1].clone().cuda(),
+                TimeseriesState(moves_after(g, t), g["step_x"][t - 1].cuda(), es), g["step_w"][t - 1].clone().cuda(),
                 g["step_ll"][t - 1].cuda(), g["step_idx"][t - 1].cuda(),
             )
         state = filt.filter(y[t], prev)

@@ -73,6 +73,8 @@ def _recorded(g, case, dtype):
 def test_fixed_lag_smoothing_matches_reference(golden_dir, name, dt):
     """``smooth(states, "fl")`` of the reference (particle/base.py:136-152) is pure index chasing: exact."""
     case = next(c for c in CASES if c["name"] == name)
+    if case.get("observe_every_step", 1) != 1:
+        pytest.skip("recorded states of a thinned run skip moves: no ancestor chain to follow")
     g = load(golden_dir, name, dt)
     xs, _, inds = _recorded(g, case, DT[dt])
     assert torch.equal(cpu_ref.smooth_fl(xs, inds), g["smooth_fl"])

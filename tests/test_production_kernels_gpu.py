@@ -122,7 +122,8 @@ def _expect_variant(case, steps_observed, first):
     return 2
 
 
-@pytest.mark.parametrize("name", [c["name"] for c in CASES])
+# (cases observed at every move: a thinned run's propagate-only moves are the NaN-observation launches the *_nan cases cover)
+@pytest.mark.parametrize("name", [c["name"] for c in CASES if c.get("observe_every_step", 1) == 1])
 def test_production_step_kernels_match_oracle_on_their_own_draws(name):
     case = next(c for c in CASES if c["name"] == name)
     dt = "f32" if "f32" in case["dtypes"] else "f64"  # the teacher states: the reference's own (cast to float32 if need be)

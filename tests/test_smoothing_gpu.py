@@ -9,7 +9,7 @@ import torch
 from oracle import cpu_ref
 from oracle.cases import CASES, build_spec
 from pyfilter_amd import ops
-from tests.helpers import DT, build_filter_from_case, load_golden
+from tests.helpers import DT, build_filter_from_case, load_golden, moves_after
 
 pytestmark = pytest.mark.gpu
 F64 = [c["name"] for c in CASES]
@@ -25,12 +25,14 @@ def test_fused_run_records_every_state(name):
     g = load_golden(name, "f64")
     filt = build_filter_from_case(case, g, torch.float64, "cuda", record_states=True)
     res = filt.batch_filter(g["y"].cuda(), bar=False)
-    assert filt._last_run["plan"].ring == g["y"].shape[0]  # the fused route, one history slot per recorded move
+    thinned = case.get("observe_every_step", 1) != 1
+    # the fused route, one history slot per move from the first recorded one on
+    assert filt._last_run["plan"].ring == moves_after(g, g["y"].shape[0]) - moves_after(g, 1) + 1
     states = res.states
     assert len(states) == g["y"].shape[0] + 1
     torch.testing.assert_close(states[0].timeseries_state.value.cpu(), g["x0"], **TOL)
     for t, st in enumerate(states[1:]):
-        assert int(st.timeseries_state.time_index) == t + 1
+        assert int(st.timeseries_state.time_index) == moves_after(g, t + 1)
         assert torch.equal(st.previous_indices.cpu(), g["step_idx"][t]), f"ancestors differ at step {t}"
         torch.testing.assert_close(st.timeseries_state.value.cpu(), g["step_x"][t], **TOL)
         torch.testing.assert_close(st.weights.cpu(), g["step_w"][t], equal_nan=True, **TOL)
@@ -38,6 +40,8 @@ def test_fused_run_records_every_state(name):
         torch.testing.assert_close(st.get_mean().cpu(), g["filter_means"][t + 1], **TOL)
     torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **TOL)
     torch.testing.assert_close(res.loglikelihood.cpu(), g["loglikelihood"], **TOL)
+    if thinned:  # (the recorded states skip moves: no ancestor chain to follow)
+        return
     # fixed-lag smoothing: pure ancestor chasing over the recorded history
     sm = filt.smooth(states, "fl")
     assert sm.shape == g["smooth_fl"].shape
