@@ -130,6 +130,7 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
     es = init.timeseries_state.event_shape
     y = g["y"].cuda()
     n, b = case["N"], case["B"]
+    spec64 = build_spec(case, torch.float64)
     flips = 0
     for t in range(y.shape[0]):
         if t == 0:
@@ -149,10 +150,32 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
         assert (dx[ok.expand_as(dx)] <= 1e-5 * scale + 1e-6).all(), f"step {t}: {dx[ok.expand_as(dx)].max()}"
         dw = (state.weights.cpu() - g["step_w"][t]).abs()
         fin = same & torch.isfinite(g["step_w"][t])
-        assert (dw[fin] <= 2e-5 * g["step_w"][t][fin].abs() + 2e-4).all(), f"step {t}: {dw[fin].max()}"
+        # The bar knows the step's conditioning: ``ref_err`` is how far the REFERENCE's own float32 weights are from exact
+        # arithmetic on this very step (the float64 oracle teacher-forced from the same float32 state and draws).  For most
+        # models that is ~1e-6; the optimal proposal on Lorenz-63 - transition density 1 / (2 inc^2) = 50 times a squared
+        # difference of numbers of magnitude 25 - sits at 1.5e-3 (round 5).  The kernel must be within the usual bar of the
+        # reference's float32 weights once that is allowed for, and no further from EXACT arithmetic than the reference is.
+        ref_err = 0.0
+        if case.get("observe_every_step", 1) == 1 and not bool(g["y"][t].isnan().all()):
+            x_in = (g["x0"] if t == 0 else g["step_x"][t - 1]).double()
+            w_in = (torch.zeros(x_in.shape[:2]) if t == 0 else g["step_w"][t - 1]).double()
+            i_in = torch.arange(n).unsqueeze(-1).expand(n, b) if t == 0 else g["step_idx"][t - 1]
+            y64, z64, u64 = g["y"][t].double(), g["z_tape"][t].double(), g["u_tape"][t].double()
+            if case["filter"] == "sisr":
+                step = cpu_ref.sisr_step(spec64, case["proposal"], y64, x_in, w_in, i_in, z64, u64, case["ess_threshold"] * n)
+            else:
+                step = cpu_ref.apf_step(spec64, case["proposal"], y64, x_in, w_in, z64, u64)
+            w64 = step[1]
+            ok64 = fin & torch.isfinite(w64) & (step[3] == g["step_idx"][t])
+            if ok64.any():
+                ref_err = float((g["step_w"][t].double() - w64).abs()[ok64].max())
+                d64 = (state.weights.cpu().double() - w64).abs()
+                assert (d64[ok64] <= 2e-5 * w64[ok64].abs() + 2e-4 + ref_err).all(), \
+                    f"step {t}: {d64[ok64].max()} from exact arithmetic (the reference's float32 run: {ref_err})"
+        assert (dw[fin] <= 2e-5 * g["step_w"][t][fin].abs() + 2e-4 + 2.0 * ref_err).all(), f"step {t}: {dw[fin].max()} (reference's own float32 error {ref_err})"
         # a flipped ancestor is one different particle among N: it moves the likelihood estimate by O(1/N)
         n_flip = (~same).sum().item()
-        torch.testing.assert_close(state.get_loglikelihood().cpu(), g["step_ll"][t], rtol=1e-4, atol=1e-4 + 10.0 * n_flip / n)
+        torch.testing.assert_close(state.get_loglikelihood().cpu(), g["step_ll"][t], rtol=1e-4, atol=1e-4 + 2.0 * ref_err + 10.0 * n_flip / n)
     assert flips <= max(2, int(2e-4 * n * b * y.shape[0])), f"{flips} ancestor flips"
 
 

@@ -416,3 +416,89 @@ def test_config5_theta_shard_full_size_against_the_exact_kalman_likelihood():
     dm = (got_m - torch.stack(means)).abs()
     post_sd = torch.stack([p.sqrt()] * t_len)
     assert (dm <= 8.0 * post_sd / math.sqrt(n) * 3.0 + 1e-4).all(), (dm / (post_sd / math.sqrt(n))).max().item()
+
+
+@pytest.mark.parametrize("route", ["per_step", "auto"])
+@pytest.mark.parametrize("skewed", [False, True])
+@pytest.mark.parametrize("filt_name,prop", [("sisr", "lgo"), ("apf", "lgo"), ("sisr", "bootstrap"), ("apf", "bootstrap")])
+@pytest.mark.parametrize("hid,d,o", [("rw", 2, 0), ("rw", 2, 1), ("rw", 2, 2), ("rw", 2, 3), ("rw", 3, 3), ("lorenz", 3, 0),
+                                     ("lorenz", 3, 1), ("lorenz", 3, 2), ("lorenz", 3, 3)])
+def test_production_kernels_random_linear_observations(hid, d, o, filt_name, prop, skewed, route, monkeypatch):
+    """Every (D, O) the fused kernels accept for a vector state, with a DENSE random observation matrix, offset and noise
+    scales (``o = 0``: a scalar observation, ``event_shape = Size([])``) - the float32 production instantiations on their own
+    Philox draws against the oracle, from uniform weights (SISR does not resample) and from skewed ones (it does).  Round 5:
+    the first dense 3x3 fixture exposed a miscompiled packed multiply-add in the optimal proposal's 3x3 inverse that every
+    sparser matrix hides (profiles/r05_slp_pk_fma_miscompile.txt); the fixtures pin a handful of matrices, this sweeps them."""
+    from oracle import models as M
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, SISR, proposals
+    from pyfilter_amd.hints import HINTS
+    from pyfilter_amd.timeseries import models
+
+    monkeypatch.setattr(HINTS, "route", 1 if route == "per_step" else 0)
+    n, b = 768, 2
+    gen = torch.Generator().manual_seed(1000 * d + 100 * o + 10 * len(filt_name) + len(prop) + (5 if skewed else 0))
+    od = max(o, 1)
+    a = torch.randn(od, d, generator=gen, dtype=torch.float64) * 0.6 + (torch.eye(od, d, dtype=torch.float64) if od <= d else 0.0)
+    off = 0.3 * torch.randn(od, generator=gen, dtype=torch.float64)
+    s = 0.2 + 0.5 * torch.rand(od, generator=gen, dtype=torch.float64)
+    if o == 0:
+        a, off, s = a[0], off[0], s[0]
+    t = lambda v: v.to(F32).cuda()  # noqa: E731
+    if hid == "rw":
+        sig = 0.3 + 0.5 * torch.rand(d, generator=gen, dtype=torch.float64)
+        centre = torch.zeros(d, dtype=torch.float64)
+        hidden = models.RandomWalk(t(sig), initial_mean=t(centre), initial_scale=t(sig), dim=d)
+        hid_spec = (M.HID_LINEAR, (torch.zeros(d, dtype=torch.float64), torch.ones(d, dtype=torch.float64), sig), d, 1.0, (centre, sig))
+    else:
+        centre = torch.tensor([-5.9, -5.5, 24.6], dtype=torch.float64)
+        hidden = models.Lorenz63(t(torch.tensor(10.0)), t(torch.tensor(28.0)), t(torch.tensor(8.0 / 3.0)), t(torch.tensor(1.0)), dt=0.01,
+                                 initial_mean=t(centre), initial_scale=t(torch.full((3,), math.sqrt(10.0))))
+        hid_spec = (M.HID_LORENZ63_EM, (10.0, 28.0, 8.0 / 3.0, 1.0), 3, 0.01, (centre, torch.full((3,), math.sqrt(10.0), dtype=torch.float64)))
+    ssm = ts.LinearStateSpaceModel(hidden, (t(a), t(off), t(s)), torch.Size([o]) if o else torch.Size([])).to("cuda")
+    spec64 = M.ModelSpec(*hid_spec, M.OBS_LINEAR, (a, off, s), o)
+    spec32 = M.ModelSpec(hid_spec[0], tuple(p.to(F32) if isinstance(p, torch.Tensor) else p for p in hid_spec[1]), d, hid_spec[3],
+                         tuple(p.to(F32) for p in hid_spec[4]), M.OBS_LINEAR, (a.to(F32), off.to(F32), s.to(F32)), o)
+    y_oracle = lambda v: v  # noqa: E731
+    if o == 0 and filt_name == "apf" and prop == "lgo":
+        # the one combination the reference cannot run: its LinearGaussianObservations.pre_weight mixes (N, B, D) and (N, B)
+        # tensors for a scalar observation of a vector state (proposals/linear.py:79-81 - it raises; the oracle restates that
+        # line).  The product evaluates what the formula means; the oracle side takes the same observation declared as a
+        # vector of length one (event_shape = Size([1]): identical arithmetic, golden case lorenz_o1_apf_lgo)
+        as_vec = lambda sp: M.ModelSpec(sp.hidden, sp.hidden_params, sp.dim, sp.dt, sp.init, M.OBS_LINEAR,  # noqa: E731
+                                        (sp.obs_params[0].unsqueeze(0), sp.obs_params[1].reshape(1), sp.obs_params[2].reshape(1)), 1)
+        spec64, spec32 = as_vec(spec64), as_vec(spec32)
+        y_oracle = lambda v: v.unsqueeze(-1)  # noqa: E731
+    case = dict(filter=filt_name, proposal=prop, ess_threshold=0.5)
+    cls = {"sisr": SISR, "apf": APF}[filt_name]
+    p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
+    filt = cls(ssm, n, proposal=p, ess_threshold=0.5, record_states=True)
+    filt.set_batch_shape(torch.Size([b]))
+    run_len = 2 if filt_name == "apf" else 1
+    u = torch.rand(run_len, b, generator=gen).to(F32)
+    filt.set_tape(u=u)
+    spread = 0.5 if hid == "rw" else 2.0
+    x_prev = (centre + spread * torch.randn(n, b, d, generator=gen, dtype=torch.float64)).to(F32)
+    w_prev = (2.5 * torch.randn(n, b, generator=gen)).to(F32) if skewed else torch.zeros(n, b, dtype=F32)
+    loc = off + (a * centre).sum(-1) if o == 0 else off + a @ centre
+    y = (loc + 0.5 * torch.randn((run_len,) + tuple(loc.shape), generator=gen, dtype=torch.float64)).to(F32)
+    idx_prev = torch.arange(n).unsqueeze(-1).expand(n, b).contiguous()
+    prev = _teacher_state(filt._model.hidden.event_shape, 0, x_prev.cuda(), w_prev.clone().cuda(), torch.zeros(b).cuda(), idx_prev.cuda())
+    res = filt.batch_filter(y.cuda(), bar=False, init_state=prev)
+    torch.cuda.synchronize()
+    z = _normals_ref_layout(filt, run_len, n, b, d, True)
+    last = res.latest_state
+    tag = f"{hid} D={d} O={o} {filt_name}+{prop} skewed={skewed} {route}"
+    if run_len == 2:
+        mid = res.states[-2]
+        x1, w1 = mid.timeseries_state.value.cpu(), mid.weights.cpu()
+        r64 = _oracle_step(spec64, case, y_oracle(y[0]), x_prev, w_prev, idx_prev, z[0], u[0], torch.float64)
+        r32 = _oracle_step(spec32, case, y_oracle(y[0]), x_prev, w_prev, idx_prev, z[0], u[0], F32)
+        _compare_step(tag + " step0", x1, w1, None, mid.previous_indices.cpu(), r64, r32, n)
+        r64 = _oracle_step(spec64, case, y_oracle(y[1]), x1, w1, r64[3], z[1], u[1], torch.float64)
+        r32 = _oracle_step(spec32, case, y_oracle(y[1]), x1, w1, r32[3], z[1], u[1], F32)
+    else:
+        r64 = _oracle_step(spec64, case, y_oracle(y[0]), x_prev, w_prev, idx_prev, z[0], u[0], torch.float64)
+        r32 = _oracle_step(spec32, case, y_oracle(y[0]), x_prev, w_prev, idx_prev, z[0], u[0], F32)
+    _compare_step(tag, last.timeseries_state.value.cpu(), last.weights.cpu(), last.get_loglikelihood().cpu(),
+                  last.previous_indices.cpu(), r64, r32, n)
