@@ -159,6 +159,24 @@ def _build_spec(case, dtype=torch.float64) -> M.ModelSpec:
             M.HID_LINEAR, (torch.zeros_like(sig), torch.ones_like(sig), sig), 2, 1.0, (torch.zeros_like(sig), sig),
             M.OBS_LINEAR, (a, off, s), 2,
         )
+    if m == "rw_rand":
+        # development sweeps (tools/fuzz_parity.py, tests): a D-dimensional random walk (case["D"] in {2, 3}) under a DENSE random
+        # linear observation - case["O"] in {0 (scalar, event_shape = Size([])), 1, 2, 3} - drawn from the case's seed; with
+        # case["per_filter"] every filter has its own (sigma, A, s) rows (and its own offset when the proposal is Bootstrap)
+        d, o = int(case["D"]), int(case["O"])
+        gen = torch.Generator().manual_seed(int(case["seed"]) * 31 + 7)
+        rows = (b,) if case.get("per_filter") else ()
+        od = max(o, 1)
+        sig = (0.05 + 0.1 * torch.rand(rows + (d,), generator=gen, dtype=torch.float64)).to(dtype)
+        a = 0.5 * torch.randn(rows + (od, d), generator=gen, dtype=torch.float64) + (torch.eye(od, d, dtype=torch.float64) if od <= d else 0.0)
+        off_rows = rows if case.get("proposal") == "bootstrap" else ()  # (the reference's optimal proposal cannot take a per-filter offset)
+        off = 0.2 * torch.randn(off_rows + (od,), generator=gen, dtype=torch.float64)
+        sc = 0.1 + 0.2 * torch.rand(rows + (od,), generator=gen, dtype=torch.float64)
+        a, off, sc = a.to(dtype), off.to(dtype), sc.to(dtype)
+        if o == 0:
+            a, off, sc = a[..., 0, :], off[..., 0], sc[..., 0]
+        return M.ModelSpec(M.HID_LINEAR, (torch.zeros_like(sig), torch.ones_like(sig), sig), d, 1.0, (torch.zeros_like(sig), sig),
+                           M.OBS_LINEAR, (a, off, sc), o)
     if m == "rw2d":  # tests/filters/models.py:28-52: x' = I2 x + (0.05, 0.1) e, x0 ~ N(0, sigma), y ~ N(I2 x, 0.15)
         sig = t([0.05, 0.1])
         return M.ModelSpec(
@@ -180,7 +198,7 @@ def simulate(case, spec: M.ModelSpec, dtype=torch.float64) -> torch.Tensor:
     t_len = case["T"]
     b = case["B"]
     per_series = case["model"] == "sv_batched"
-    shape = (1, b) if (per_series or case["model"] in ("ou_batched", "rw2d_theta", "rw2d_theta_b")) else (1, 1)
+    shape = (1, b) if (per_series or (case["model"] in ("ou_batched", "rw2d_theta", "rw2d_theta_b") or bool(case.get("per_filter")))) else (1, 1)
     if spec.dim > 0:
         shape = shape + (spec.dim,)
     x = M.initial_sample(spec, torch.randn(shape, generator=g, dtype=dtype))

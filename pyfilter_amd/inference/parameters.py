@@ -234,20 +234,38 @@ class ThetaParticles:
         out = torch.cat(cols, dim=-1)
         if not constrained:
             self._cache["u"] = out
+            # (a bijection may change the event size - simplex / stick-breaking: the unconstrained columns of a prior are then
+            # NOT its constrained numel; the widths are what slices ``u`` back apart)
+            self._u_widths = [c.shape[-1] for c in cols]
         return out
+
+    def _unconstrained_widths(self):
+        """Columns every prior occupies in the stacked UNCONSTRAINED tensor (``stack_parameters(False)``)."""
+        w = getattr(self, "_u_widths", None)
+        if w is None:
+            w = self._u_widths = [prior.get_unconstrained(self._values[name]).reshape(self.batch_shape[0], -1).shape[-1]
+                                  for name, prior in self.priors.items()]
+        return w
 
     def unstack_parameters(self, x: torch.Tensor, constrained: bool = True):
         """Writes ``x (B, P)`` back into the parameter tensors - in place."""
         at = 0
-        for name, prior in self.priors.items():
+        widths = [] if constrained else self._unconstrained_widths()
+        for i, (name, prior) in enumerate(self.priors.items()):
             v = self._values[name]
-            k = max(1, v[0].numel())
-            part = x[..., at:at + k].reshape(v.shape)
-            v.copy_(part if constrained else prior.get_constrained(part))
+            k = max(1, v[0].numel()) if constrained else widths[i]
+            part = x[..., at:at + k]
+            if constrained:
+                v.copy_(part.reshape(v.shape))
+            else:
+                same = k == max(1, v[0].numel())
+                v.copy_(prior.get_constrained(part.reshape(v.shape) if same else part.reshape(v.shape[:1] + (k,))).reshape(v.shape))
             at += k
         self._cache.clear()
-        if not constrained and x.dim() == 2 and x.shape[0] == self.batch_shape[0]:
-            self._cache["u"] = x  # (the caller's own unconstrained values: what a later stack / prior evaluation starts from)
+        if not constrained and x.dim() == 2 and x.shape[0] == self.batch_shape[0] and at == x.shape[1]:
+            # the unconstrained values a later stack / prior evaluation starts from - a COPY in the particles' own type: ``x`` is
+            # the caller's tensor (a proposal may reuse its sample buffer in place)
+            self._cache["u"] = x.detach().to(self.dtype).clone()
 
     def eval_priors(self, constrained: bool = True) -> torch.Tensor:
         """``(B,)`` sum of the log priors (``context.py:245-253``).  Unconstrained: the density of ``u = bijection^-1(x)``,
@@ -258,10 +276,11 @@ class ThetaParticles:
         if "prior_u" in self._cache:
             return self._cache["prior_u"]
         u_all, at, total = self._cache.get("u"), 0, 0.0
-        for name, prior in self.priors.items():
+        widths = self._unconstrained_widths() if u_all is not None else None
+        for i, (name, prior) in enumerate(self.priors.items()):
             v = self._values[name]
-            k = max(1, v[0].numel())
-            if u_all is None:
+            k = widths[i] if widths is not None else 0
+            if u_all is None or k != max(1, v[0].numel()):  # (a size-changing bijection: evaluated on the prior's own tensors)
                 lp = prior.eval_prior(v, False)
             else:
                 u = u_all[..., at:at + k].reshape(v.shape)

@@ -31,6 +31,13 @@ class GaussianKernel:
     def sample(self, size=torch.Size([])):
         return self.as_torch().sample(size)
 
+    def __getattr__(self, name):
+        # anything else of the ``torch.distributions`` surface (``covariance_matrix``, ``rsample``, ``entropy``, ...): a user
+        # kernel or a trace consumer written against the reference's ``MultivariateNormal`` finds it here
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.as_torch(), name)
+
 
 class SymmetricMH:
     """The proposal of the SMC^2 paper (``proposals/symmetric_mh.py``): a Gaussian fitted to the weighted theta-particles
@@ -41,7 +48,7 @@ class SymmetricMH:
 
     SCALE = 1.1
 
-    def build(self, theta, state, filter_, y) -> Distribution:
+    def build(self, theta, state, filter_, y):  # -> Distribution | GaussianKernel (same read surface)
         values = theta.stack_parameters(constrained=False)
         weights_log = state.w
         shard = getattr(theta, "shard", None)
@@ -64,7 +71,7 @@ class RandomWalk:
     def __init__(self, scale=1e-2):
         self._scale = scale
 
-    def build(self, theta, state, filter_, y) -> Distribution:
+    def build(self, theta, state, filter_, y):  # -> Distribution | GaussianKernel (same read surface)
         loc = theta.stack_parameters(constrained=False).clone()  # (re-centred in place after accepted moves: a tensor of its own)
         scale = torch.as_tensor(self._scale, device=loc.device, dtype=loc.dtype).expand_as(loc).clone()
         return Independent(Normal(loc, scale, validate_args=False), 1, validate_args=False)

@@ -403,7 +403,13 @@ class SMC2:
 
     def fit(self, y: torch.Tensor, block: Optional[int] = None) -> SMC2State:
         """All observations of ``y``.  ``block`` (default: the constructor's) = how many observations the filters run
-        ahead of the rejuvenation test; 1 = the reference's observation-by-observation loop (``step``)."""
+        ahead of the rejuvenation test; 1 = the reference's observation-by-observation loop (``step``).
+
+        Reproducibility: for a fixed seed a fit is a function of ``(seed, block)``.  A block's moves draw from ONE Philox
+        stream keyed by (the block's draw epoch, move index) - a cut block is replayed on exactly those draws - so another
+        block length (or ``step()``, one epoch per move) is another, equally valid, Monte-Carlo run of the same algorithm;
+        the SEQUENCE of decisions (when to rejuvenate, which moves are accepted given the numbers) is the reference's in
+        every case (tests/test_inference_reference_gpu.py replays its event logs with ``block`` 1 and 16)."""
         state = self.initialize()
         k = self._block if block is None else max(1, int(block))
         flags = None
@@ -430,6 +436,7 @@ class SMC2:
             # speculate: the next block starts where this one ends - issued before the host looks at this one's statistics
             t_next = t + n
             n_next = min(k, total - t_next)
+            draws_mark = getattr(self.filter, "_draws", None)  # (the filter's draw-epoch counter before the speculative issue)
             if n_next >= 2:
                 slot ^= 1
                 pending = self._issue_block(y[t_next:t_next + n_next], flags[t_next:t_next + n_next], blk["res"].latest_state,
@@ -438,7 +445,11 @@ class SMC2:
             if hit is None:
                 state, t = self._commit(blk, n, state), t_next
                 continue
-            pending = None  # (the speculative successor started from a state that never was)
+            if pending is not None and draws_mark is not None:
+                # the speculative successor started from a state that never was: it is dropped, and the draw epoch it took is
+                # handed back - the sequence of seeds a fit consumes does not depend on how often speculation failed
+                self.filter._draws = draws_mark
+            pending = None
             take = hit + 1
             if take < n:
                 blk = self._cut(blk, take, state)

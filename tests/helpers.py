@@ -68,14 +68,14 @@ def build_ssm_from_case(case, dtype, device):
             ssm = ts.LinearStateSpaceModel(hidden, (t(_RW2D_A_S), t(0.05), t(0.15)), torch.Size([]))
         else:
             ssm = ts.LinearStateSpaceModel(hidden, (t([_RW2D_A_S]), t([0.05]), t([0.15])), torch.Size([1]))
-    elif m in ("rw2d_theta", "rw2d_theta_b"):  # B distinct (sigma, A, [b], s) rows - the very tensors of the oracle's spec
+    elif m in ("rw2d_theta", "rw2d_theta_b", "rw_rand"):  # (per-filter) sigma, A, b, s - the very tensors of the oracle's spec
         from oracle.cases import build_spec
 
         spec = build_spec(case, dtype)
         sig = spec.hidden_params[2].to(device)
         a, off, s = (p.to(device) for p in spec.obs_params)
-        hidden = models.RandomWalk(sig, initial_mean=torch.zeros_like(sig), initial_scale=sig, dim=2)
-        ssm = ts.LinearStateSpaceModel(hidden, (a, off, s), torch.Size([2]))
+        hidden = models.RandomWalk(sig, initial_mean=torch.zeros_like(sig), initial_scale=sig, dim=spec.dim)
+        ssm = ts.LinearStateSpaceModel(hidden, (a, off, s), torch.Size([spec.obs_dim]) if spec.obs_dim else torch.Size([]))
     elif m == "rw2d":  # the reference's own 2-D model (tests/filters/models.py:28-52)
         sig = t([0.05, 0.1])
         hidden = models.RandomWalk(sig, initial_mean=t([0.0, 0.0]), initial_scale=sig, dim=2)

@@ -48,14 +48,35 @@ def _model(kind, b, dtype):
         hidden = models.RandomWalk(sig if b > 1 else sig[0], dim=2)
         a = _t([[1.0, 0.0], [0.0, 1.0]], dtype)
         return ts.LinearStateSpaceModel(hidden, (a, _t([0.15, 0.15], dtype)), torch.Size([2])), (2,)
+    if kind in _DENSE:
+        # round 5: DENSE linear observations of a vector state - (hidden process, D, O); O = 0 is a scalar observation
+        # (event_shape = Size([])); one noise-scale row per filter
+        hid, d, o = _DENSE[kind]
+        od = max(o, 1)
+        gen = torch.Generator().manual_seed(17 * d + o)
+        a = (0.5 * torch.randn(od, d, generator=gen) + (torch.eye(od, d) if od <= d else 0.0)).to(dtype).to(DEV)
+        off = (0.2 * torch.randn(od, generator=gen)).to(dtype).to(DEV)
+        sc = _t([[0.3 + 0.05 * ((i + k) % 4) for k in range(od)] for i in range(b)], dtype)
+        if hid == "lorenz":
+            hidden = models.Lorenz63(_t(10.0, dtype), _t(28.0, dtype), _t(8.0 / 3.0, dtype), _t(1.0, dtype), dt=0.01)
+        else:
+            hidden = models.RandomWalk(_t([0.05, 0.1, 0.07][:d], dtype), dim=d)
+        if o == 0:
+            return ts.LinearStateSpaceModel(hidden, (a[0], off[0], sc[:, 0] if b > 1 else sc[0, 0]), torch.Size([])), ()
+        return ts.LinearStateSpaceModel(hidden, (a, off, sc if b > 1 else sc[0]), torch.Size([o])), (o,)
     raise KeyError(kind)
 
 
-def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(), seed=7, ess=0.9, generic=False):
+_DENSE = {"lorenz_o3": ("lorenz", 3, 3), "lorenz_s": ("lorenz", 3, 0), "lorenz_o1": ("lorenz", 3, 1), "rw3_o3": ("rw", 3, 3),
+          "rw2_o3": ("rw", 2, 3), "rw2_o1": ("rw", 2, 1), "rw2_s": ("rw", 2, 0), "rw3_o2": ("rw", 3, 2)}
+
+
+def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(), seed=7, ess=0.9, generic=False, oes=1):
     from pyfilter_amd import ops, resampling
     from pyfilter_amd.filters.particle import APF, SISR, proposals
 
     ssm, o = _model(kind, b, dtype)
+    ssm.observe_every_step = oes
     cls = {"sisr": SISR, "apf": APF}[filt_name]
     p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
     rs = {"systematic": resampling.systematic, "multinomial": resampling.multinomial}[resampler]
@@ -65,6 +86,11 @@ def _run(route, kind, filt_name, prop, resampler, n, b, t_len, dtype, nan_at=(),
     g = torch.Generator().manual_seed(3)
     if kind == "lorenz":
         y = torch.tensor([-4.7, 19.6]) + 0.5 * torch.randn((t_len, 2), generator=g)
+    elif kind in _DENSE and _DENSE[kind][0] == "lorenz":  # around the observation of the initial mean
+        a_, b_, _ = (p.detach().cpu().double() for p in ssm.parameters)
+        c0 = torch.tensor([-5.91652, -5.52332, 24.5723], dtype=torch.float64)
+        loc = b_ + ((a_ * c0).sum(-1) if a_.dim() == 1 else a_ @ c0)
+        y = loc + 0.5 * torch.randn((t_len,) + tuple(loc.shape), generator=g, dtype=torch.float64)
     elif kind == "sv":
         y = 0.05 + torch.randn((t_len,), generator=g)
     else:
@@ -116,6 +142,19 @@ CASES = [
     ("lorenz", "sisr", "bootstrap", "multinomial", 256, 2, 15, ()),
     ("lg", "sisr", "bootstrap", "systematic", 2, 3, 12, ()),
     ("lg", "apf", "bootstrap", "systematic", 1, 2, 8, ()),
+    # round 5: dense observation matrices for every (D, O) the kernels accept, a scalar observation of a vector state included
+    ("lorenz_o3", "apf", "lgo", "systematic", 512, 2, 15, (3,)),
+    ("lorenz_o3", "sisr", "lgo", "systematic", 333, 3, 15, ()),
+    ("lorenz_s", "sisr", "lgo", "systematic", 256, 2, 15, ()),
+    ("lorenz_s", "apf", "lgo", "systematic", 256, 3, 15, (5,)),
+    ("lorenz_o1", "apf", "lgo", "multinomial", 512, 2, 15, ()),
+    ("rw3_o3", "apf", "lgo", "systematic", 1024, 3, 30, ()),
+    ("rw3_o2", "sisr", "lgo", "systematic", 700, 2, 30, (9,)),
+    ("rw2_o3", "apf", "lgo", "systematic", 512, 4, 30, ()),
+    ("rw2_o3", "sisr", "bootstrap", "systematic", 333, 2, 30, ()),
+    ("rw2_o1", "apf", "lgo", "systematic", 256, 2, 30, (0, 1)),
+    ("rw2_s", "sisr", "lgo", "systematic", 2048, 1, 20, ()),
+    ("rw2_s", "apf", "bootstrap", "multinomial", 400, 3, 20, ()),
 ]
 
 
@@ -251,28 +290,29 @@ def test_smc2_shaped_workload_is_one_launch_per_run():
 
 
 def test_random_cross_route_sweep():
-    """60 random (model, filter, proposal, resampler, N in [1, 2048], B, T, NaN pattern, ESS threshold) configurations, float64,
+    """90 random (model, filter, proposal, resampler, N in [1, 2048], B, T, NaN pattern, ESS threshold) configurations, float64,
     Philox draws: the column-persistent kernel and the per-step kernels consume the same random numbers and must agree -
     identical ancestors, 1e-9.  Unlike ``tools/fuzz_parity.py`` (oracle, taped draws, systematic only) this covers the
     multinomial resampler and the kernels' own generators."""
     import random
 
     rng = random.Random(5)
-    for i in range(60):
-        kind = rng.choice(["sine", "lg", "ou", "sv", "lorenz", "rw2d"])
+    for i in range(90):
+        kind = rng.choice(["sine", "lg", "ou", "sv", "lorenz", "rw2d"] + sorted(_DENSE))
         filt_name = rng.choice(["sisr", "apf"])
         prop = "bootstrap" if kind == "sv" else rng.choice(["bootstrap", "lgo"])
         resampler = rng.choice(["systematic", "systematic", "multinomial"])
         n = rng.choice([rng.randint(1, 70), rng.randint(71, 700), rng.randint(701, 2048), rng.choice([64, 256, 1024, 2048])])
-        if kind == "lorenz":
+        if kind == "lorenz" or (kind in _DENSE and _DENSE[kind][1] == 3):
             n = min(n, 1536)  # (float64, D = 3: the cdf + three particle planes of 2 048 particles exceed the 64 KB of LDS)
         b = rng.choice([1, 2, 3, 7, 33])
         t_len = rng.randint(1, 30)
         nan_at = tuple(k for k in range(t_len) if rng.random() < 0.12)
         ess = rng.choice([0.1, 0.5, 0.9])
-        tag = f"#{i} {kind} {filt_name} {prop} {resampler} N={n} B={b} T={t_len} nan={nan_at} ess={ess}"
-        col = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at, seed=100 + i, ess=ess)
-        ref = _run("per_step", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at, seed=100 + i, ess=ess)
+        oes = rng.choice([1, 1, 1, 2, 3])  # observe_every_step
+        tag = f"#{i} {kind} {filt_name} {prop} {resampler} N={n} B={b} T={t_len} nan={nan_at} ess={ess} oes={oes}"
+        col = _run("column", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at, seed=100 + i, ess=ess, oes=oes)
+        ref = _run("per_step", kind, filt_name, prop, resampler, n, b, t_len, torch.float64, nan_at, seed=100 + i, ess=ess, oes=oes)
         assert col["SPEC"] == 9 and ref["SPEC"] != 9, tag
         assert torch.equal(col["idx"], ref["idx"]), tag + ": final ancestors differ"
         torch.testing.assert_close(col["means"], ref["means"], rtol=1e-9, atol=1e-11, equal_nan=True, msg=lambda m: tag + ": " + m)

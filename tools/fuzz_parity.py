@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 def main():
     from oracle import cpu_ref
     from oracle.cases import build_spec, simulate
+    from pyfilter_amd.filters.schedule import expand
     from pyfilter_amd.hints import HINTS
     from tests.helpers import build_filter_from_case
 
@@ -22,9 +23,19 @@ def main():
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = ties = 0
     for i in range(cases):
-        model = rng.choice(["lg1d", "sine", "sv_batched", "lorenz", "ou_batched", "rw2d"])
+        model = rng.choice(["lg1d", "sine", "sv_batched", "lorenz", "ou_batched", "rw2d", "lorenz_s", "lorenz_o1", "lorenz_o3", "rw2d_o1",
+                            "rw2d_theta", "rw_rand", "rw_rand", "rw_rand"])
         filt_name = rng.choice(["sisr", "apf"])
         prop = rng.choice(["bootstrap", "lgo"]) if model != "sv_batched" else "bootstrap"
+        extra = {}
+        if model == "rw_rand":  # dense random observation matrices for every (D, O) the kernels take, shared or per filter
+            extra = dict(D=rng.choice([2, 3]), O=rng.choice([0, 1, 2, 3]), per_filter=rng.random() < 0.4)
+        scalar_obs = model == "lorenz_s" or extra.get("O") == 0
+        if scalar_obs and filt_name == "apf" and prop == "lgo":
+            # (the one combination the reference - and therefore the oracle - cannot run: proposals/linear.py:79-81 mixes (N, B, D)
+            # and (N, B) tensors for a scalar observation of a vector state)
+            prop = "bootstrap"
+        oes = rng.choice([1, 1, 1, 1, 2, 3, 5])  # observe_every_step (filters/base.py:204-210)
         n = rng.choice([rng.randint(2, 40), rng.randint(41, 1100), rng.randint(1101, 9000), rng.choice([1024, 2048, 4096, 8192, 12288, 65536]),
                         rng.randint(9001, 70000)])
         b = rng.choice([1, 1, 2, 3, 5, 9, 17]) if n < 20000 else rng.choice([1, 2, 3])
@@ -37,12 +48,16 @@ def main():
         # threshold, and which side of it ESS = 1 / sum W^2 lands on is a rounding tie between any two implementations)
         target = rng.choice([None, None, 4, 64, 4096])  # geometry: few big tiles ... many small ones
         seed = rng.randint(0, 10 ** 6)
-        case = dict(name="fuzz", model=model, filter=filt_name, proposal=prop, N=n, B=b, T=t_len, ess_threshold=ess, seed=seed)
+        if model == "rw_rand" and extra["per_filter"]:
+            b = max(b, 2)
+        case = dict(name="fuzz", model=model, filter=filt_name, proposal=prop, N=n, B=b, T=t_len, ess_threshold=ess, seed=seed,
+                    observe_every_step=oes, **extra)
         spec = build_spec(case, torch.float64)
         gen = torch.Generator().manual_seed(seed)
         d = (spec.dim,) if spec.dim > 0 else ()
-        g = dict(z_tape=torch.randn((t_len, n, b) + d, generator=gen, dtype=torch.float32),
-                 u_tape=torch.rand(t_len, b, generator=gen, dtype=torch.float32),
+        moves = expand(0, t_len, oes).moves  # (the tapes are per move: an observation every oes-th move)
+        g = dict(z_tape=torch.randn((moves, n, b) + d, generator=gen, dtype=torch.float32),
+                 u_tape=torch.rand(moves, b, generator=gen, dtype=torch.float32),
                  z0=torch.randn((n, b) + d, generator=gen, dtype=torch.float32))
         y = simulate(case, spec, torch.float64)
         for s in range(t_len):
@@ -124,7 +139,8 @@ def main():
                         print(f"      column {c}: position {fi}: kernel {int(idx_g[fi, c])} oracle {int(idx_r[fi, c])}; neighbours kernel {idx_g[max(fi-2,0):fi+3, c].tolist()} oracle {idx_r[max(fi-2,0):fi+3, c].tolist()}")
                         break
         bad += 0 if ok else 1
-        print(f"{i:3d} {'ok ' if ok else 'BAD'} {model:10s} {filt_name:4s} {prop:9s} N={n:6d} B={b:2d} T={t_len} ess={ess} target_wgs={target} seed={seed} {route} {why}", flush=True)
+        tag = model + (f"[D{extra['D']}O{extra['O']}{'p' if extra['per_filter'] else ''}]" if extra else "")
+        print(f"{i:3d} {'ok ' if ok else 'BAD'} {tag:14s} {filt_name:4s} {prop:9s} N={n:6d} B={b:2d} T={t_len} oes={oes} ess={ess} target_wgs={target} seed={seed} {route} {why}", flush=True)
     print("failures:", bad, " rounding ties:", ties)
     return 1 if bad else 0
 
