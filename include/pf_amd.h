@@ -239,6 +239,13 @@ int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t*
 #define PF_ROUTE_AUTO 0           /* filters of <= column_max_n particles: the column-persistent kernel, else one kernel per step */
 #define PF_ROUTE_PER_STEP 1       /* always one k_fused_step launch per time step */
 #define PF_ROUTE_COLUMN_GENERIC 2 /* as AUTO, but the column kernel's run-time instantiation (no model kind folded in) */
+#define PF_ROUTE_CLUSTER 3        /* as AUTO, and self-contained runs of filters of 2 049 .. 16 384 particles (N % 4 == 0,
+                                   * systematic resampling, built-in model) take the column-CLUSTER kernel: ceil(N / 1024)
+                                   * workgroups per filter hold it in registers for the whole run and exchange one record per
+                                   * wave and step (pf_cluster.hpp).  Opt-in because those workgroups wait for each other: the
+                                   * caller promises that no two such runs are in flight on DIFFERENT streams of one device
+                                   * (each could hold slots the other needs; a launch that cannot make progress gives up after
+                                   * ~1 s and returns NaN log-likelihoods rather than hang) */
 typedef struct pf_run_hints {
     int32_t route;           /* PF_ROUTE_* */
     int32_t column_max_n;    /* largest filter the column-persistent kernel takes; 0 = the default (2048) */

@@ -151,10 +151,10 @@ def _build_spec(case, dtype=torch.float64) -> M.ModelSpec:
         # B distinct (sigma, A, s) rows: theta on the batch dim of a vector model.  The offset b is shared by the filters
         # under the optimal proposal - the reference's find_optimal_density takes ``y - b`` of shape (B, O) for a MATRIX
         # (proposals/utils.py:260 ``o_inv_cov.matmul(y)``) and raises - and per filter in the ``_b`` variant (Bootstrap)
-        sig = torch.stack([t([0.05 + 0.02 * i, 0.1 - 0.02 * i]) for i in range(b)])               # (B, 2)
+        sig = torch.stack([t([0.05 + 0.02 * (i % 4), 0.1 - 0.02 * (i % 4)]) for i in range(b)])   # (B, 2); (% 4: scales stay positive for any B)
         a = torch.stack([(1.0 + 0.25 * i) * t([[1.0, 0.2 * i], [-0.1 * i, 1.0]]) for i in range(b)])  # (B, 2, 2)
         off = torch.stack([t([0.02 * i, -0.03 * i]) for i in range(b)]) if m == "rw2d_theta_b" else t([0.02, -0.03])
-        s = torch.stack([t([0.15 + 0.05 * i, 0.2 - 0.03 * i]) for i in range(b)])                  # (B, 2)
+        s = torch.stack([t([0.15 + 0.05 * (i % 4), 0.2 - 0.03 * (i % 4)]) for i in range(b)])      # (B, 2)
         return M.ModelSpec(
             M.HID_LINEAR, (torch.zeros_like(sig), torch.ones_like(sig), sig), 2, 1.0, (torch.zeros_like(sig), sig),
             M.OBS_LINEAR, (a, off, s), 2,

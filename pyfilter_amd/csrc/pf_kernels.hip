@@ -83,8 +83,16 @@ struct WsLayout {
     size_t off_piv0;   // double [B][PF_MAXD]: the run's moment pivots
     size_t off_ctab;   // double [2][B][tiles * rounds_per_tile * 4][2]: per-chunk (offset, factor) of the chunk-local scans
     size_t ctab_elems;
+    size_t off_clu;    // cluster route (pf_cluster.hpp; columns of PF_CLUSTER_MIN_N < N <= PF_CLUSTER_MAX_N particles): int32 error
+                       // word (256 B) | granule records [2][B][PF_CLUSTER_NG][64] x 16 B; absent (clu_bytes = 0) otherwise
+    size_t clu_bytes;
     size_t total;
 };
+
+// the cluster route's column sizes: above what one workgroup holds (pf_column.hpp), at most 64 chunks of 256 particles
+#define PF_CLUSTER_MIN_N 2048
+#define PF_CLUSTER_MAX_N 16384
+#define PF_CLUSTER_NG 8  // granules per chunk record, the largest instantiation (double, D = 3: 24 words)
 
 static inline size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 
@@ -109,6 +117,10 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.off_ctab = o;
     w.ctab_elems = (size_t)g.B * g.tiles * g.rounds_per_tile * PF_NWAVES * 2;
     o = align256(o + 2 * sizeof(double) * w.ctab_elems);
+    w.off_clu = o;
+    w.clu_bytes = (g.N > PF_CLUSTER_MIN_N && g.N <= PF_CLUSTER_MAX_N && g.N % 4 == 0)
+                      ? 256 + (size_t)2 * g.B * PF_CLUSTER_NG * 64 * 16 : 0;
+    o = align256(o + w.clu_bytes);
     w.total = o;
     return w;
 }
@@ -1127,6 +1139,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_ffbs(ModelDesc md, const T* __rest
 
 #include "pf_fused.hpp"
 #include "pf_column.hpp"
+#include "pf_cluster.hpp"
 
 // =================================================================================================================
 // C ABI
@@ -1173,7 +1186,8 @@ static inline ModelDesc to_desc(const pf_model* m) {
 //   ... each of the kernel units additionally with -DPF_TU_MULTI=0|1: only the kernels of single-round / multi-round
 //   tiles (the MULTI template argument of k_fused_step; entries carry the suffix _m0 / _m1)
 // Without any of the macros the file is a single self-contained unit.
-#if defined(PF_TU_COLUMN_F32) || defined(PF_TU_COLUMN_F64)  // the column-persistent kernels of one arithmetic type, nothing else
+#if defined(PF_TU_COLUMN_F32) || defined(PF_TU_COLUMN_F64) || defined(PF_TU_CLUSTER_F32) || defined(PF_TU_CLUSTER_F64)
+// the column-persistent / column-cluster kernels of one arithmetic type, nothing else
 #define PF_TU_NO_API
 #define PF_TU_NO_F64
 #define PF_TU_NO_F32DN
@@ -2125,6 +2139,165 @@ PF_DEFINE_COLUMN(pf_run_column_f32, float)
 PF_DEFINE_COLUMN(pf_run_column_f64, double)
 #endif
 
+// ---- the column-cluster route (pf_cluster.hpp): filters of 2 049 .. 16 384 particles, c workgroups per filter, one launch per
+// run and group of columns -------------------------------------------------------------------------------------------------------
+#ifndef PFK_HOST_VEC
+#define PFK_HOST_VEC 4  // particles per lane of the cluster kernels (a build-time choice: -DPFK_HOST_VEC=8 for A/B builds)
+#endif
+static inline size_t cluster_lds_bytes(int D, size_t tsize) {
+    return (size_t)(PFK_WIN_P2 + D * PFK_WIN) * tsize + 2 * PFK_FOLD * sizeof(double);  // window planes | the folds of two states
+}
+// Opt-in (pf_run_hints.route == PF_ROUTE_CLUSTER): the members of a column spin on each other, so all workgroups of a launch
+// must be resident together - two such launches issued on DIFFERENT streams of one device could hold each other's slots.  A caller
+// that issues its fused runs on one stream (the Python host mirror, SMC^2) opts in; the all-zero hints of the C ABI never take it.
+static inline bool cluster_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
+    if (A->hints.route != PF_ROUTE_CLUSTER) return false;
+    if (!finalize || n_steps < 1 || A->ring >= 3) return false;
+    if (A->N <= PF_CLUSTER_MIN_N || A->N > PF_CLUSTER_MAX_N || A->N % PFK_HOST_VEC != 0) return false;
+    if (A->resampler != PF_RESAMPLE_SYSTEMATIC || A->model.hid_kind == PF_HID_USER_AFFINE) return false;
+    (void)g;
+    return true;
+}
+// resident workgroups of `kernel` on the current device: CUs x min(occupancy query, 6) - the query can be one block per CU high
+// near the SGPR-limited edges (MI355X_MICROARCH.md, "Residency and cooperative launch"); 6 is below every such edge
+template <typename K> static inline int cluster_slots(K kernel, size_t lds) {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PFK_TPB, lds) != hipSuccess) return 0;
+    if (per_cu > 6) per_cu = 6;
+    return cus * per_cu;
+}
+template <typename T, int D>
+static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
+                            hipStream_t st, float* kernel_ms) {
+    constexpr int VEC = PFK_HOST_VEC;
+    FusedArgs<T> a = make_fused_args<T>(A, g, wl, t0);
+    const size_t lds = cluster_lds_bytes(D, sizeof(T));
+    const bool auto_flags = !A->observed && !A->observed_dev;
+    a.obs_dev = A->observed_dev;
+    if (auto_flags) {
+        uint8_t* fl = (uint8_t*)A->ws + wl.off_ctr + 64;
+        const int64_t row = A->y_rows * (int64_t)A->model.obs_dim;
+        hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * row, row, fl);
+        a.obs_dev = fl - t0;
+    }
+    const int c = (int)((A->N + PFK_TPB * VEC - 1) / (PFK_TPB * VEC));
+    const int nchunks = (int)((A->N + 64 * VEC - 1) / (64 * VEC));
+    // which instantiation: float runs of the built-in scalar closed-form models on Philox normals take KIND / FILT / PROP folded
+    // (as on the column route), everything else the run-time kernel
+    bool spec_ok = false;
+    if constexpr (sizeof(T) == 4 && D == 1) {
+        const int hk = A->model.hid_kind;
+        spec_ok = !A->z_tape && A->hints.column_max_n >= 0 && A->model.obs_kind == PF_OBS_LINEAR &&
+                  (hk == PF_HID_LINEAR || hk == PF_HID_SINE_EM || hk == PF_HID_OU) &&
+                  (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
+    }
+    auto with_kernel = [&](auto&& f) {
+        if constexpr (sizeof(T) == 4 && D == 1) {
+            if (spec_ok) {
+                auto with_prop = [&](auto kind_c, auto filt_c) {
+                    if (A->proposal == PF_PROP_LGO)
+                        f(k_fused_cluster<T, D, VEC, decltype(kind_c)::value, decltype(filt_c)::value, PF_PROP_LGO>);
+                    else
+                        f(k_fused_cluster<T, D, VEC, decltype(kind_c)::value, decltype(filt_c)::value, PF_PROP_BOOTSTRAP>);
+                };
+                auto with_filt = [&](auto kind_c) {
+                    if (A->filter == PF_FILTER_APF) with_prop(kind_c, std::integral_constant<int, PF_FILTER_APF>{});
+                    else with_prop(kind_c, std::integral_constant<int, PF_FILTER_SISR>{});
+                };
+                const int hk = A->model.hid_kind;
+                if (hk == PF_HID_LINEAR) with_filt(std::integral_constant<int, PF_HID_LINEAR>{});
+                else if (hk == PF_HID_SINE_EM) with_filt(std::integral_constant<int, PF_HID_SINE_EM>{});
+                else with_filt(std::integral_constant<int, PF_HID_OU>{});
+                return;
+            }
+        }
+        f(k_fused_cluster<T, D, VEC, -1, -1, -1>);
+    };
+    int rc = PF_OK;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (kernel_ms) {
+        for (auto& e : ev)
+            if (hipEventCreate(&e) != hipSuccess) return (int)hipGetLastError();
+        (void)hipEventRecord(ev[0], st);
+    }
+    with_kernel([&](auto kernel) {
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            rc = PF_EUNSUPPORTED;
+            return;
+        }
+        const int slots = cluster_slots(kernel, lds);
+        int per_launch = slots / c;  // columns whose members are all resident at once
+        if (per_launch >= 8) per_launch &= ~7;
+        if (per_launch < 1) {
+            rc = PF_EUNSUPPORTED;
+            return;
+        }
+        unsigned char* clu = (unsigned char*)A->ws + wl.off_clu;
+        for (int64_t done = 0; done < n_steps;) {
+            ColumnRun r;
+            r.t0 = (int)(t0 + done);
+            r.n_steps = (int)((n_steps - done < 32 * PFC_OBS_WORDS) ? n_steps - done : 32 * PFC_OBS_WORDS);
+            r.use_bits = (a.obs_dev == nullptr) ? 1 : 0;
+            for (int w = 0; w < PFC_OBS_WORDS; ++w) r.obs_bits[w] = 0u;
+            if (r.use_bits)
+                for (int q = 0; q < r.n_steps; ++q)
+                    if (A->observed[r.t0 + q]) r.obs_bits[q >> 5] |= 1u << (q & 31);
+            a.step = r.t0;
+            // fresh tags for this piece: error word + every record of the batch (a kernel, not a memset node - see k_zero_words)
+            const size_t words = wl.clu_bytes / sizeof(uint32_t);
+            hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3((unsigned)((words + PF_BLOCK - 1) / PF_BLOCK)), dim3(PF_BLOCK), 0, st,
+                               (uint32_t*)clu, words);
+            trace_launch(r.t0, (int)sizeof(T), D, VEC, 0, A->proposal, spec_ok ? 1 : 0, /*SPEC*/ 10, spec_ok ? A->model.hid_kind : 0, c);
+            for (int b0 = 0; b0 < g.B; b0 += per_launch) {
+                ClusterRun cr;
+                cr.b0 = b0;
+                cr.nb = (g.B - b0 < per_launch) ? g.B - b0 : per_launch;
+                cr.nbp = (cr.nb + 7) & ~7;
+                cr.c = c;
+                cr.nchunks = nchunks;
+                cr.err = (int*)clu;
+                cr.rec = clu + 256 + (size_t)b0 * 2 * PF_CLUSTER_NG * 64 * 16;  // (this group's [2][nb][NG][64] block)
+                hipLaunchKernelGGL(kernel, dim3((unsigned)(cr.nbp * c)), dim3(PFK_TPB), lds, st, a, r, cr);
+            }
+            done += r.n_steps;
+        }
+    });
+    if (rc != PF_OK) {
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
+        return rc;
+    }
+    if (kernel_ms) {
+        (void)hipEventRecord(ev[1], st);
+        hipError_t se = hipStreamSynchronize(st);
+        if (se != hipSuccess) return (int)se;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        kernel_ms[0] = kernel_ms[2] = ms / (float)n_steps;
+        kernel_ms[1] = 0.f;
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PF_OK : (int)e;
+}
+int pf_run_cluster_f32(PF_COL_ARGS);
+int pf_run_cluster_f64(PF_COL_ARGS);
+#define PF_DEFINE_CLUSTER(NAME, T)                                                        \
+    int NAME(PF_COL_ARGS) {                                                               \
+        const int D = A->model.dim;                                                       \
+        if (D == 1) return cluster_run_impl<T, 1>(A, g, wl, t0, n_steps, st, kernel_ms);  \
+        if (D == 2) return cluster_run_impl<T, 2>(A, g, wl, t0, n_steps, st, kernel_ms);  \
+        return cluster_run_impl<T, 3>(A, g, wl, t0, n_steps, st, kernel_ms);              \
+    }
+#if defined(PF_TU_CLUSTER_F32) || !defined(PF_TU_SPLIT)
+PF_DEFINE_CLUSTER(pf_run_cluster_f32, float)
+#endif
+#if defined(PF_TU_CLUSTER_F64) || !defined(PF_TU_SPLIT)
+PF_DEFINE_CLUSTER(pf_run_cluster_f64, double)
+#endif
+
 // one entry per arithmetic type / state dimension / vector width / tile geometry (see the translation-unit note above)
 #define PF_RUN_ARGS const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps, int finalize, \
                     hipStream_t st, float* kernel_ms
@@ -2272,7 +2445,7 @@ extern "C" int pf_filter_graph_destroy(void* handle) {
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms) {
     if (!A || A->struct_size != sizeof(pf_filter_args)) return PF_EINVAL;  // (another ABI version: include/pf_amd.h)
-    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_COLUMN_GENERIC || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
+    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
         return PF_EINVAL;
     int rc = check_model(&A->model, true);
     if (rc) return rc;
@@ -2298,6 +2471,12 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    if (!column_eligible(A, g, n_steps, finalize) && cluster_eligible(A, g, n_steps, finalize)) {
+        if (A->ws_bytes < wl.total || wl.clu_bytes == 0) return PF_EWORKSPACE;
+        if (A->dtype == PF_F32) return pf_run_cluster_f32(A, g, wl, t0, n_steps, st, kernel_ms);
+        if (A->dtype == PF_F64) return pf_run_cluster_f64(A, g, wl, t0, n_steps, st, kernel_ms);
+        return PF_EINVAL;
+    }
     if (column_eligible(A, g, n_steps, finalize)) {
         if (A->dtype == PF_F32) return pf_run_column_f32(A, g, wl, t0, n_steps, st, kernel_ms);
         if (A->dtype == PF_F64) return pf_run_column_f64(A, g, wl, t0, n_steps, st, kernel_ms);

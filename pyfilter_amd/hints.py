@@ -6,7 +6,7 @@ command line, the ``PF_*`` variables of a test driver's subprocess) - the packag
 
 The kernel-side choices travel to the library per call in ``pf_filter_args.hints`` (``include/pf_amd.h: pf_run_hints``)."""
 
-ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC = 0, 1, 2
+ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC, ROUTE_CLUSTER = 0, 1, 2, 3
 
 
 class RunHints:
@@ -38,10 +38,11 @@ class RunHints:
         h.resume = h.prepare_next = 0  # (per-call facts, set by the move loops that know them)
 
     def apply_mapping(self, m):
-        """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
+        """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_CLUSTER / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
         PF_NO_FUSED_BATCH / PF_NO_GRAPH / PF_DIRECT / PF_NO_THETA_KERNELS`` of a mapping the CALLER owns -> attributes (absent keys: the defaults)."""
         on = lambda k: str(m.get(k, "0")) not in ("", "0")  # noqa: E731
-        self.route = ROUTE_PER_STEP if on("PF_NO_COLUMN") else (ROUTE_COLUMN_GENERIC if on("PF_COLUMN_GENERIC") else ROUTE_AUTO)
+        self.route = ROUTE_PER_STEP if on("PF_NO_COLUMN") else (ROUTE_COLUMN_GENERIC if on("PF_COLUMN_GENERIC") else
+                                                                (ROUTE_CLUSTER if on("PF_CLUSTER") else ROUTE_AUTO))
         self.column_max_n = int(m.get("PF_COLUMN_MAX_N", 0) or 0)
         self.tile_target = int(m.get("PF_TARGET_WGS", 0) or 0)
         self.ancestor_search = 1 if on("PF_FORCE_SEARCH") else 0

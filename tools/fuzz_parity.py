@@ -30,6 +30,8 @@ def main():
         extra = {}
         if model == "rw_rand":  # dense random observation matrices for every (D, O) the kernels take, shared or per filter
             extra = dict(D=rng.choice([2, 3]), O=rng.choice([0, 1, 2, 3]), per_filter=rng.random() < 0.4)
+            if extra["O"] == 0:  # (a per-filter (B, D) row of a scalar observation cannot be told from an O x D matrix: shared rows)
+                extra["per_filter"] = False
         scalar_obs = model == "lorenz_s" or extra.get("O") == 0
         if scalar_obs and filt_name == "apf" and prop == "lgo":
             # (the one combination the reference - and therefore the oracle - cannot run: proposals/linear.py:79-81 mixes (N, B, D)
@@ -38,6 +40,9 @@ def main():
         oes = rng.choice([1, 1, 1, 1, 2, 3, 5])  # observe_every_step (filters/base.py:204-210)
         n = rng.choice([rng.randint(2, 40), rng.randint(41, 1100), rng.randint(1101, 9000), rng.choice([1024, 2048, 4096, 8192, 12288, 65536]),
                         rng.randint(9001, 70000)])
+        if os.environ.get("FUZZ_CLUSTER"):  # the column-cluster route's sizes (2 048 < N <= 16 384, N % 4 == 0), hints.route = 3
+            n = random.Random(1000 * i + 7).choice([2052, 3000, 4096, 5120, 8192, 8196, 12288, 16384, 16380])
+            HINTS.route = 3
         b = rng.choice([1, 1, 2, 3, 5, 9, 17]) if n < 20000 else rng.choice([1, 2, 3])
         t_len = rng.randint(1, 9) if (n > 4096 or rng.random() < 0.5) else rng.randint(10, 40)  # (long runs: the column loop)
         if rng.random() < 0.3:  # columns of 2 049 .. 4 096 particles on the column-persistent route too (16-wave workgroups)
