@@ -245,7 +245,10 @@ int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t*
                                    * wave and step (pf_cluster.hpp).  Opt-in because those workgroups wait for each other: the
                                    * caller promises that no two such runs are in flight on DIFFERENT streams of one device
                                    * (each could hold slots the other needs; a launch that cannot make progress gives up after
-                                   * ~1 s and returns NaN log-likelihoods rather than hang) */
+                                   * ~1 s and returns NaN log-likelihoods rather than hang).  Batches of more than two
+                                   * launches' worth of member workgroups (B ceil(N / 1024) > 2 048) stay on the per-step route,
+                                   * which is the faster one there */
+#define PF_ROUTE_CLUSTER_ALWAYS 4 /* as CLUSTER for a batch of any size (consecutive launches; tests and measurements) */
 typedef struct pf_run_hints {
     int32_t route;           /* PF_ROUTE_* */
     int32_t column_max_n;    /* largest filter the column-persistent kernel takes; 0 = the default (2048) */

@@ -469,13 +469,16 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
                 draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)(colN + i0), z);
             }
         }
+        // the column's systematic offset: the caller's tape, or ONE Philox chain per workgroup (wave 0, under the hand-off; the
+        // other waves read it with the fold) - every thread drawing the same number cost ~100 VALU per wave and step
         T u = T(0);
         if (a.u_tape) u = a.u_tape[(int64_t)t * g.B + b];
-        else u = uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)t, (uint64_t)b);
+        else if (wid == 0) fold_lds[(s & 1) * PFK_FOLD + 15] = (double)uniform_draw<T>(seed, PF_STREAM_UNIFORM, (uint32_t)t, (uint64_t)b);
 
         PFK_MARK(20_draws_done);
         // ---- the state's records: moments row t, log-likelihood increment of the previous move, the decision -------------------
         const Fold f = poll_fold(s);
+        if (!a.u_tape) u = (T)fold_lds[(s & 1) * PFK_FOLD + 15];
         write_moments(t, f);
         const double lse_w = f.M1 + log_sum<T>(f.S1);
         if (book) {

@@ -2151,10 +2151,15 @@ static inline size_t cluster_lds_bytes(int D, size_t tsize) {
 // must be resident together - two such launches issued on DIFFERENT streams of one device could hold each other's slots.  A caller
 // that issues its fused runs on one stream (the Python host mirror, SMC^2) opts in; the all-zero hints of the C ABI never take it.
 static inline bool cluster_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
-    if (A->hints.route != PF_ROUTE_CLUSTER) return false;
+    if (A->hints.route != PF_ROUTE_CLUSTER && A->hints.route != PF_ROUTE_CLUSTER_ALWAYS) return false;
     if (!finalize || n_steps < 1 || A->ring >= 3) return false;
     if (A->N <= PF_CLUSTER_MIN_N || A->N > PF_CLUSTER_MAX_N || A->N % PFK_HOST_VEC != 0) return false;
     if (A->resampler != PF_RESAMPLE_SYSTEMATIC || A->model.hid_kind == PF_HID_USER_AFFINE) return false;
+    // Where it pays (same-box A/Bs, profiles/r05_cluster_route.txt): a launch holds ~1 024 resident member workgroups (2^20
+    // particles) and larger batches run as consecutive launches of ~8.5 us per step each, while a per-step launch of 2^21+
+    // particles costs 33 us and grows by 3 us per 2^20 more - two launches' worth is the break-even
+    const int64_t members = ((A->N + PFK_TPB * PFK_HOST_VEC - 1) / (PFK_TPB * PFK_HOST_VEC)) * A->B;
+    if (A->hints.route == PF_ROUTE_CLUSTER && members > 2 * 1024) return false;
     (void)g;
     return true;
 }
@@ -2189,7 +2194,7 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
     bool spec_ok = false;
     if constexpr (sizeof(T) == 4 && D == 1) {
         const int hk = A->model.hid_kind;
-        spec_ok = !A->z_tape && A->hints.column_max_n >= 0 && A->model.obs_kind == PF_OBS_LINEAR &&
+        spec_ok = !A->z_tape && A->model.obs_kind == PF_OBS_LINEAR &&
                   (hk == PF_HID_LINEAR || hk == PF_HID_SINE_EM || hk == PF_HID_OU) &&
                   (A->proposal == PF_PROP_BOOTSTRAP || A->proposal == PF_PROP_LGO);
     }
@@ -2445,7 +2450,7 @@ extern "C" int pf_filter_graph_destroy(void* handle) {
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms) {
     if (!A || A->struct_size != sizeof(pf_filter_args)) return PF_EINVAL;  // (another ABI version: include/pf_amd.h)
-    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
+    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER_ALWAYS || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
         return PF_EINVAL;
     int rc = check_model(&A->model, true);
     if (rc) return rc;

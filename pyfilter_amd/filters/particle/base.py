@@ -403,13 +403,16 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         return self._batch_filter_fused(y, init_state)
 
     def _single_launch_run(self, y) -> bool:
-        """A run the library issues as ONE launch of the column-persistent kernel (filters of <= 2 048 particles) with nothing
+        """A run the library issues as ONE launch of the column-persistent kernel (filters of <= 2 048 particles) - or one or two
+        of the column-cluster kernel (2 049 .. 16 384 particles, ``HINTS.cluster_takes``) - with nothing
         recorded but the moments: there is no launch sequence for a hipGraph to replay, so the persistent plan of the general
         driver (its buffers, staging copies and per-shape cache - PMMH re-filters a data set of another length at every
         rejuvenation) only costs host time."""
         return (y.shape[0] > 0 and FilterResult.states_kept(self.record_states) == 1 and not getattr(self, "_time_kernels", False)
                 and not self._move_by_move and not self._kernel_kind().is_user and int(self._model.observe_every_step) == 1
-                and (HINTS.direct or (HINTS.route != 1 and self._base_particles[0] <= (HINTS.column_max_n or 2048)))
+                and (HINTS.direct or (HINTS.route != 1 and self._base_particles[0] <= (HINTS.column_max_n or 2048))
+                     or HINTS.cluster_takes(self._base_particles[0], self.batch_shape[0] if self._batched else 1,
+                                            self._resampler_kind() == L.RESAMPLE_SYSTEMATIC))
                 and self._ctx_tapes_none())
 
     def _batch_filter_lean(self, y: torch.Tensor, init_state=None) -> FilterResult:

@@ -6,18 +6,22 @@ command line, the ``PF_*`` variables of a test driver's subprocess) - the packag
 
 The kernel-side choices travel to the library per call in ``pf_filter_args.hints`` (``include/pf_amd.h: pf_run_hints``)."""
 
-ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC, ROUTE_CLUSTER = 0, 1, 2, 3
+ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC, ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS = 0, 1, 2, 3, 4
 
 
 class RunHints:
     __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph", "direct",
-                 "theta_kernels")
+                 "theta_kernels", "cluster")
 
     def __init__(self):
         self.reset()
 
     def reset(self):
         self.route = ROUTE_AUTO      # pf_run_hints.route
+        self.cluster = True          # ROUTE_AUTO travels as PF_ROUTE_CLUSTER: self-contained runs of filters of 2 049 .. 16 384
+        #                              particles take the column-cluster kernel (include/pf_amd.h: opt-in at the C ABI because its
+        #                              workgroups wait for each other - this package issues its fused runs on ONE stream, torch's
+        #                              current one; set False when driving filters from several streams of one device at once)
         self.column_max_n = 0        # pf_run_hints.column_max_n (0 = the library's 2048)
         self.tile_target = 0         # pf_run_hints.tile_target (0 = the library's 1024 workgroups per launch)
         self.ancestor_search = 0     # pf_run_hints.ancestor_search
@@ -29,20 +33,35 @@ class RunHints:
 
     def key(self):
         """What a cached launch plan depends on."""
-        return (self.route, self.column_max_n, self.tile_target, self.ancestor_search)
+        return (self.kernel_route(), self.column_max_n, self.tile_target, self.ancestor_search)
+
+    def kernel_route(self):
+        """``pf_run_hints.route`` of the next call."""
+        return ROUTE_CLUSTER if (self.route == ROUTE_AUTO and self.cluster) else self.route
+
+    def cluster_takes(self, n, b, resampler_systematic=True):
+        """Does a self-contained run of ``b`` filters of ``n`` particles take the column-cluster kernel (the library's rule,
+        ``pf_kernels.hip: cluster_eligible``)?  One launch per run - or two - with nothing for a hipGraph to replay."""
+        route = self.kernel_route()
+        if route not in (ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS) or not resampler_systematic:
+            return False
+        if n <= max(2048, self.column_max_n or 2048) or n > 16384 or n % 4:
+            return False
+        return route == ROUTE_CLUSTER_ALWAYS or ((n + 1023) // 1024) * b <= 2048
 
     def fill(self, args):
         """Writes the kernel-side choices into a ``PfFilterArgs``."""
         h = args.hints
-        h.route, h.column_max_n, h.tile_target, h.ancestor_search = self.route, self.column_max_n, self.tile_target, self.ancestor_search
+        h.route, h.column_max_n, h.tile_target, h.ancestor_search = self.kernel_route(), self.column_max_n, self.tile_target, self.ancestor_search
         h.resume = h.prepare_next = 0  # (per-call facts, set by the move loops that know them)
 
     def apply_mapping(self, m):
-        """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_CLUSTER / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
+        """``PF_NO_COLUMN / PF_COLUMN_GENERIC / PF_CLUSTER (always) / PF_NO_CLUSTER / PF_COLUMN_MAX_N / PF_TARGET_WGS / PF_FORCE_SEARCH / PF_NO_FUSED_STEP /
         PF_NO_FUSED_BATCH / PF_NO_GRAPH / PF_DIRECT / PF_NO_THETA_KERNELS`` of a mapping the CALLER owns -> attributes (absent keys: the defaults)."""
         on = lambda k: str(m.get(k, "0")) not in ("", "0")  # noqa: E731
         self.route = ROUTE_PER_STEP if on("PF_NO_COLUMN") else (ROUTE_COLUMN_GENERIC if on("PF_COLUMN_GENERIC") else
-                                                                (ROUTE_CLUSTER if on("PF_CLUSTER") else ROUTE_AUTO))
+                                                                (ROUTE_CLUSTER_ALWAYS if on("PF_CLUSTER") else ROUTE_AUTO))
+        self.cluster = not on("PF_NO_CLUSTER")
         self.column_max_n = int(m.get("PF_COLUMN_MAX_N", 0) or 0)
         self.tile_target = int(m.get("PF_TARGET_WGS", 0) or 0)
         self.ancestor_search = 1 if on("PF_FORCE_SEARCH") else 0

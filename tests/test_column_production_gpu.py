@@ -63,9 +63,15 @@ def _cases():
 
 @pytest.mark.parametrize("kind,filt_name,prop,n", _cases())
 def test_production_column_kernels_match_oracle_on_their_own_draws(kind, filt_name, prop, n):
+    own_draws_check(kind, filt_name, prop, n, 9, 1 if _specialised(kind, n) else 0)
+
+
+def own_draws_check(kind, filt_name, prop, n, spec_id, fast, bt=None):
+    """The procedure of the module docstring for one configuration; ``spec_id`` / ``fast``: what the launch trace must show (9 = the
+    column kernel, 10 = the column-cluster kernel of ``tests/test_cluster_route_gpu.py``)."""
     from pyfilter_amd.filters.particle import APF, SISR, proposals
 
-    b, t_len = (5, 10) if n < 1024 else (3, 7)
+    b, t_len = bt if bt is not None else ((5, 10) if n < 1024 else (3, 7))
     ess = 0.9 if filt_name == "apf" else 0.6
     case = dict(name=f"{kind}_{filt_name}_{prop}_{n}", model=MODEL_OF[kind], filter=filt_name, proposal=prop, N=n, B=b,
                 T=t_len, ess_threshold=ess, seed=900 + n, dtypes=("f32",))
@@ -88,8 +94,8 @@ def test_production_column_kernels_match_oracle_on_their_own_draws(kind, filt_na
     full = filt._batch_filter_fused(y.cuda(), s0._restarted())
     torch.cuda.synchronize()
     tr = ops.debug_launch_trace(1)[-1]
-    assert tr["SPEC"] == 9 and tr["tbytes"] == 4 and tr["D"] == d and tr["step"] == 0, tr
-    assert tr["FAST"] == (1 if _specialised(kind, n) else 0), (tr, "expected a specialised instantiation")
+    assert tr["SPEC"] == spec_id and tr["tbytes"] == 4 and tr["D"] == d and tr["step"] == 0, tr
+    assert tr["FAST"] == fast, (tr, "expected a specialised instantiation" if fast else "expected the run-time kernel")
     seed = filt._last_run["seed_eff"]
     ll_steps = filt._last_run["ll_steps"].cpu()  # (t_len, B): the moves' log-likelihood increments
     z = _normals_ref_layout(filt, t_len, n, b, d, has_event)  # (t_len, N, B, [D]): exactly what the kernel drew
@@ -100,7 +106,7 @@ def test_production_column_kernels_match_oracle_on_their_own_draws(kind, filt_na
             return s0
         r = filt._batch_filter_fused(y[:j].cuda(), s0._restarted(), replay=(seed, None))
         trj = ops.debug_launch_trace(1)[-1]
-        assert trj["SPEC"] == 9 and trj["FAST"] == tr["FAST"]
+        assert trj["SPEC"] == spec_id and trj["FAST"] == tr["FAST"]
         torch.testing.assert_close(filt._last_run["ll_steps"].cpu(), ll_steps[:j], rtol=0, atol=0)  # the same run, cut
         return r.latest_state
 

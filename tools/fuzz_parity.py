@@ -42,7 +42,7 @@ def main():
                         rng.randint(9001, 70000)])
         if os.environ.get("FUZZ_CLUSTER"):  # the column-cluster route's sizes (2 048 < N <= 16 384, N % 4 == 0), hints.route = 3
             n = random.Random(1000 * i + 7).choice([2052, 3000, 4096, 5120, 8192, 8196, 12288, 16384, 16380])
-            HINTS.route = 3
+            HINTS.route = 4  # (PF_ROUTE_CLUSTER_ALWAYS)
         b = rng.choice([1, 1, 2, 3, 5, 9, 17]) if n < 20000 else rng.choice([1, 2, 3])
         t_len = rng.randint(1, 9) if (n > 4096 or rng.random() < 0.5) else rng.randint(10, 40)  # (long runs: the column loop)
         if rng.random() < 0.3:  # columns of 2 049 .. 4 096 particles on the column-persistent route too (16-wave workgroups)
