@@ -62,6 +62,7 @@ template <typename T> struct FusedArgs {
     Geom g;
     double thr_abs;  // ess_threshold * N
     double logN;
+    T rcN;           // 1 / N rounded to T on the host (the IEEE quotient the kernels would compute: ~10 VALU per thread saved)
     uint64_t seed;
     const uint64_t* seed_dev;  // optional device word added to `seed` (lets a captured graph draw fresh numbers per replay)
     T* x[2];
@@ -1216,7 +1217,11 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     const T* cdf_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;  // the local scans of this step's parity
     const int64_t base = (int64_t)k * g.tile_elems;
     const T nT = T(N);
+#ifdef PF_NO_HOST_RCN
     const T rcN = T(1) / nT;
+#else
+    const T rcN = a.rcN;
+#endif
     const bool pow2 = (N & (N - 1)) == 0;                  // then the grid division is an exact multiplication
 
     bool poison = false;
@@ -1375,9 +1380,19 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                     for (int j = 0; j < V1; ++j)
                         m1[j] = winb ? cdf_from_local<T>(m1[j], Cb, gb, tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
                 } else {
+#ifdef PF_NO_TILE_LAST_SPLIT
 #pragma unroll
                     for (int j = 0; j < VEC; ++j)
                         m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
+#else
+                    // a tile's (and the column's) last element is the LAST element of its staged vector (tile_elems % VEC == 0,
+                    // N % VEC == 0 for VEC > 1): the pinned value T(P_{k+1}) / 1 is selected for that one element only
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const bool tl = (j == VEC - 1) && (wja + j == la);
+                        m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, tl, tl && (wja + j == N - 1)) : Lim<T>::inf();
+                    }
+#endif
 #pragma unroll
                     for (int j = 0; j < V1; ++j)
                         m1[j] = winb ? cdf_from_local<T>(m1[j], tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();

@@ -631,10 +631,16 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                      and HINTS.graph and not kind.is_user and not self._move_by_move)
         key = (n, b, d, o, steps, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
                self._resampler_kind(), self._seed, float(self._resample_threshold), observed_host.numpy().tobytes(), HINTS.key())
-        plan = self._fused_plans.get(key) if use_graph else None
+        # a user-defined affine process that opted in (``graph_callable = True`` on the process): the run's whole launch sequence -
+        # per move the callable's own torch launches and the library's kernel - is captured ONCE as a hipGraph (torch.cuda.graph)
+        # and replayed: the callable's launches are a few microseconds of kernel each, issued eagerly they set the pace of a move
+        user_graph = (kind.is_user and bool(getattr(self._model.hidden, "graph_callable", False)) and (not taped) and not ring
+                      and replay is None and not getattr(self, "_time_kernels", False) and HINTS.graph
+                      and not isinstance(self._move_by_move, (list, tuple)))
+        plan = self._fused_plans.get(key) if (use_graph or user_graph) else None
         if plan is None:
             plan = _FusedPlan(self, kind, n, b, d, o, steps, rows, dtype, device, observed_host, ring=ring)
-            if use_graph:
+            if use_graph or user_graph:
                 if len(self._fused_plans) >= 4:  # a handful of (shape, schedule) combinations at most
                     self._fused_plans.pop(next(iter(self._fused_plans))).destroy()
                 self._fused_plans[key] = plan
@@ -700,33 +706,66 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                     L.check(lib.pf_filter_run(C.byref(a), t_piece, n_piece, fin, L.stream_ptr()), "pf_filter_run")
                     t_piece += n_piece
                 assert t_piece == steps, "the pieces do not cover the run"
-            for s_ in range(steps if (kind.is_user or not isinstance(self._move_by_move, (list, tuple))) else 0):
-                if not kind.is_user:  # (``_move_by_move``: a built-in model issued the same way - the pieces of one run)
-                    L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
-                    continue
-                ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
-                loc, scale = hidden.mean_scale(ts)
-                v = ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event)
-                # (already a (D, B, N) plane - an unbatched scalar state's loc: read in place, kept alive past the launch)
-                loc_p = v if v.is_contiguous() else plan.user_loc.copy_(v)
-                percol = self._scale_per_column(scale, full, dtype)
-                if percol is not None:  # a state-independent diffusion: one scale per filter and component, no plane to fill
-                    scale_p = percol
-                else:
-                    v = ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event)
-                    scale_p = v if v.is_contiguous() else plan.user_scale.copy_(v)
-                keep = [loc_p, scale_p]
-                a.user_loc, a.user_scale = loc_p.data_ptr(), scale_p.data_ptr()
-                a.user_scale_per_column = 0 if percol is None else 1
-                last_move = s_ == steps - 1
-                # (prepared first-stage weights are only taken when this move's scale IS the one they were computed with - a
-                # time-dependent diffusion hands over another tensor, and the move re-reduces like any other)
-                a.hints.resume = 1 if (chained and s_ > 0 and (self._FILTER_KIND == L.FILTER_SISR or
-                                                               (prepared_with is not None and percol is prepared_with))) else 0
-                prepare = bool(chained and apf_lgo and percol is not None and not last_move and observed_host[s_ + 1])
-                a.hints.prepare_next = 1 if prepare else 0
-                prepared_with = percol if prepare else None
-                L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1 if (last_move or not chained) else 0, L.stream_ptr()), "pf_filter_run")
+            def issue_moves():
+                nonlocal keep, prepared_with
+                for s_ in range(steps if (kind.is_user or not isinstance(self._move_by_move, (list, tuple))) else 0):
+                    if not kind.is_user:  # (``_move_by_move``: a built-in model issued the same way - the pieces of one run)
+                        L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
+                        continue
+                    ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
+                    loc, scale = hidden.mean_scale(ts)
+                    v = ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event)
+                    # (already a (D, B, N) plane - an unbatched scalar state's loc: read in place, kept alive past the launch)
+                    loc_p = v if v.is_contiguous() else plan.user_loc.copy_(v)
+                    percol = self._scale_per_column(scale, full, dtype)
+                    if percol is not None:  # a state-independent diffusion: one scale per filter and component, no plane to fill
+                        scale_p = percol
+                    else:
+                        v = ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event)
+                        scale_p = v if v.is_contiguous() else plan.user_scale.copy_(v)
+                    keep = [loc_p, scale_p]
+                    a.user_loc, a.user_scale = loc_p.data_ptr(), scale_p.data_ptr()
+                    a.user_scale_per_column = 0 if percol is None else 1
+                    last_move = s_ == steps - 1
+                    # (prepared first-stage weights are only taken when this move's scale IS the one they were computed with - a
+                    # time-dependent diffusion hands over another tensor, and the move re-reduces like any other)
+                    a.hints.resume = 1 if (chained and s_ > 0 and (self._FILTER_KIND == L.FILTER_SISR or
+                                                                   (prepared_with is not None and percol is prepared_with))) else 0
+                    prepare = bool(chained and apf_lgo and percol is not None and not last_move and observed_host[s_ + 1])
+                    a.hints.prepare_next = 1 if prepare else 0
+                    prepared_with = percol if prepare else None
+                    L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1 if (last_move or not chained) else 0, L.stream_ptr()), "pf_filter_run")
+
+            captured = False
+            if user_graph and plan.runs >= 1 and not plan.user_graph_failed:
+                # (the first run of a configuration is issued eagerly: it warms up whatever the callable initialises lazily, and a
+                # configuration used once never pays for a capture).  A graph is tied to the tensors the callable read when it was
+                # captured: another parameter tensor (not an in-place update of the same one) captures again
+                sig = (id(ctx),) + tuple(p.data_ptr() for p in hidden.parameters if isinstance(p, torch.Tensor))
+                if plan.user_graph is None or plan.user_graph_sig != sig:
+                    graph = torch.cuda.CUDAGraph()
+                    # (the per-filter scale rows derived from the callable's scale are remembered across moves by the tensor's
+                    # identity and version: inside a capture they must be COMPUTED - once, by the first move - so that a replay
+                    # derives them from the parameter's current values; the entry is dropped again afterwards)
+                    self._percol_cache = None
+                    try:
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                            issue_moves()
+                        plan.user_graph, plan.user_graph_sig, plan.user_graph_keep = graph, sig, (list(keep), self._percol_cache)
+                        self._percol_cache = None
+                    except Exception as e:  # the callable does something a capture cannot record (a host read, an allocation-
+                        # dependent branch): this configuration stays eager
+                        import warnings
+
+                        plan.user_graph, plan.user_graph_failed = None, True
+                        self._percol_cache = None
+                        warnings.warn(f"graph_callable: capturing the callable failed ({type(e).__name__}: {e}); the run is issued eagerly")
+                        torch.cuda.synchronize()
+                if plan.user_graph is not None:
+                    plan.user_graph.replay()
+                    captured = True
+            if not captured:
+                issue_moves()
             if kind.is_user:
                 a.user_loc, a.user_scale = plan.user_loc.data_ptr(), plan.user_scale.data_ptr()
                 a.user_scale_per_column, a.hints.resume, a.hints.prepare_next = 0, 0, 0
@@ -935,6 +974,8 @@ class _FusedPlan:
             self.user_loc = torch.empty((d, b, n), device=device, dtype=dtype)
             self.user_scale = torch.empty((d, b, n), device=device, dtype=dtype)
         self.graph = None
+        self.user_graph = self.user_graph_sig = self.user_graph_keep = None  # torch.cuda.CUDAGraph of a user-affine run (graph_callable)
+        self.user_graph_failed = False
 
         a = L.PfFilterArgs()
         a.model = ops.make_model_struct(kind, self.params)

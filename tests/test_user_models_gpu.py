@@ -213,3 +213,67 @@ def test_a_time_dependent_diffusion_is_not_resumed_on_stale_weights():
     torch.testing.assert_close(chained.filter_means, moves.filter_means, **tol)
     torch.testing.assert_close(chained.loglikelihood, moves.loglikelihood, **tol)
     assert torch.equal(chained.latest_state.previous_indices, moves.latest_state.previous_indices)
+
+
+@pytest.mark.parametrize("model,cls_name,prop,n,b", [("sine", "APF", "lgo", 4096, 3), ("sine", "SISR", "bootstrap", 1 << 16, 1),
+                                                      ("lorenz", "APF", "lgo", 2048, 2), ("ou_batched", "SISR", "lgo", 512, 5)])
+def test_graph_callable_runs_equal_the_eager_runs(model, cls_name, prop, n, b):
+    """``graph_callable = True`` on a user-defined affine process: from a configuration's second run on, the whole launch sequence
+    (the callable's torch launches and the library's kernel, move after move) is ONE captured hipGraph.  Same seed, same data:
+    run for run the graph-replayed filter must return exactly what the eagerly issued one returns - fresh draws every run, an
+    in-place parameter update seen by the replays - and a callable a capture cannot record falls back to eager launches."""
+    import warnings
+
+    from pyfilter_amd.filters import particle as pfm
+    from pyfilter_amd.filters.particle import proposals
+
+    dtype = torch.float32
+    g = torch.Generator().manual_seed(77)
+    t_len = 12
+    outs = {}
+    for graphed in (False, True):
+        ssm = _lambda_ssm(model, b, dtype)
+        ssm.hidden.graph_callable = graphed
+        o = tuple(ssm.event_shape) if hasattr(ssm, "event_shape") else ()
+        y = (0.1 * torch.randn((t_len,) + ((2,) if model == "lorenz" else ()), generator=torch.Generator().manual_seed(5))).cumsum(0).to(DEV)
+        p = {"bootstrap": proposals.Bootstrap, "lgo": proposals.LinearGaussianObservations}[prop]()
+        filt = getattr(pfm, cls_name)(ssm, n, proposal=p, seed=99)
+        if b > 1:
+            filt.set_batch_shape(torch.Size([b]))
+        runs = []
+        torch.manual_seed(4242)  # (a lambda-defined initial distribution samples from torch's global generator, as in the reference)
+        for rep in range(4):
+            if rep == 3:  # an in-place update of a parameter the callable reads: the captured graph reads the same tensor
+                ssm.hidden.parameters[-1].mul_(1.5)
+            res = filt.batch_filter(y, bar=False)
+            runs.append((res.filter_means.cpu(), res.loglikelihood.cpu(), res.latest_state.previous_indices.cpu()))
+        outs[graphed] = runs
+        if graphed:
+            plans = [pl for pl in filt._fused_plans.values()]
+            assert plans and plans[0].user_graph is not None, "the run was not captured"
+    for rep, (e, c) in enumerate(zip(outs[False], outs[True])):
+        assert torch.equal(e[2], c[2]), f"run {rep}: ancestors differ"
+        torch.testing.assert_close(c[0], e[0], rtol=0, atol=0)
+        torch.testing.assert_close(c[1], e[1], rtol=0, atol=0)
+    assert not torch.equal(outs[True][0][0], outs[True][1][0]), "replays must draw fresh numbers"
+
+    # a callable that reads the device on the host cannot be captured: eager launches, a warning, the same results
+    from torch.distributions import Normal
+
+    from pyfilter_amd import timeseries as ts
+
+    t = lambda v: torch.tensor(v, dtype=dtype, device=DEV)  # noqa: E731
+
+    def nosy(x, a, s):
+        return a * x.value + float(x.value.reshape(-1)[0].item()) * 0.0, s
+
+    hidden = ts.AffineProcess(nosy, (t(0.9), t(0.1)), Normal(t(0.0), t(1.0)), lambda a, s: Normal(t(0.0), t(0.2)))
+    hidden.graph_callable = True
+    filt = pfm.SISR(ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.2))), 4096, seed=5)
+    yy = (0.1 * torch.randn(6)).cumsum(0).to(DEV)
+    first = filt.batch_filter(yy, bar=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        second = filt.batch_filter(yy, bar=False)
+    assert any("graph_callable" in str(x.message) for x in w)
+    assert torch.isfinite(second.loglikelihood).all() and torch.isfinite(first.loglikelihood).all()

@@ -44,6 +44,7 @@ def make(model, filt, prop, n, b, dtype=torch.float32, resampler="systematic"):
         from torch.distributions import Normal
         hidden = ts.AffineEulerMaruyama(lambda x, gm, s: (torch.sin(x.value - gm), s), (t(0.0, dtype), t(1.0, dtype)),
                                         Normal(t(0.0, dtype), t(math.sqrt(0.1), dtype)), 0.1, lambda gm, s: Normal(t(0.0, dtype), t(1.0, dtype)))
+        hidden.graph_callable = bool(os.environ.get("KB_GRAPH_CALLABLE"))  # the run as one captured hipGraph (callable + library)
         ssm = ts.LinearStateSpaceModel(hidden, (t(1.0, dtype), t(0.1, dtype)))
         o = ()
     elif model == "lorenz":

@@ -7,7 +7,7 @@ i = m.start(); j = txt.index('.Lfunc_end', i)
 body = txt[i:j].splitlines()
 cur = '00_prologue'; counts = {}; order = []
 for ln in body:
-    mm = re.search(r'; PFK_MARK (\S+)', ln)
+    mm = re.search(r'; PF[K]?_MARK (\S+)', ln)
     if mm:
         cur = mm.group(1)
         if cur not in order: order.append(cur)
