@@ -159,19 +159,26 @@ def smc2_step_kernel_roofline(w, b_local, dtype, device, t_len=64):
     torch.cuda.synchronize()
     filt._time_kernels = False
     step_ms = filt.kernel_ms[2]
+    from pyfilter_amd import ops
+
+    spec = ops.debug_launch_trace(1)[-1]["SPEC"]  # which route the library took at this shape: 10 = the column-cluster kernel
+    kname = {10: "k_fused_cluster", 9: "k_fused_column"}.get(spec, "k_fused_step")
     esz = 8 if dtype == torch.float64 else 4
     bm = byte_models(dict(w, D=1, filter="apf"), esz)
     units = w["N"] * b_local
     gbs = {k: v * units / (step_ms * 1e-3) / 1e9 for k, v in bm.items()}
     return {
         "bound": "valu" if gbs["as_built"] / HBM_PEAK_GBS < 0.30 else "hbm", "priced_against": "hbm",
-        "kernel": "k_fused_step", "achieved": gbs["survey_8d"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": kname, "achieved": gbs["survey_8d"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": gbs["survey_8d"] / HBM_PEAK_GBS, "traffic": None,
+        "route": {"k_fused_cluster": "column-cluster: ceil(N / 1024) workgroups per filter hold it in registers for the whole run "
+                                     "(one launch per block of moves; the state's HBM traffic is its exchange through L2)",
+                  "k_fused_column": "column-persistent", "k_fused_step": "one launch per time step"}[kname],
         "shape": f"{b_local} filters x {w['N']} particles per launch (this rank's theta-block), APF + lgo, OU",
         "byte_model": "survey_8d: SURVEY.md 8(d) APF bytes (32 + 16 D) x particles per launch / the step kernel's in-sequence duration",
         "bytes_per_particle": bm, "bytes_per_launch": {k: v * units for k, v in bm.items()},
-        "kernel_us": {"k_fused_step": 1e3 * step_ms},
-        "duration_source": "HIP events on the launch stream around the step launches of a 64-move run at this shape (pf_filter_run_timed)",
+        "kernel_us": {kname: 1e3 * step_ms},
+        "duration_source": "HIP events on the launch stream around a 64-move run at this shape / 64 (pf_filter_run_timed)",
         "as_built": {"achieved": gbs["as_built"], "frac": gbs["as_built"] / HBM_PEAK_GBS},
     }
 

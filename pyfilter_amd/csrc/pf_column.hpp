@@ -478,6 +478,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             for (int j = 0; j < VEC; ++j) q[j] = (int)(pp[j] * nT);
             if (false)
 #endif
+#ifdef PFC_SEARCH_BY_INDEX
             for (int st = np2 >> 1; st >= 1; st >>= 1) {
                 T v[VEC];
 #pragma unroll
@@ -486,8 +487,32 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
                 for (int j = 0; j < VEC; ++j) q[j] += (v[j] < pp[j]) ? st : 0;
             }
 #pragma unroll
+            for (int j = 0; j < VEC; ++j) q[j] += (cdfs[q[j]] < pp[j]) ? 1 : 0;
+#else
+            {
+                // (round 5: the rounds unrolled with the positions as BYTE offsets - a probe is one ds_read with an immediate
+                // offset, a round compare + select + add per position: 16 VALU per round of four positions against 21 for the
+                // run-time loop over element indices; rounds above the column's power of two are skipped, uniformly)
+                const unsigned char* const cb = reinterpret_cast<const unsigned char*>(cdfs);
+#pragma unroll
+                for (int st = 2048; st >= 1; st >>= 1) {
+                    if (st < np2) {
+                        T v[VEC];
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) v[j] = *reinterpret_cast<const T*>(cb + q[j] + (st - 1) * (int)sizeof(T));
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) q[j] += (v[j] < pp[j]) ? st * (int)sizeof(T) : 0;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    q[j] += (*reinterpret_cast<const T*>(cb + q[j]) < pp[j]) ? (int)sizeof(T) : 0;
+                    q[j] /= (int)sizeof(T);
+                }
+            }
+#endif
+#pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                q[j] += (cdfs[q[j]] < pp[j]) ? 1 : 0;
                 idx[j] = q[j] > N - 1 ? N - 1 : q[j];
 #pragma unroll
                 for (int d = 0; d < D; ++d) xr[j][d] = xs[d * NP + idx[j]];
