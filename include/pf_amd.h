@@ -249,6 +249,10 @@ int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t*
                                    * launches' worth of member workgroups (B ceil(N / 1024) > 2 048) stay on the per-step route,
                                    * which is the faster one there */
 #define PF_ROUTE_CLUSTER_ALWAYS 4 /* as CLUSTER for a batch of any size (consecutive launches; tests and measurements) */
+#define PF_ROUTE_CLUSTER_SPREAD 5 /* as CLUSTER_ALWAYS with the members of a filter on DIFFERENT XCDs (consecutive workgroup ids) and
+                                   * the exchange in its placement-independent form - agent-scope write-through stores and
+                                   * L1-bypassing loads, never the same-XCD fast path: what a run falls back to whenever its
+                                   * members do not share an XCD, pinned by the tests on every box */
 typedef struct pf_run_hints {
     int32_t route;           /* PF_ROUTE_* */
     int32_t column_max_n;    /* largest filter the column-persistent kernel takes; 0 = the default (2048) */

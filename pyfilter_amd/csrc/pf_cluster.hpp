@@ -12,9 +12,10 @@
 //              scan L_i of those weights and the particles themselves (write-through `sc1` stores into the state buffer the
 //              per-step route would have written, and into the scan planes), as 16-byte {3 words, tag} granules - tag = state
 //              index + 1, written by one `sc1` store each, so a record needs no flag and no second drain;
-//              every wave of the column polls the column's <= 64 records (lane l <-> chunk l, `sc1` loads: L1 bypassed) and
-//              folds them with wave-level DPP operations: identical arithmetic in every wave, so every member takes the same
-//              decisions (ESS test, window) bit for bit.  No workgroup ever waits for a workgroup of ANOTHER column;
+//              wave 0 of every member polls the column's <= 64 records (lane l <-> chunk l, `sc1` loads: L1 bypassed - one poller
+//              per workgroup: what a hand-off costs is set by the traffic in the consumer CU's own memory queue), folds them with
+//              wave-level DPP operations and broadcasts the fold through LDS: identical arithmetic in every member, so all take
+//              the same decisions (ESS test, window) bit for bit.  No workgroup ever waits for a workgroup of ANOTHER column;
 //              ancestors: the positions of a member lie in a contiguous range of the cdf; the chunks that can hold their
 //              ancestors (conservative bounds from the folded chunk totals) are staged into LDS as cdf values
 //              T(inv_tot (C_c + g_c L_i)) - the column kernel's formula, one rounding - with their particles, <= 3 072 entries
@@ -27,7 +28,9 @@
 // Residency: a member spins on its siblings, so every workgroup of a launch must be resident at once - the host sizes each
 // launch by the occupancy query (columns per launch = resident slots / c) and runs the columns of a larger batch in
 // consecutive launches.  Siblings get the linear ids b + nbp k (nbp % 8 == 0): the same XCD under the observed id % 8
-// placement - for speed only, correctness never depends on it (agent-scope `sc1` on both sides).  Every spin is bounded:
+// placement - then (checked: the first records carry the XCC ids) the exchange stays in that XCD's L2: plain stores, L1-bypassing
+// loads; otherwise agent-scope `sc1` on both sides, correct under any placement (PF_ROUTE_CLUSTER_SPREAD pins that form in the
+// tests).  Every spin is bounded:
 // a launch that cannot make progress poisons its log-likelihoods with NaN and raises the error word instead of hanging.
 //
 // Mirrors the same reference code as the other routes: sisr.py:14-56, apf.py:16-46, particle/utils.py:7-65,
@@ -55,6 +58,9 @@ struct ClusterRun {
     int c;               // member workgroups per column
     int nchunks;         // waves with particles per column = ceil(N / (64 VEC))
     int* err;            // |= 1: a poll ran out of patience, |= 2: an ancestor fell outside the staged chunks
+    int spread;          // != 0 (PF_ROUTE_CLUSTER_SPREAD, tests): the members of a column get CONSECUTIVE ids - one per XCD under
+                         // the id % 8 placement - so the exchange runs on its placement-independent form (agent-scope `sc1` on both
+                         // sides, never the same-XCD fast path)
 };
 
 typedef unsigned pfk_u4 __attribute__((ext_vector_type(4)));
@@ -121,7 +127,8 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
 
     const Geom& g = a.g;
     const int N = (int)g.N;
-    const int bl = (int)(blockIdx.x % (unsigned)cr.nbp), k = (int)(blockIdx.x / (unsigned)cr.nbp);
+    const int bl = cr.spread ? (int)(blockIdx.x / (unsigned)cr.c) : (int)(blockIdx.x % (unsigned)cr.nbp);
+    const int k = cr.spread ? (int)(blockIdx.x % (unsigned)cr.c) : (int)(blockIdx.x / (unsigned)cr.nbp);
     if (bl >= cr.nb) return;  // (padding ids: they only keep the siblings' ids congruent mod 8)
     const int b = cr.b0 + bl;
     const int tid = threadIdx.x;
@@ -213,11 +220,11 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
         T e1[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            T ej = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - mw1);
-            if (lw[j] != lw[j]) ej = lw[j];
+            // (log-weights are sanitised: never NaN.  An APF never looks at the weights' ESS - FILT known: sum e^2 is not formed)
+            const T ej = (lw[j] == -Lim<T>::inf()) ? T(0) : pf_exp_w(lw[j] - mw1);
             e1[j] = ej;
             v[0] += ej;
-            v[1] += ej * ej;
+            if constexpr (FILT != PF_FILTER_APF) v[1] += ej * ej;
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const T xd = x[d][j] - piv[d];
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2 + 2 * D; ++i) v[i] = wave_sum<T>(v[i]);
+        for (int i = 0; i < 2 + 2 * D; ++i)
+            if (FILT != PF_FILTER_APF || i != 1) v[i] = wave_sum<T>(v[i]);
         bool poison_pre = false;
         T er[VEC], mw2 = mw1;
         if (two_next) {
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
         for (int i = 0; i < 2 * D; ++i) f.mom[i] = fl[6 + i];
         f.poison_w = (flags & 1) != 0;
         f.poison_pre = (flags & 2) != 0;
-        if (s == 0) fastx = (flags & 4) != 0;
+        if (s == 0) fastx = (flags & 4) != 0 && !cr.spread;
         dead = dead || (flags & 8) != 0;
         f.ci = fl + 16;
         f.cex = fl + 16 + 64;

@@ -1374,8 +1374,10 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                     const double* cgb = ct_col + 2 * ((winb ? wjb : 0) / (PF_WAVE * VEC));
                     const double Ca = cga[0], ga = cga[1], Cb = cgb[0], gb = cgb[1];
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        m0[j] = wina ? cdf_from_local<T>(m0[j], Ca, ga, tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
+                    for (int j = 0; j < VEC; ++j) {  // (only a staged vector's LAST element can be a tile's last: see below)
+                        const bool tl = (j == VEC - 1) && (wja + j == la);
+                        m0[j] = wina ? cdf_from_local<T>(m0[j], Ca, ga, tPa, tFa, tNa, tl, tl && (wja + j == N - 1)) : Lim<T>::inf();
+                    }
 #pragma unroll
                     for (int j = 0; j < V1; ++j)
                         m1[j] = winb ? cdf_from_local<T>(m1[j], Cb, gb, tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();

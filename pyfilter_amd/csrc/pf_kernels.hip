@@ -2173,7 +2173,7 @@ static inline size_t cluster_lds_bytes(int D, size_t tsize) {
 // must be resident together - two such launches issued on DIFFERENT streams of one device could hold each other's slots.  A caller
 // that issues its fused runs on one stream (the Python host mirror, SMC^2) opts in; the all-zero hints of the C ABI never take it.
 static inline bool cluster_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
-    if (A->hints.route != PF_ROUTE_CLUSTER && A->hints.route != PF_ROUTE_CLUSTER_ALWAYS) return false;
+    if (A->hints.route != PF_ROUTE_CLUSTER && A->hints.route != PF_ROUTE_CLUSTER_ALWAYS && A->hints.route != PF_ROUTE_CLUSTER_SPREAD) return false;
     if (!finalize || n_steps < 1 || A->ring >= 3) return false;
     if (A->N <= PF_CLUSTER_MIN_N || A->N > PF_CLUSTER_MAX_N || A->N % PFK_HOST_VEC != 0) return false;
     if (A->resampler != PF_RESAMPLE_SYSTEMATIC || A->model.hid_kind == PF_HID_USER_AFFINE) return false;
@@ -2285,6 +2285,7 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
                 cr.c = c;
                 cr.nchunks = nchunks;
                 cr.err = (int*)clu;
+                cr.spread = A->hints.route == PF_ROUTE_CLUSTER_SPREAD ? 1 : 0;
                 cr.rec = clu + 256 + (size_t)b0 * 2 * PF_CLUSTER_NG * 64 * 16;  // (this group's [2][nb][NG][64] block)
                 hipLaunchKernelGGL(kernel, dim3((unsigned)(cr.nbp * c)), dim3(PFK_TPB), lds, st, a, r, cr);
             }
@@ -2472,7 +2473,7 @@ extern "C" int pf_filter_graph_destroy(void* handle) {
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms) {
     if (!A || A->struct_size != sizeof(pf_filter_args)) return PF_EINVAL;  // (another ABI version: include/pf_amd.h)
-    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER_ALWAYS || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
+    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER_SPREAD || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
         return PF_EINVAL;
     int rc = check_model(&A->model, true);
     if (rc) return rc;

@@ -6,7 +6,7 @@ command line, the ``PF_*`` variables of a test driver's subprocess) - the packag
 
 The kernel-side choices travel to the library per call in ``pf_filter_args.hints`` (``include/pf_amd.h: pf_run_hints``)."""
 
-ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC, ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS = 0, 1, 2, 3, 4
+ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC, ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS, ROUTE_CLUSTER_SPREAD = 0, 1, 2, 3, 4, 5
 
 
 class RunHints:
@@ -43,11 +43,11 @@ class RunHints:
         """Does a self-contained run of ``b`` filters of ``n`` particles take the column-cluster kernel (the library's rule,
         ``pf_kernels.hip: cluster_eligible``)?  One launch per run - or two - with nothing for a hipGraph to replay."""
         route = self.kernel_route()
-        if route not in (ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS) or not resampler_systematic:
+        if route not in (ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS, ROUTE_CLUSTER_SPREAD) or not resampler_systematic:
             return False
         if n <= max(2048, self.column_max_n or 2048) or n > 16384 or n % 4:
             return False
-        return route == ROUTE_CLUSTER_ALWAYS or ((n + 1023) // 1024) * b <= 2048
+        return route != ROUTE_CLUSTER or ((n + 1023) // 1024) * b <= 2048
 
     def fill(self, args):
         """Writes the kernel-side choices into a ``PfFilterArgs``."""

@@ -55,7 +55,7 @@ def _run(route, kind, filt_name, prop, n, b, t_len, dtype=torch.float64, nan_at=
     for k in nan_at:
         y[k] = float("nan")
     saved = HINTS.route
-    HINTS.route = 1 if route == "per_step" else 4  # (PF_ROUTE_CLUSTER_ALWAYS: batches of any size)
+    HINTS.route = {"per_step": 1, "cluster": 4, "spread": 5}[route]  # (4: PF_ROUTE_CLUSTER_ALWAYS, 5: PF_ROUTE_CLUSTER_SPREAD)
     try:
         res = filt.batch_filter(y.to(DEV), bar=False)
         torch.cuda.synchronize()
@@ -102,6 +102,53 @@ def test_cluster_route_equals_per_step_route_float64(kind, filt_name, prop, n, b
     torch.testing.assert_close(got["means"], ref["means"], rtol=1e-9, atol=1e-11)
     torch.testing.assert_close(got["var"], ref["var"], rtol=1e-7, atol=1e-11)
     torch.testing.assert_close(got["ll"], ref["ll"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("kind,filt_name,prop,n,b,t_len,opt", [c for c in CASES if c[4] <= 9])
+def test_cluster_members_on_different_xcds_float64(kind, filt_name, prop, n, b, t_len, opt):
+    """``PF_ROUTE_CLUSTER_SPREAD``: the members of a filter on eight different XCDs, the exchange on agent-scope write-through stores
+    and L1-bypassing loads only - the form a run falls back to when its members do not share an XCD - must give what the same-XCD
+    fast path gives, bit for bit (the arithmetic is the same; only the memory path differs)."""
+    fast = _run("cluster", kind, filt_name, prop, n, b, t_len, **opt)
+    got = _run("spread", kind, filt_name, prop, n, b, t_len, **opt)
+    assert got["SPEC"] == 10 and torch.isfinite(got["ll"]).all()
+    for key in ("idx", "x", "w", "means", "var", "ll"):
+        assert torch.equal(got[key], fast[key]) or torch.allclose(got[key], fast[key], rtol=0, atol=0, equal_nan=True), key
+
+
+@pytest.mark.parametrize("kind,dtype,n", [("sine", torch.float32, 8192), ("lorenz", torch.float64, 4096), ("rw2d", torch.float64, 5120)])
+def test_cluster_runs_replayed_from_a_captured_graph(kind, dtype, n):
+    """``observe_every_step = 2`` keeps a run on the general fused driver, whose repeated runs of one configuration replay a captured
+    hipGraph: the cluster launches (and, for float64 vector states, their > 64 KB of dynamic LDS) are captured like any other
+    kernel - run for run the same numbers as the per-step route's replayed graph (float64) / finite and fresh (float32)."""
+    from pyfilter_amd import resampling
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.hints import HINTS
+
+    outs = {}
+    for route in ("per_step", "cluster"):
+        ssm, o = _model(kind, 2, dtype)
+        ssm.observe_every_step = 2
+        filt = APF(ssm, n, proposal=proposals.Bootstrap(), resampling=resampling.systematic, seed=21)
+        filt.set_batch_shape(torch.Size([2]))
+        g = torch.Generator().manual_seed(8)
+        y = (torch.tensor([-4.7, 19.6]) + 0.5 * torch.randn((6, 2), generator=g)) if kind == "lorenz" else (0.1 * torch.randn((6,) + o, generator=g)).cumsum(0)
+        saved = HINTS.route
+        HINTS.route = 1 if route == "per_step" else 4
+        try:
+            outs[route] = [filt.batch_filter(y.to(dtype).to(DEV), bar=False) for _ in range(4)]
+            torch.cuda.synchronize()
+            assert any(pl.graph is not None for pl in filt._fused_plans.values()), "the run was not replayed from a graph"
+        finally:
+            HINTS.route = saved
+    for rep in range(4):
+        a, b = outs["cluster"][rep], outs["per_step"][rep]
+        assert torch.isfinite(a.loglikelihood).all()
+        if dtype == torch.float64:
+            assert torch.equal(a.latest_state.previous_indices, b.latest_state.previous_indices)
+            torch.testing.assert_close(a.filter_means, b.filter_means, rtol=1e-9, atol=1e-11)
+            torch.testing.assert_close(a.loglikelihood, b.loglikelihood, rtol=1e-9, atol=1e-9)
+    assert not torch.equal(outs["cluster"][1].filter_means, outs["cluster"][2].filter_means), "replays must draw fresh numbers"
 
 
 def test_cluster_fuzz_against_the_oracle(monkeypatch):

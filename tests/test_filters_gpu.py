@@ -434,9 +434,12 @@ def _full_size_case(model, filt_name, prop, n, b, t_len, seed, ess=0.9):
     ("ou_batched", "apf", "bootstrap", 8192, 16, 8),   # configs[4]: theta on the batch dim, 8 192 state particles
     ("lg1d", "sisr", "bootstrap", 1000, 1, 50),        # configs[0]
 ])
-def test_fp64_parity_at_benchmark_sizes(model, filt_name, prop, n, b, t_len):
+@both_routes
+def test_fp64_parity_at_benchmark_sizes(model, filt_name, prop, n, b, t_len, kernel_route):
     """BASELINE.json shapes in float64, identical draws: filter_means / log-likelihood within 1e-9 of the oracle (bar:
-    1e-5) and the final ancestors identical - at 2^20 particles there are ~10^7 searchsorted decisions per step."""
+    1e-5) and the final ancestors identical - at 2^20 particles there are ~10^7 searchsorted decisions per step.
+    (``kernel_route``: the library's own choice - the column-cluster kernel for the 16 x 8 192 theta-block since round 5 - and
+    one launch per step, which is what the full 1 024 x 8 192 job takes.)"""
     case, spec, g, y = _full_size_case(model, filt_name, prop, n, b, t_len, seed=900 + n % 97)
     x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
     ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=0.9)
@@ -456,8 +459,10 @@ def test_fp64_parity_at_benchmark_sizes(model, filt_name, prop, n, b, t_len):
     ("lorenz", "sisr", "bootstrap", 4100, 1),  # several partially filled tiles, D = 3
     ("ou_batched", "apf", "lgo", 6148, 5),     # ragged last tile, per-filter parameters
 ])
-def test_fp64_parity_ragged_sizes(model, filt_name, prop, n, b):
-    """Particle counts that are not powers of two / not multiples of the vector width: same bar as the benchmark sizes."""
+@both_routes
+def test_fp64_parity_ragged_sizes(model, filt_name, prop, n, b, kernel_route):
+    """Particle counts that are not powers of two / not multiples of the vector width: same bar as the benchmark sizes (on the
+    library's own route - the column-cluster kernel for 3 000 / 4 100 / 6 148 particles - and on one launch per step)."""
     case, spec, g, y = _full_size_case(model, filt_name, prop, n, b, 12, seed=77 + n)
     x0 = cpu_ref.M.initial_sample(spec, g["z0"].double())
     ref = cpu_ref.batch_filter(spec, filt_name, prop, y, x0, g["z_tape"].double(), g["u_tape"].double(), ess_threshold=0.9)
@@ -680,14 +685,14 @@ def test_multi_round_tiles_pass_the_parity_suite():
 
     here = os.path.dirname(os.path.abspath(__file__))
     for wgs in ("2", "16"):
-        env = dict(os.environ, PF_TARGET_WGS=wgs)
+        env = dict(os.environ, PF_TARGET_WGS=wgs, PF_NO_CLUSTER="1")  # (the per-step kernels are what the tile geometry is about)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_filters_gpu.py"), "-m", "gpu", "-q", "-x",
                             "-k", "benchmark_sizes or ragged or weight_collapse or matches_reference"],
                            env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=1500)
         assert r.returncode == 0, f"PF_TARGET_WGS={wgs}\n" + r.stdout[-3000:] + r.stderr[-2000:]
     # the float32 production instantiations of the multi-round geometry against the oracle on their own draws
     for wgs in ("64", "4"):
-        env = dict(os.environ, PF_TARGET_WGS=wgs)
+        env = dict(os.environ, PF_TARGET_WGS=wgs, PF_NO_CLUSTER="1")
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_production_kernels_gpu.py"), "-m", "gpu", "-q",
                             "-x", "-k", "production_step_kernels"], env=env, cwd=os.path.dirname(here), capture_output=True,
                            text=True, timeout=1500)
