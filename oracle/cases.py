@@ -97,6 +97,14 @@ CASES = [
          ess_threshold=0.9, seed=130, observe_every_step=3, nan_steps=(7,), dtypes=("f64", "f32")),
     dict(name="lorenz_sisr_boot_oes2", model="lorenz", filter="sisr", proposal="bootstrap", N=256, B=2, T=10,
          ess_threshold=0.5, seed=131, observe_every_step=2, dtypes=("f64",)),
+    # a SCALAR state under a VECTOR observation (D = 1, O = 2): the ``hidden_is_1d`` branch of find_optimal_density with a matrix
+    # observation (proposals/utils.py:243-245) - in this package the one linear-Gaussian shape that stays on the torch route
+    # (filters/particle/proposals/linear.py::_ObservationUpdate).  SISR only: the reference's APF + LinearGaussianObservations
+    # ``pre_weight`` multiplies an (O, 1) matrix into (N, B, 1) particles (proposals/linear.py:79-81) and cannot run it
+    dict(name="lg1d_o2_sisr_lgo", model="lg1d_o2", filter="sisr", proposal="lgo", N=200, B=2, T=15,
+         ess_threshold=0.9, seed=133, nan_steps=(6,), dtypes=("f64", "f32")),
+    dict(name="lg1d_o2_sisr_boot", model="lg1d_o2", filter="sisr", proposal="bootstrap", N=128, B=3, T=15,
+         ess_threshold=0.8, seed=134, dtypes=("f64",)),
     dict(name="sv_apf_boot_oes5", model="sv_batched", filter="apf", proposal="bootstrap", N=256, B=4, T=8,
          ess_threshold=0.9, seed=132, observe_every_step=5, dtypes=("f64",)),  # the SV notebook's own setting (:83)
 ]
@@ -106,6 +114,8 @@ _LORENZ_A_O3 = [[0.8, 0.1, 0.0], [-0.2, 0.9, 0.05], [0.0, 0.3, 0.7]]
 _RW2D_A_S = [1.0, 0.5]
 
 CASE_BY_NAME = {c["name"]: c for c in CASES}
+# the cases whose model the fused kernels take (D > 1 or O == 1); ``lg1d_o2_*`` runs on the torch route (tests/test_torch_route_golden.py)
+FUSED_CASES = [c for c in CASES if c["model"] != "lg1d_o2"]
 
 
 def build_spec(case, dtype=torch.float64) -> M.ModelSpec:
@@ -120,6 +130,9 @@ def _build_spec(case, dtype=torch.float64) -> M.ModelSpec:
 
     if m == "lg1d":  # tests/filters/models.py:10-15
         return M.ModelSpec(M.HID_LINEAR, (0.0, 0.99, 0.05), 0, 1.0, (0.0, 0.05), M.OBS_LINEAR, (1.0, 0.0, 0.15), 0)
+    if m == "lg1d_o2":  # the same AR(1) state seen by two sensors: y = b + a x + s v, a = (1, 0.5)
+        return M.ModelSpec(M.HID_LINEAR, (0.0, 0.99, 0.05), 0, 1.0, (0.0, 0.05), M.OBS_LINEAR,
+                           (t([1.0, 0.5]), t([0.0, 0.1]), t([0.15, 0.2])), 2)
     if m == "sine":  # README.md:44-67
         return M.ModelSpec(M.HID_SINE_EM, (0.0, 1.0), 0, 0.1, (0.0, 1.0), M.OBS_LINEAR, (1.0, 0.0, 0.1), 0)
     if m == "sv_batched":  # stochastic-volatility.ipynb, B distinct parameter rows + B distinct series

@@ -130,7 +130,7 @@ def obs_loc_scale(spec: ModelSpec, x: torch.Tensor):
     if spec.obs == OBS_LINEAR:
         a, b, s = [_t(q, x) for q in spec.obs_params]
         if spec.dim == 0:
-            loc = b + a * x
+            loc = b + a * (x.unsqueeze(-1) if spec.obs_dim > 0 else x)  # (a scalar state under a vector observation: a of shape (O,))
         else:
             loc = b + (a @ x.unsqueeze(-1)).squeeze(-1)
         return loc, s

@@ -160,7 +160,9 @@ class LinearStateSpaceModel(StateSpaceModel):
 
         def _f(x, a, b, s):
             if hidden_is_1d:
-                loc = b + a * x.value
+                # (a scalar state under a VECTOR observation - a of shape (O,): b + a x with x broadcast along the observation
+                # axis, the reading under which proposals/utils.py:243-245 ``c = c.unsqueeze(-1)`` is an (O, 1) matrix)
+                loc = b + a * (x.value.unsqueeze(-1) if len(self._obs_event_shape) == 1 else x.value)
             else:
                 loc = b + (a @ x.value.unsqueeze(-1)).squeeze(-1)
             d = Normal(loc, s, validate_args=False)

@@ -275,7 +275,10 @@ class LinearStateSpaceModel(StateSpaceModel):
         hidden_is_1d = hidden.n_dim == 0
 
         def _f(x, a, b, s):
-            loc = b + a * x.value if hidden_is_1d else b + (a @ x.value.unsqueeze(-1)).squeeze(-1)
+            if hidden_is_1d:  # (a scalar state under a vector observation: a of shape (O,), x broadcast along the observation axis)
+                loc = b + a * (x.value.unsqueeze(-1) if len(obs_event) == 1 else x.value)
+            else:
+                loc = b + (a @ x.value.unsqueeze(-1)).squeeze(-1)
             d = Normal(loc, s, validate_args=False)
             return Independent(d, 1) if len(obs_event) == 1 else d
 

@@ -32,6 +32,9 @@ def build_ssm_from_case(case, dtype, device):
     if m == "lg1d":
         hidden = models.AR(t(0.0), t(0.99), t(0.05), initial=(t(0.0), t(0.05)))
         ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.15)))
+    elif m == "lg1d_o2":  # a scalar state under a vector observation: the torch route's linear-Gaussian shape (oracle/cases.py)
+        hidden = models.AR(t(0.0), t(0.99), t(0.05), initial=(t(0.0), t(0.05)))
+        ssm = ts.LinearStateSpaceModel(hidden, (t([1.0, 0.5]), t([0.0, 0.1]), t([0.15, 0.2])), torch.Size([2]))
     elif m == "sine":
         hidden = models.SineDiffusion(t(0.0), t(1.0), dt=0.1)
         ssm = ts.LinearStateSpaceModel(hidden, (t(1.0), t(0.1)))

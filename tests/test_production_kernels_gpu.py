@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from oracle import cpu_ref
-from oracle.cases import CASES, build_spec
+from oracle.cases import FUSED_CASES as CASES, build_spec  # (lg1d_o2_*: the torch route, tests/test_torch_route_golden.py)
 from pyfilter_amd import ops
 from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden
 
