@@ -2273,7 +2273,10 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
                     if (A->observed[r.t0 + q]) r.obs_bits[q >> 5] |= 1u << (q & 31);
             a.step = r.t0;
             // fresh tags for this piece: error word + every record of the batch (a kernel, not a memset node - see k_zero_words)
-            const size_t words = wl.clu_bytes / sizeof(uint32_t);
+            // (only what this instantiation's records occupy: NG granule rows of 1 KB per column and parity, after the error word)
+            const size_t ng = ((size_t)(5 + 2 * D) * (sizeof(T) / 4) + 2 + 2) / 3;
+            size_t words = (256 + (size_t)2 * g.B * PF_CLUSTER_NG * 64 * 16) / sizeof(uint32_t);
+            if (g.B <= per_launch) words = (256 + (size_t)2 * g.B * ng * 64 * 16) / sizeof(uint32_t);  // (one group: its block is compact)
             hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3((unsigned)((words + PF_BLOCK - 1) / PF_BLOCK)), dim3(PF_BLOCK), 0, st,
                                (uint32_t*)clu, words);
             trace_launch(r.t0, (int)sizeof(T), D, VEC, 0, A->proposal, spec_ok ? 1 : 0, /*SPEC*/ 10, spec_ok ? A->model.hid_kind : 0, c);
