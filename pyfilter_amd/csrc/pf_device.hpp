@@ -136,6 +136,17 @@ template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_ge
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
     return __hiloint2double(hi, lo);
 }
+// the same with the identity ZERO (sums, scans): lanes without a valid source read 0 through `bound_ctrl` when every row takes
+// part (ROW_MASK = 0xF) - the `old` operand is then dead and the compiler does not have to zero the destination before every
+// exchange (two v_mov per fp64 exchange); rows masked out by ROW_MASK keep `old`, which must then really be zero
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_get0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF));
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_get0(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ float lane_get(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -144,15 +155,30 @@ __device__ __forceinline__ double lane_get(double v, int lane) {
 }
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-    v += dpp_get<PF_DPP_QUAD_XOR1>(v, T(0));
-    v += dpp_get<PF_DPP_QUAD_XOR2>(v, T(0));
-    v += dpp_get<PF_DPP_ROW_HALF_MIRROR>(v, T(0));
-    v += dpp_get<PF_DPP_ROW_MIRROR>(v, T(0));
+    v += dpp_get0<PF_DPP_QUAD_XOR1>(v);
+    v += dpp_get0<PF_DPP_QUAD_XOR2>(v);
+    v += dpp_get0<PF_DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_get0<PF_DPP_ROW_MIRROR>(v);
     return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
 #ifndef PF_NO_FMAX_WAVE_MAX
-// float: v_max_f32 takes the DPP operand directly - one instruction per exchange instead of move + compare + select (inputs
-// are NaN-free maxima of sanitised log-weights; -inf is an ordinary operand of v_max)
+// float: v_max_f32 takes the DPP operand directly - ONE instruction per exchange.  Written as inline asm since round 5: from
+// `fmaxf(v, dpp(v))` the compiler emits v_mov_b32 + v_mov_b32_dpp + a canonicalising v_max_f32 v, v, v + the v_max_f32 (IEEE
+// mode: the DPP move's result is not known to be quiet), i.e. four VALU instructions per exchange - 30 such canonicalisations
+// in the headline step kernel alone.  `s_nop 1`: a DPP operand must not be read within two wait states of the VALU write that
+// produced it (the compiler pads its own DPP instructions; inside asm nobody does).  Inputs are NaN-free maxima of sanitised
+// log-weights; -inf is an ordinary operand of v_max.  PF_WAVE_MAX_BUILTIN restores the compiler's form (A/B).
+#ifndef PF_WAVE_MAX_BUILTIN
+#define PF_DPP_MAX_F32(r, v, CTRL) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v))
+__device__ __forceinline__ float wave_max_f32(float v) {
+    float a, b, c, d;
+    PF_DPP_MAX_F32(a, v, "quad_perm:[1,0,3,2]");
+    PF_DPP_MAX_F32(b, a, "quad_perm:[2,3,0,1]");
+    PF_DPP_MAX_F32(c, b, "row_half_mirror");
+    PF_DPP_MAX_F32(d, c, "row_mirror");
+    return __builtin_fmaxf(__builtin_fmaxf(lane_get(d, 0), lane_get(d, 16)), __builtin_fmaxf(lane_get(d, 32), lane_get(d, 48)));
+}
+#else
 __device__ __forceinline__ float wave_max_f32(float v) {
     v = __builtin_fmaxf(v, dpp_get<PF_DPP_QUAD_XOR1>(v, v));
     v = __builtin_fmaxf(v, dpp_get<PF_DPP_QUAD_XOR2>(v, v));
@@ -160,6 +186,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     v = __builtin_fmaxf(v, dpp_get<PF_DPP_ROW_MIRROR>(v, v));
     return __builtin_fmaxf(__builtin_fmaxf(lane_get(v, 0), lane_get(v, 16)), __builtin_fmaxf(lane_get(v, 32), lane_get(v, 48)));
 }
+#endif
 #endif
 template <typename T> __device__ __forceinline__ T wave_max(T v) {
 #ifndef PF_NO_FMAX_WAVE_MAX
@@ -180,12 +207,12 @@ template <typename T> __device__ __forceinline__ T wave_max(T v) {
 }
 // inclusive scan across the 64 lanes of a wave
 template <typename T> __device__ __forceinline__ T wave_scan_incl(T v, int /*lane*/) {
-    v += dpp_get<PF_DPP_ROW_SHR(1)>(v, T(0));
-    v += dpp_get<PF_DPP_ROW_SHR(2)>(v, T(0));
-    v += dpp_get<PF_DPP_ROW_SHR(4)>(v, T(0));
-    v += dpp_get<PF_DPP_ROW_SHR(8)>(v, T(0));
-    v += dpp_get<PF_DPP_ROW_BCAST15, 0xA>(v, T(0));  // lane 15 -> row 1, lane 47 -> row 3
-    v += dpp_get<PF_DPP_ROW_BCAST31, 0xC>(v, T(0));  // lane 31 -> rows 2, 3
+    v += dpp_get0<PF_DPP_ROW_SHR(1)>(v);
+    v += dpp_get0<PF_DPP_ROW_SHR(2)>(v);
+    v += dpp_get0<PF_DPP_ROW_SHR(4)>(v);
+    v += dpp_get0<PF_DPP_ROW_SHR(8)>(v);
+    v += dpp_get0<PF_DPP_ROW_BCAST15, 0xA>(v);  // lane 15 -> row 1, lane 47 -> row 3
+    v += dpp_get0<PF_DPP_ROW_BCAST31, 0xC>(v);  // lane 31 -> rows 2, 3
     return v;
 }
 
