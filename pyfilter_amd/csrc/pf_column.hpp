@@ -225,7 +225,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             if (lw[j] != lw[j]) ej = lw[j];
             e1[j] = ej;
             v[0] += ej;
-            v[1] += ej * ej;
+            if constexpr (FILT != PF_FILTER_APF) v[1] += ej * ej;  // (an APF never looks at the weights' ESS: FILT known -> not formed)
 #if !(PFC_EXP & 8)
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -236,7 +236,8 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #endif
         }
 #pragma unroll
-        for (int k = 0; k < ((PFC_EXP & 8) ? 2 : 2 + 2 * D); ++k) v[k] = wave_sum<T>(v[k]);
+        for (int k = 0; k < ((PFC_EXP & 8) ? 2 : 2 + 2 * D); ++k)
+            if (FILT != PF_FILTER_APF || k != 1) v[k] = wave_sum<T>(v[k]);
         bool any = __ballot(poison) != 0ull;
         if (nw == 1) {
             M1 = (double)mw1;

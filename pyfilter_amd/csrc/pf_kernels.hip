@@ -118,7 +118,8 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.ctab_elems = (size_t)g.B * g.tiles * g.rounds_per_tile * PF_NWAVES * 2;
     o = align256(o + 2 * sizeof(double) * w.ctab_elems);
     w.off_clu = o;
-    w.clu_bytes = (g.N > PF_CLUSTER_MIN_N && g.N <= PF_CLUSTER_MAX_N && g.N % 4 == 0)
+    // (16 KB per column - reserved only for batches the route can take in a handful of launches: <= 8 192 member workgroups)
+    w.clu_bytes = (g.N > PF_CLUSTER_MIN_N && g.N <= PF_CLUSTER_MAX_N && g.N % 4 == 0 && ((g.N + 1023) / 1024) * (int64_t)g.B <= 8192)
                       ? 256 + (size_t)2 * g.B * PF_CLUSTER_NG * 64 * 16 : 0;
     o = align256(o + w.clu_bytes);
     w.total = o;
@@ -2502,8 +2503,8 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (!column_eligible(A, g, n_steps, finalize) && cluster_eligible(A, g, n_steps, finalize)) {
-        if (A->ws_bytes < wl.total || wl.clu_bytes == 0) return PF_EWORKSPACE;
+    if (!column_eligible(A, g, n_steps, finalize) && cluster_eligible(A, g, n_steps, finalize) && wl.clu_bytes != 0) {
+        if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
         if (A->dtype == PF_F32) return pf_run_cluster_f32(A, g, wl, t0, n_steps, st, kernel_ms);
         if (A->dtype == PF_F64) return pf_run_cluster_f64(A, g, wl, t0, n_steps, st, kernel_ms);
         return PF_EINVAL;

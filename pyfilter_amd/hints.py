@@ -47,7 +47,8 @@ class RunHints:
             return False
         if n <= max(2048, self.column_max_n or 2048) or n > 16384 or n % 4:
             return False
-        return route != ROUTE_CLUSTER or ((n + 1023) // 1024) * b <= 2048
+        members = ((n + 1023) // 1024) * b
+        return members <= 2048 if route == ROUTE_CLUSTER else members <= 8192  # (beyond: no record space is reserved)
 
     def fill(self, args):
         """Writes the kernel-side choices into a ``PfFilterArgs``."""
