@@ -114,9 +114,9 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     // LDS carve-up: cdf (np2 Ts, +inf beyond N) | x planes (D x N Ts) | wave records
     constexpr int KB = 4 + 2 * D;  // the state's record: max, sum e, sum e^2, poison, sum e (x - c)[D], sum e (x - c)^2[D]
     T* const cdfs = reinterpret_cast<T*>(pfc_lds);
-    T* const xs = cdfs + np2;
+    T* const xs = cdfs + np2 + PF_PROBE;  // (PF_PROBE readable +inf entries behind the cdf: sorted_lower_bound's probe)
     const int NP = ((N + VEC - 1) / VEC) * VEC;  // stride of a particle plane in LDS: N rounded up to the lanes' VEC particles
-    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + (size_t)D * NP) * sizeof(T) + 15) & ~(size_t)15));
+    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + PF_PROBE + (size_t)D * NP) * sizeof(T) + 15) & ~(size_t)15));
     double* const recB = recA + 2 * PFC_MAXW;  // [2][PFC_MAXW][KB]: double buffered by step parity
 
     const bool apf = FILT >= 0 ? (FILT == PF_FILTER_APF) : (a.filter == PF_FILTER_APF);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             }
         }
     }
-    for (int q = N + tid; q < np2; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
+    for (int q = N + tid; q < np2 + PF_PROBE; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
 
     // the column's parameters and everything derived from them alone: once per run
     ColParams<T, D> cp;
@@ -339,6 +339,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     request_inputs(0);
     uint32_t bits = 0u;
 
+    ProbeState probe{0, PF_PROBE_BACKOFF};  // (sorted_lower_bound's wave-uniform back-off state)
     for (int s = 0; s < run.n_steps; ++s) {
         const int t = run.t0 + s;
         if ((s & 31) == 0) bits = run.obs_bits[s >> 5];  // (one scalar load per 32 steps)
@@ -479,39 +480,15 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             for (int j = 0; j < VEC; ++j) q[j] = (int)(pp[j] * nT);
             if (false)
 #endif
-#ifdef PFC_SEARCH_BY_INDEX
-            for (int st = np2 >> 1; st >= 1; st >>= 1) {
-                T v[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) v[j] = cdfs[q[j] + st - 1];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) q[j] += (v[j] < pp[j]) ? st : 0;
-            }
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) q[j] += (cdfs[q[j]] < pp[j]) ? 1 : 0;
-#else
             {
-                // (round 5: the rounds unrolled with the positions as BYTE offsets - a probe is one ds_read with an immediate
-                // offset, a round compare + select + add per position: 16 VALU per round of four positions against 21 for the
-                // run-time loop over element indices; rounds above the column's power of two are skipped, uniformly)
-                const unsigned char* const cb = reinterpret_cast<const unsigned char*>(cdfs);
-#pragma unroll
-                for (int st = 2048; st >= 1; st >>= 1) {
-                    if (st < np2) {
-                        T v[VEC];
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j) v[j] = *reinterpret_cast<const T*>(cb + q[j] + (st - 1) * (int)sizeof(T));
-#pragma unroll
-                        for (int j = 0; j < VEC; ++j) q[j] += (v[j] < pp[j]) ? st * (int)sizeof(T) : 0;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    q[j] += (*reinterpret_cast<const T*>(cb + q[j]) < pp[j]) ? (int)sizeof(T) : 0;
-                    q[j] /= (int)sizeof(T);
-                }
+                // (round 5: the rounds unrolled with the positions as BYTE offsets - 16 VALU per round of four positions against 21 for a
+                // run-time loop over element indices - and, for systematic grids, only the lane's FIRST position searched: the other
+                // three by a probe of the eight entries from its answer on; sorted_lower_bound, pf_device.hpp.  The sorted
+                // positions of the multinomial resampler are Exp(1) spacings apart - more than eight entries often enough - and
+                // keep the search)
+                if (multinomial) probe.skip = 1 << 30;
+                sorted_lower_bound<T, VEC, 4096>(cdfs, np2, pp, q, probe);
             }
-#endif
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 idx[j] = q[j] > N - 1 ? N - 1 : q[j];

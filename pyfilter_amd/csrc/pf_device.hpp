@@ -348,6 +348,90 @@ __device__ __forceinline__ void store_out(T* __restrict__ base, int elem, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// lower_bound of a lane's VEC NON-DECREASING targets in a sorted LDS array (the persistent kernels' ancestor search: a lane's
+// positions are consecutive points of the systematic grid).
+//   lb_search     the branch-free binary search, rounds unrolled with BYTE offsets (a probe is one ds_read with an immediate
+//                 offset; compare + select + add per target and round), rounds above the power of two `np2` skipped (uniform).
+//   sorted_lower_bound   all targets by lb_search, side by side (one chain of dependent LDS round trips).  With -DPF_SEARCH_PROBE
+//                 (A/B builds) only the first target is searched and the others come from a PROBE of the PF_PROBE entries from its
+//                 answer on - with c_k the entries at q_0 + k, target j lies at q_0 + #{k : c_k < p_j} whenever that count is below
+//                 PF_PROBE; a wave in which any lane's count overflows searches targets 1 .. VEC - 1 the long way and stops probing
+//                 for a while (ProbeState: 8 calls after a first failure, doubled at every further one).  Identical answers, ~100 of
+//                 ~1 000 VALU per wave and step fewer - and NOT faster: the probe hangs a second dependent LDS round trip and the
+//                 counting behind the first target's eleven rounds (same-box A/B, profiles/r05_search_probe_ab.txt: column route
+//                 4.81 -> 5.04 us per step at 1 024 x 512, cluster route 8.34 -> 8.38 APF + LGO, 7.66 -> 8.25 SISR).  Entries
+//                 [0, np2 + PF_PROBE) must be readable, +inf behind the data.
+// ---------------------------------------------------------------------------------------------------------------
+#define PF_PROBE 8
+#define PF_PROBE_BACKOFF 8
+// wave-uniform state a caller keeps across steps: calls left without probing, and how many a failed probe costs next time (doubled
+// at every failure up to 512, reset by a success: a run whose weights stay degenerate pays for a wasted probe ever more rarely)
+struct ProbeState {
+    int skip, backoff;
+};
+template <typename T, int NP, int MAXP2>
+__device__ __forceinline__ void lb_search(const unsigned char* cb, int np2, const T* __restrict__ p, int* __restrict__ qb) {
+    constexpr int SZ = (int)sizeof(T);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) qb[j] = 0;
+#pragma unroll
+    for (int st = MAXP2 / 2; st >= 1; st >>= 1) {
+        if (st < np2) {
+            T v[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const T*>(cb + qb[j] + (st - 1) * SZ);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? st * SZ : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) qb[j] += (*reinterpret_cast<const T*>(cb + qb[j]) < p[j]) ? SZ : 0;
+}
+template <typename T, int VEC, int MAXP2>
+__device__ __forceinline__ void sorted_lower_bound(const T* win, int np2, const T (&p)[VEC], int (&out)[VEC], ProbeState& ps) {
+    constexpr int SZ = (int)sizeof(T);
+    const unsigned char* const cb = reinterpret_cast<const unsigned char*>(win);
+#ifdef PF_SEARCH_PROBE  // (measured, not adopted: see the note above)
+    if constexpr (VEC > 1) {
+        if (ps.skip == 0) {
+            int q0b[1];
+            lb_search<T, 1, MAXP2>(cb, np2, &p[0], q0b);
+            out[0] = q0b[0] / SZ;
+            T c[PF_PROBE];
+#pragma unroll
+            for (int k = 0; k < PF_PROBE; ++k) c[k] = *reinterpret_cast<const T*>(cb + q0b[0] + k * SZ);
+            int cnt[VEC];
+#pragma unroll
+            for (int j = 1; j < VEC; ++j) {
+                cnt[j] = 0;
+#pragma unroll
+                for (int k = 0; k < PF_PROBE; ++k) cnt[j] += (c[k] < p[j]) ? 1 : 0;
+                out[j] = out[0] + cnt[j];
+            }
+            // (targets are non-decreasing, so are the counts: the last one says whether any target lies beyond the probe)
+            if (__ballot(cnt[VEC - 1] == PF_PROBE) == 0ull) {
+                ps.backoff = PF_PROBE_BACKOFF;
+                return;
+            }
+            ps.skip = ps.backoff;
+            ps.backoff = ps.backoff < 512 ? 2 * ps.backoff : 512;
+            int qb[VEC - 1];
+            lb_search<T, VEC - 1, MAXP2>(cb, np2, &p[1], qb);
+#pragma unroll
+            for (int j = 1; j < VEC; ++j) out[j] = qb[j - 1] / SZ;
+            return;
+        }
+        --ps.skip;
+    }
+#endif
+    // every target by the search, side by side (ONE chain of dependent LDS round trips)
+    int qb[VEC];
+    lb_search<T, VEC, MAXP2>(cb, np2, &p[0], qb);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = qb[j] / SZ;
+}
+
 // Online (max, sum-exp) accumulator; sums are carried in double, the exponentials are evaluated in T.
 template <typename T> struct OnlineLse {
     T m;

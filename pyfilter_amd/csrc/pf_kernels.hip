@@ -1991,7 +1991,7 @@ static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize, int vec) {
     int64_t np2 = 64;
     while (np2 < N) np2 <<= 1;
     const int64_t NP = ((N + vec - 1) / vec) * vec;  // (the kernel's padded plane stride)
-    const size_t planes = (((size_t)(np2 + (int64_t)D * NP) * tsize) + 15) & ~(size_t)15;
+    const size_t planes = (((size_t)(np2 + PF_PROBE + (int64_t)D * NP) * tsize) + 15) & ~(size_t)15;  // (cdf + the probe's pad | particle planes)
     return planes + sizeof(double) * (2 + 2 * (4 + 2 * D)) * PFC_MAXW + 16;  // scan records + the state's records (x 2)
 }
 // (measured, profiles/r03_column_route.txt: 1024 x 2048 runs 21 us per step here against 29 on the per-step route, 1024 x
