@@ -375,6 +375,7 @@ __device__ __forceinline__ void lb_search(const unsigned char* cb, int np2, cons
     constexpr int SZ = (int)sizeof(T);
 #pragma unroll
     for (int j = 0; j < NP; ++j) qb[j] = 0;
+#ifndef PF_SEARCH_TWO_LEVELS
 #pragma unroll
     for (int st = MAXP2 / 2; st >= 1; st >>= 1) {
         if (st < np2) {
@@ -385,6 +386,51 @@ __device__ __forceinline__ void lb_search(const unsigned char* cb, int np2, cons
             for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? st * SZ : 0;
         }
     }
+#else
+    // (A/B builds, -DPF_SEARCH_TWO_LEVELS: measured, not adopted) TWO levels of the binary search per LDS round trip: the three
+    // pivots q + s/2 - 1, q + s - 1, q + 3s/2 - 1 are read together, the middle one decides the upper level and which of the other
+    // two decides the lower one - half the dependent round trips for about the same VALU count, but half as many LDS reads again
+    // and twelve values in flight per lane: cluster route 8.35 -> 8.88 us per step, column route +- 0 .. + 4 %
+    // (profiles/r05_search_probe_ab.txt)
+    static_assert((MAXP2 & (MAXP2 - 1)) == 0 && MAXP2 >= 4, "power-of-two bound");
+    constexpr int TOP = MAXP2 / 2;
+    // (levels st = TOP, TOP / 2, .., 1 are paired from the top; with an odd number of levels the LAST one stands alone)
+    constexpr int LEVELS = __builtin_ctz(MAXP2);
+#pragma unroll
+    for (int l = 0; l + 1 < LEVELS; l += 2) {
+        const int s = TOP >> l, h = s >> 1;  // the pair's steps
+        if (s < np2) {
+            T v1[NP], v2[NP], v3[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                v1[j] = *reinterpret_cast<const T*>(cb + qb[j] + (h - 1) * SZ);
+                v2[j] = *reinterpret_cast<const T*>(cb + qb[j] + (s - 1) * SZ);
+                v3[j] = *reinterpret_cast<const T*>(cb + qb[j] + (s + h - 1) * SZ);
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const bool up = v2[j] < p[j];
+                const T second = up ? v3[j] : v1[j];
+                qb[j] += (up ? s * SZ : 0) + ((second < p[j]) ? h * SZ : 0);
+            }
+        } else if (h < np2) {
+            T v[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const T*>(cb + qb[j] + (h - 1) * SZ);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? h * SZ : 0;
+        }
+    }
+    if constexpr (LEVELS % 2 == 1) {  // the unpaired last level: st = 1
+        if (1 < np2) {
+            T v[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const T*>(cb + qb[j]);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? SZ : 0;
+        }
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < NP; ++j) qb[j] += (*reinterpret_cast<const T*>(cb + qb[j]) < p[j]) ? SZ : 0;
 }
