@@ -2,7 +2,8 @@
 // the HIP runtime.  It is what a binding from any other host language does: describe the model (pf_model), size the
 // workspace, hand over raw device pointers, run T steps (pf_filter_run), read the results back.  AR(1) + linear Gaussian
 // observation (tests/filters/models.py:13-15 of the reference), SISR + Bootstrap + systematic and APF + the optimal
-// proposal, checked against the exact Kalman filter computed here on the host.
+// proposal - and the same APF as 16 filters of 8 192 particles on the opt-in column-cluster route -, checked against the exact
+// Kalman filter computed here on the host.
 //   g++ -O2 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I<repo>/include standalone.cpp -o standalone \
 //       -L<repo>/pyfilter_amd -lpfamd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,<repo>/pyfilter_amd
 #include <hip/hip_runtime_api.h>
@@ -134,6 +135,76 @@ int main() {
                         variant == 0 ? "SISR+Bootstrap" : "APF+LGO", c, h_ll[c], kll, last, km);
             if (!(std::fabs(h_ll[c] - kll) < 0.25) || !(std::fabs(last - km) < 0.01)) ++failures;
         }
+    }
+    // ---- the column-cluster route (include/pf_amd.h: PF_ROUTE_CLUSTER): 16 filters of 8 192 particles - the same number of
+    // particles, so the state buffers above serve - held in registers by 8 workgroups each for the whole run, ONE launch.  Opt-in
+    // through pf_run_hints: this program issues its runs on one stream, which is what the route asks of its caller.
+    {
+        const int64_t N2 = 8192, B2 = 16;
+        static_assert(8192 * 16 == (1 << 16) * 2, "the cluster block reuses the state buffers");
+        float *params2, *means2, *vars2, *ll_steps2, *ll_total2;
+        void* ws2;
+        size_t ws2_bytes = 0;
+        PF_CALL(pf_workspace_bytes(N2, B2, D, &ws2_bytes));
+        HIP_OK(hipMalloc(&ws2, ws2_bytes));
+        HIP_OK(hipMalloc((void**)&means2, sizeof(float) * (T + 1) * B2 * D));
+        HIP_OK(hipMalloc((void**)&vars2, sizeof(float) * (T + 1) * B2 * D));
+        HIP_OK(hipMalloc((void**)&ll_steps2, sizeof(float) * T * B2));
+        HIP_OK(hipMalloc((void**)&ll_total2, sizeof(float) * B2));
+        std::vector<float> prow2(B2 * NP);
+        for (int c = 0; c < B2; ++c) {
+            const float row[7] = {(float)alpha, (float)beta, (float)sigma, 0.f, (float)a, (float)b, (float)s};
+            for (int k = 0; k < NP; ++k) prow2[c * NP + k] = row[k];
+        }
+        HIP_OK(hipMalloc((void**)&params2, sizeof(float) * prow2.size()));
+        HIP_OK(hipMemcpy(params2, prow2.data(), sizeof(float) * prow2.size(), hipMemcpyHostToDevice));
+        pf_filter_args A = {};
+        A.struct_size = sizeof(A);
+        A.hints.route = PF_ROUTE_CLUSTER;
+        A.model.hid_kind = PF_HID_LINEAR;
+        A.model.obs_kind = PF_OBS_LINEAR;
+        A.model.dim = (int32_t)D;
+        A.model.obs_dim = 1;
+        A.model.dt = 1.0;
+        A.model.inc_scale = 1.0;
+        A.model.params = params2;
+        A.filter = PF_FILTER_APF;
+        A.proposal = PF_PROP_LGO;
+        A.resampler = PF_RESAMPLE_SYSTEMATIC;
+        A.dtype = PF_F32;
+        A.N = N2;
+        A.B = B2;
+        A.ess_threshold = 0.9;
+        A.seed = 4321;
+        A.x[0] = x0; A.x[1] = x1;
+        A.logw[0] = w0; A.logw[1] = w1;
+        A.anc = anc; A.cdf = cdf; A.pos = pos;
+        A.y = yd; A.y_rows = 1; A.observed = observed.data();
+        A.means = means2; A.vars = vars2; A.ll_steps = ll_steps2; A.ll_total = ll_total2;
+        A.ws = ws2; A.ws_bytes = ws2_bytes;
+        const double m0v[1] = {m0}, s0v[1] = {s0};
+        PF_CALL(pf_initial_sample(m0v, s0v, nullptr, A.seed ^ 0x9E3779B97F4A7C15ull, x0, N2, B2, D, PF_F32, nullptr));
+        HIP_OK(hipMemset(w0, 0, plane));
+        HIP_OK(hipMemset(ll_total2, 0, sizeof(float) * B2));
+        for (int64_t i = 0; i < B2 * N2; ++i) iota[i] = (int32_t)(i % N2);
+        HIP_OK(hipMemcpy(anc, iota.data(), sizeof(int32_t) * B2 * N2, hipMemcpyHostToDevice));
+        PF_CALL(pf_filter_run(&A, 0, T, 1, nullptr));
+        HIP_OK(hipDeviceSynchronize());
+        int32_t trace[10] = {0};
+        const int got = pf_debug_launch_trace(trace, 1);  // which kernel the library took: field 7 = 10 for the cluster kernel
+        std::vector<float> h_means((T + 1) * B2 * D), h_ll(B2);
+        HIP_OK(hipMemcpy(h_means.data(), means2, sizeof(float) * h_means.size(), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(h_ll.data(), ll_total2, sizeof(float) * B2, hipMemcpyDeviceToHost));
+        double ll_mean = 0.0;
+        for (int c = 0; c < B2; ++c) {
+            const double last = h_means[(T * B2 + c) * D];
+            ll_mean += h_ll[c] / B2;
+            if (c < 2)
+                std::printf("APF+LGO, cluster route (launch trace %d) column %d: loglikelihood %.4f (Kalman %.4f)  final mean %.5f (Kalman %.5f)\n",
+                            got == 1 ? trace[7] : -1, c, h_ll[c], kll, last, km);
+            if (!(std::fabs(h_ll[c] - kll) < 0.6) || !(std::fabs(last - km) < 0.03)) ++failures;  // (8 192 particles per filter)
+        }
+        if (got != 1 || trace[7] != 10 || !(std::fabs(ll_mean - kll) < 0.25)) ++failures;
     }
     // ---- the theta-level entry points (what an SMC^2 driver in any host language does with the filters' log-likelihoods):
     // ESS of B_t log-weights, their systematic resampling, the Gaussian fit of the proposal - against the same arithmetic on

@@ -27,5 +27,6 @@ def test_standalone_program_against_kalman(tmp_path):
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
-    assert "c-abi ok" in run.stdout and run.stdout.count("Kalman") == 8  # 2 variants x 2 columns x (ll, mean)
+    assert "c-abi ok" in run.stdout and run.stdout.count("Kalman") == 12  # (2 variants + the cluster route) x 2 columns x (ll, mean)
+    assert "cluster route (launch trace 10)" in run.stdout
     assert "theta level: ESS" in run.stdout

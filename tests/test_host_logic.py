@@ -507,3 +507,29 @@ def test_theta_particles_carry_their_derived_quantities_through_every_move():
     torch.testing.assert_close(th.stack_parameters(False), fresh_u(th), **tol)
     th.initialize_parameters(torch.Generator().manual_seed(3))
     assert not th._cache
+
+
+def test_hints_cluster_rule_mirrors_the_library():
+    """``HINTS.cluster_takes`` is the Python statement of ``pf_kernels.hip::cluster_eligible`` (which runs take the column-cluster
+    kernel, i.e. the lean single-launch driver): 2 049 .. 16 384 particles, N % 4 == 0, systematic, two launches' worth of member
+    workgroups under the default hints, any batch the workspace reserves records for under the tests' routes."""
+    from pyfilter_amd.hints import ROUTE_CLUSTER, ROUTE_CLUSTER_ALWAYS, ROUTE_PER_STEP, RunHints
+
+    h = RunHints()
+    assert h.kernel_route() == ROUTE_CLUSTER
+    assert h.cluster_takes(8192, 128) and h.cluster_takes(8192, 256) and not h.cluster_takes(8192, 257)
+    assert h.cluster_takes(2052, 682) and not h.cluster_takes(2052, 683)          # 3 members per filter
+    assert not h.cluster_takes(2048, 1) and not h.cluster_takes(16388, 1) and not h.cluster_takes(8190, 1)
+    assert not h.cluster_takes(8192, 4, resampler_systematic=False)
+    h.column_max_n = 4096                                                            # the column kernel takes precedence up to its bound
+    assert not h.cluster_takes(4096, 4) and h.cluster_takes(4100, 4)
+    h.column_max_n = 0
+    h.cluster = False
+    assert h.kernel_route() == 0 and not h.cluster_takes(8192, 4)
+    h.cluster, h.route = True, ROUTE_PER_STEP
+    assert not h.cluster_takes(8192, 4)
+    h.route = ROUTE_CLUSTER_ALWAYS
+    assert h.cluster_takes(8192, 1024) and not h.cluster_takes(8192, 1025)         # 8 192 member workgroups: the record space reserved
+    m = RunHints().apply_mapping({"PF_NO_CLUSTER": "1"})
+    assert m.kernel_route() == 0
+    assert RunHints().apply_mapping({"PF_CLUSTER": "1"}).kernel_route() == ROUTE_CLUSTER_ALWAYS
