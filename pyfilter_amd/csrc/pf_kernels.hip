@@ -608,7 +608,27 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
     if (colmask && !colmask[b]) return;
-    const ColLse c = combine_partials(part, PQ_M1, PQ_S1, -1, b, k, g.B, g.tiles, red, redm);
+    ColLse c;
+    if constexpr (FROM_W) {
+        // normalised weights: every tile record is (max 0, plain sum) - the prefix is the plain sum of the tile sums before k, in
+        // combine_partials' order (its factors exp(0 - 0) are exactly 1: identical values) without the maxima's exchange and
+        // four double-precision exp() per thread: k_scan at 2^20 x 1 (1 024 tile records per workgroup) 10.3 -> see
+        // profiles/r05_primitives_baseline_shapes.txt
+        const double* ps = part + PQ_S1 * ((int64_t)g.B * g.tiles) + (int64_t)b * g.tiles;
+        double v[2] = {0.0, 0.0};
+        for (int t = threadIdx.x; t < g.tiles; t += PF_BLOCK) {
+            const double sv = ps[t];
+            v[0] += sv;
+            if (t < k) v[1] += sv;
+        }
+        block_sum<2>(v, red);
+        c.M = 0.0;
+        c.S = v[0];
+        c.Q = 0.0;
+        c.prefix = v[1];
+    } else {
+        c = combine_partials(part, PQ_M1, PQ_S1, -1, b, k, g.B, g.tiles, red, redm);
+    }
     const int64_t stride = (int64_t)g.B * g.tiles;
     const double mk = part[PQ_M1 * stride + (int64_t)b * g.tiles + k];
     const double sk = part[PQ_S1 * stride + (int64_t)b * g.tiles + k];
@@ -673,25 +693,31 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
                     for (int j = 0; j < VEC; ++j) zero[j] = 0;
                     if (VEC == 1) hd[tid] = 0; else store_vec<int, VEC>(hd + tid * VEC, zero);
                 }
-                T c0[VEC], c1[VEC];
-                const int ja = ws + tid * VEC, jb = ws + (PF_BLOCK + tid) * VEC;
+                // the window: 256 (VEC + 1) entries from the round's exact start (the fused step kernel's geometry, round 5 - the
+                // ancestors of 256 VEC consecutive grid positions span at most 256 VEC + 1 entries; every staged entry is an entry
+                // read and counted: 2 x 256 VEC cost k_search a third more per round); a stretch the window does not reach walks on
+                // window by window inside inverse_grid_round
+                constexpr int V1 = 1;
+                constexpr int STAGED = PF_BLOCK * (VEC + V1);
+                T c0[VEC], c1[V1];
+                const int ja = ws + tid * VEC, jb = ws + PF_BLOCK * VEC + tid * V1;
                 if (ja < N) { if (VEC == 1) c0[0] = col[ja]; else load_vec<T, VEC>(col + ja, c0); }
-                if (jb < N) { if (VEC == 1) c1[0] = col[jb]; else load_vec<T, VEC>(col + jb, c1); }
+                if (jb < N) c1[0] = col[jb];
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) {
+                for (int j = 0; j < VEC; ++j)
                     if (!(ja < N)) c0[j] = Lim<T>::inf();
-                    if (!(jb < N)) c1[j] = Lim<T>::inf();
-                }
+                if (!(jb < N)) c1[0] = Lim<T>::inf();
                 int res[VEC];
-                inverse_grid_round<T, VEC, VEC>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
-                                           [&](int it, T (&d0)[VEC], T (&d1)[VEC]) -> bool {
-                                               const int w0 = ws + it * SearchWin<T, VEC>::WIN;
+                inverse_grid_round<T, VEC, V1>(c0, c1, ws, (int)r0, g.round_elems, N, ub, nT, rcN, pow2, i0, hd, sh_cl, sh_wm,
+                                           [&](int it, T (&d0)[VEC], T (&d1)[V1]) -> bool {
+                                               const int w0 = ws + it * STAGED;
                                                if (w0 >= N) return false;
-                                               const int wja = w0 + tid * VEC, wjb = w0 + (PF_BLOCK + tid) * VEC;
+                                               const int wja = w0 + tid * VEC, wjb = w0 + PF_BLOCK * VEC + tid * V1;
 #pragma unroll
-                                               for (int j = 0; j < VEC; ++j) d0[j] = d1[j] = Lim<T>::inf();
+                                               for (int j = 0; j < VEC; ++j) d0[j] = Lim<T>::inf();
+                                               d1[0] = Lim<T>::inf();
                                                if (wja < N) { if (VEC == 1) d0[0] = col[wja]; else load_vec<T, VEC>(col + wja, d0); }
-                                               if (wjb < N) { if (VEC == 1) d1[0] = col[wjb]; else load_vec<T, VEC>(col + wjb, d1); }
+                                               if (wjb < N) d1[0] = col[wjb];
                                                return true;
                                            },
                                            [&](int64_t i, int from) { return thread_lower_bound<T>(col, from, N, grid_position<T>(i, ub, nT)); },
