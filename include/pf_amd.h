@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2 /* 2: pf_filter_args starts with its own size and ends with pf_run_hints; the library has no
+#define PF_ABI_VERSION 3 /* 3: pf_filter_args.user_dt (an Euler-Maruyama user process hands over its DRIFT; the kernels form x + f dt).
+                          * 2: pf_filter_args starts with its own size and ends with pf_run_hints; the library has no
                           * environment variables and no process-wide switches - every choice a caller can override is an
                           * argument */
 
@@ -331,6 +332,10 @@ typedef struct pf_filter_args {
     int64_t user_scale_per_column; /* 0: user_scale is a (D, B, N) plane like user_loc; 1: a (D, B) array - ONE transition scale
                                     * per filter and state component (a diffusion that does not depend on the state: the common
                                     * case, and no plane to fill per move) */
+    double user_dt;         /* PF_HID_USER_AFFINE: 0 = user_loc is the one-step mean itself; != 0 = user_loc is the DRIFT f(x) of an
+                             * Euler-Maruyama discretisation (README.md:44-62: AffineEulerMaruyama) and the kernels form the mean
+                             * x + f(x) dt at the parent themselves - the addition is one elementwise launch of the caller's less
+                             * per move (~5 us at 2^20 particles) */
     pf_run_hints hints;     /* all zero = the library's own choices */
 } pf_filter_args;
 

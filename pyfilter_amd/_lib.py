@@ -47,7 +47,7 @@ class PfModel(C.Structure):
     ]
 
 
-ABI_VERSION = 2  # include/pf_amd.h: PF_ABI_VERSION
+ABI_VERSION = 3  # include/pf_amd.h: PF_ABI_VERSION
 
 
 class PfRunHints(C.Structure):
@@ -75,6 +75,7 @@ class PfFilterArgs(C.Structure):
         ("observed_dev", C.c_void_p),
         ("ring", C.c_int64),
         ("user_loc", C.c_void_p), ("user_scale", C.c_void_p), ("user_scale_per_column", C.c_int64),
+        ("user_dt", C.c_double),
         ("hints", PfRunHints),
     ]
 

@@ -189,6 +189,9 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     }
     const T* const z_tape = (KIND >= 0) ? nullptr : a.z_tape;  // (specialised runs draw their normals: Philox)
     cc.prepare(md, cp);
+    if constexpr (USER) {  // one transition scale per column: the scalar closed forms around the caller's mean (ColConsts::prepare_user)
+        if (a.user_scale_percol) cc.prepare_user(md, cp, a.user_scale[b]);
+    }
     if constexpr (KIND >= 0) __builtin_assume(cc.fast == (D == 1 && KIND != PF_HID_VERHULST_EM));
     auto y_row = [&](int t) { return a.y + ((int64_t)t * a.y_rows + (a.y_rows == 1 ? 0 : b)) * O; };
 
@@ -363,7 +366,12 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = x[d][j];
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if constexpr (user) { if (ok[j]) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j, a.user_scale_percol != 0, b, g.B); }
+                if constexpr (user) {
+                    if (ok[j]) {
+                        um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, i0 + j, a.user_scale_percol != 0, b, g.B);
+                        um.euler(xj, a.user_dt);
+                    }
+                }
                 const T pre = pre_weight<T, D>(md, proposal, cp, cc, xj, false, um);
                 if (ok[j] && is_nan_or_posinf(pre)) poison = true;
                 rw[j] = ok[j] ? sanitize_logw(pre + lw[j]) : -Lim<T>::inf();
@@ -543,7 +551,10 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
         for (int j = 0; j < VEC; ++j) {
             T xn[D], w_new;
             UserMS<T, D> um = UserMS<T, D>::none();
-            if constexpr (user) um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j], a.user_scale_percol != 0, b, g.B);  // the parent's
+            if constexpr (user) {  // the parent's
+                um.gather(a.user_loc, a.user_scale, (int64_t)b * N, (int64_t)g.B * N, idx[j], a.user_scale_percol != 0, b, g.B);
+                um.euler(xr[j], a.user_dt);
+            }
             if (obs) {
                 const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn, um);
                 if (apf) {

@@ -79,6 +79,7 @@ template <typename T> struct FusedArgs {
     const T* user_loc;    // PF_HID_USER_AFFINE: (D, B, N) one-step means / transition scales of the incoming particles, evaluated
     const T* user_scale;  // by the caller's callable (pf_filter_args.user_loc / user_scale)
     int user_scale_percol;  // user_scale is a (D, B) array: one scale per column and component
+    T user_dt;              // != 0: user_loc holds the drift f(x) of an Euler-Maruyama process, the mean is x + f dt (pf_filter_args.user_dt)
     T* means;
     T* vars;
     T* ll_steps;
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
     load_col_params<T, D>(a, b, a.step, pre_on, cp);
     ColConsts<T, D> cc;
     cc.prepare(a.md, cp);
+    if (user && a.user_scale_percol) cc.prepare_user(a.md, cp, a.user_scale[b]);  // (scalar states: the closed forms, as in the step kernel)
 
     const T* lw_col = a.logw[slot] + (int64_t)b * g.N;
     const T* x_base = a.x[slot];
@@ -538,8 +540,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) xj[d] = xv[d][j];
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if (user && pre_on)  // the particle's own one-step mean / scale (the caller's planes)
+                if (user && pre_on) {  // the particle's own one-step mean / scale (the caller's planes)
                     um.gather(a.user_loc, a.user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, i0 + j, a.user_scale_percol != 0, b, g.B);
+                    um.euler(xj, a.user_dt);
+                }
                 pre[j] = pre_on ? pre_weight<T, D>(a.md, a.proposal, cp, cc, xj, false, um) : T(0);
                 if (pre_on && is_nan_or_posinf(pre[j])) acc.poison = true;
                 rw[j] = pre_on ? sanitize_logw(pre[j] + lw[j]) : lw[j];
@@ -1485,7 +1489,14 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
             load_col_params<T, D>(a, b, step, obs, cp, late);
             if (pre_next) cp.load_next(a.y + ((int64_t)(step + 1) * a.y_rows + (a.y_rows == 1 ? 0 : b)) * a.md.obs_dim + late);
             cc.prepare(md, cp);
-            __builtin_assume(cc.fast == FAST);
+            if constexpr (USER) {
+                // one transition scale per column (pf_filter_args.user_scale_per_column): the optimal proposal / the weights in
+                // closed form around the caller's one-step mean (ColConsts::prepare_user) - the generic arithmetic costs a user-defined
+                // model two reciprocals, a square root and two logarithms per PARTICLE
+                if (la->user_scale_percol) cc.prepare_user(md, cp, la->user_scale[b]);
+            } else {
+                __builtin_assume(cc.fast == FAST);
+            }
         } else if (r == 0) {  // D > 1: the rows were loaded up front (register room, and no exposed latency here)
             cc.prepare(md, cp);
             __builtin_assume(cc.fast == FAST);
@@ -1519,7 +1530,10 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                 T w_new;
                 // user-defined affine models (MK = 3): the parent's one-step mean / scale from the caller's planes
                 UserMS<T, D> um = UserMS<T, D>::none();
-                if constexpr (USER) um.gather(la->user_loc, la->user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, idx[j], la->user_scale_percol != 0, b, g.B);
+                if constexpr (USER) {
+                    um.gather(la->user_loc, la->user_scale, (int64_t)b * g.N, (int64_t)g.B * g.N, idx[j], la->user_scale_percol != 0, b, g.B);
+                    um.euler(xr[j], la->user_dt);
+                }
                 if (obs) {
                     T wi, pre_anc = T(0);
                     if constexpr (FAST) {

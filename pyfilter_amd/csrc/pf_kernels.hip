@@ -461,6 +461,10 @@ struct ColLse {
     double M, S, Q;
     double prefix;  // sum of the rescaled tile sums strictly before tile k (un-normalised)
 };
+// (T: the filter's arithmetic type - float columns take the fast float exp for the tile factors exp(m_t - M), as the fused kernels'
+// tables do: the factors multiply float-precision tile sums, and four double-precision exp() per thread were most of what a
+// workgroup of k_normalize_write / k_scan spent at 1 024 tiles per column)
+template <typename T = double>
 __device__ __forceinline__ ColLse combine_partials(const double* __restrict__ part, int slot_m, int slot_s, int slot_q,
                                                    int b, int k, int B, int tiles, double* red, double* redm) {
     const int64_t stride = (int64_t)B * tiles;
@@ -472,7 +476,7 @@ __device__ __forceinline__ ColLse combine_partials(const double* __restrict__ pa
     const double M = block_max<double>(m, redm);
     double v[3] = {0.0, 0.0, 0.0};
     for (int t = threadIdx.x; t < tiles; t += PF_BLOCK) {
-        const double f = exp_diff(pm[t], M);
+        const double f = exp_diff_t<T>(pm[t], M);
         const double s = ps[t] * f;
         v[0] += s;
         if (pq) v[1] += pq[t] * f * f;
@@ -492,7 +496,7 @@ __device__ __forceinline__ void normalize_write_body(const T* __restrict__ logw,
                                                      T* __restrict__ ess, const double* __restrict__ part, const Geom& g, int b, int k) {
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
-    const ColLse c = combine_partials(part, PQ_M1, PQ_S1, PQ_Q1, b, k, g.B, g.tiles, red, redm);
+    const ColLse c = combine_partials<T>(part, PQ_M1, PQ_S1, PQ_Q1, b, k, g.B, g.tiles, red, redm);
     if (k == 0 && threadIdx.x == 0) {
         if (lse) lse[b] = (T)(c.M + log(c.S));
         if (ess) ess[b] = (T)(c.S * c.S / c.Q);
@@ -627,7 +631,7 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
         c.Q = 0.0;
         c.prefix = v[1];
     } else {
-        c = combine_partials(part, PQ_M1, PQ_S1, -1, b, k, g.B, g.tiles, red, redm);
+        c = combine_partials<T>(part, PQ_M1, PQ_S1, -1, b, k, g.B, g.tiles, red, redm);
     }
     const int64_t stride = (int64_t)g.B * g.tiles;
     const double mk = part[PQ_M1 * stride + (int64_t)b * g.tiles + k];
@@ -638,7 +642,7 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
         fk = 1.0;
         Pnext = Pk + sk;
     } else {
-        fk = exp_diff(mk, c.M) / c.S;
+        fk = exp_diff_t<T>(mk, c.M) / c.S;  // (the factor combine_partials<T> gives this tile inside the later tiles' prefixes)
         Pk = c.prefix / c.S;
         Pnext = Pk + sk * fk;
     }
@@ -871,7 +875,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_loglik_final(const double* __restr
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
     const int b = blockIdx.x;
-    const ColLse c = combine_partials(part, PQ_M1, PQ_S1, -1, b, 0, g.B, g.tiles, red, redm);
+    const ColLse c = combine_partials<T>(part, PQ_M1, PQ_S1, -1, b, 0, g.B, g.tiles, red, redm);
     if (threadIdx.x == 0) out[b] = (T)(c.M + log(c.S));
 }
 
@@ -1771,6 +1775,7 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
     a.user_loc = (const T*)A->user_loc;
     a.user_scale = (const T*)A->user_scale;
     a.user_scale_percol = A->user_scale_per_column != 0 ? 1 : 0;
+    a.user_dt = (T)A->user_dt;
     a.means = (T*)A->means;
     a.vars = (T*)A->vars;
     a.ll_steps = (T*)A->ll_steps;

@@ -166,6 +166,12 @@ template <typename T, int D> struct ColConsts {
                 }
             }
             ou_e = (md.hid_kind == PF_HID_OU) ? pf_exp(-cp.hp[0][0] * dt) : T(0);
+            finish_fast(md, cp);
+        }
+    }
+    // everything of the closed forms that follows from the transition scale g and the observation parameters
+    __device__ __forceinline__ void finish_fast(const ModelDesc& md, const ColParams<T, D>& cp) {
+        if constexpr (D == 1) {
             inv_g = pf_rcp_c(g);
             inc = (T)md.inc_scale;
             a = cp.A[0][0];
@@ -187,6 +193,19 @@ template <typename T, int D> struct ColConsts {
             const T cvar = s * s + a * (g * g) * a;
             i2c = T(0.5) * pf_rcp_c(cvar);
             kc = T(0.5) * pf_log_c(cvar) + T(PF_LOG_SQRT_2PI);
+        }
+    }
+    // PF_HID_USER_AFFINE with ONE transition scale per column (pf_filter_args.user_scale_per_column) under a linear-Gaussian
+    // observation of a scalar state: the closed forms with g = that scale - the one-step mean is the caller's (UserMS::loc,
+    // gathered at the parent), everything that does not depend on the particle is evaluated here once per thread instead of per
+    // particle (the generic arithmetic: two reciprocals, a square root and two logarithms per particle for the optimal proposal)
+    __device__ __forceinline__ void prepare_user(const ModelDesc& md, const ColParams<T, D>& cp, T g_user) {
+        if constexpr (D == 1) {
+            if (md.obs_kind != PF_OBS_LINEAR) return;
+            fast = true;
+            g = g_user;
+            ou_e = T(0);
+            finish_fast(md, cp);
         }
     }
 
@@ -453,6 +472,14 @@ template <typename T, int D> struct UserMS {
             scale[d] = percol ? pscale[d * nb + b] : pscale[col0 + d * plane + i];
         }
     }
+    // pf_filter_args.user_dt != 0: what was gathered is the drift f(x) of an Euler-Maruyama process - the one-step mean is
+    // x + f dt with x the particle the drift belongs to (the parent)
+    __device__ __forceinline__ void euler(const T (&x)[D], T dt) {
+        if (dt != T(0)) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) loc[d] = x[d] + loc[d] * dt;
+        }
+    }
 };
 
 // APF first-stage weight  (proposal.pre_weight(y, x))
@@ -462,7 +489,7 @@ __device__ __forceinline__ T pre_weight(const ModelDesc& md, int proposal, const
                                         const UserMS<T, D>& um = UserMS<T, D>::none()) {
     if constexpr (D == 1) {
         if (cc.fast) {
-            if (proposal == PF_PROP_BOOTSTRAP) return cc.obs_lp(cc.loc1(md, cp, x[0]), next);  // log p(y | E[x_t | x_{t-1}])
+            if (proposal == PF_PROP_BOOTSTRAP) return cc.obs_lp(um.on ? um.loc[0] : cc.loc1(md, cp, x[0]), next);  // log p(y | E[x_t | x_{t-1}])
             const T r = (next ? cc.ybn : cc.yb) - cc.a * x[0];                               // LGO: evaluated at x_{t-1} itself
             return -(r * r) * cc.i2c - cc.kc;
         }
@@ -524,7 +551,7 @@ __device__ __forceinline__ T sample_and_weight(const ModelDesc& md, int proposal
                                                const UserMS<T, D>& um = UserMS<T, D>::none()) {
     if constexpr (D == 1) {
         if (cc.fast) {
-            const T loc = cc.loc1(md, cp, x[0]);
+            const T loc = um.on ? um.loc[0] : cc.loc1(md, cp, x[0]);  // (a user-defined process: the caller's one-step mean of the parent)
             if (proposal == PF_PROP_BOOTSTRAP) {
                 xn[0] = loc + cc.g * (z[0] * cc.inc);
                 return cc.obs_lp(xn[0]);

@@ -17,7 +17,7 @@ from ... import _lib as L
 from ... import ops
 from ...hints import HINTS
 from ...resampling import multinomial, systematic
-from ...timeseries import StateSpaceModel, TimeseriesState
+from ...timeseries import AffineEulerMaruyama, StateSpaceModel, TimeseriesState
 from ...timeseries.models import pack_params
 from ..base import BaseFilter
 from ..result import FilterResult
@@ -355,7 +355,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             # The user's mean_scale callable, ONCE per step, on the incoming particles (torch ops on the device): it acts per
             # particle, so loc(x[anc]) = loc(x)[anc] - the kernels gather these planes at the ancestors instead of
             # evaluating a built-in closed form.  Everything else of the step stays in the fused kernels.
-            loc, scale = self._model.hidden.mean_scale(ts_in)
+            loc, scale, a.user_dt = self._user_mean_scale(self._model.hidden, ts_in)
             full = ts_in.value.shape
             percol = self._scale_per_column(scale, full, dtype)
             planes = (ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event).contiguous(),
@@ -461,6 +461,18 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ll = run["ll_steps"]
         u = run["u"]  # (a cached plan's buffer, redrawn by the next run: the token keeps a copy)
         return res, (ll if self._batched else ll[:, 0]), (run["seed_eff"], None if u is None else u.clone())
+
+    @staticmethod
+    def _user_mean_scale(hidden, ts):
+        """``(loc, scale, dt)`` of a user-defined affine process for one fused move: the callable's one-step mean and scale
+        with ``dt = 0``, or - an exact ``AffineEulerMaruyama`` with a plain-number ``dt`` - its DRIFT, scale and ``dt``: the
+        kernels then form ``x + f dt`` at the parent themselves (``pf_filter_args.user_dt``)."""
+        if type(hidden) is AffineEulerMaruyama:
+            fg = hidden.drift_scale(ts)
+            if fg is not None:
+                return fg
+        loc, scale = hidden.mean_scale(ts)
+        return loc, scale, 0.0
 
     def _scale_per_column(self, scale: torch.Tensor, full, dtype) -> Optional[torch.Tensor]:
         """The user's transition scale as a ``(D, B)`` array when it does not vary along the particle dimension (a broadcast
@@ -713,7 +725,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                         L.check(lib.pf_filter_run(C.byref(a), s_, 1, 1, L.stream_ptr()), "pf_filter_run")
                         continue
                     ts = TimeseriesState(t_start + s_, ops.from_soa(plan.x[s_ & 1], self._batched, self._has_event), es_u)
-                    loc, scale = hidden.mean_scale(ts)
+                    loc, scale, a.user_dt = self._user_mean_scale(hidden, ts)
                     v = ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event)
                     # (already a (D, B, N) plane - an unbatched scalar state's loc: read in place, kept alive past the launch)
                     loc_p = v if v.is_contiguous() else plan.user_loc.copy_(v)

@@ -175,6 +175,19 @@ class AffineEulerMaruyama(AffineProcess):
             return x.value + f * dt, g
 
         super().__init__(_ms, parameters, increment_distribution, initial_kernel, initial_parameters)
+        self._dynamics = dynamics
+
+    def drift_scale(self, x: TimeseriesState):
+        """``(f(x), g(x), dt)`` for the fused kernels, which form ``x + f dt`` at the parent themselves
+        (``pf_filter_args.user_dt``: one elementwise launch per move less) - or None when that does not apply (a tensor-valued
+        ``dt``, a drift that is not a tensor of the state's dtype): the caller then takes ``mean_scale``."""
+        if isinstance(self.dt, torch.Tensor) or not self.dt:
+            return None
+        f, g = self._dynamics(x, *self.parameters)
+        if not isinstance(f, torch.Tensor) or f.dtype != x.value.dtype:
+            return None
+        f, g = torch.broadcast_tensors(f, _as_tensor(g, device=f.device, dtype=f.dtype))
+        return f, g, float(self.dt)
 
 
 def _user_affine_kind(hidden: "AffineProcess") -> Optional[KernelKind]:

@@ -42,8 +42,19 @@ def make(model, filt, prop, n, b, dtype=torch.float32, resampler="systematic"):
         o = ()
     elif model == "user_sine":  # the README's sine diffusion the reference's way: a python lambda (README.md:44-67)
         from torch.distributions import Normal
-        hidden = ts.AffineEulerMaruyama(lambda x, gm, s: (torch.sin(x.value - gm), s), (t(0.0, dtype), t(1.0, dtype)),
+        frozen = {}
+
+        def dyn(x, gm, s):
+            if os.environ.get("KB_USER_FROZEN"):  # (a callable without launches: what the library's share of a move costs)
+                if "f" not in frozen:
+                    frozen["f"] = torch.sin(x.value - gm)
+                return frozen["f"], s
+            return torch.sin(x.value - gm), s
+
+        hidden = ts.AffineEulerMaruyama(dyn, (t(0.0, dtype), t(1.0, dtype)),
                                         Normal(t(0.0, dtype), t(math.sqrt(0.1), dtype)), 0.1, lambda gm, s: Normal(t(0.0, dtype), t(1.0, dtype)))
+        if os.environ.get("KB_USER_MEAN"):  # the callable hands over the one-step mean x + f dt itself (no pf_filter_args.user_dt)
+            hidden.__class__ = ts.AffineProcess
         hidden.graph_callable = bool(os.environ.get("KB_GRAPH_CALLABLE"))  # the run as one captured hipGraph (callable + library)
         ssm = ts.LinearStateSpaceModel(hidden, (t(1.0, dtype), t(0.1, dtype)))
         o = ()
