@@ -224,7 +224,8 @@ int pf_theta_accept(const void* u_cur, const void* u_star, const void* mean_f, c
 
 /* The theta-weights along a block of n observations (sequential/state.py:35-44, n times): w_path (n, B) <- w0 (B) + the
  * running sum of the log-likelihood increments ll (n, B); stats (n, 2) <- (ESS, 1 if every weight is finite) per row, as
- * pf_theta_ess reports them. */
+ * pf_theta_ess reports them.  n = 1: w_path may be w0 itself (the weights updated in place - one observation of the
+ * reference's step(), smc2.py:53-65). */
 int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats, void* stream);
 
 /* Systematic resampling of B theta-particles from their log-weights (kernels/mh.py:52-56: pyfilter.utils.normalize, then

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_accept(const T* __restrict__
 // observation, as `w0 + ll.cumsum(0)` does - and stats[r] = (ESS, every weight finite) of row r (k_theta_ess).  One
 // workgroup per row; row r re-adds its r + 1 increments (n <= a few dozen).
 template <typename T>
-__global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* __restrict__ w0, const T* __restrict__ ll, int64_t B,
-                                                         T* __restrict__ w_path, T* __restrict__ stats) {
+__global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* __restrict__ ll, int64_t B,
+                                                         T* w_path, T* __restrict__ stats) {  // (n = 1: w_path may BE w0)
     __shared__ T redm[PF_NWAVES];
     __shared__ double red[3 * PF_NWAVES];
     const int r = blockIdx.x;

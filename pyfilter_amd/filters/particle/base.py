@@ -66,6 +66,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._z0 = None
         self._fused_plans = {}   # (shape, schedule) -> _FusedPlan (captured hipGraphs; a handful, evicted oldest first)
         self._single_plans = {}  # shape -> _SingleStepPlan (scratch of the online move; never evicted)
+        self._single_last = None  # (the plan of the previous online move: checked field by field before the dictionary is asked)
         self._move_by_move = False  # testing knob: a fused run issued as its pieces (pf_filter_run(args, s, 1, 1), s = 0, 1, ..)
         self._draws = 0          # draw epoch: every new stream of random numbers (initial sample, fused run, online
                                  # move, step-by-step run) takes the next one - repeated calls are independent runs
@@ -308,29 +309,47 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if (not isinstance(y, torch.Tensor) or not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1
                 or self._record_intermediary or not HINTS.fused_step):
             return super().filter(y, correction, result=result)
-        new = self._filter_fused_single(y, correction)
-        if result is not None:
-            result.append(new)
+        if result is None:
+            return self._filter_fused_single(y, correction)
+        # (the run adds the move's log-likelihood to the result's running total itself - ``pf_filter_args.ll_total`` IS that
+        # tensor - when it can be handed over as it is: one elementwise launch per online move less)
+        new = self._filter_fused_single(y, correction, ll_into=result._loglikelihood)
+        result.append(new, _ll_accumulated=self._ll_accumulated)
         return new
 
-    def _filter_fused_single(self, y: torch.Tensor, state: ParticleFilterCorrection) -> ParticleFilterCorrection:
+    def _filter_fused_single(self, y: torch.Tensor, state: ParticleFilterCorrection, ll_into: torch.Tensor = None) -> ParticleFilterCorrection:
+        # (the host's share of an online move is what SMC2.step() / a driver's loop over filter() run at - every torch call here
+        # costs 1 - 1.5 us: the buffers of a state this method produced are remembered with it, a plan keeps what does not
+        # change between moves, pointers into the move's statistics block are computed, not sliced)
         ctx = self._ensure_context()
         kind = ctx.kind
         ts_in = state.timeseries_state
-        x_in = ops.to_soa(ts_in.value, self._batched, self._has_event)   # views of library buffers: no copies
-        lw_in = ops.to_cols(state.weights)
+        batched, has_event = self._batched, self._has_event
+        soa = getattr(state, "_soa", None)
+        if soa is not None and soa[0] is ts_in.value and soa[1] is state["_w"]:
+            x_in, lw_in = soa[2], soa[3]  # (the kernels' own buffers of a state nobody replaced since)
+        else:
+            x_in = ops.to_soa(ts_in.value, batched, has_event)   # views of library buffers: no copies
+            lw_in = ops.to_cols(state.weights)
         device, dtype = x_in.device, x_in.dtype
         d, b, n = x_in.shape
         o = kind.obs_dim
-        y_dev = y.to(device=device, dtype=dtype).reshape(1, -1, o).contiguous()
-        if y_dev.shape[1] not in (1, b):
-            raise L.PfAmdError(f"observation of shape {tuple(y.shape)} does not broadcast against batch {b}")
+        y_dev = (y if (y.dtype == dtype and y.device == device) else y.to(device=device, dtype=dtype)).reshape(1, -1, o)
+        if not y_dev.is_contiguous():
+            y_dev = y_dev.contiguous()
         rows = y_dev.shape[1]
-        key = (n, b, d, o, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL,
-               self._resampler_kind(), float(self._resample_threshold))
-        plan = self._single_plans.get(key)
-        if plan is None:
-            plan = self._single_plans[key] = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
+        if rows != 1 and rows != b:
+            raise L.PfAmdError(f"observation of shape {tuple(y.shape)} does not broadcast against batch {b}")
+        rs_kind, thr = self._resampler_kind(), float(self._resample_threshold)
+        plan = self._single_last
+        if (plan is None or plan.n != n or plan.b != b or plan.d != d or plan.o != o or plan.rows != rows or plan.dtype != dtype
+                or plan.device != device or plan.rs_kind != rs_kind or plan.thr != thr or plan.kind is not kind):
+            key = (n, b, d, o, rows, dtype, device, self._FILTER_KIND, self._proposal._KERNEL_PROPOSAL, rs_kind, thr)
+            plan = self._single_plans.get(key)
+            if plan is None:
+                plan = self._single_plans[key] = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
+            plan.rs_kind, plan.thr, plan.kind = rs_kind, thr, kind
+            self._single_last = plan
         t_start = int(ts_in.time_index)
         # all-NaN observation -> propagate only (filters/base.py:212).  The reference branches on the host; here the flag
         # is derived on the device by the run itself (neither flag array passed), so consecutive filter() calls never
@@ -343,12 +362,17 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         else:  # SISR keeps the previous ancestors when it does not resample (sisr.py:25-26)
             own = state._anc32 is not None  # the kernels' buffer of the incoming state: copied, it stays that state's
             anc = state.ancestors32().clone() if own else state.ancestors32().reshape(b, n).contiguous()
-        stats = torch.zeros((4 * d + 2, b), device=device, dtype=dtype)  # means (2, B, D) | variances (2, B, D) | ll | total
-        means, variances = stats[:2 * d].reshape(2, b, d), stats[2 * d:4 * d].reshape(2, b, d)
-        ll_steps, ll_total = stats[4 * d].reshape(1, b), stats[4 * d + 1]
+        # the move's statistics block, zeroed: means (2, B, D) | variances (2, B, D) | ll (B) | total (B)
+        mean_new, var_new, ll_new, stats_ptr = plan.zeroed_stats(batched)
+        es = plan.elem_size
+        self._ll_accumulated = (ll_into is not None and ll_into.device == device and ll_into.dtype == dtype and ll_into.numel() == b
+                                and ll_into.is_contiguous())
 
         a = plan.args
-        HINTS.fill(a)
+        hk = HINTS.key()
+        if plan.hints_key != hk or a.hints.resume or a.hints.prepare_next:
+            HINTS.fill(a)
+            plan.hints_key = hk
         a.model.params = ctx.params.data_ptr()
         planes = None
         if kind.is_user:
@@ -358,8 +382,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             loc, scale, a.user_dt = self._user_mean_scale(self._model.hidden, ts_in)
             full = ts_in.value.shape
             percol = self._scale_per_column(scale, full, dtype)
-            planes = (ops.to_soa(loc.to(dtype).expand(full), self._batched, self._has_event).contiguous(),
-                      percol if percol is not None else ops.to_soa(scale.to(dtype).expand(full), self._batched, self._has_event).contiguous())
+            planes = (ops.to_soa(loc.to(dtype).expand(full), batched, has_event).contiguous(),
+                      percol if percol is not None else ops.to_soa(scale.to(dtype).expand(full), batched, has_event).contiguous())
             a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
             a.user_scale_per_column = 0 if percol is None else 1
         a.y, a.y_rows = y_dev.data_ptr(), rows
@@ -368,8 +392,10 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
         a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
         a.anc = anc.data_ptr()
-        a.means, a.vars = means.data_ptr(), variances.data_ptr()
-        a.ll_steps, a.ll_total = ll_steps.data_ptr(), ll_total.data_ptr()
+        db = d * b * es
+        a.means, a.vars = stats_ptr, stats_ptr + 2 * db
+        a.ll_steps = stats_ptr + 4 * db
+        a.ll_total = ll_into.data_ptr() if self._ll_accumulated else stats_ptr + 4 * db + b * es
         z_tape = u_tape = None
         if ctx.z_tape is not None:
             z_tape = ctx.z_tape[t_start:t_start + 1].contiguous()
@@ -377,17 +403,15 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + 1].contiguous()
         a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: every workgroup draws its column's u (Philox)
-        L.check(L.load().pf_filter_run(C.byref(a), 0, 1, 1, L.stream_ptr()), "pf_filter_run")
+        L.check(plan.run(plan.args_ref, 0, 1, 1, L.stream_ptr()), "pf_filter_run")
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
                               keep=(x_in, lw_in, y_dev, ctx.params, planes))
 
-        final_x = TimeseriesState(t_start + 1, ops.from_soa(x_out, self._batched, self._has_event),
-                                  self._model.hidden.event_shape)
-        shape_md = (lambda t: t if self._batched else t[0])
-        new = ParticleFilterCorrection(
-            final_x, ops.from_cols(lw_out, self._batched), shape_md(ll_steps[0]) if self._batched else ll_steps[0, 0],
-            None, _moments=(shape_md(means[1]), shape_md(variances[1])), _anc32=(anc, self._batched),
-        )
+        x_view = ops.from_soa(x_out, batched, has_event)
+        w_view = ops.from_cols(lw_out, batched)
+        new = ParticleFilterCorrection(TimeseriesState(t_start + 1, x_view, self._model.hidden.event_shape), w_view, ll_new, None,
+                                       _moments=(mean_new, var_new), _anc32=(anc, batched))
+        new._soa = (x_view, w_view, x_out, lw_out)
         return new
 
     def batch_filter(self, y, bar=True, init_state=None) -> FilterResult:
@@ -949,6 +973,36 @@ class _SingleStepPlan:
         a.step_counter = None
         a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         self.args = a
+        self.args_ref = C.byref(a)
+        self.run = L.load().pf_filter_run
+        self.n, self.b, self.d, self.o, self.rows, self.dtype, self.device = n, b, d, o, rows, dtype, device
+        self.kind, self.rs_kind, self.thr, self.hints_key = kind, None, None, None
+        self.elem_size = torch.empty((), dtype=dtype).element_size()
+        self._pool = None
+        self._pool_next = 0
+
+    _STATS_POOL = 64
+
+    def zeroed_stats(self, batched: bool):
+        """One move's zeroed statistics block - means (2, B, D) | variances (2, B, D) | ll (B) | total (B), ``4 D + 2`` rows of
+        ``B`` - cut from a pool that is zeroed 64 moves at a time (one fill launch per 64 moves instead of one per move).
+        Returns the NEW state's views (mean, variance, log-likelihood increment - in the state's own shapes) and the block's
+        device address; the kernels get pointers computed from it.  A block is handed out ONCE: the states keep views of it, and an
+        exhausted pool is replaced, never refilled."""
+        if self._pool is None or self._pool_next == self._STATS_POOL:
+            d, b = self.d, self.b
+            pool = torch.zeros((self._STATS_POOL, 4 * d + 2, b), device=self.device, dtype=self.dtype)
+            mean = pool[:, d:2 * d].reshape(self._STATS_POOL, b, d)       # (the block's means[1], variances[1], ll rows)
+            var = pool[:, 3 * d:4 * d].reshape(self._STATS_POOL, b, d)
+            ll = pool[:, 4 * d]
+            if not batched:
+                mean, var, ll = mean[:, 0], var[:, 0], ll[:, 0]
+            self._pool = (pool, mean, var, ll, pool.data_ptr(), (4 * d + 2) * b * self.elem_size)
+            self._pool_next = 0
+        i = self._pool_next
+        self._pool_next = i + 1
+        _, mean, var, ll, base, stride = self._pool
+        return mean[i], var[i], ll[i], base + i * stride
 
 
 class _FusedPlan:

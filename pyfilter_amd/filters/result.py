@@ -38,13 +38,52 @@ class MomentLog:
     window slides; the buffer is compacted (one copy of ``maxlen - 1`` rows) whenever the window reaches its end, so an
     online run of any length costs O(maxlen) memory and amortised O(1) copies per step."""
 
+    # Rows appended one at a time (``append``: the online ``filter()`` loop) are only REMEMBERED - the state's own (mean,
+    # variance) tensors - and written into the buffer ``_PENDING_MAX`` at a time (two stacks + one strided copy each) or when
+    # somebody looks: an online move then costs no launch for its moment row (it cost two strided copies).
+    _PENDING_MAX = 64
+
     def __init__(self, maxlen: Optional[int]):
         self.maxlen = maxlen
-        self._buf: Optional[torch.Tensor] = None
-        self._stop = 0
-        self.rows = 0
+        self._buf_: Optional[torch.Tensor] = None
+        self._stop_ = 0
+        self._rows_ = 0
+        self._pending = []
         self._row_shape: Optional[torch.Size] = None  # shape of ONE state's mean, e.g. (B, D), (D,), (B,), ()
         self._batched = False
+
+    # (every reader / writer of the buffer's bookkeeping sees the remembered rows written first)
+    def _flush(self):
+        if self._pending:
+            rows, self._pending = self._pending, []
+            self.extend(torch.stack([m for m, _ in rows]), torch.stack([v for _, v in rows]))
+
+    @property
+    def _buf(self):
+        self._flush()
+        return self._buf_
+
+    @_buf.setter
+    def _buf(self, value):
+        self._buf_ = value
+
+    @property
+    def _stop(self):
+        self._flush()
+        return self._stop_
+
+    @_stop.setter
+    def _stop(self, value):
+        self._stop_ = value
+
+    @property
+    def rows(self):
+        self._flush()
+        return self._rows_
+
+    @rows.setter
+    def rows(self, value):
+        self._rows_ = value
 
     # ---- geometry -----------------------------------------------------------------------------------------------
     def _adopt_shape(self, mean: torch.Tensor, batched: bool):
@@ -88,13 +127,21 @@ class MomentLog:
 
     # ---- writing ------------------------------------------------------------------------------------------------
     def append(self, mean: torch.Tensor, var: torch.Tensor, batched: bool):
-        if self._buf is None:
+        if self._buf_ is None:
             self._adopt_shape(mean, batched)
-        self._room_for(1)
-        d = self._dim
-        self._buf[:, self._stop, :d] = self._canon(mean, 0)
-        self._buf[:, self._stop, d:] = self._canon(var, 0)
-        self._advance(1)
+        if mean.shape != self._row_shape or var.shape != mean.shape:  # (a row of another shape: written at once, as it always was)
+            self._room_for(1)
+            d = self._dim
+            self._buf[:, self._stop, :d] = self._canon(mean, 0)
+            self._buf[:, self._stop, d:] = self._canon(var, 0)
+            self._advance(1)
+            return
+        pending = self._pending
+        pending.append((mean, var))
+        if self.maxlen is not None and len(pending) > self.maxlen:
+            del pending[0]  # (a bounded history: the remembered rows alone fill the window, an older one can never be seen)
+        elif len(pending) >= self._PENDING_MAX:
+            self._flush()
 
     def extend(self, means: torch.Tensor, variances: torch.Tensor):
         """Adopts ``steps`` rows at once: ``means`` / ``variances`` are ``(steps, *row_shape)`` (the fused kernels' rows)."""
@@ -223,11 +270,14 @@ class FilterResult(dict, Generic[TCorrection]):
         return tc
 
     # ---- writing ------------------------------------------------------------------------------------------------
-    def append(self, state: TCorrection):
-        """One more state (result.py:119-133): its moments join the log, its log-likelihood the running total."""
+    def append(self, state: TCorrection, _ll_accumulated: bool = False):
+        """One more state (result.py:119-133): its moments join the log, its log-likelihood the running total
+        (``_ll_accumulated``: the fused move that produced the state already added it - the total was its
+        ``pf_filter_args.ll_total``)."""
         batched = self._loglikelihood.dim() > 0
         self._moments.append(state.get_mean(), state.get_variance(), batched)
-        self._loglikelihood.add_(state.get_loglikelihood())
+        if not _ll_accumulated:
+            self._loglikelihood.add_(state.get_loglikelihood())
         self._states.append(state)
         return self
 

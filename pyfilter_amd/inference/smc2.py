@@ -77,7 +77,18 @@ class SMC2State:
 
     def append(self, filter_state):
         """``w += ll_t`` and the new ESS (state.py:35-44).  Sharded: the all-gather of the increments happens here."""
-        self.w += filter_state.get_loglikelihood()
+        ll = filter_state.get_loglikelihood()
+        w = self.w
+        if (w.is_cuda and (self.shard is None or not self.shard.collective) and ll.dim() == 1 and ll.dtype == w.dtype
+                and ll.shape == w.shape and w.is_contiguous() and ll.is_contiguous()):
+            from .. import ops
+            from ..hints import HINTS
+
+            if HINTS.theta_kernels:  # the update and its statistics in ONE launch (pf_theta_path with a block of one observation)
+                self.stats = ops.theta_path(w, ll.reshape(1, -1), in_place=True)[1][0]
+                self.ess.append(self.stats[0])
+                return
+        self.w += ll
         self.ess.append(self._ess())
 
     def append_data(self, y: torch.Tensor):

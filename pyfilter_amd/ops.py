@@ -399,13 +399,17 @@ def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def theta_path(w0: torch.Tensor, ll: torch.Tensor):
+def theta_path(w0: torch.Tensor, ll: torch.Tensor, in_place: bool = False):
     """``w0 (B,)``, ``ll (n, B)`` -> ``(w0 + ll.cumsum(0) (n, B), (n, 2) ESS / all-finite rows)`` in one launch
     (pf_theta_path; ``sequential/state.py:35-44`` for the n observations of a block)."""
     L.require_gpu(w0, ll)
     n, b = ll.shape
     assert w0.shape == (b,) and w0.dtype == ll.dtype and w0.is_contiguous() and ll.is_contiguous()
-    w_path = torch.empty_like(ll)
+    if in_place:  # ONE observation, the new weights written over the old (each thread reads the entry it overwrites)
+        assert n == 1
+        w_path = w0.reshape(1, b)
+    else:
+        w_path = torch.empty_like(ll)
     stats = torch.empty((n, 2), dtype=ll.dtype, device=ll.device)
     L.check(L.load().pf_theta_path(w0.data_ptr(), ll.data_ptr(), n, b, L.dtype_code(ll.dtype), w_path.data_ptr(), stats.data_ptr(),
                                    L.stream_ptr()), "pf_theta_path")

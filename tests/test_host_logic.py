@@ -533,3 +533,44 @@ def test_hints_cluster_rule_mirrors_the_library():
     m = RunHints().apply_mapping({"PF_NO_CLUSTER": "1"})
     assert m.kernel_route() == 0
     assert RunHints().apply_mapping({"PF_CLUSTER": "1"}).kernel_route() == ROUTE_CLUSTER_ALWAYS
+
+
+@pytest.mark.parametrize("maxlen", [None, 1, 2, 5, 70])
+@pytest.mark.parametrize("batched", [False, True])
+def test_moment_log_remembers_single_rows_and_writes_them_when_somebody_looks(maxlen, batched):
+    """``MomentLog.append`` only remembers a state's (mean, variance) tensors (no launch per online move); any reader - the
+    series, ``rows``, ``extend``, a whole-filter gather - must see exactly what a deque of that ``maxlen`` would hold
+    (``pyfilter/container.py:10-18`` + ``result.py:119-133``)."""
+    from collections import deque
+
+    from pyfilter_amd.filters.result import MomentLog
+
+    g = torch.Generator().manual_seed(3)
+    shape = (4, 2) if batched else (2,)
+    log, ref = MomentLog(maxlen), deque(maxlen=maxlen)
+    import random
+
+    rnd = random.Random(11)
+    for i in range(400):
+        op = rnd.random()
+        if op < 0.8:
+            m, v = torch.randn(shape, generator=g), torch.rand(shape, generator=g)
+            log.append(m, v, batched)
+            ref.append((m, v))
+        elif op < 0.9 and log._buf_ is not None:
+            k = rnd.randint(1, 7)
+            ms, vs = torch.randn((k,) + shape, generator=g), torch.rand((k,) + shape, generator=g)
+            log.extend(ms, vs)
+            ref.extend(zip(ms.unbind(0), vs.unbind(0)))
+        elif op < 0.95 and batched and len(ref):
+            idx = torch.randint(0, shape[0], (shape[0],), generator=g)
+            log.gather_filters(idx)
+            ref = deque(((m[idx], v[idx]) for m, v in ref), maxlen=maxlen)
+        else:
+            assert log.rows == len(ref)
+            if len(ref):
+                assert torch.equal(log.means(), torch.stack([m for m, _ in ref]))
+                assert torch.equal(log.variances(), torch.stack([v for _, v in ref]))
+    assert log.rows == len(ref)
+    assert torch.equal(log.means(), torch.stack([m for m, _ in ref]))
+    assert torch.equal(log.variances(), torch.stack([v for _, v in ref]))
