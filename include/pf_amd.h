@@ -228,6 +228,17 @@ int pf_theta_accept(const void* u_cur, const void* u_star, const void* mean_f, c
  * reference's step(), smc2.py:53-65). */
 int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats, void* stream);
 
+/* ONE observation of the reference's SMC2.step() (smc2.py:53-65; sequential/state.py:35-44): w (B) += ll (B) in place and stats
+ * (2) <- (ESS, 1 if every weight is finite) as pf_theta_ess reports them - pf_theta_path with n = 1 - and, host_slot != NULL,
+ * the same two values as doubles followed by the 64-bit `seq` into 24 bytes of pf_host_alloc memory: the reference tests the
+ * ESS on the host after every observation (smc2.py:59-62), and a host thread that polls the third word for `seq` has the two
+ * values without a device -> host copy command and its synchronisation (~12 us per observation). */
+int pf_theta_step(void* w, const void* ll, int64_t B, int dtype, void* stats, void* host_slot, uint64_t seq, void* stream);
+
+/* Host memory the device writes and the host polls (hipHostMalloc, coherent + mapped, zero-filled); pf_host_free releases it. */
+int pf_host_alloc(size_t bytes, void** out);
+int pf_host_free(void* p);
+
 /* Systematic resampling of B theta-particles from their log-weights (kernels/mh.py:52-56: pyfilter.utils.normalize, then
  * resampling.py:24-52 with the uniform u in [0, 1]): ancestors (B, int64).  cdf_scratch: B values of `dtype`. */
 int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t* ancestors, void* cdf_scratch, void* stream);

@@ -9,7 +9,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <vector>
 
 #include <type_traits>
@@ -1622,13 +1625,48 @@ extern "C" int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PF_F32)
         hipLaunchKernelGGL((k_theta_path<float>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const float*)w0, (const float*)ll, B,
-                           (float*)w_path, (float*)stats);
+                           (float*)w_path, (float*)stats, (double*)nullptr, 0ull);
     else if (dtype == PF_F64)
         hipLaunchKernelGGL((k_theta_path<double>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const double*)w0, (const double*)ll, B,
-                           (double*)w_path, (double*)stats);
+                           (double*)w_path, (double*)stats, (double*)nullptr, 0ull);
     else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;
+}
+
+extern "C" int pf_theta_step(void* w, const void* ll, int64_t B, int dtype, void* stats, void* host_slot, uint64_t seq, void* stream) {
+    if (!w || !ll || !stats || B < 1 || ((uintptr_t)host_slot & 7) != 0) return PF_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PF_F32)
+        hipLaunchKernelGGL((k_theta_path<float>), dim3(1), dim3(PF_BLOCK), 0, st, (const float*)w, (const float*)ll, B, (float*)w,
+                           (float*)stats, (double*)host_slot, (unsigned long long)seq);
+    else if (dtype == PF_F64)
+        hipLaunchKernelGGL((k_theta_path<double>), dim3(1), dim3(PF_BLOCK), 0, st, (const double*)w, (const double*)ll, B, (double*)w,
+                           (double*)stats, (double*)host_slot, (unsigned long long)seq);
+    else return PF_EINVAL;
+    PF_CHECK_LAUNCH();
+    return PF_OK;
+}
+
+extern "C" int pf_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return PF_EINVAL;
+    *out = nullptr;
+    // coherent (fine-grained) + mapped: a device store with system scope is visible to a polling host thread while the stream runs on
+    const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return (int)e;  // (a HIP error code, like a failed launch)
+    }
+    memset(*out, 0, bytes);
+    return PF_OK;
+}
+
+extern "C" int pf_host_free(void* p) {
+    if (!p) return PF_OK;
+    const hipError_t e = hipHostFree(p);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? PF_OK : (int)e;
 }
 
 extern "C" int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t* ancestors, void* cdf_scratch,
@@ -2219,12 +2257,28 @@ static inline bool cluster_eligible(const pf_filter_args* A, const Geom& g, int6
 }
 // resident workgroups of `kernel` on the current device: CUs x min(occupancy query, 6) - the query can be one block per CU high
 // near the SGPR-limited edges (MI355X_MICROARCH.md, "Residency and cooperative launch"); 6 is below every such edge
+// (asked once per kernel, LDS size and device: an online move is one such run per observation, and the three queries cost as much
+// host time as a launch)
 template <typename K> static inline int cluster_slots(K kernel, size_t lds) {
-    int dev = 0, cus = 0, per_cu = 0;
+    struct Seen { const void* k; size_t lds; int dev, slots; };
+    static Seen seen[32];
+    static std::atomic<int> n_seen{0};
+    static std::mutex mu;
+    int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const int have = n_seen.load(std::memory_order_acquire);
+    for (int i = 0; i < have; ++i)
+        if (seen[i].k == (const void*)kernel && seen[i].lds == lds && seen[i].dev == dev) return seen[i].slots;
+    int cus = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PFK_TPB, lds) != hipSuccess) return 0;
     if (per_cu > 6) per_cu = 6;
+    std::lock_guard<std::mutex> lock(mu);
+    const int at = n_seen.load(std::memory_order_relaxed);
+    if (at < 32) {
+        seen[at] = Seen{(const void*)kernel, lds, dev, cus * per_cu};
+        n_seen.store(at + 1, std::memory_order_release);
+    }
     return cus * per_cu;
 }
 template <typename T, int D>

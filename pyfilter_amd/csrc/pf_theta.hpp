@@ -270,7 +270,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_accept(const T* __restrict__
 // workgroup per row; row r re-adds its r + 1 increments (n <= a few dozen).
 template <typename T>
 __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* __restrict__ ll, int64_t B,
-                                                         T* w_path, T* __restrict__ stats) {  // (n = 1: w_path may BE w0)
+                                                         T* w_path, T* __restrict__ stats,  // (n = 1: w_path may BE w0)
+                                                         double* host_slot, unsigned long long seq) {
     __shared__ T redm[PF_NWAVES];
     __shared__ double red[3 * PF_NWAVES];
     const int r = blockIdx.x;
@@ -289,6 +290,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* _
     }
     // (every thread reads back the entries it wrote itself)
     theta_ess_row<T>(row, B, stats + 2 * (int64_t)r, redm, red);
+    // pf_theta_step: the last row's statistics also go to host memory the caller polls (pf_host_alloc: coherent, mapped) - two
+    // doubles, then the sequence number with system-scope release, so a host that sees `seq` sees the values
+    if (host_slot != nullptr && r == (int)gridDim.x - 1 && threadIdx.x == 0) {
+        const T* o = stats + 2 * (int64_t)r;  // (thread 0 wrote them)
+        host_slot[0] = (double)o[0];
+        host_slot[1] = (double)o[1];
+        __threadfence_system();
+        __hip_atomic_store((unsigned long long*)(host_slot + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Systematic resampling of the B theta-particles from their log-weights in one launch (kernels/mh.py:52-56 ->

@@ -407,8 +407,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
                               keep=(x_in, lw_in, y_dev, ctx.params, planes))
 
-        x_view = ops.from_soa(x_out, batched, has_event)
-        w_view = ops.from_cols(lw_out, batched)
+        x_view, w_view = plan.state_views(x_out, lw_out, batched, has_event)
         new = ParticleFilterCorrection(TimeseriesState(t_start + 1, x_view, self._model.hidden.event_shape), w_view, ll_new, None,
                                        _moments=(mean_new, var_new), _anc32=(anc, batched))
         new._soa = (x_view, w_view, x_out, lw_out)
@@ -980,6 +979,7 @@ class _SingleStepPlan:
         self.elem_size = torch.empty((), dtype=dtype).element_size()
         self._pool = None
         self._pool_next = 0
+        self._view_geo = None
 
     _STATS_POOL = 64
 
@@ -997,12 +997,25 @@ class _SingleStepPlan:
             ll = pool[:, 4 * d]
             if not batched:
                 mean, var, ll = mean[:, 0], var[:, 0], ll[:, 0]
+            # (NOT unbound into 3 x 64 views here: that many tracked objects created at once push CPython's generation-0 counter
+            # over its threshold again and again, and every hundredth of those collections is a full one - 40 ms in a process
+            # that has imported torch; three index calls per move keep the allocation rate flat)
             self._pool = (pool, mean, var, ll, pool.data_ptr(), (4 * d + 2) * b * self.elem_size)
             self._pool_next = 0
         i = self._pool_next
         self._pool_next = i + 1
         _, mean, var, ll, base, stride = self._pool
         return mean[i], var[i], ll[i], base + i * stride
+
+    def state_views(self, x_out: torch.Tensor, lw_out: torch.Tensor, batched: bool, has_event: bool):
+        """The reference's ``(N, [B], [D])`` / ``(N, [B])`` views of the kernels' ``(D, B, N)`` / ``(B, N)`` buffers - one
+        ``as_strided`` each (``ops.from_soa / from_cols`` spell them as a permute and up to two selects)."""
+        geo = self._view_geo
+        if geo is None or geo[0] != (batched, has_event):
+            xv, wv = ops.from_soa(x_out, batched, has_event), ops.from_cols(lw_out, batched)
+            geo = self._view_geo = ((batched, has_event), tuple(xv.shape), tuple(xv.stride()), tuple(wv.shape), tuple(wv.stride()))
+            return xv, wv
+        return x_out.as_strided(geo[1], geo[2]), lw_out.as_strided(geo[3], geo[4])
 
 
 class _FusedPlan:

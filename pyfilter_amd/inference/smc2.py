@@ -20,7 +20,9 @@ from ..distributed import Shard
 from ..filters.result import FilterResult
 from .parameters import ThetaParticles
 from .pmmh import SymmetricMH, as_draws, run_pmmh
+from .. import ops as _ops
 from ..hints import HINTS
+from ..hints import HINTS as _HINTS
 from .utils import theta_ess, theta_normalize, theta_systematic
 
 
@@ -75,21 +77,20 @@ class SMC2State:
         self.stats = _theta_stats(self.global_weights())
         return self.stats[0]
 
-    def append(self, filter_state):
-        """``w += ll_t`` and the new ESS (state.py:35-44).  Sharded: the all-gather of the increments happens here."""
+    def append(self, filter_state, slot=None) -> bool:
+        """``w += ll_t`` and the new ESS (state.py:35-44).  Sharded: the all-gather of the increments happens here.
+        ``slot`` (an ``ops.HostSlot``): the statistics also land in host memory - returns True when they will."""
         ll = filter_state.get_loglikelihood()
         w = self.w
-        if (w.is_cuda and (self.shard is None or not self.shard.collective) and ll.dim() == 1 and ll.dtype == w.dtype
+        if (w.is_cuda and (self.shard is None or not self.shard.collective) and w.dim() == 1 and ll.dtype == w.dtype
                 and ll.shape == w.shape and w.is_contiguous() and ll.is_contiguous()):
-            from .. import ops
-            from ..hints import HINTS
-
-            if HINTS.theta_kernels:  # the update and its statistics in ONE launch (pf_theta_path with a block of one observation)
-                self.stats = ops.theta_path(w, ll.reshape(1, -1), in_place=True)[1][0]
+            if _HINTS.theta_kernels:  # the update and its statistics in ONE launch (pf_theta_step)
+                self.stats = _ops.theta_step(w, ll, slot)
                 self.ess.append(self.stats[0])
-                return
+                return slot is not None
         self.w += ll
         self.ess.append(self._ess())
+        return False
 
     def append_data(self, y: torch.Tensor):
         self.parsed.append(y)
@@ -340,9 +341,14 @@ class SMC2:
         """One observation (``smc2.py:53-65``)."""
         state.append_data(y)
         filter_state = self.filter.filter(y, state.filter_state.latest_state, result=state.filter_state)
-        state.append(filter_state)
-        # the reference's host branch (smc2.py:59-62): one small device -> host copy per observation
-        ess, finite = state.stats.tolist()
+        # the reference's host branch (smc2.py:59-62) needs (ESS, all finite) on the host after every observation: the kernel
+        # that updates the theta-weights writes the pair into host memory as well, and the host polls for it - no copy command
+        slot = self.__dict__.get("_host_slot")
+        if slot is None and state.w.is_cuda:
+            from .. import ops
+
+            slot = self._host_slot = ops.HostSlot()
+        ess, finite = slot.wait() if state.append(filter_state, slot) else state.stats.tolist()
         if ess < self._threshold * self.particles[0] or not finite:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
         return state

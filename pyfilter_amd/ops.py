@@ -399,21 +399,71 @@ def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def theta_path(w0: torch.Tensor, ll: torch.Tensor, in_place: bool = False):
+def theta_path(w0: torch.Tensor, ll: torch.Tensor):
     """``w0 (B,)``, ``ll (n, B)`` -> ``(w0 + ll.cumsum(0) (n, B), (n, 2) ESS / all-finite rows)`` in one launch
     (pf_theta_path; ``sequential/state.py:35-44`` for the n observations of a block)."""
     L.require_gpu(w0, ll)
     n, b = ll.shape
     assert w0.shape == (b,) and w0.dtype == ll.dtype and w0.is_contiguous() and ll.is_contiguous()
-    if in_place:  # ONE observation, the new weights written over the old (each thread reads the entry it overwrites)
-        assert n == 1
-        w_path = w0.reshape(1, b)
-    else:
-        w_path = torch.empty_like(ll)
+    w_path = torch.empty_like(ll)
     stats = torch.empty((n, 2), dtype=ll.dtype, device=ll.device)
     L.check(L.load().pf_theta_path(w0.data_ptr(), ll.data_ptr(), n, b, L.dtype_code(ll.dtype), w_path.data_ptr(), stats.data_ptr(),
                                    L.stream_ptr()), "pf_theta_path")
     return w_path, stats
+
+
+def _free_host(ptr: int):
+    try:
+        L.load().pf_host_free(ptr)
+    except Exception:  # (interpreter shutdown)
+        pass
+
+
+class HostSlot:
+    """24 bytes of host memory the DEVICE writes and the host polls (``pf_host_alloc``: coherent, mapped): the (ESS, all finite)
+    pair of ``theta_step`` followed by a sequence number.  ``wait()`` spins on the sequence number - the reference's host test
+    of the ESS after every observation (``smc2.py:59-62``) without a device -> host copy command and its synchronisation."""
+
+    SPINS = 1 << 22  # (~0.5 s of polling: then the stream is synchronised and the slot read once more)
+
+    def __init__(self):
+        import weakref
+
+        p = C.c_void_p()
+        L.check(L.load().pf_host_alloc(64, C.byref(p)), "pf_host_alloc")
+        self.ptr = p.value
+        self._vals = (C.c_double * 2).from_address(self.ptr)
+        self._seq = C.c_uint64.from_address(self.ptr + 16)
+        self.seq = 0
+        fin = weakref.finalize(self, _free_host, self.ptr)
+        fin.atexit = False
+
+    def __deepcopy__(self, memo):
+        return HostSlot()
+
+    def wait(self):
+        """(ESS, all-finite flag) of the latest ``theta_step`` issued with this slot, as Python floats."""
+        want, cell = self.seq, self._seq
+        for _ in range(self.SPINS):
+            if cell.value == want:
+                return self._vals[0], self._vals[1]
+        torch.cuda.current_stream().synchronize()
+        if cell.value != want:
+            raise L.PfAmdError("pf_theta_step: the device's write to the host slot never became visible")
+        return self._vals[0], self._vals[1]
+
+
+def theta_step(w: torch.Tensor, ll: torch.Tensor, slot: Optional[HostSlot] = None) -> torch.Tensor:
+    """``w (B,) += ll (B,)`` in place and its ``(2,)`` statistics (ESS, all finite) in one launch (pf_theta_step: one
+    observation of ``sequential/state.py:35-44``); with a ``slot`` the pair also lands in host memory (``slot.wait()``)."""
+    stats = torch.empty(2, dtype=w.dtype, device=w.device)
+    sp, seq = (None, 0)
+    if slot is not None:
+        slot.seq += 1
+        sp, seq = slot.ptr, slot.seq
+    L.check(L.load().pf_theta_step(w.data_ptr(), ll.data_ptr(), w.shape[0], L.dtype_code(w.dtype), stats.data_ptr(), sp, seq,
+                                   L.stream_ptr()), "pf_theta_step")
+    return stats
 
 
 def theta_resample(log_w: torch.Tensor, u: float) -> torch.Tensor:

@@ -201,6 +201,35 @@ def test_theta_path_is_the_running_weights_and_their_ess(dtype, n, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("b", [128, 37, 4097])
+def test_theta_step_updates_in_place_and_reports_to_the_host_slot(dtype, b):
+    """``pf_theta_step`` (one observation of ``SMC2.step``): ``w += ll`` in place equal to torch's addition to the last bit,
+    statistics equal to ``pf_theta_ess`` of the result - on the device AND, polled without any copy command, in the host slot
+    (``pf_host_alloc`` memory), observation after observation (the sequence number tells them apart)."""
+    g = torch.Generator().manual_seed(b)
+    w = torch.randn(b, generator=g, dtype=torch.float64).to(dtype).cuda()
+    slot = ops.HostSlot()
+    for t in range(60):
+        ll = torch.randn(b, generator=g, dtype=torch.float64).mul(1.5).to(dtype).cuda()
+        if t == 40:
+            ll[5] = -math.inf
+        want = w + ll
+        stats = ops.theta_step(w, ll, slot if t % 7 != 3 else None)  # (a step without the slot in between leaves it alone)
+        if t % 7 != 3:
+            ess, finite = slot.wait()
+            assert slot._seq.value == slot.seq
+            ref = ops.theta_ess(want).tolist()
+            assert [ess, finite] == ref, (t, ess, finite, ref)
+        assert torch.equal(w, want)
+        assert torch.equal(stats, ops.theta_ess(want))
+    assert stats[1] == 0  # (the -inf from observation 40 on)
+    import copy
+
+    other = copy.deepcopy(slot)
+    assert other.ptr != slot.ptr and other.seq == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("b", [1000, 37, 5000])
 def test_theta_resample_is_normalize_then_systematic(dtype, b):
     from pyfilter_amd.inference.utils import theta_systematic

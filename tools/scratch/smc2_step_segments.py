@@ -79,16 +79,19 @@ def main():
             state.append_data(yt)
             fs = alg.filter.filter(yt, state.filter_state.latest_state, result=state.filter_state)
             tb = time.perf_counter()
-            state.append(fs)
+            slot = alg.__dict__.get("_host_slot")
+            if slot is None:
+                slot = alg._host_slot = ops.HostSlot()
+            on_host = state.append(fs, slot)
             tc = time.perf_counter()
-            ess, finite = state.stats.tolist()
+            ess, finite = slot.wait() if on_host else state.stats.tolist()
             td = time.perf_counter()
             if ess < alg._threshold * alg.particles[0] or not finite:
                 state = alg._kernel.update(alg.theta, alg.filter, state, generator=alg._gen)
             state.current_iteration += 1
             acc["filter() incl. result.append"] = acc.get("filter() incl. result.append", 0.0) + tb - ta
             acc["state.append (theta weights + ESS)"] = acc.get("state.append (theta weights + ESS)", 0.0) + tc - tb
-            acc["stats.tolist() (device -> host)"] = acc.get("stats.tolist() (device -> host)", 0.0) + td - tc
+            acc["host has (ESS, finite) (slot.wait)  "] = acc.get("host has (ESS, finite) (slot.wait)  ", 0.0) + td - tc
         torch.cuda.synchronize()
         total = time.perf_counter() - t0
         lib.pf_filter_run = real_run
