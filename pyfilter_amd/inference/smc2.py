@@ -345,9 +345,11 @@ class SMC2:
         # that updates the theta-weights writes the pair into host memory as well, and the host polls for it - no copy command
         slot = self.__dict__.get("_host_slot")
         if slot is None and state.w.is_cuda:
-            from .. import ops
-
-            slot = self._host_slot = ops.HostSlot()
+            try:
+                slot = self._host_slot = _ops.HostSlot()
+            except Exception:  # (no coherent host memory to be had: the copy command per observation it is)
+                slot = self._host_slot = False
+        slot = slot or None
         ess, finite = slot.wait() if state.append(filter_state, slot) else state.stats.tolist()
         if ess < self._threshold * self.particles[0] or not finite:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)

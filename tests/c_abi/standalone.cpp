@@ -8,6 +8,7 @@
 //       -L<repo>/pyfilter_amd -lpfamd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,<repo>/pyfilter_amd
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -263,6 +264,42 @@ int main() {
             !(std::fabs(mean[1] - m[1]) < 1e-5) || !(std::fabs(chol[0] - 1.1 * l00) < 1e-5) || !(std::fabs(chol[2] - 1.1 * l10) < 1e-5) ||
             !(std::fabs(chol[3] - 1.1 * l11) < 1e-5) || chol[1] != 0.0f)
             ++failures;
+        // one observation of SMC2.step (smc2.py:53-65): w += ll in place, the (ESS, all finite) pair on the device and - polled, no
+        // copy command - in pf_host_alloc memory; three observations through one slot, the sequence number tells them apart
+        void* slot = nullptr;
+        PF_CALL(pf_host_alloc(64, &slot));
+        volatile double* hv = (volatile double*)slot;
+        volatile unsigned long long* hseq = (volatile unsigned long long*)((char*)slot + 16);
+        std::vector<float> w(lw), inc(BT);
+        float* d_inc;
+        HIP_OK(hipMalloc((void**)&d_inc, sizeof(float) * BT));
+        int64_t slot_bad = 0;
+        for (unsigned long long seq = 1; seq <= 3; ++seq) {
+            for (int64_t i = 0; i < BT; ++i) inc[i] = 0.25f * std::sin(0.37f * (float)(i + 11 * seq));
+            HIP_OK(hipMemcpy(d_inc, inc.data(), sizeof(float) * BT, hipMemcpyHostToDevice));
+            PF_CALL(pf_theta_step(d_lw, d_inc, BT, PF_F32, d_stats, slot, seq, nullptr));
+            long long spins = 0;
+            while (*hseq != seq && ++spins < (1ll << 31)) {}
+            const double ess_slot = hv[0], fin_slot = hv[1];
+            double mxs = -1e300, s1 = 0.0, s2 = 0.0;
+            for (int64_t i = 0; i < BT; ++i) { w[i] = w[i] + inc[i]; mxs = std::max(mxs, (double)w[i]); }
+            for (int64_t i = 0; i < BT; ++i) { const double e = std::exp((double)w[i] - mxs); s1 += e; s2 += e * e; }
+            HIP_OK(hipDeviceSynchronize());
+            float st2[2];
+            std::vector<float> wdev(BT);
+            HIP_OK(hipMemcpy(st2, d_stats, sizeof(st2), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(wdev.data(), d_lw, sizeof(float) * BT, hipMemcpyDeviceToHost));
+            int64_t wdiff = 0;
+            for (int64_t i = 0; i < BT; ++i) wdiff += wdev[i] != w[i];
+            if (*hseq != seq || ess_slot != (double)st2[0] || fin_slot != (double)st2[1] || wdiff != 0 ||
+                !(std::fabs(ess_slot - s1 * s1 / s2) < 1e-3 * s1 * s1 / s2) || fin_slot != 1.0)
+                ++slot_bad;
+            if (seq == 3)
+                std::printf("theta step: observation %llu polled from host memory after %lld spins: ESS %.3f (device copy %.3f, host %.3f), weights differing %lld\n",
+                            seq, spins, ess_slot, (double)st2[0], s1 * s1 / s2, (long long)wdiff);
+        }
+        PF_CALL(pf_host_free(slot));
+        if (slot_bad) ++failures;
     }
     std::printf("%s (%s)\n", failures ? "c-abi FAILED" : "c-abi ok", pf_version());
     return failures ? 1 : 0;

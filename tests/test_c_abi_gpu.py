@@ -2,7 +2,7 @@
 HIP runtime, allocates device memory itself and runs SISR + Bootstrap and APF + LinearGaussianObservations on the
 reference's AR(1) test model - the whole time loop behind one ``pf_filter_run`` call - against an exact Kalman filter
 computed on the host (log-likelihood within 0.25, final mean within 0.01 at 65 536 particles) - and the theta-level entry
-points (``pf_theta_ess / _resample / _fit``) against the same arithmetic on the host."""
+points (``pf_theta_ess / _resample / _fit``, ``pf_theta_step`` with its polled host slot) against the same arithmetic on the host."""
 import os
 import subprocess
 
@@ -30,3 +30,4 @@ def test_standalone_program_against_kalman(tmp_path):
     assert "c-abi ok" in run.stdout and run.stdout.count("Kalman") == 12  # (2 variants + the cluster route) x 2 columns x (ll, mean)
     assert "cluster route (launch trace 10)" in run.stdout
     assert "theta level: ESS" in run.stdout
+    assert "theta step: observation 3 polled from host memory" in run.stdout
