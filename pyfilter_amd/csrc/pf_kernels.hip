@@ -572,7 +572,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_tile_sum(const T* __restrict__ W, 
 //   otherwise: e_j = exp(logw_j - m_k),   f_k = exp(m_k - M) / S,      P_k = normalised prefix
 template <typename T, int VEC, bool FROM_W>
 __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __restrict__ cdf_col, const Geom& g, int k,
-                                          T tile_max, double Pk, double fk, double Pnext, double* red) {
+                                          T tile_max, double Pk, double fk, double Pnext, double* red, const T (&v_first)[VEC]) {
     double carry = 0.0;
     const int64_t base = (int64_t)k * g.tile_elems;
     for (int r = 0; r < g.rounds_per_tile; ++r) {
@@ -582,6 +582,12 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
         const bool on = i0 < g.N;
         T v[VEC];
         double e[VEC];
+#ifndef PF_SCAN_NO_PREFETCH
+        if (r == 0) {  // (loaded by the caller BEFORE it combined the tile records: one round trip to memory instead of two in a row)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] = v_first[j];
+        } else
+#endif
         if (on) {
             if (VEC == 1) v[0] = src_col[i0]; else load_vec<T, VEC>(src_col + i0, v);
         }
@@ -615,6 +621,19 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
     if (colmask && !colmask[b]) return;
+    // the tile's first round of elements: issued now, used after the tile records are combined
+    T v_first[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v_first[j] = T(0);
+#ifndef PF_SCAN_NO_PREFETCH
+    {
+        const int64_t i0 = (int64_t)k * g.tile_elems + threadIdx.x * VEC;
+        if (i0 < g.N) {
+            const T* sc = src + (int64_t)b * g.N;
+            if (VEC == 1) v_first[0] = sc[i0]; else load_vec<T, VEC>(sc + i0, v_first);
+        }
+    }
+#endif
     ColLse c;
     if constexpr (FROM_W) {
         // normalised weights: every tile record is (max 0, plain sum) - the prefix is the plain sum of the tile sums before k, in
@@ -649,7 +668,7 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
         Pk = c.prefix / c.S;
         Pnext = Pk + sk * fk;
     }
-    scan_tile<T, VEC, FROM_W>(src + (int64_t)b * g.N, cdf + (int64_t)b * g.N, g, k, (T)mk, Pk, fk, Pnext, red);
+    scan_tile<T, VEC, FROM_W>(src + (int64_t)b * g.N, cdf + (int64_t)b * g.N, g, k, (T)mk, Pk, fk, Pnext, red, v_first);
 }
 template <typename T, int VEC, bool FROM_W>
 __global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T* __restrict__ cdf,
@@ -675,6 +694,9 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
     if (!multinomial) {
         const T* u_elem = u_per_elem ? u + (int64_t)b * g.N : nullptr;
         const T ub = u_per_elem ? u_elem[base < g.N ? base : 0] : u[b];
+        // (the whole workgroup bracketing the answer with 256 or 1 024 counted probes per round - two or three dependent round
+        // trips instead of one wave's four or five - measured SLOWER: k_search 6.3 -> 8.3 / 9.8 us at 2^20 x 1, 13.6 -> 15.9 / 21.9
+        // at 64 x 65 536: 1 024 workgroups x 1 024 probes is traffic, and two barriers per round; profiles/r05h_primitives_ab.txt)
         if (threadIdx.x < PF_WAVE) {
             const int j0 = wave_lower_bound<T>(col, N, grid_position<T>(base, ub, T(N)), lane);
             if (lane == 0) sh_j0 = j0;
