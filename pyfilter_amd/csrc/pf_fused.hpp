@@ -1720,6 +1720,25 @@ __global__ __launch_bounds__(PF_WAVE) void k_observed_flags(const T* __restrict_
     if (threadIdx.x == 0) out[blockIdx.x] = bal ? 1 : 0;
 }
 
+// both of the above in ONE launch - what a fresh self-contained run that derives its flags starts with (an online filter() move is
+// such a run per observation: one launch less per move): the first `zero_blocks` workgroups clear, workgroup zero_blocks + k flags y[k]
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_zero_and_flags(uint32_t* __restrict__ p, size_t n, unsigned zero_blocks, const T* __restrict__ y,
+                                                             int64_t row_elems, uint8_t* __restrict__ out) {
+    if (blockIdx.x < zero_blocks) {
+        const size_t i = (size_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+        if (i < n) p[i] = 0u;
+        return;
+    }
+    if (threadIdx.x >= PF_WAVE) return;
+    const unsigned k = blockIdx.x - zero_blocks;
+    const T* row = y + (int64_t)k * row_elems;
+    bool any = false;
+    for (int64_t i = threadIdx.x; i < row_elems; i += PF_WAVE) any |= !(row[i] != row[i]);
+    const unsigned long long bal = __ballot(any);
+    if (threadIdx.x == 0) out[k] = bal ? 1 : 0;
+}
+
 // theta-level bookkeeping of SMC^2 in one launch (sequential/state.py:35-44, smc2.py:59-62): effective sample size of B
 // log-weights under pyfilter.utils.normalize (NaN / +inf count as -inf; all -inf -> uniform) and whether every weight is
 // finite.  One workgroup per row of B weights (B = the number of theta-particles, 10^2 .. 10^5; rows = the observations of

@@ -1897,14 +1897,22 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
 #else
     const dim3 grid(g.B, g.tiles + (a.book_inline ? 0 : 1));
 #endif
+    // neither flag array given: the flags are derived from y on the device, into the workspace (runs of <= PF_AUTO_FLAGS steps)
+    const bool auto_flags = !A->observed && !A->observed_dev && n_steps > 0;
+    uint8_t* const auto_fl = (uint8_t*)A->ws + wl.off_ctr + 64;
+    const int64_t auto_row = A->y_rows * (int64_t)A->model.obs_dim;
     if (t0 == 0) {
         // fresh filter: no previous step to account for (column records + poison flags)
         // (a kernel, not hipMemsetAsync: captured as a memset node the fill stopped clearing these records after ~195
         // replays of the same executable graph on ROCm 7.2 - every log-likelihood of the run came back NaN, "poisoned" -
         // tools/graph_replays.py)
         const size_t words = (wl.off_ctr - wl.off_stat) / sizeof(uint32_t);  // (256-byte aligned regions)
-        hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3((unsigned)((words + PF_BLOCK - 1) / PF_BLOCK)), dim3(PF_BLOCK), 0, st,
-                           (uint32_t*)((char*)A->ws + wl.off_stat), words);
+        const unsigned zb = (unsigned)((words + PF_BLOCK - 1) / PF_BLOCK);
+        if (auto_flags)  // (the flags ride along: one launch)
+            hipLaunchKernelGGL((k_zero_and_flags<T>), dim3(zb + (unsigned)n_steps), dim3(PF_BLOCK), 0, st,
+                               (uint32_t*)((char*)A->ws + wl.off_stat), words, zb, (const T*)A->y + t0 * auto_row, auto_row, auto_fl);
+        else
+            hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3(zb), dim3(PF_BLOCK), 0, st, (uint32_t*)((char*)A->ws + wl.off_stat), words);
     }
     // state history: slot pointers per launch (the kernels keep addressing "buffer step & 1 is read, the other written")
     const int64_t ring = A->ring >= 3 ? A->ring : 0;
@@ -1921,15 +1929,12 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     place(t0);
     // partials of the incoming state (afterwards every step kernel leaves the partials of the state it wrote)
     a.step = (int)t0;
-    // neither flag array given: the flags are derived from y on the device, into the workspace (runs of <= PF_AUTO_FLAGS steps)
-    const bool auto_flags = !A->observed && !A->observed_dev && n_steps > 0;
     const bool dev_flags = A->observed_dev != nullptr || auto_flags;  // the kernels read the flags themselves
     a.obs_dev = A->observed_dev;
     if (auto_flags) {
-        uint8_t* fl = (uint8_t*)A->ws + wl.off_ctr + 64;
-        const int64_t row = A->y_rows * (int64_t)A->model.obs_dim;
-        hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * row, row, fl);
-        a.obs_dev = fl - t0;  // (indexed by the absolute step)
+        if (t0 != 0)
+            hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * auto_row, auto_row, auto_fl);
+        a.obs_dev = auto_fl - t0;  // (indexed by the absolute step)
     }
     a.obs = n_steps > 0 ? (dev_flags ? -1 : (observed[t0] != 0)) : 0;
     a.obs_next = 0;
@@ -2311,12 +2316,10 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
     const size_t lds = cluster_lds_bytes(D, sizeof(T));
     const bool auto_flags = !A->observed && !A->observed_dev;
     a.obs_dev = A->observed_dev;
-    if (auto_flags) {
-        uint8_t* fl = (uint8_t*)A->ws + wl.off_ctr + 64;
-        const int64_t row = A->y_rows * (int64_t)A->model.obs_dim;
-        hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * row, row, fl);
-        a.obs_dev = fl - t0;
-    }
+    uint8_t* const auto_fl = (uint8_t*)A->ws + wl.off_ctr + 64;
+    const int64_t auto_row = A->y_rows * (int64_t)A->model.obs_dim;
+    bool flags_pending = auto_flags;  // (derived by the launch that clears the first piece's records: k_zero_and_flags)
+    if (auto_flags) a.obs_dev = auto_fl - t0;
     const int c = (int)((A->N + PFK_TPB * VEC - 1) / (PFK_TPB * VEC));
     const int nchunks = (int)((A->N + 64 * VEC - 1) / (64 * VEC));
     // which instantiation: float runs of the built-in scalar closed-form models on Philox normals take KIND / FILT / PROP folded
@@ -2385,8 +2388,13 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
             const size_t ng = ((size_t)(5 + 2 * D) * (sizeof(T) / 4) + 2 + 2) / 3;
             size_t words = (256 + (size_t)2 * g.B * PF_CLUSTER_NG * 64 * 16) / sizeof(uint32_t);
             if (g.B <= per_launch) words = (256 + (size_t)2 * g.B * ng * 64 * 16) / sizeof(uint32_t);  // (one group: its block is compact)
-            hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3((unsigned)((words + PF_BLOCK - 1) / PF_BLOCK)), dim3(PF_BLOCK), 0, st,
-                               (uint32_t*)clu, words);
+            const unsigned zb = (unsigned)((words + PF_BLOCK - 1) / PF_BLOCK);
+            if (flags_pending)
+                hipLaunchKernelGGL((k_zero_and_flags<T>), dim3(zb + (unsigned)n_steps), dim3(PF_BLOCK), 0, st, (uint32_t*)clu, words, zb,
+                                   (const T*)A->y + t0 * auto_row, auto_row, auto_fl);
+            else
+                hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3(zb), dim3(PF_BLOCK), 0, st, (uint32_t*)clu, words);
+            flags_pending = false;
             trace_launch(r.t0, (int)sizeof(T), D, VEC, 0, A->proposal, spec_ok ? 1 : 0, /*SPEC*/ 10, spec_ok ? A->model.hid_kind : 0, c);
             for (int b0 = 0; b0 < g.B; b0 += per_launch) {
                 ClusterRun cr;
