@@ -170,6 +170,51 @@ def test_a_float32_fit_takes_the_theta_kernels_and_finds_the_posterior():
     assert torch.isfinite(post).all() and 0.0 < float(post[0]) < 0.5 and 0.0 < float(post[2]) < 0.5
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_step_by_step_with_the_polled_host_slot_is_step_by_step_with_the_copy(dtype, monkeypatch):
+    """``SMC2.step()`` - the reference's loop, one host ESS test per observation (``smc2.py:53-65``) - reads the (ESS, all finite)
+    pair from the host slot ``pf_theta_step`` writes; with no coherent host memory to be had it falls back to the copy command.
+    Same seeds: the two loops rejuvenate at the same observations and end in the same theta-weights and posterior, bit for bit."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+    obs = (t(1.0), t(0.05))
+
+    def build(theta):
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), obs)
+
+    g = torch.Generator().manual_seed(5)
+    x, ys = 0.0, []
+    for _ in range(60):
+        x = x * math.exp(-0.05) + 0.15 * math.sqrt((1 - math.exp(-0.1)) / 0.1) * float(torch.randn((), generator=g))
+        ys.append(x + 0.05 * float(torch.randn((), generator=g)))
+    y = torch.tensor(ys, dtype=dtype, device="cuda")
+    pri = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+    outs = {}
+    for how in ("slot", "copy"):
+        if how == "copy":
+            def no_slot():
+                raise RuntimeError("no coherent host memory")
+            monkeypatch.setattr(ops, "HostSlot", no_slot)
+        alg = SMC2(APF(build, 300, proposal=proposals.LinearGaussianObservations(), seed=11), 128, pri, threshold=0.5, device="cuda",
+                   dtype=dtype, seed=3)
+        alg._kernel.trace = []
+        state = alg.initialize()
+        for yt in y:
+            state = alg.step(yt, state)
+        slot = alg.__dict__.get("_host_slot")
+        assert (slot is not None and slot is not False and slot.seq > 0) if how == "slot" else slot is False
+        outs[how] = (state.w.cpu(), alg.posterior_mean(state).cpu(), sum(1 for tr in alg._kernel.trace if tr["kind"] == "rejuvenate"),
+                     torch.stack(state.ess).cpu())
+    assert outs["slot"][2] == outs["copy"][2] and outs["slot"][2] >= 1, outs["slot"][2]
+    for a, b in zip(outs["slot"], outs["copy"]):
+        if isinstance(a, torch.Tensor):
+            assert torch.equal(a, b)
+
+
 def test_priors_outside_the_kernels_families_take_the_torch_route():
     from torch.distributions import Independent, StudentT
 
