@@ -76,6 +76,8 @@ CONFIGS = {
     "apf_lgo_1m": ("sine", "apf", "lgo", 1 << 20, 1),
     "user_apf_lgo_1m": ("user_sine", "apf", "lgo", 1 << 20, 1),       # lambda-defined model on the fused single-step route
     "user_sisr_boot_1m": ("user_sine", "sisr", "bootstrap", 1 << 20, 1),
+    "user_apf_boot_1m": ("user_sine", "apf", "bootstrap", 1 << 20, 1),   # (its first stage needs the callable's plane: a reduce launch per move)
+    "user_sisr_lgo_1m": ("user_sine", "sisr", "lgo", 1 << 20, 1),
     "user_apf_lgo_1024x512": ("user_sine", "apf", "lgo", 512, 1024),
     "apf_boot_1m": ("sine", "apf", "bootstrap", 1 << 20, 1),
     "sisr_boot_1m": ("sine", "sisr", "bootstrap", 1 << 20, 1),
