@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3 /* 3: pf_filter_args.user_dt (an Euler-Maruyama user process hands over its DRIFT; the kernels form x + f dt).
+#define PF_ABI_VERSION 4 /* 4: pf_filter_args.status + pf_run_hints.cluster_patience (a column-cluster launch that cannot make
+                          * progress reports it; the caller re-issues the piece on the per-step route), pf_theta_step takes the
+                          * running total to accumulate into and that status word.
+                          * 3: pf_filter_args.user_dt (an Euler-Maruyama user process hands over its DRIFT; the kernels form x + f dt).
                           * 2: pf_filter_args starts with its own size and ends with pf_run_hints; the library has no
                           * environment variables and no process-wide switches - every choice a caller can override is an
                           * argument */
@@ -230,10 +233,15 @@ int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtyp
 
 /* ONE observation of the reference's SMC2.step() (smc2.py:53-65; sequential/state.py:35-44): w (B) += ll (B) in place and stats
  * (2) <- (ESS, 1 if every weight is finite) as pf_theta_ess reports them - pf_theta_path with n = 1 - and, host_slot != NULL,
- * the same two values as doubles followed by the 64-bit `seq` into 24 bytes of pf_host_alloc memory: the reference tests the
- * ESS on the host after every observation (smc2.py:59-62), and a host thread that polls the third word for `seq` has the two
- * values without a device -> host copy command and its synchronisation (~12 us per observation). */
-int pf_theta_step(void* w, const void* ll, int64_t B, int dtype, void* stats, void* host_slot, uint64_t seq, void* stream);
+ * the same two values as doubles, the 64-bit `seq` and (fourth word) the run status into 32 bytes of pf_host_alloc memory:
+ * the reference tests the ESS on the host after every observation (smc2.py:59-62), and a host thread that polls the third
+ * word for `seq` has the values without a device -> host copy command and its synchronisation (~12 us per observation).
+ * acc (B) or NULL: the filters' running log-likelihood, acc += ll as well (filters/result.py:130 - one elementwise launch of
+ * the caller's less).  status or NULL: the pf_filter_args.status word of the move that produced ll - when it is non-zero
+ * NOTHING is updated (w and acc keep their values, stats <- (NaN, 0)) and the slot's fourth word carries it: the caller
+ * re-issues the move on the per-step route and calls again. */
+int pf_theta_step(void* w, const void* ll, int64_t B, int dtype, void* stats, void* host_slot, uint64_t seq, void* acc,
+                  const int32_t* status, void* stream);
 
 /* Host memory the device writes and the host polls (hipHostMalloc, coherent + mapped, zero-filled); pf_host_free releases it. */
 int pf_host_alloc(size_t bytes, void** out);
@@ -255,12 +263,20 @@ int pf_theta_resample(const void* logw, int64_t B, double u, int dtype, int64_t*
 #define PF_ROUTE_CLUSTER 3        /* as AUTO, and self-contained runs of filters of 2 049 .. 16 384 particles (N % 4 == 0,
                                    * systematic resampling, built-in model) take the column-CLUSTER kernel: ceil(N / 1024)
                                    * workgroups per filter hold it in registers for the whole run and exchange one record per
-                                   * wave and step (pf_cluster.hpp).  Opt-in because those workgroups wait for each other: the
-                                   * caller promises that no two such runs are in flight on DIFFERENT streams of one device
-                                   * (each could hold slots the other needs; a launch that cannot make progress gives up after
-                                   * ~1 s and returns NaN log-likelihoods rather than hang).  Batches of more than two
-                                   * launches' worth of member workgroups (B ceil(N / 1024) > 2 048) stay on the per-step route,
-                                   * which is the faster one there */
+                                   * wave and step (pf_cluster.hpp).  Those workgroups wait for each other.  Their ids are
+                                   * grouped so that the resident workgroups of a launch are whole filters (plus one partly
+                                   * dispatched filter per XCD) whatever else runs on the device: any number of such runs may be
+                                   * in flight on different streams, threads or processes - they share the slots, none starves
+                                   * (tests/test_cluster_route_gpu.py drives two streams from two threads).  HIP promises no
+                                   * dispatch order, so every wait is bounded all the same: a launch that cannot make progress
+                                   * (a foreign kernel holding the device for seconds) gives up, returns NaN log-likelihoods and
+                                   * sets bit 0 of pf_filter_args.status.  Opt-in because of that contract: a caller that takes
+                                   * this route passes `status`, looks at it where it next waits for the device, and on a
+                                   * non-zero word re-issues the piece from the same incoming state with PF_ROUTE_PER_STEP - the
+                                   * draws are keyed by (seed, step, particle), so the numbers are the one-piece run's.  Batches
+                                   * of more than two launches' worth of member workgroups (B ceil(N / 1024) > 2 048) stay on
+                                   * the per-step route, which is the faster one there; so do runs the kernel cannot be launched
+                                   * for (no resident slot for one filter's workgroups) */
 #define PF_ROUTE_CLUSTER_ALWAYS 4 /* as CLUSTER for a batch of any size (consecutive launches; tests and measurements) */
 #define PF_ROUTE_CLUSTER_SPREAD 5 /* as CLUSTER_ALWAYS with the members of a filter on DIFFERENT XCDs (consecutive workgroup ids) and
                                    * the exchange in its placement-independent form - agent-scope write-through stores and
@@ -285,6 +301,9 @@ typedef struct pf_run_hints {
                               * and user_scale_per_column: the optimal proposal's first-stage weight (linear.py:57-86) needs
                               * the particle and its transition scale - not the caller's one-step mean, which does not exist
                               * yet for the new particles */
+    int32_t cluster_patience; /* polls a workgroup of the column-cluster kernel spends on one wait for its siblings before it
+                               * gives up (see PF_ROUTE_CLUSTER); 0 = the default, 2^21 (seconds).  -1 (tests): every workgroup
+                               * gives up at its first wait whatever it finds - the give-up path, deterministically */
 } pf_run_hints;
 
 typedef struct pf_filter_args {
@@ -348,6 +367,11 @@ typedef struct pf_filter_args {
                              * Euler-Maruyama discretisation (README.md:44-62: AffineEulerMaruyama) and the kernels form the mean
                              * x + f(x) dt at the parent themselves - the addition is one elementwise launch of the caller's less
                              * per move (~5 us at 2^20 particles) */
+    int32_t* status;        /* optional DEVICE word owned by the caller: the run ORs bits into it and never clears it (the caller
+                             * zeroes it when it starts watching).  bit 0: a column-cluster launch gave up waiting for a
+                             * sibling workgroup; bit 1: an ancestor fell outside the chunks a cluster member staged.  Non-zero =
+                             * the log-likelihoods of that run are NaN and its final state is not to be used: re-issue the piece
+                             * with PF_ROUTE_PER_STEP (see PF_ROUTE_CLUSTER).  The other routes never touch it */
     pf_run_hints hints;     /* all zero = the library's own choices */
 } pf_filter_args;
 

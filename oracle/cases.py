@@ -109,11 +109,27 @@ CASES = [
          ess_threshold=0.9, seed=132, observe_every_step=5, dtypes=("f64",)),  # the SV notebook's own setting (:83)
 ]
 
+# ---- round 6: reference runs at the sizes the column-CLUSTER kernel takes (2 049 .. 16 384 particles; pf_cluster.hpp) - kept apart
+# from CASES: the suites parametrised over those pin the column / per-step routes of small filters, these pin the cluster kernel
+# (``kernel_route`` "cluster" / "spread", tests/conftest.py) and the per-step route at the same sizes.  No smoothing arrays
+# (the fixtures stay a few hundred KB).
+CLUSTER_CASES = [
+    # SISR: ess_threshold 0.5 - moves with and without resampling; the column = 4 member workgroups x 2 filters
+    dict(name="lg1d_sisr_boot_n4096", model="lg1d", filter="sisr", proposal="bootstrap", N=4096, B=2, T=8,
+         ess_threshold=0.5, seed=201, dtypes=("f64", "f32"), no_smooth=True),
+    # the headline model at the per-rank size of BASELINE configs[4]: 8 members, one NaN row
+    dict(name="sine_apf_lgo_n8192", model="sine", filter="apf", proposal="lgo", N=8192, B=1, T=6,
+         ess_threshold=0.9, seed=202, nan_steps=(3,), dtypes=("f64", "f32"), no_smooth=True),
+    # D = 3 / O = 1, and a column that ends 4 particles into its third member
+    dict(name="lorenz_o1_apf_lgo_n2052", model="lorenz_o1", filter="apf", proposal="lgo", N=2052, B=2, T=6,
+         ess_threshold=0.9, seed=203, dtypes=("f64", "f32"), no_smooth=True),
+]
+
 _LORENZ_A_S = [0.8, 0.0, 0.3]
 _LORENZ_A_O3 = [[0.8, 0.1, 0.0], [-0.2, 0.9, 0.05], [0.0, 0.3, 0.7]]
 _RW2D_A_S = [1.0, 0.5]
 
-CASE_BY_NAME = {c["name"]: c for c in CASES}
+CASE_BY_NAME = {c["name"]: c for c in CASES + CLUSTER_CASES}
 # the cases whose model the fused kernels take (D > 1 or O == 1); ``lg1d_o2_*`` runs on the torch route (tests/test_torch_route_golden.py)
 FUSED_CASES = [c for c in CASES if c["model"] != "lg1d_o2"]
 

@@ -62,7 +62,7 @@ def _main_child(dtype_name: str, only=None):
     import torch.distributions.multivariate_normal as mvn_mod
 
     from oracle import models as M
-    from oracle.cases import CASES, build_spec, simulate
+    from oracle.cases import CASES, CLUSTER_CASES, build_spec, simulate
 
     # ---------------------------------------------------------------------------------------------------------
     class Tape:
@@ -163,7 +163,7 @@ def _main_child(dtype_name: str, only=None):
     # ---------------------------------------------------------------------------------------------------------
     os.makedirs(GOLDEN, exist_ok=True)
 
-    for case in CASES:
+    for case in CASES + CLUSTER_CASES:
         if dtype_name not in case["dtypes"] or (only is not None and case["name"] not in only):
             continue
         oes = int(case.get("observe_every_step", 1))
@@ -244,7 +244,7 @@ def _main_child(dtype_name: str, only=None):
             out[f"step_{k}"] = torch.stack(v).numpy()
         # smoothing over the recorded states (particle/base.py:105-157); everything the filtering part of the fixture
         # holds was produced above - the calls below only consume further random numbers
-        if oes == 1:  # (recorded states of a thinned run skip moves: their ancestors do not chain)
+        if oes == 1 and not case.get("no_smooth"):  # (recorded states of a thinned run skip moves: their ancestors do not chain)
             out["smooth_fl"] = filt.smooth(all_states, "fl").numpy()
         if case["name"] in FFBS_CASES and dtype_name == "f64":
             tape.mask = torch.ones(b, dtype=torch.bool)

@@ -48,12 +48,12 @@ class PfModel(C.Structure):
     ]
 
 
-ABI_VERSION = 3  # include/pf_amd.h: PF_ABI_VERSION
+ABI_VERSION = 4  # include/pf_amd.h: PF_ABI_VERSION
 
 
 class PfRunHints(C.Structure):
     _fields_ = [("route", C.c_int32), ("column_max_n", C.c_int32), ("tile_target", C.c_int32), ("ancestor_search", C.c_int32),
-                ("resume", C.c_int32), ("prepare_next", C.c_int32)]
+                ("resume", C.c_int32), ("prepare_next", C.c_int32), ("cluster_patience", C.c_int32)]
 
 
 class PfFilterArgs(C.Structure):
@@ -77,6 +77,7 @@ class PfFilterArgs(C.Structure):
         ("ring", C.c_int64),
         ("user_loc", C.c_void_p), ("user_scale", C.c_void_p), ("user_scale_per_column", C.c_int64),
         ("user_dt", C.c_double),
+        ("status", C.c_void_p),
         ("hints", PfRunHints),
     ]
 
@@ -132,7 +133,7 @@ def load() -> C.CDLL:
     lib.pf_theta_ess.argtypes = [vp, i64, i64, i32, vp, vp]
     lib.pf_theta_path.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp]
     lib.pf_theta_resample.argtypes = [vp, i64, C.c_double, i32, vp, vp, vp]
-    lib.pf_theta_step.argtypes = [vp, vp, i64, i32, vp, vp, u64, vp]
+    lib.pf_theta_step.argtypes = [vp, vp, i64, i32, vp, vp, u64, vp, vp, vp]
     lib.pf_host_alloc.argtypes = [sz, C.POINTER(vp)]
     lib.pf_host_free.argtypes = [vp]
     lib.pf_initial_sample_cols.argtypes = [vp, i64, i64, vp, i64, i64, vp, u64, vp, i64, i64, i64, i32, vp]

@@ -25,13 +25,22 @@
 //   the state is read once and written once per run (its last publish IS the final state); moments rows / log-likelihood
 //   increments are written by thread 0 of member 0 from the same folds.
 //
-// Residency: a member spins on its siblings, so every workgroup of a launch must be resident at once - the host sizes each
-// launch by the occupancy query (columns per launch = resident slots / c) and runs the columns of a larger batch in
-// consecutive launches.  Siblings get the linear ids b + nbp k (nbp % 8 == 0): the same XCD under the observed id % 8
-// placement - then (checked: the first records carry the XCC ids) the exchange stays in that XCD's L2: plain stores, L1-bypassing
-// loads; otherwise agent-scope `sc1` on both sides, correct under any placement (PF_ROUTE_CLUSTER_SPREAD pins that form in the
-// tests).  Every spin is bounded:
-// a launch that cannot make progress poisons its log-likelihoods with NaN and raises the error word instead of hanging.
+// Residency: a member spins on its siblings, so the members of a column must be resident together.  The workgroup ids are
+// GROUPED: eight columns share 8 c consecutive ids, member k of column (group, j) has id 8 c group + 8 k + j - its siblings are
+// the ids congruent to j mod 8 next to it, i.e. (observed id % 8 placement, in-order dispatch per XCD) they sit on ONE XCD and
+// are dispatched back to back.  Whatever else runs on the device - another stream's or another process's cluster launch
+// included - the workgroups of a launch that are resident at any moment are therefore whole columns plus at most one partly
+// dispatched column per XCD: < c slots of an XCD's >= 128 wait for a slot, all others make progress and free theirs when their
+// run ends.  No two launches can hold each other's slots for good (the previous numbering, b + nbp k, dispatched member 0 of
+// EVERY column first: two concurrent launches could each own half the chip without one complete column).  The host still sizes
+// a launch by the occupancy query (columns per launch = resident slots / c: no workgroup queues behind a whole run of its
+// own launch) and runs the columns of a larger batch in consecutive launches.  On one XCD (checked: the first records carry the
+// XCC ids) the exchange stays in that XCD's L2: plain stores, L1-bypassing loads; otherwise agent-scope `sc1` on both sides,
+// correct under any placement (PF_ROUTE_CLUSTER_SPREAD pins that form in the tests).  HIP promises neither the placement nor
+// the dispatch order, so every spin is bounded all the same (ClusterRun.patience polls; the wait for a sibling's FIRST record -
+// the one that can include waiting for a slot behind a foreign kernel - gets that plus 1 024 polls per step of the run): a
+// launch that cannot make progress poisons its log-likelihoods with NaN, raises the error word and - pf_filter_args.status -
+// the caller's status word, and the caller re-issues the piece on the per-step route (same draws, same numbers).
 //
 // Mirrors the same reference code as the other routes: sisr.py:14-56, apf.py:16-46, particle/utils.py:7-65,
 // resampling.py:24-52, filters/base.py:188-221 (NaN observation -> propagate only).
@@ -58,23 +67,19 @@ struct ClusterRun {
     int c;               // member workgroups per column
     int nchunks;         // waves with particles per column = ceil(N / (64 VEC))
     int* err;            // |= 1: a poll ran out of patience, |= 2: an ancestor fell outside the staged chunks
+    int* status;         // pf_filter_args.status (or null): the same bits, never cleared by the library
+    int patience;        // polls of one wait before a member gives up
     int spread;          // != 0 (PF_ROUTE_CLUSTER_SPREAD, tests): the members of a column get CONSECUTIVE ids - one per XCD under
                          // the id % 8 placement - so the exchange runs on its placement-independent form (agent-scope `sc1` on both
                          // sides, never the same-XCD fast path)
 };
 
-typedef unsigned pfk_u4 __attribute__((ext_vector_type(4)));
+typedef pf_u4 pfk_u4;
 
-// 16-byte agent-scope accesses through a buffer descriptor (`base` wave-uniform, byte offset per lane): `sc1` loads bypass
-// this CU's L1 (another CU's stores are never seen there), `sc1` stores write through to the memory side
-__device__ __forceinline__ pfk_u4 pfk_load16(const void* base, int byte_off) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, /*sc1*/ 16);
-}
-__device__ __forceinline__ void pfk_store16(void* base, int byte_off, pfk_u4 v) {
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, /*sc1*/ 16);
-}
+// 16-byte agent-scope accesses through a buffer descriptor (pf_device.hpp: `sc1` loads bypass this CU's L1 - another CU's stores
+// are never seen there -, `sc1` stores write through to the memory side)
+__device__ __forceinline__ pfk_u4 pfk_load16(const void* base, int byte_off) { return ld16_sc1(base, byte_off); }
+__device__ __forceinline__ void pfk_store16(void* base, int byte_off, pfk_u4 v) { st16_sc1(base, byte_off, v); }
 // VEC consecutive elements of a plane another member wrote (sc1 stores) - L1 bypassed
 template <typename T, int VEC> __device__ __forceinline__ void pfk_load_vec(const T* base, int elem, T (&out)[VEC]) {
     constexpr int BYTES = (int)sizeof(T) * VEC;
@@ -127,8 +132,10 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
 
     const Geom& g = a.g;
     const int N = (int)g.N;
-    const int bl = cr.spread ? (int)(blockIdx.x / (unsigned)cr.c) : (int)(blockIdx.x % (unsigned)cr.nbp);
-    const int k = cr.spread ? (int)(blockIdx.x % (unsigned)cr.c) : (int)(blockIdx.x / (unsigned)cr.nbp);
+    // grouped ids (see the residency note above): id = 8 c group + 8 k + j  <->  member k of column 8 group + j
+    const unsigned in_grp = blockIdx.x % (8u * (unsigned)cr.c);
+    const int bl = cr.spread ? (int)(blockIdx.x / (unsigned)cr.c) : (int)(8u * (blockIdx.x / (8u * (unsigned)cr.c)) + (in_grp & 7u));
+    const int k = cr.spread ? (int)(blockIdx.x % (unsigned)cr.c) : (int)(in_grp >> 3);
     if (bl >= cr.nb) return;  // (padding ids: they only keep the siblings' ids congruent mod 8)
     const int b = cr.b0 + bl;
     const int tid = threadIdx.x;
@@ -321,6 +328,9 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
             const unsigned char* base = cr.rec + ((size_t)((s & 1) * cr.nb + bl) * NG) * (64 * 16);
             pfk_u4 gr[NG];
             const unsigned want = (unsigned)(s + 1);
+            // (the first records of a run may have to wait for a sibling's SLOT - behind whatever else occupies the device -
+            // not only for its arithmetic: that wait is given time in proportion to the run)
+            const int limit = (s == 0) ? cr.patience + ((run.n_steps < (1 << 19) ? run.n_steps : (1 << 19)) << 10) : cr.patience;
             int spins = 0;
             for (;;) {
                 // (one poller wave per workgroup: all NG rows every time - a second round trip for the rest of a record would cost
@@ -331,13 +341,24 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
 #pragma unroll
                 for (int gi = 0; gi < NG; ++gi) ok = ok && gr[gi].w == want;
                 ok = ok || lane >= nchunks || dead;
+                if (cr.patience < 0) {  // (tests: every member gives up at its first wait, whatever it finds)
+                    dead = true;
+                    if (lane == 0) {
+                        atomicOr(cr.err, 1);
+                        if (cr.status) atomicOr(cr.status, 1);
+                    }
+                    break;
+                }
                 if (__ballot(ok) == ~0ull) break;
 #ifdef PFK_NOWAIT  // (timing experiments: nobody waits - garbage results, the price of the compute and the memory traffic alone)
                 break;
 #endif
-                if (++spins > PFK_SPIN_LIMIT) {
+                if (++spins > limit) {
                     dead = true;
-                    if (lane == 0) atomicOr(cr.err, 1);
+                    if (lane == 0) {
+                        atomicOr(cr.err, 1);
+                        if (cr.status) atomicOr(cr.status, 1);
+                    }
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
@@ -623,7 +644,10 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
             bool miss = false;
 #pragma unroll
             for (int j = 0; j < VEC; ++j) miss = miss || !done[j];
-            if (__ballot(miss) != 0ull && lane == 0) atomicOr(cr.err, 2);
+            if (__ballot(miss) != 0ull && lane == 0) {
+                atomicOr(cr.err, 2);
+                if (cr.status) atomicOr(cr.status, 2);
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {

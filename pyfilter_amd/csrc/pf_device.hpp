@@ -349,6 +349,38 @@ __device__ __forceinline__ void store_out(T* __restrict__ base, int elem, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Agent-scope accesses for data handed between workgroups INSIDE a launch (MI355X_MICROARCH.md, "inter-workgroup visibility": a CU's
+// L1 is never refreshed by another CU's stores, the per-XCD L2s are not coherent with each other): `sc1` stores write through to
+// the memory side, `sc1` loads bypass this CU's L1.  Through a buffer descriptor (`base` wave-uniform, byte offset per lane) so
+// the compiler keeps tracking them.  16-byte {3 words, tag} granules written by ONE such store need no flag and no fence.
+// ---------------------------------------------------------------------------------------------------------------
+typedef unsigned pf_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pf_u4 ld16_sc1(const void* base, int byte_off) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, /*sc1*/ 16);
+}
+__device__ __forceinline__ void st16_sc1(void* base, int byte_off, pf_u4 v) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, /*sc1*/ 16);
+}
+// one element of a plane another workgroup wrote with write-through stores (L1 bypassed); `base` wave-uniform
+template <typename T> __device__ __forceinline__ T ld1_sc1(const T* base, int elem) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);
+    if constexpr (sizeof(T) == 4) {
+        const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, elem * 4, 0, /*sc1*/ 16);
+        T r;
+        __builtin_memcpy(&r, &w, 4);
+        return r;
+    } else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        const u2 w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, elem * 8, 0, /*sc1*/ 16);
+        T r;
+        __builtin_memcpy(&r, &w, 8);
+        return r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // lower_bound of a lane's VEC NON-DECREASING targets in a sorted LDS array (the persistent kernels' ancestor search: a lane's
 // positions are consecutive points of the systematic grid).
 //   lb_search     the branch-free binary search, rounds unrolled with BYTE offsets (a probe is one ds_read with an immediate

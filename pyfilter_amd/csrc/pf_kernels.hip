@@ -1647,24 +1647,25 @@ extern "C" int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PF_F32)
         hipLaunchKernelGGL((k_theta_path<float>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const float*)w0, (const float*)ll, B,
-                           (float*)w_path, (float*)stats, (double*)nullptr, 0ull);
+                           (float*)w_path, (float*)stats, (double*)nullptr, 0ull, (float*)nullptr, (const int*)nullptr);
     else if (dtype == PF_F64)
         hipLaunchKernelGGL((k_theta_path<double>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const double*)w0, (const double*)ll, B,
-                           (double*)w_path, (double*)stats, (double*)nullptr, 0ull);
+                           (double*)w_path, (double*)stats, (double*)nullptr, 0ull, (double*)nullptr, (const int*)nullptr);
     else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;
 }
 
-extern "C" int pf_theta_step(void* w, const void* ll, int64_t B, int dtype, void* stats, void* host_slot, uint64_t seq, void* stream) {
+extern "C" int pf_theta_step(void* w, const void* ll, int64_t B, int dtype, void* stats, void* host_slot, uint64_t seq, void* acc,
+                             const int32_t* status, void* stream) {
     if (!w || !ll || !stats || B < 1 || ((uintptr_t)host_slot & 7) != 0) return PF_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PF_F32)
         hipLaunchKernelGGL((k_theta_path<float>), dim3(1), dim3(PF_BLOCK), 0, st, (const float*)w, (const float*)ll, B, (float*)w,
-                           (float*)stats, (double*)host_slot, (unsigned long long)seq);
+                           (float*)stats, (double*)host_slot, (unsigned long long)seq, (float*)acc, (const int*)status);
     else if (dtype == PF_F64)
         hipLaunchKernelGGL((k_theta_path<double>), dim3(1), dim3(PF_BLOCK), 0, st, (const double*)w, (const double*)ll, B, (double*)w,
-                           (double*)stats, (double*)host_slot, (unsigned long long)seq);
+                           (double*)stats, (double*)host_slot, (unsigned long long)seq, (double*)acc, (const int*)status);
     else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;
@@ -2263,12 +2264,13 @@ PF_DEFINE_COLUMN(pf_run_column_f64, double)
 #ifndef PFK_HOST_VEC
 #define PFK_HOST_VEC 4  // particles per lane of the cluster kernels (a build-time choice: -DPFK_HOST_VEC=8 for A/B builds)
 #endif
+#define PF_CLUSTER_INFEASIBLE (-1000)  // internal: the cluster kernel cannot be launched here (no launch was issued)
 static inline size_t cluster_lds_bytes(int D, size_t tsize) {
     return (size_t)(PFK_WIN_P2 + D * PFK_WIN) * tsize + 2 * PFK_FOLD * sizeof(double);  // window planes | the folds of two states
 }
-// Opt-in (pf_run_hints.route == PF_ROUTE_CLUSTER): the members of a column spin on each other, so all workgroups of a launch
-// must be resident together - two such launches issued on DIFFERENT streams of one device could hold each other's slots.  A caller
-// that issues its fused runs on one stream (the Python host mirror, SMC^2) opts in; the all-zero hints of the C ABI never take it.
+// Opt-in (pf_run_hints.route == PF_ROUTE_CLUSTER): the members of a column wait for each other - a launch that cannot make
+// progress reports it through pf_filter_args.status instead of a result, and the caller re-issues the piece on the per-step
+// route (include/pf_amd.h: PF_ROUTE_CLUSTER); the all-zero hints of the C ABI never take it.
 static inline bool cluster_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
     if (A->hints.route != PF_ROUTE_CLUSTER && A->hints.route != PF_ROUTE_CLUSTER_ALWAYS && A->hints.route != PF_ROUTE_CLUSTER_SPREAD) return false;
     if (!finalize || n_steps < 1 || A->ring >= 3) return false;
@@ -2361,15 +2363,17 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
         (void)hipEventRecord(ev[0], st);
     }
     with_kernel([&](auto kernel) {
+        // (nothing has been launched yet: PF_CLUSTER_INFEASIBLE sends the caller - filter_run_checked - to the per-step route)
         if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            rc = PF_EUNSUPPORTED;
+            (void)hipGetLastError();
+            rc = PF_CLUSTER_INFEASIBLE;
             return;
         }
         const int slots = cluster_slots(kernel, lds);
         int per_launch = slots / c;  // columns whose members are all resident at once
         if (per_launch >= 8) per_launch &= ~7;
         if (per_launch < 1) {
-            rc = PF_EUNSUPPORTED;
+            rc = PF_CLUSTER_INFEASIBLE;
             return;
         }
         unsigned char* clu = (unsigned char*)A->ws + wl.off_clu;
@@ -2404,6 +2408,8 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
                 cr.c = c;
                 cr.nchunks = nchunks;
                 cr.err = (int*)clu;
+                cr.status = A->status;
+                cr.patience = A->hints.cluster_patience != 0 ? A->hints.cluster_patience : PFK_SPIN_LIMIT;
                 cr.spread = A->hints.route == PF_ROUTE_CLUSTER_SPREAD ? 1 : 0;
                 cr.rec = clu + 256 + (size_t)b0 * 2 * PF_CLUSTER_NG * 64 * 16;  // (this group's [2][nb][NG][64] block)
                 hipLaunchKernelGGL(kernel, dim3((unsigned)(cr.nbp * c)), dim3(PFK_TPB), lds, st, a, r, cr);
@@ -2592,7 +2598,8 @@ extern "C" int pf_filter_graph_destroy(void* handle) {
 static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                               float* kernel_ms) {
     if (!A || A->struct_size != sizeof(pf_filter_args)) return PF_EINVAL;  // (another ABI version: include/pf_amd.h)
-    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER_SPREAD || A->hints.column_max_n < 0 || A->hints.tile_target < 0)
+    if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER_SPREAD || A->hints.column_max_n < 0 || A->hints.tile_target < 0 ||
+        A->hints.cluster_patience < -1 || A->hints.cluster_patience > (1 << 30))
         return PF_EINVAL;
     int rc = check_model(&A->model, true);
     if (rc) return rc;
@@ -2619,10 +2626,10 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
     if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (!column_eligible(A, g, n_steps, finalize) && cluster_eligible(A, g, n_steps, finalize) && wl.clu_bytes != 0) {
-        if (A->ws_bytes < wl.total) return PF_EWORKSPACE;
-        if (A->dtype == PF_F32) return pf_run_cluster_f32(A, g, wl, t0, n_steps, st, kernel_ms);
-        if (A->dtype == PF_F64) return pf_run_cluster_f64(A, g, wl, t0, n_steps, st, kernel_ms);
-        return PF_EINVAL;
+        if (A->dtype != PF_F32 && A->dtype != PF_F64) return PF_EINVAL;
+        rc = A->dtype == PF_F32 ? pf_run_cluster_f32(A, g, wl, t0, n_steps, st, kernel_ms)
+                                : pf_run_cluster_f64(A, g, wl, t0, n_steps, st, kernel_ms);
+        if (rc != PF_CLUSTER_INFEASIBLE) return rc;  // (else: no slot for one filter's workgroups / LDS refused - the per-step route)
     }
     if (column_eligible(A, g, n_steps, finalize)) {
         if (A->dtype == PF_F32) return pf_run_column_f32(A, g, wl, t0, n_steps, st, kernel_ms);

@@ -271,11 +271,30 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_accept(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* __restrict__ ll, int64_t B,
                                                          T* w_path, T* __restrict__ stats,  // (n = 1: w_path may BE w0)
-                                                         double* host_slot, unsigned long long seq) {
+                                                         double* host_slot, unsigned long long seq, T* acc = nullptr,
+                                                         const int* status = nullptr) {
     __shared__ T redm[PF_NWAVES];
     __shared__ double red[3 * PF_NWAVES];
     const int r = blockIdx.x;
     T* row = w_path + (int64_t)r * B;
+    // pf_theta_step: the move that produced `ll` reports through `status` - non-zero: it did not happen, nothing is updated
+    const int st = status != nullptr ? *status : 0;
+    if (st != 0) {
+        if (threadIdx.x == 0) {
+            stats[2 * (int64_t)r] = T(__builtin_nan(""));
+            stats[2 * (int64_t)r + 1] = T(0);
+            if (host_slot != nullptr && r == (int)gridDim.x - 1) {
+                host_slot[0] = __builtin_nan("");
+                host_slot[1] = 0.0;
+                reinterpret_cast<unsigned long long*>(host_slot)[3] = (unsigned long long)(unsigned)st;
+                __threadfence_system();
+                __hip_atomic_store((unsigned long long*)(host_slot + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        return;
+    }
+    if (acc != nullptr && r == 0)  // (pf_theta_step: one row) the filters' running log-likelihood, filters/result.py:130
+        for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) acc[i] = acc[i] + ll[i];
     for (int64_t i = threadIdx.x; i < B; i += PF_BLOCK) {
         T c = ll[i];
         for (int k0 = 1; k0 <= r; k0 += 8) {  // (eight independent loads in flight, then the additions in order)
@@ -296,6 +315,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* _
         const T* o = stats + 2 * (int64_t)r;  // (thread 0 wrote them)
         host_slot[0] = (double)o[0];
         host_slot[1] = (double)o[1];
+        reinterpret_cast<unsigned long long*>(host_slot)[3] = 0ull;
         __threadfence_system();
         __hip_atomic_store((unsigned long long*)(host_slot + 2), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

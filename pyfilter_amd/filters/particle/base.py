@@ -71,6 +71,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._draws = 0          # draw epoch: every new stream of random numbers (initial sample, fused run, online
                                  # move, step-by-step run) takes the next one - repeated calls are independent runs
         self._copies = 0
+        self._online_cluster = False  # set by a caller that verifies its online moves (SMC2.step): see _filter_fused_single
+        self._watched_move = None     # (status word, redo) of the latest online move when it took the column-cluster kernel
         self._obs_cache = None   # (identity of y, host copy of its observed flags): re-filtering the same data costs no sync
 
     # ------------------------------------------------------------------------------------------------------------
@@ -314,7 +316,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         # (the run adds the move's log-likelihood to the result's running total itself - ``pf_filter_args.ll_total`` IS that
         # tensor - when it can be handed over as it is: one elementwise launch per online move less)
         new = self._filter_fused_single(y, correction, ll_into=result._loglikelihood)
-        result.append(new, _ll_accumulated=self._ll_accumulated)
+        # (a watched move - ``_online_cluster`` - leaves the accumulation to its caller's pf_theta_step: ``_watched_move``)
+        result.append(new, _ll_accumulated=self._ll_accumulated or self._watched_move is not None)
         return new
 
     def _filter_fused_single(self, y: torch.Tensor, state: ParticleFilterCorrection, ll_into: torch.Tensor = None) -> ParticleFilterCorrection:
@@ -365,14 +368,20 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         # the move's statistics block, zeroed: means (2, B, D) | variances (2, B, D) | ll (B) | total (B)
         mean_new, var_new, ll_new, stats_ptr = plan.zeroed_stats(batched)
         es = plan.elem_size
-        self._ll_accumulated = (ll_into is not None and ll_into.device == device and ll_into.dtype == dtype and ll_into.numel() == b
-                                and ll_into.is_contiguous())
-
         a = plan.args
-        hk = HINTS.key()
+        # An online move is not verified by anybody who waits for it - the caller may never look at the device again before the
+        # next move - so it takes the column-cluster kernel (whose launches can give up, hints.py) only on behalf of a caller
+        # that reads the move's status word with the next thing it waits for: SMC2.step() (``_online_cluster``; the word travels
+        # through pf_theta_step into the host slot it polls).  Everybody else's moves of that size stay on the per-step route.
+        verified = self._online_cluster and HINTS.kernel_route() == 3 and HINTS.cluster_takes(n, b, rs_kind == L.RESAMPLE_SYSTEMATIC)
+        hk = (HINTS.key(), verified)
         if plan.hints_key != hk or a.hints.resume or a.hints.prepare_next:
             HINTS.fill(a)
+            if a.hints.route == 3 and not verified:
+                a.hints.route = 0  # PF_ROUTE_AUTO
             plan.hints_key = hk
+        if verified:
+            ll_into = None  # (the running total is accumulated by pf_theta_step, under the same status word: SMC2State.append)
         a.model.params = ctx.params.data_ptr()
         planes = None
         if kind.is_user:
@@ -395,6 +404,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         db = d * b * es
         a.means, a.vars = stats_ptr, stats_ptr + 2 * db
         a.ll_steps = stats_ptr + 4 * db
+        self._ll_accumulated = (ll_into is not None and ll_into.device == device and ll_into.dtype == dtype and ll_into.numel() == b
+                                and ll_into.is_contiguous())
         a.ll_total = ll_into.data_ptr() if self._ll_accumulated else stats_ptr + 4 * db + b * es
         z_tape = u_tape = None
         if ctx.z_tape is not None:
@@ -406,6 +417,20 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         L.check(plan.run(plan.args_ref, 0, 1, 1, L.stream_ptr()), "pf_filter_run")
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
                               keep=(x_in, lw_in, y_dev, ctx.params, planes))
+        self._watched_move = None
+        if verified:
+            pool_row = plan._pool[0][plan._pool_next - 1]
+
+            def redo():
+                """The same move again on the per-step route, into the same tensors (the argument block still describes it)."""
+                self._cluster_gave_up(plan)
+                if not apf:
+                    anc.copy_(state.ancestors32().reshape(b, n))
+                pool_row[4 * d + 1].zero_()  # (the move's own total: accumulated, not written)
+                a.hints.route, plan.hints_key = 1, None  # PF_ROUTE_PER_STEP (the next move re-writes the hints)
+                L.check(plan.run(plan.args_ref, 0, 1, 1, L.stream_ptr()), "pf_filter_run")
+
+            self._watched_move = (plan.status, redo)
 
         x_view, w_view = plan.state_views(x_out, lw_out, batched, has_event)
         new = ParticleFilterCorrection(TimeseriesState(t_start + 1, x_view, self._model.hidden.event_shape), w_view, ll_new, None,
@@ -459,7 +484,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         return flags
 
     def filter_block(self, y: torch.Tensor, state: ParticleFilterCorrection, observed: Optional[torch.Tensor] = None,
-                     replay=None):
+                     replay=None, per_step: bool = False, defer_status: bool = False):
         """``len(y)`` consecutive moves from ``state`` as ONE fused run - what a caller that decides something on the host
         after every observation (SMC^2: rejuvenate or not, ``smc2.py:59-62``) uses to look ahead: it runs a block, reads
         the per-move log-likelihood increments once, and if its decision fell at move ``j`` inside the block asks for the
@@ -469,15 +494,21 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         Returns ``(result, ll_steps, token)``: the run's ``FilterResult`` (moment rows incl. the incoming state's, total
         log-likelihood, final state), the increments ``(len(y), *batch_shape)`` and the token for a replay.  ``observed``:
         optional host flags (uint8, one per observation) when the caller already knows which observations are not
-        all-NaN (saves the device round trip per call).  None when the fused route does not apply."""
+        all-NaN (saves the device round trip per call).  None when the fused route does not apply.
+
+        A block that took the column-cluster kernel is verified before it is handed back (its status word read, the block
+        re-issued on the per-step route had the launch given up - ``_filter_block_lean``).  ``defer_status``: the caller reads
+        the word itself - ``result.status``, a device int32 tensor or None, valid in stream order after the block - and on a
+        non-zero value calls ``_cluster_gave_up`` and asks again with ``replay = token, per_step = True``."""
         x = state.timeseries_state.value
         if (not self._fused_capable(x.device) or int(self._model.observe_every_step) != 1 or self._record_intermediary
                 or self._kernel_kind().is_user):
             return None
         if (FilterResult.states_kept(self.record_states) == 1 and not getattr(self, "_time_kernels", False)
                 and not self._move_by_move and self._ctx_tapes_none()):
-            return self._filter_block_lean(y, state, observed, replay)
+            return self._filter_block_lean(y, state, observed, replay, per_step=per_step, defer_status=defer_status)
         res = self._batch_filter_fused(y, state._restarted(), observed=observed, replay=replay)
+        res.status = None
         run = self._last_run
         # the moves' own moment rows (row 0 = the incoming state) - copies: a cached plan's buffers are rewritten by its next run
         res.block_rows = (run["rows"][0][1:].clone(), run["rows"][1][1:].clone())
@@ -526,7 +557,19 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ctx = self._ensure_context()
         return ctx.z_tape is None and ctx.u_tape is None
 
-    def _filter_block_lean(self, y: torch.Tensor, state: ParticleFilterCorrection, observed, replay, host_u: bool = False):
+    def _cluster_gave_up(self, plan):
+        """A column-cluster launch of ``plan`` reported that it could not make progress: the word is cleared for the next
+        run and the event is announced once per filter object (the caller re-issues the piece on the per-step route)."""
+        plan.status.zero_()
+        self.cluster_fallbacks = getattr(self, "cluster_fallbacks", 0) + 1
+        if self.cluster_fallbacks == 1:
+            import warnings
+
+            warnings.warn("pyfilter_amd: a column-cluster launch gave up waiting for its sibling workgroups (the device was held "
+                          "by other work); the piece is re-issued on the per-step route - same draws, same results")
+
+    def _filter_block_lean(self, y: torch.Tensor, state: ParticleFilterCorrection, observed, replay, host_u: bool = False,
+                           per_step: bool = False, defer_status: bool = False):
         """``filter_block`` for the caller it exists for - SMC^2, which issues a block of ~16 moves per host decision, a few
         dozen blocks per fit: at 1 000 theta x 400 particles such a block is 90 us of kernel time, and the general fused
         driver (persistent plan, staging copies in and out, a ``FilterResult`` with its moment log per call: ~25 small
@@ -568,17 +611,23 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         first = xl_out if steps % 2 == 0 else plan.xl
         other = plan.xl if steps % 2 == 0 else xl_out
         xl_in = getattr(state, "_xl", None)
-        if (xl_in is not None and xl_in.shape == first.shape and xl_in.dtype == dtype and xl_in.data_ptr() == x_in.data_ptr()
-                and xl_in[d].data_ptr() == lw_in.data_ptr()):
-            first.copy_(xl_in)  # (a state this route produced and nobody replaced since: particles and log-weights sit in one buffer)
-        else:
-            first[:d].copy_(x_in)
-            first[d].copy_(lw_in)
-        if self._FILTER_KIND != L.FILTER_APF:  # (an APF names new ancestors at every move: it never reads the incoming ones)
-            anc.copy_(state.ancestors32().reshape(b, n))
+        packed = (xl_in is not None and xl_in.shape == first.shape and xl_in.dtype == dtype and xl_in.data_ptr() == x_in.data_ptr()
+                  and xl_in[d].data_ptr() == lw_in.data_ptr())
 
+        def load_state():
+            if packed:
+                first.copy_(xl_in)  # (a state this route produced and nobody replaced since: particles and log-weights sit in one buffer)
+            else:
+                first[:d].copy_(x_in)
+                first[d].copy_(lw_in)
+            if self._FILTER_KIND != L.FILTER_APF:  # (an APF names new ancestors at every move: it never reads the incoming ones)
+                anc.copy_(state.ancestors32().reshape(b, n))
+
+        load_state()
         a = plan.args
         HINTS.fill(a)
+        if per_step:
+            a.hints.route = 1  # PF_ROUTE_PER_STEP: the re-issue of a piece whose column-cluster launch gave up
         a.model.params = ctx.params.data_ptr()
         a.y, a.y_rows = y_dev.data_ptr(), rows
         a.observed, a.observed_dev = flags.data_ptr(), None
@@ -599,6 +648,17 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.means, a.vars = rows_buf[0].data_ptr(), rows_buf[1].data_ptr()
         a.ll_steps, a.ll_total = ll.data_ptr(), ll[steps].data_ptr()
         L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
+        # A column-cluster launch reports through the plan's status word when it could not make progress (include/pf_amd.h:
+        # PF_ROUTE_CLUSTER).  ``batch_filter`` looks at it here (one small device -> host read per run); a caller that pipelines
+        # blocks (SMC2.fit) takes the word with the block (``defer_status``), reads it with the block's statistics and asks for
+        # the block again with ``per_step = True`` - a replay on the same draws, so the numbers are the one-piece run's.
+        watched = (not per_step) and HINTS.cluster_takes(n, b, self._resampler_kind() == L.RESAMPLE_SYSTEMATIC)
+        if watched and not defer_status and int(plan.status.item()) != 0:
+            self._cluster_gave_up(plan)
+            load_state()
+            ll.zero_()
+            a.hints.route = 1
+            L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
         self._last_run = dict(plan=plan, z=None, u=u_tape, ws=plan.ws, seed_eff=seed_eff, ll_steps=ll[:steps],
                               keep=(x_in, lw_in, y_dev, flags, ctx.params))
 
@@ -612,6 +672,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         )
         last._xl = xl_out
         res = _BlockResult(means, variances, ll[steps] if self._batched else ll[steps, 0], last)
+        res.status = plan.status if (watched and defer_status) else None  # (device int32 word, sticky: see above)
+        res.plan = plan
         return res, ll_steps, (seed_eff, None)
 
     def _batch_filter_fused(self, y: torch.Tensor, init_state=None, observed=None, replay=None) -> FilterResult:
@@ -681,12 +743,15 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                 self._fused_plans[key] = plan
 
         # ---- load the inputs into the plan's (persistent) buffers -------------------------------------------------------
+        def load_state():
+            plan.x[0].copy_(ops.to_soa(x0, self._batched, self._has_event))
+            plan.logw[0].copy_(ops.to_cols(state.weights))
+            (plan.anc_hist[0] if ring else plan.anc).copy_(state.ancestors32().reshape(b, n))
+            plan.ll_total.zero_()
+
         plan.params.copy_(ctx.params)
-        plan.x[0].copy_(ops.to_soa(x0, self._batched, self._has_event))
-        plan.logw[0].copy_(ops.to_cols(state.weights))
-        (plan.anc_hist[0] if ring else plan.anc).copy_(state.ancestors32().reshape(b, n))
+        load_state()
         plan.y.copy_(y_steps)
-        plan.ll_total.zero_()
         # fresh Philox draws for every call: the base seed is baked into the (captured) launch arguments, the kernels add
         # the device word `epoch` to it - set here so that base + epoch = this run's draw seed (mod 2^64)
         seed_eff = self._next_draw_seed() if replay is None else replay[0]
@@ -820,6 +885,14 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         else:
             L.check(lib.pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
         plan.runs += 1
+        # (this driver carries cluster-route runs only in its taped / timed / piecewise modes - tests and tools; plain runs of
+        # that size take the lean driver: a launch that gave up is re-issued on the per-step route there and here alike)
+        if (not ring and not kind.is_user and HINTS.cluster_takes(n, b, self._resampler_kind() == L.RESAMPLE_SYSTEMATIC)
+                and int(plan.status.item()) != 0):
+            self._cluster_gave_up(plan)
+            load_state()
+            a.hints.route = 1  # PF_ROUTE_PER_STEP
+            L.check(lib.pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=seed_eff)  # keep device buffers alive
 
         # ---- hand the results over in the reference's shapes (copies: a cached plan's buffers are reused) ------------
@@ -957,6 +1030,7 @@ class _SingleStepPlan:
         self.cdf = torch.empty((b, n), device=device, dtype=dtype)
         self.pos = torch.empty((b, n), device=device, dtype=dtype)
         self.ws = L.new_workspace(n, b, device)
+        self.status = torch.zeros(1, device=device, dtype=torch.int32)  # pf_filter_args.status: sticky, cleared by _cluster_gave_up
         self.rows = rows
         self.xl = None  # (``_filter_block_lean``: the second state slot of a multi-move run, allocated on first use)
         self.u_gen = None
@@ -971,6 +1045,7 @@ class _SingleStepPlan:
         a.y, a.y_rows, a.observed, a.observed_dev = None, rows, None, None  # (flags: derived from y by the run)
         a.step_counter = None
         a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        a.status = self.status.data_ptr()
         self.args = a
         self.args_ref = C.byref(a)
         self.run = L.load().pf_filter_run
@@ -1047,6 +1122,7 @@ class _FusedPlan:
         self.u_gen = torch.Generator(device=device)
         self.params = torch.empty_like(filt._ctx.params)
         self.ws = L.new_workspace(n, b, device)
+        self.status = torch.zeros(1, device=device, dtype=torch.int32)  # pf_filter_args.status (see _SingleStepPlan)
         self.observed_host = observed_host
         self.user_loc = self.user_scale = None
         if kind.is_user:  # the callable's one-step mean / scale of the current particles, refreshed before every move
@@ -1072,6 +1148,7 @@ class _FusedPlan:
         a.ll_steps, a.ll_total = self.ll_steps.data_ptr(), self.ll_total.data_ptr()
         a.step_counter = self.epoch.data_ptr()
         a.ws, a.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        a.status = self.status.data_ptr()
         a.ring = ring
         a.user_loc, a.user_scale = L.ptr(self.user_loc), L.ptr(self.user_scale)
         self.args = a

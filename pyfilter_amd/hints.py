@@ -11,7 +11,7 @@ ROUTE_AUTO, ROUTE_PER_STEP, ROUTE_COLUMN_GENERIC, ROUTE_CLUSTER, ROUTE_CLUSTER_A
 
 class RunHints:
     __slots__ = ("route", "column_max_n", "tile_target", "ancestor_search", "fused_step", "fused_batch", "graph", "direct",
-                 "theta_kernels", "cluster")
+                 "theta_kernels", "cluster", "cluster_patience")
 
     def __init__(self):
         self.reset()
@@ -19,9 +19,13 @@ class RunHints:
     def reset(self):
         self.route = ROUTE_AUTO      # pf_run_hints.route
         self.cluster = True          # ROUTE_AUTO travels as PF_ROUTE_CLUSTER: self-contained runs of filters of 2 049 .. 16 384
-        #                              particles take the column-cluster kernel (include/pf_amd.h: opt-in at the C ABI because its
-        #                              workgroups wait for each other - this package issues its fused runs on ONE stream, torch's
-        #                              current one; set False when driving filters from several streams of one device at once)
+        #                              particles take the column-cluster kernel.  Opt-in at the C ABI because its workgroups wait
+        #                              for each other and a launch that cannot make progress REPORTS it (pf_filter_args.status)
+        #                              instead of hanging: this package passes the status word with every such run, reads it
+        #                              where it next waits for the device and re-issues the piece on the per-step route - same
+        #                              draws, same numbers (filters/particle/base.py: _verified_block, inference/smc2.py).  Runs on
+        #                              several streams / threads / processes of one device share the slots (pf_cluster.hpp)
+        self.cluster_patience = 0    # pf_run_hints.cluster_patience (0 = the library's 2^21 polls; tests: -1 forces the give-up path)
         self.column_max_n = 0        # pf_run_hints.column_max_n (0 = the library's 2048)
         self.tile_target = 0         # pf_run_hints.tile_target (0 = the library's 1024 workgroups per launch)
         self.ancestor_search = 0     # pf_run_hints.ancestor_search
@@ -33,7 +37,7 @@ class RunHints:
 
     def key(self):
         """What a cached launch plan depends on."""
-        return (self.kernel_route(), self.column_max_n, self.tile_target, self.ancestor_search)
+        return (self.kernel_route(), self.column_max_n, self.tile_target, self.ancestor_search, self.cluster_patience)
 
     def kernel_route(self):
         """``pf_run_hints.route`` of the next call."""
@@ -54,6 +58,7 @@ class RunHints:
         """Writes the kernel-side choices into a ``PfFilterArgs``."""
         h = args.hints
         h.route, h.column_max_n, h.tile_target, h.ancestor_search = self.kernel_route(), self.column_max_n, self.tile_target, self.ancestor_search
+        h.cluster_patience = self.cluster_patience
         h.resume = h.prepare_next = 0  # (per-call facts, set by the move loops that know them)
 
     def apply_mapping(self, m):
@@ -69,6 +74,7 @@ class RunHints:
         self.fused_step, self.fused_batch, self.graph = not on("PF_NO_FUSED_STEP"), not on("PF_NO_FUSED_BATCH"), not on("PF_NO_GRAPH")
         self.direct = on("PF_DIRECT")
         self.theta_kernels = not on("PF_NO_THETA_KERNELS")
+        self.cluster_patience = int(m.get("PF_CLUSTER_PATIENCE", 0) or 0)
         return self
 
 

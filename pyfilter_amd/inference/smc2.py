@@ -77,17 +77,28 @@ class SMC2State:
         self.stats = _theta_stats(self.global_weights())
         return self.stats[0]
 
-    def append(self, filter_state, slot=None) -> bool:
+    def _theta_step_applies(self) -> bool:
+        """``append`` updates the weights with ``pf_theta_step`` (one launch; the host slot, the running total and a move's status
+        word can ride along): one GPU's own block of contiguous weights, no collective, theta kernels enabled."""
+        w = self.w
+        return bool(w.is_cuda and (self.shard is None or not self.shard.collective) and w.dim() == 1 and w.is_contiguous()
+                    and _HINTS.theta_kernels)
+
+    def append(self, filter_state, slot=None, acc: Optional[torch.Tensor] = None, status: Optional[torch.Tensor] = None) -> bool:
         """``w += ll_t`` and the new ESS (state.py:35-44).  Sharded: the all-gather of the increments happens here.
-        ``slot`` (an ``ops.HostSlot``): the statistics also land in host memory - returns True when they will."""
+        ``slot`` (an ``ops.HostSlot``): the statistics also land in host memory - returns True when they will.  ``acc`` /
+        ``status``: the filters' running log-likelihood to add ``ll_t`` to as well and the status word of the move that produced
+        it (``ops.theta_step``: a non-zero word leaves everything as it was and shows in ``slot.status``)."""
         ll = filter_state.get_loglikelihood()
         w = self.w
-        if (w.is_cuda and (self.shard is None or not self.shard.collective) and w.dim() == 1 and ll.dtype == w.dtype
-                and ll.shape == w.shape and w.is_contiguous() and ll.is_contiguous()):
-            if _HINTS.theta_kernels:  # the update and its statistics in ONE launch (pf_theta_step)
-                self.stats = _ops.theta_step(w, ll, slot)
-                self.ess.append(self.stats[0])
-                return slot is not None
+        if self._theta_step_applies() and ll.dtype == w.dtype and ll.shape == w.shape and ll.is_contiguous():
+            # the update and its statistics in ONE launch (pf_theta_step)
+            self.stats = _ops.theta_step(w, ll, slot, acc=acc, status=status)
+            self.ess.append(self.stats[0])
+            return slot is not None
+        assert status is None, "a watched move needs the pf_theta_step route (SMC2._step checks _theta_step_applies first)"
+        if acc is not None:
+            acc += ll
         self.w += ll
         self.ess.append(self._ess())
         return False
@@ -340,17 +351,42 @@ class SMC2:
     def _step(self, y: torch.Tensor, state: SMC2State) -> SMC2State:
         """One observation (``smc2.py:53-65``)."""
         state.append_data(y)
-        filter_state = self.filter.filter(y, state.filter_state.latest_state, result=state.filter_state)
         # the reference's host branch (smc2.py:59-62) needs (ESS, all finite) on the host after every observation: the kernel
         # that updates the theta-weights writes the pair into host memory as well, and the host polls for it - no copy command
         slot = self.__dict__.get("_host_slot")
         if slot is None and state.w.is_cuda:
             try:
                 slot = self._host_slot = _ops.HostSlot()
-            except Exception:  # (no coherent host memory to be had: the copy command per observation it is)
+            except _ops.L.PfAmdError as e:  # (no coherent host memory to be had: the copy command per observation it is)
+                import warnings
+
+                warnings.warn(f"SMC2.step: no host slot ({e}); the statistics travel by a copy command per observation")
                 slot = self._host_slot = False
         slot = slot or None
-        ess, finite = slot.wait() if state.append(filter_state, slot) else state.stats.tolist()
+        # With the slot this loop reads something the device wrote after EVERY move - so the move may take the column-cluster
+        # kernel, whose launches report instead of hanging when they cannot make progress (hints.py): the move's status word
+        # rides through pf_theta_step into the slot, and a move that gave up is issued again on the per-step route.
+        filt = self.filter
+        watching = slot is not None and state._theta_step_applies() and hasattr(filt, "_online_cluster")
+        if watching:
+            filt._online_cluster = True
+        try:
+            filter_state = filt.filter(y, state.filter_state.latest_state, result=state.filter_state)
+        finally:
+            if watching:
+                filt._online_cluster = False
+        watched = getattr(filt, "_watched_move", None) if watching else None
+        if watched is None:
+            ess, finite = slot.wait() if state.append(filter_state, slot) else state.stats.tolist()
+        else:
+            total = state.filter_state._loglikelihood
+            state.append(filter_state, slot, acc=total, status=watched[0])
+            ess, finite = slot.wait()
+            if slot.status:  # the launch gave up: nothing was added - the move again, on the per-step route, and its update
+                watched[1]()
+                state.ess.pop()
+                state.append(filter_state, slot, acc=total)
+                ess, finite = slot.wait()
         if ess < self._threshold * self.particles[0] or not finite:
             state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
         return state
@@ -366,31 +402,50 @@ class SMC2:
     # Blocks are PIPELINED: block k + 1 is issued (from block k's final state, as if no rejuvenation were due) before the
     # host waits for block k's statistics, so the device never idles while the host prepares launches; when block k does
     # contain a rejuvenation, the speculative successor is simply dropped.
-    def _issue_block(self, ys: torch.Tensor, flags: torch.Tensor, latest, w: torch.Tensor, slot: int):
+    def _issue_block(self, ys: torch.Tensor, flags: torch.Tensor, latest, w: torch.Tensor, slot: int, token=None, per_step: bool = False):
         """Issues one block from (``latest`` state, theta-weights ``w``); nothing here waits for the device.  Returns None
-        when the filter has no fused block route."""
+        when the filter has no fused block route.  ``token`` / ``per_step``: the block again on the draws of an earlier issue,
+        on the per-step kernel route (what ``_verified`` asks for when a column-cluster launch gave up)."""
         filt, shard = self.filter, self.shard
-        out = filt.filter_block(ys, latest, observed=flags)
+        out = filt.filter_block(ys, latest, observed=flags, replay=token, per_step=per_step, defer_status=True)
         if out is None:
             return None
         res, ll, token = out
         w_path, stats = _theta_path(w, ll, shard)  # (n, B_local) theta-weights after each observation; (n, 2): ESS, all finite
-        event = None
+        event, status_host = None, None
         if stats.is_cuda:  # one small asynchronous copy into pinned memory + an event: the host later waits for THIS block only
             host = self._pinned(slot, stats)
             host.copy_(stats, non_blocking=True)
+            status = getattr(res, "status", None)
+            if status is not None:  # the block took the column-cluster kernel: its status word travels with the statistics
+                status_host = self._pinned(("status", slot), status, rows=1)
+                status_host.copy_(status, non_blocking=True)
             event = torch.cuda.Event()
             event.record()
         else:
             host = stats
-        return dict(ys=ys, flags=flags, latest=latest, res=res, ll=ll, token=token, w_path=w_path, stats=stats, host=host, event=event)
+        return dict(ys=ys, flags=flags, latest=latest, res=res, ll=ll, token=token, w_path=w_path, stats=stats, host=host, event=event,
+                    w0=w, slot=slot, status_host=status_host)
 
-    def _pinned(self, slot: int, like: torch.Tensor) -> torch.Tensor:
+    def _verified(self, blk):
+        """Waits for the block (its statistics and, for a column-cluster run, its status word).  A launch that gave up - the
+        device was held by other work for seconds - is issued again on the per-step route from the same state on the same draws."""
+        if blk["event"] is not None:
+            blk["event"].synchronize()
+        if blk["status_host"] is None or int(blk["status_host"][0]) == 0:
+            return blk, False
+        self.filter._cluster_gave_up(blk["res"].plan)
+        again = self._issue_block(blk["ys"], blk["flags"], blk["latest"], blk["w0"], blk["slot"], token=blk["token"], per_step=True)
+        again["event"].synchronize()
+        return again, True
+
+    def _pinned(self, slot, like: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
         bufs = self.__dict__.setdefault("_pinned_bufs", {})
         key = (slot, like.dtype)
         buf = bufs.get(key)
         if buf is None or buf.shape[0] < like.shape[0]:
-            buf = bufs[key] = torch.empty((max(like.shape[0], self._block), 2), dtype=like.dtype, pin_memory=True)
+            shape = (max(like.shape[0], self._block), 2) if rows is None else (rows,)
+            buf = bufs[key] = torch.empty(shape, dtype=like.dtype, pin_memory=True)
         return buf[: like.shape[0]]
 
     def _first_hit(self, blk) -> Optional[int]:
@@ -458,6 +513,14 @@ class SMC2:
             draws_mark = getattr(self.filter, "_draws", None)  # (the filter's draw-epoch counter before the speculative issue)
             if n_next >= 2:
                 slot ^= 1
+                pending = self._issue_block(y[t_next:t_next + n_next], flags[t_next:t_next + n_next], blk["res"].latest_state,
+                                            blk["w_path"][n - 1], slot)
+            blk, reissued = self._verified(blk)
+            if reissued and pending is not None:
+                # (the speculative successor started from the state of a launch that gave up: dropped like one behind a
+                # rejuvenation, its draw epoch handed back, and issued again from the re-issued block's state)
+                if draws_mark is not None:
+                    self.filter._draws = draws_mark
                 pending = self._issue_block(y[t_next:t_next + n_next], flags[t_next:t_next + n_next], blk["res"].latest_state,
                                             blk["w_path"][n - 1], slot)
             hit = self._first_hit(blk)

@@ -420,9 +420,10 @@ def _free_host(ptr: int):
 
 
 class HostSlot:
-    """24 bytes of host memory the DEVICE writes and the host polls (``pf_host_alloc``: coherent, mapped): the (ESS, all finite)
-    pair of ``theta_step`` followed by a sequence number.  ``wait()`` spins on the sequence number - the reference's host test
-    of the ESS after every observation (``smc2.py:59-62``) without a device -> host copy command and its synchronisation."""
+    """32 bytes of host memory the DEVICE writes and the host polls (``pf_host_alloc``: coherent, mapped): the (ESS, all finite)
+    pair of ``theta_step`` followed by a sequence number and the status word of the move that was folded in.  ``wait()`` spins
+    on the sequence number - the reference's host test of the ESS after every observation (``smc2.py:59-62``) without a
+    device -> host copy command and its synchronisation."""
 
     SPINS = 1 << 22  # (~0.5 s of polling: then the stream is synchronised and the slot read once more)
 
@@ -434,6 +435,7 @@ class HostSlot:
         self.ptr = p.value
         self._vals = (C.c_double * 2).from_address(self.ptr)
         self._seq = C.c_uint64.from_address(self.ptr + 16)
+        self._status = C.c_uint64.from_address(self.ptr + 24)
         self.seq = 0
         fin = weakref.finalize(self, _free_host, self.ptr)
         fin.atexit = False
@@ -442,27 +444,36 @@ class HostSlot:
         return HostSlot()
 
     def wait(self):
-        """(ESS, all-finite flag) of the latest ``theta_step`` issued with this slot, as Python floats."""
+        """(ESS, all-finite flag) of the latest ``theta_step`` issued with this slot, as Python floats.  ``self.status`` holds
+        the status word that step was given (non-zero: the move behind it gave up - nothing was updated)."""
         want, cell = self.seq, self._seq
         for _ in range(self.SPINS):
             if cell.value == want:
-                return self._vals[0], self._vals[1]
-        torch.cuda.current_stream().synchronize()
-        if cell.value != want:
-            raise L.PfAmdError("pf_theta_step: the device's write to the host slot never became visible")
+                break
+        else:
+            torch.cuda.current_stream().synchronize()
+            if cell.value != want:
+                raise L.PfAmdError("pf_theta_step: the device's write to the host slot never became visible")
+        self.status = int(self._status.value)
         return self._vals[0], self._vals[1]
 
 
-def theta_step(w: torch.Tensor, ll: torch.Tensor, slot: Optional[HostSlot] = None) -> torch.Tensor:
+def theta_step(w: torch.Tensor, ll: torch.Tensor, slot: Optional[HostSlot] = None, acc: Optional[torch.Tensor] = None,
+               status: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``w (B,) += ll (B,)`` in place and its ``(2,)`` statistics (ESS, all finite) in one launch (pf_theta_step: one
-    observation of ``sequential/state.py:35-44``); with a ``slot`` the pair also lands in host memory (``slot.wait()``)."""
+    observation of ``sequential/state.py:35-44``); with a ``slot`` the pair also lands in host memory (``slot.wait()``).
+    ``acc (B,)``: the filters' running log-likelihood, ``acc += ll`` in the same launch.  ``status``: the int32 status word of
+    the move that produced ``ll`` (``pf_filter_args.status``) - non-zero on the device: nothing is updated, the slot reports it."""
     stats = torch.empty(2, dtype=w.dtype, device=w.device)
+    if acc is not None:
+        assert acc.dtype == w.dtype and acc.shape == w.shape and acc.is_contiguous() and acc.device == w.device
     sp, seq = (None, 0)
     if slot is not None:
-        slot.seq += 1
-        sp, seq = slot.ptr, slot.seq
+        sp, seq = slot.ptr, slot.seq + 1
     L.check(L.load().pf_theta_step(w.data_ptr(), ll.data_ptr(), w.shape[0], L.dtype_code(w.dtype), stats.data_ptr(), sp, seq,
-                                   L.stream_ptr()), "pf_theta_step")
+                                   L.ptr(acc), L.ptr(status), L.stream_ptr()), "pf_theta_step")
+    if slot is not None:
+        slot.seq = seq  # (committed only once the launch was accepted: a refused call leaves host and device counters in step)
     return stats
 
 

@@ -139,7 +139,9 @@ int main() {
     }
     // ---- the column-cluster route (include/pf_amd.h: PF_ROUTE_CLUSTER): 16 filters of 8 192 particles - the same number of
     // particles, so the state buffers above serve - held in registers by 8 workgroups each for the whole run, ONE launch.  Opt-in
-    // through pf_run_hints: this program issues its runs on one stream, which is what the route asks of its caller.
+    // through pf_run_hints, with the contract of the route: the caller passes a status word, looks at it where it waits for the
+    // device anyway, and re-issues the piece with PF_ROUTE_PER_STEP when a launch reported that it gave up - driven below both
+    // ways: the default patience (nothing gives up) and cluster_patience = -1 (every launch gives up; the fallback's result counts).
     {
         const int64_t N2 = 8192, B2 = 16;
         static_assert(8192 * 16 == (1 << 16) * 2, "the cluster block reuses the state buffers");
@@ -183,16 +185,65 @@ int main() {
         A.y = yd; A.y_rows = 1; A.observed = observed.data();
         A.means = means2; A.vars = vars2; A.ll_steps = ll_steps2; A.ll_total = ll_total2;
         A.ws = ws2; A.ws_bytes = ws2_bytes;
+        int32_t* status_dev = nullptr;
+        HIP_OK(hipMalloc((void**)&status_dev, sizeof(int32_t)));
+        HIP_OK(hipMemset(status_dev, 0, sizeof(int32_t)));
+        A.status = status_dev;
         const double m0v[1] = {m0}, s0v[1] = {s0};
-        PF_CALL(pf_initial_sample(m0v, s0v, nullptr, A.seed ^ 0x9E3779B97F4A7C15ull, x0, N2, B2, D, PF_F32, nullptr));
-        HIP_OK(hipMemset(w0, 0, plane));
-        HIP_OK(hipMemset(ll_total2, 0, sizeof(float) * B2));
         for (int64_t i = 0; i < B2 * N2; ++i) iota[i] = (int32_t)(i % N2);
-        HIP_OK(hipMemcpy(anc, iota.data(), sizeof(int32_t) * B2 * N2, hipMemcpyHostToDevice));
+        auto load_state = [&]() -> int {  // the incoming state of the run: what a re-issue starts from again
+            PF_CALL(pf_initial_sample(m0v, s0v, nullptr, A.seed ^ 0x9E3779B97F4A7C15ull, x0, N2, B2, D, PF_F32, nullptr));
+            HIP_OK(hipMemset(w0, 0, plane));
+            HIP_OK(hipMemset(ll_total2, 0, sizeof(float) * B2));
+            HIP_OK(hipMemcpy(anc, iota.data(), sizeof(int32_t) * B2 * N2, hipMemcpyHostToDevice));
+            return 0;
+        };
+        int32_t trace[10] = {0};
+        int got = 0;
+        // 1. cluster_patience = -1: the launch gives up, says so, and the piece is issued again on the per-step route
+        {
+            std::vector<float> h_forced(B2), h_per_step(B2);
+            if (load_state()) return 1;
+            A.hints.cluster_patience = -1;
+            PF_CALL(pf_filter_run(&A, 0, T, 1, nullptr));
+            HIP_OK(hipDeviceSynchronize());
+            int32_t st = 0;
+            HIP_OK(hipMemcpy(&st, status_dev, sizeof(st), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(h_forced.data(), ll_total2, sizeof(float) * B2, hipMemcpyDeviceToHost));
+            int nan_ll = 0;
+            for (int c = 0; c < B2; ++c) nan_ll += std::isnan(h_forced[c]) ? 1 : 0;
+            if (!(st & 1) || nan_ll == 0) {
+                std::printf("FAIL: a cluster launch with cluster_patience = -1 did not report (status %d, %d NaN log-likelihoods)\n", st, nan_ll);
+                ++failures;
+            }
+            HIP_OK(hipMemset(status_dev, 0, sizeof(int32_t)));  // (the caller's word: the library only ever sets bits)
+            if (load_state()) return 1;
+            A.hints.route = PF_ROUTE_PER_STEP;
+            PF_CALL(pf_filter_run(&A, 0, T, 1, nullptr));
+            HIP_OK(hipDeviceSynchronize());
+            HIP_OK(hipMemcpy(&st, status_dev, sizeof(st), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(h_per_step.data(), ll_total2, sizeof(float) * B2, hipMemcpyDeviceToHost));
+            int bad = st != 0;
+            for (int c = 0; c < B2; ++c) bad += !(std::fabs(h_per_step[c] - kll) < 0.6);
+            std::printf("cluster route, cluster_patience = -1: status %d -> re-issued with PF_ROUTE_PER_STEP: loglikelihood %.4f (Kalman %.4f)\n",
+                        nan_ll ? 1 : 0, h_per_step[0], kll);
+            if (bad) ++failures;
+            A.hints.route = PF_ROUTE_CLUSTER;
+            A.hints.cluster_patience = 0;
+        }
+        // 2. the default patience
+        if (load_state()) return 1;
         PF_CALL(pf_filter_run(&A, 0, T, 1, nullptr));
         HIP_OK(hipDeviceSynchronize());
-        int32_t trace[10] = {0};
-        const int got = pf_debug_launch_trace(trace, 1);  // which kernel the library took: field 7 = 10 for the cluster kernel
+        {
+            int32_t st = -1;
+            HIP_OK(hipMemcpy(&st, status_dev, sizeof(st), hipMemcpyDeviceToHost));
+            if (st != 0) {
+                std::printf("FAIL: the cluster run reported status %d\n", st);
+                ++failures;
+            }
+        }
+        got = pf_debug_launch_trace(trace, 1);  // which kernel the library took: field 7 = 10 for the cluster kernel
         std::vector<float> h_means((T + 1) * B2 * D), h_ll(B2);
         HIP_OK(hipMemcpy(h_means.data(), means2, sizeof(float) * h_means.size(), hipMemcpyDeviceToHost));
         HIP_OK(hipMemcpy(h_ll.data(), ll_total2, sizeof(float) * B2, hipMemcpyDeviceToHost));
@@ -277,7 +328,7 @@ int main() {
         for (unsigned long long seq = 1; seq <= 3; ++seq) {
             for (int64_t i = 0; i < BT; ++i) inc[i] = 0.25f * std::sin(0.37f * (float)(i + 11 * seq));
             HIP_OK(hipMemcpy(d_inc, inc.data(), sizeof(float) * BT, hipMemcpyHostToDevice));
-            PF_CALL(pf_theta_step(d_lw, d_inc, BT, PF_F32, d_stats, slot, seq, nullptr));
+            PF_CALL(pf_theta_step(d_lw, d_inc, BT, PF_F32, d_stats, slot, seq, nullptr, nullptr, nullptr));
             long long spins = 0;
             while (*hseq != seq && ++spins < (1ll << 31)) {}
             const double ess_slot = hv[0], fin_slot = hv[1];

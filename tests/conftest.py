@@ -50,10 +50,14 @@ def golden_dir():
 def kernel_route(request, monkeypatch):
     """Which fused route a small filter (N <= 4096) takes: "column" - the column-persistent kernel, one launch per run
     (``pf_column.hpp``; the library's default for such shapes) - or "per_step" - one ``k_fused_step`` launch per time step
-    (``HINTS.route = 1``; what larger filters always take).  Tests parametrised over it pin BOTH against the reference."""
+    (``HINTS.route = 1``; what larger filters always take).  Tests parametrised over it pin BOTH against the reference.
+    Filters of 2 049 .. 16 384 particles (``oracle/cases.py: CLUSTER_CASES``): "cluster" - the column-cluster kernel
+    (``pf_cluster.hpp``; ``HINTS.route = 4``, PF_ROUTE_CLUSTER_ALWAYS) - and "spread" - the same kernel with a filter's workgroups
+    on different XCDs, i.e. its placement-independent exchange (``HINTS.route = 5``)."""
     route = getattr(request, "param", "column")
-    monkeypatch.setattr(HINTS, "route", 1 if route == "per_step" else 0)
+    monkeypatch.setattr(HINTS, "route", {"per_step": 1, "cluster": 4, "spread": 5}.get(route, 0))
     return route
 
 
 both_routes = pytest.mark.parametrize("kernel_route", ["column", "per_step"], indirect=True)
+cluster_routes = pytest.mark.parametrize("kernel_route", ["cluster", "spread", "per_step"], indirect=True)

@@ -134,9 +134,10 @@ class OracleAPF:
             result.append(new)
         return new
 
-    def filter_block(self, y, state, observed=None, replay=None):
+    def filter_block(self, y, state, observed=None, replay=None, per_step=False, defer_status=False):
         """The product's look-ahead interface (``ParticleFilter.filter_block``): the moves are keyed by (column, time, run),
-        so a cut replay repeats them exactly."""
+        so a cut replay repeats them exactly.  (``per_step`` / ``defer_status``: kernel-route matters of the HIP filters -
+        nothing to watch here, ``result.status`` stays absent.)"""
         start = state._restarted()
         result = self.initialize_with_result(start)
         lls, s = [], start

@@ -27,7 +27,9 @@ def test_standalone_program_against_kalman(tmp_path):
     assert build.returncode == 0, build.stderr[-3000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-3000:] + run.stderr[-3000:]
-    assert "c-abi ok" in run.stdout and run.stdout.count("Kalman") == 12  # (2 variants + the cluster route) x 2 columns x (ll, mean)
+    # (2 variants + the cluster route) x 2 columns x (ll, mean) + the line of the forced give-up
+    assert "c-abi ok" in run.stdout and run.stdout.count("Kalman") == 13
     assert "cluster route (launch trace 10)" in run.stdout
+    assert "cluster_patience = -1: status 1 -> re-issued with PF_ROUTE_PER_STEP" in run.stdout
     assert "theta level: ESS" in run.stdout
     assert "theta step: observation 3 polled from host memory" in run.stdout

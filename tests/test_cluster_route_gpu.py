@@ -253,3 +253,162 @@ def test_auto_route_takes_the_cluster_kernel_where_it_pays():
         got = ops.debug_launch_trace(1)[-1]["SPEC"]
         assert (got == spec) if spec is not None else (got not in (9, 10)), (n, b, got)
         assert torch.isfinite(res.loglikelihood).all()
+
+
+# ---- round 6: the route is safe to take by default ---------------------------------------------------------------------------------
+def _concurrent_filter(seed, b=128, n=8192):
+    from pyfilter_amd import resampling, timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.timeseries import models
+
+    t = lambda v: torch.tensor(v, dtype=torch.float32, device=DEV)  # noqa: E731
+    ssm = ts.LinearStateSpaceModel(models.AR(t(0.0), t(0.99), t(0.05)), (t(1.0), t(0.15)))
+    f = APF(ssm, n, proposal=proposals.LinearGaussianObservations(), resampling=resampling.systematic, seed=seed)
+    f.set_batch_shape(torch.Size([b]))
+    return f
+
+
+def test_two_threads_on_two_streams_run_cluster_filters_concurrently():
+    """different threads may each drive their own filter (the reference's thread-local ``InferenceContext``,
+    ``pyfilter/inference/context.py:41-48``, ``tests/inference/test_context.py:183-194``: a thread pool).  Two Python threads, each
+    on its own ``torch.cuda.Stream``, each filtering 128 x 8 192 particles for T = 200 on the DEFAULT hints - every run a
+    column-cluster launch of 1 024 workgroups, i.e. each launch alone fills the chip's resident slots.  The grouped workgroup ids
+    (pf_cluster.hpp) make the resident workgroups of either launch whole filters: both finish, finite, and equal - bit for bit, the
+    draws are keyed by (seed, step, particle) - to the same filters run alone; no launch gives up (``cluster_fallbacks``)."""
+    import threading
+
+    from pyfilter_amd import ops
+    from pyfilter_amd.hints import HINTS
+
+    assert HINTS.kernel_route() == 3 and HINTS.cluster_takes(8192, 128)
+    g = torch.Generator().manual_seed(17)
+    y = (0.1 * torch.randn(200, generator=g)).cumsum(0).to(DEV)
+
+    def run_alone(seed):
+        f = _concurrent_filter(seed)
+        r = f.batch_filter(y, bar=False)
+        torch.cuda.synchronize()
+        assert ops.debug_launch_trace(1)[-1]["SPEC"] == 10
+        return r.loglikelihood.cpu(), r.filter_means.cpu()
+
+    alone = {seed: run_alone(seed) for seed in (41, 42)}
+    out, errors = {}, []
+    start = threading.Barrier(2)
+
+    def worker(seed):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                f = _concurrent_filter(seed)
+                start.wait()
+                reps = [f.batch_filter(y, bar=False) for _ in range(3)]  # (three runs each: the launches overlap whatever the start skew)
+                stream.synchronize()
+                out[seed] = (reps, getattr(f, "cluster_fallbacks", 0), ops.debug_launch_trace(1)[-1]["SPEC"])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(seed,)) for seed in (41, 42)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for seed in (41, 42):
+        reps, fallbacks, spec = out[seed]
+        assert spec == 10 and fallbacks == 0, (spec, fallbacks)
+        for r in reps:
+            assert torch.isfinite(r.loglikelihood).all() and torch.isfinite(r.filter_means).all()
+        # the first run of a fresh filter object consumes the same draw epoch as the run alone did
+        assert torch.equal(reps[0].loglikelihood.cpu(), alone[seed][0])
+        assert torch.equal(reps[0].filter_means.cpu(), alone[seed][1])
+
+
+@pytest.mark.parametrize("driver", ["batch_filter", "filter_block", "general"])
+def test_a_cluster_launch_that_gives_up_falls_back_to_the_per_step_route(driver, monkeypatch):
+    """``pf_run_hints.cluster_patience = -1``: a member that does not find its siblings' records at its first look gives up - the
+    launch reports through ``pf_filter_args.status`` (NaN log-likelihoods, bit 0), and every driver re-issues the piece on the
+    per-step route from the same incoming state on the same draws: the result IS the per-step route's."""
+    import warnings
+
+    from pyfilter_amd.hints import HINTS
+
+    g = torch.Generator().manual_seed(23)
+    y = (0.1 * torch.randn(12, generator=g)).cumsum(0).to(DEV)
+    y[5] = float("nan")
+
+    def run(route, patience):
+        monkeypatch.setattr(HINTS, "route", route)
+        monkeypatch.setattr(HINTS, "cluster_patience", patience)
+        f = _concurrent_filter(7, b=6, n=8192)
+        if driver == "general":
+            f._time_kernels = True  # (the general fused driver: pf_filter_run_timed)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if driver == "filter_block":
+                state = f.initialize()
+                res, ll, _ = f.filter_block(y, state)
+            else:
+                res = f.batch_filter(y, bar=False)
+        torch.cuda.synchronize()
+        return res, getattr(f, "cluster_fallbacks", 0)
+
+    ref, _ = run(1, 0)
+    got, fallbacks = run(0, -1)
+    assert fallbacks == 1, "the forced give-up did not happen (or was not noticed)"
+    assert torch.isfinite(got.loglikelihood).all()
+    assert torch.equal(got.loglikelihood, ref.loglikelihood)
+    assert torch.equal(got.filter_means, ref.filter_means)
+    assert torch.equal(got.latest_state.timeseries_state.value, ref.latest_state.timeseries_state.value)
+    assert torch.equal(got.latest_state.previous_indices, ref.latest_state.previous_indices)
+    ok, fallbacks = run(0, 0)  # ... and with the default patience the same filter takes the cluster kernel and nothing gives up
+    assert fallbacks == 0 and torch.isfinite(ok.loglikelihood).all()
+    torch.testing.assert_close(ok.loglikelihood, ref.loglikelihood, rtol=2e-3, atol=2e-2)  # (float32: another summation order)
+
+
+def test_smc2_survives_cluster_launches_that_give_up(monkeypatch):
+    """SMC2.fit (pipelined blocks: the status word travels with the block's statistics) and SMC2.step (watched online moves: the
+    word rides through ``pf_theta_step`` into the host slot) with ``cluster_patience = -1``: every cluster launch gives up, every
+    piece is re-issued on the per-step route - the run equals the one that never took the cluster kernel (``HINTS.cluster = False``)
+    decision for decision and number for number.  (float64: a watched move's log-likelihood joins the running total in
+    ``pf_theta_step`` - the reference's ``+=`` of the increment in the tensors' type, filters/result.py:130 - where an unwatched
+    move's kernel adds its double-precision increment before rounding: one float32 ulp apart, the same number in float64.)"""
+    import warnings
+
+    from pyfilter_amd import resampling, timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.hints import HINTS
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+    from torch.distributions import Exponential, LogNormal, Normal
+
+    g = torch.Generator().manual_seed(3)
+    y = (0.05 * torch.randn(40, generator=g, dtype=torch.float64)).cumsum(0).to(DEV)
+    priors = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+    obs_a, obs_s = torch.tensor(1.0, device=DEV, dtype=torch.float64), torch.tensor(0.05, device=DEV, dtype=torch.float64)
+
+    def build(theta):
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), (obs_a, obs_s))
+
+    def fit(cluster, patience, how):
+        monkeypatch.setattr(HINTS, "cluster", cluster)
+        monkeypatch.setattr(HINTS, "cluster_patience", patience)
+        filt = APF(build, 4096, proposal=proposals.Bootstrap(), resampling=resampling.systematic, seed=5)
+        alg = SMC2(filt, 16, priors, threshold=0.5, device=torch.device(DEV), dtype=torch.float64, seed=9)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if how == "fit":
+                state = alg.fit(y, block=8)
+            else:
+                state = alg.initialize()
+                for t in range(y.shape[0]):
+                    state = alg.step(y[t], state)
+        torch.cuda.synchronize()
+        return state, getattr(filt, "cluster_fallbacks", 0)
+
+    for how in ("fit", "step"):
+        ref, fb0 = fit(False, 0, how)
+        got, fb1 = fit(True, -1, how)
+        assert fb0 == 0 and fb1 > 0, (how, fb0, fb1)
+        assert torch.equal(torch.stack(got.ess).cpu(), torch.stack(ref.ess).cpu()), how
+        assert torch.equal(got.w, ref.w), how
+        assert torch.equal(got.filter_state.loglikelihood, ref.filter_state.loglikelihood), how

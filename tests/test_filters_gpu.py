@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import cpu_ref
-from oracle.cases import FUSED_CASES as CASES, build_spec  # (lg1d_o2_*: the torch route, tests/test_torch_route_golden.py)
+from oracle.cases import CASE_BY_NAME, FUSED_CASES as CASES, build_spec  # (lg1d_o2_*: the torch route, tests/test_torch_route_golden.py)
 from pyfilter_amd.hints import HINTS
 from tests.conftest import both_routes
 from tests.helpers import DT, build_filter_from_case, build_ssm_from_case, load_golden, moves_after
@@ -28,7 +28,12 @@ def _tols(dt):
 @both_routes
 @pytest.mark.parametrize("name,dt", PARAMS)
 def test_fused_batch_filter_matches_reference(name, dt, kernel_route):
-    case = next(c for c in CASES if c["name"] == name)
+    check_fused_batch_filter(name, dt)
+
+
+def check_fused_batch_filter(name, dt):
+    """(shared with tests/test_cluster_golden_gpu.py: the reference's runs at column-cluster sizes)"""
+    case = CASE_BY_NAME[name]
     g = load_golden(name, dt)
     filt = build_filter_from_case(case, g, DT[dt], "cuda")
     res = filt.batch_filter(g["y"].cuda(), bar=False)
@@ -69,7 +74,11 @@ def test_a_run_issued_move_by_move_equals_the_run(name, kernel_route):
     """``pf_filter_run(args, s, 1, finalize = 1)`` for s = 0, 1, ... on ONE argument block (include/pf_amd.h: the workspace
     carries the bookkeeping from call to call) lands on the reference's numbers like the one-piece run does - the way the
     user-defined-model loop drives the kernels."""
-    case = next(c for c in CASES if c["name"] == name)
+    check_move_by_move(name)
+
+
+def check_move_by_move(name):
+    case = CASE_BY_NAME[name]
     g = load_golden(name, "f64")
     if case.get("observe_every_step", 1) != 1 or case.get("record_states"):
         pytest.skip("the move-by-move knob covers plain runs")
@@ -94,7 +103,12 @@ def test_a_run_issued_in_pieces_that_alternate_between_the_kernel_routes(name, p
     column-persistent kernel - the run changes route from piece to piece and only the workspace's per-filter records
     (``ColStat``: log-likelihood bases, what has been flushed) connect them.  Same numbers as the reference (float64,
     identical draws)."""
-    case = next(c for c in CASES if c["name"] == name)
+    check_pieces(name, pieces, 9)
+
+
+def check_pieces(name, pieces, one_launch_spec):
+    """``one_launch_spec``: the SPEC the launch trace shows for the self-contained pieces (9: the column kernel, 10: the cluster kernel)"""
+    case = CASE_BY_NAME[name]
     g = load_golden(name, "f64")
     filt = build_filter_from_case(case, g, DT["f64"], "cuda")
     filt._move_by_move = pieces
@@ -103,7 +117,7 @@ def test_a_run_issued_in_pieces_that_alternate_between_the_kernel_routes(name, p
     from pyfilter_amd import ops
 
     specs = {r["SPEC"] for r in ops.debug_launch_trace(64)[-g["y"].shape[0]:]}
-    assert 9 in specs and len(specs) > 1, f"both routes should have run: {specs}"
+    assert one_launch_spec in specs and len(specs) > 1, f"both routes should have run: {specs}"
     tol = _tols("f64")
     torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"], **tol)
     torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=tol["rtol"] * 10, atol=tol["atol"])
@@ -120,10 +134,14 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
     """float32, one step at a time from the reference's own previous state (so rounding cannot accumulate): new
     particles / weights / log-likelihood within 1e-5 (relative to the state's scale), ancestors identical except for
     the rare position that sits within an ulp of a CDF boundary."""
+    check_teacher_forced(name, dt)
+
+
+def check_teacher_forced(name, dt):
     from pyfilter_amd.filters.particle.state import ParticleFilterCorrection
     from pyfilter_amd.timeseries import TimeseriesState
 
-    case = next(c for c in CASES if c["name"] == name)
+    case = CASE_BY_NAME[name]
     g = load_golden(name, dt)
     filt = build_filter_from_case(case, g, DT[dt], "cuda")
     init = filt.initialize()
@@ -131,7 +149,7 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
     y = g["y"].cuda()
     n, b = case["N"], case["B"]
     spec64 = build_spec(case, torch.float64)
-    flips = 0
+    flips = ref_flips = exact_flips = 0
     for t in range(y.shape[0]):
         if t == 0:
             prev = init
@@ -166,6 +184,11 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
             else:
                 step = cpu_ref.apf_step(spec64, case["proposal"], y64, x_in, w_in, z64, u64)
             w64 = step[1]
+            # (ancestors: how many the REFERENCE's float32 step gets differently from exact arithmetic - its float32 softmax is off
+            # by ~1e-6 in the total at a few thousand particles, which moves ~N / 2 x 1e-6 of the positions across a boundary - and
+            # how many the kernel does)
+            ref_flips += int((g["step_idx"][t] != step[3]).sum())
+            exact_flips += int((state.previous_indices.cpu() != step[3]).sum())
             ok64 = fin & torch.isfinite(w64) & (step[3] == g["step_idx"][t])
             if ok64.any():
                 ref_err = float((g["step_w"][t].double() - w64).abs()[ok64].max())
@@ -176,7 +199,11 @@ def test_float32_teacher_forced_steps(name, dt, kernel_route):
         # a flipped ancestor is one different particle among N: it moves the likelihood estimate by O(1/N)
         n_flip = (~same).sum().item()
         torch.testing.assert_close(state.get_loglikelihood().cpu(), g["step_ll"][t], rtol=1e-4, atol=1e-4 + 2.0 * ref_err + 10.0 * n_flip / n)
-    assert flips <= max(2, int(2e-4 * n * b * y.shape[0])), f"{flips} ancestor flips"
+    # the kernel's ancestors are within the bar of EXACT arithmetic's, and no further from the reference's float32 run than that
+    # plus what the reference's own float32 arithmetic moved (measured above: 0 - 3 at N <= 1 000, 19 - 198 at 4 096 - 8 192)
+    base = max(2, int(2e-4 * n * b * y.shape[0]))
+    assert exact_flips <= base, f"{exact_flips} ancestors differ from exact arithmetic"
+    assert flips <= base + ref_flips, f"{flips} ancestor flips (the reference's own float32 run: {ref_flips} from exact arithmetic)"
 
 
 @pytest.mark.parametrize("name,dt", [p for p in PARAMS if p[1] == "f64"])
@@ -609,8 +636,10 @@ def test_fused_single_step_filter_matches_reference(name, kernel_route):
     """``filter()`` one observation at a time (the online / SMC^2 entry point) through the fused single-step path:
     every step's particles, weights, log-likelihood and ancestors against the reference's golden run (float64,
     identical draws) - and identical to what the step-by-step route (``HINTS.fused_step = False``) produces."""
-    from oracle.cases import CASE_BY_NAME
+    check_single_step_filter(name)
 
+
+def check_single_step_filter(name):
     if name not in CASE_BY_NAME:
         pytest.skip(f"no golden case {name}")
     case = CASE_BY_NAME[name]

@@ -8,10 +8,12 @@ import pytest
 import torch
 
 from oracle import cpu_ref
-from oracle.cases import CASES, build_spec
+from oracle.cases import CASE_BY_NAME, CASES, CLUSTER_CASES, build_spec
 
 DT = {"f64": torch.float64, "f32": torch.float32}
 PARAMS = [(c["name"], d) for c in CASES for d in c["dtypes"]]
+# (+ the reference's runs at column-cluster sizes, round 6: filtering arrays only)
+FILTER_PARAMS = PARAMS + [(c["name"], d) for c in CLUSTER_CASES for d in c["dtypes"]]
 
 
 def load(golden_dir, name, dt):
@@ -19,9 +21,9 @@ def load(golden_dir, name, dt):
         return {k: torch.from_numpy(f[k]) for k in f.files}
 
 
-@pytest.mark.parametrize("name,dt", PARAMS)
+@pytest.mark.parametrize("name,dt", FILTER_PARAMS)
 def test_filter_matches_reference(golden_dir, name, dt):
-    case = next(c for c in CASES if c["name"] == name)
+    case = CASE_BY_NAME[name]
     dtype = DT[dt]
     g = load(golden_dir, name, dt)
     spec = build_spec(case, dtype)

@@ -197,7 +197,7 @@ def test_step_by_step_with_the_polled_host_slot_is_step_by_step_with_the_copy(dt
     for how in ("slot", "copy"):
         if how == "copy":
             def no_slot():
-                raise RuntimeError("no coherent host memory")
+                raise ops.L.PfAmdError("no coherent host memory")
             monkeypatch.setattr(ops, "HostSlot", no_slot)
         alg = SMC2(APF(build, 300, proposal=proposals.LinearGaussianObservations(), seed=11), 128, pri, threshold=0.5, device="cuda",
                    dtype=dtype, seed=3)

@@ -44,6 +44,9 @@ def main():
             ("systematic(W) scan + search -> idx", lambda: ops.systematic_cols(W, u, True), 4 + 4 + 4 + 4),  # read W, write cdf, read cdf, write idx
             ("gather x[idx]", lambda: ops.gather_soa(x, idx), 4 + 4 + 4),
         ]
+        if n * b <= (1 << 24):  # the three-launch path (one offset per grid position always takes it): the A/B of the one-launch resampler
+            u_exp = u.unsqueeze(1).expand(b, n).contiguous()
+            rows.insert(2, ("systematic(W), three launches (u per position)", lambda: ops.systematic_cols(W, u_exp, True), 4 + 4 + 4 + 4))
         if b > 1:
             perm = torch.randperm(b, device="cuda")
             xx = x.permute(2, 1, 0)
