@@ -97,10 +97,18 @@ template <typename T> struct FusedArgs {
                       // state q about the mean of state q - 2 (row q - 2 of `means`: written two launches earlier)
     // per launch
     int step;       // local step index: slot = step & 1 is read, the other written
-    int obs;        // this step weighs against y[step]                     (-1: read obs_dev[step])
+    int obs;        // this step weighs against y[step]                     (-1: read obs_dev[step]; -2: look at y[step] itself)
     int obs_next;   // the next step exists and is a weighted step (its first-stage weights are prepared here; -1: device)
     const uint8_t* obs_dev;  // optional device flags (pf_filter_args.observed_dev)
-    __device__ __forceinline__ bool is_obs() const { return obs >= 0 ? obs != 0 : obs_dev[step] != 0; }
+    // -2 (one-step runs on a shared observation row, neither flag array given: the online move): "not all-NaN" of the row's <= 3
+    // values, evaluated by every workgroup itself - uniform scalar loads - instead of a flag byte a launch of its own derived
+    __device__ __forceinline__ bool y_informative() const {
+        const T* yr = y + (int64_t)step * md.obs_dim;  // (y_rows == 1)
+        bool any = false;
+        for (int o = 0; o < md.obs_dim; ++o) any = any || !(yr[o] != yr[o]);
+        return any;
+    }
+    __device__ __forceinline__ bool is_obs() const { return obs >= 0 ? obs != 0 : (obs == -1 ? obs_dev[step] != 0 : y_informative()); }
     __device__ __forceinline__ bool is_obs_next() const { return obs_next >= 0 ? obs_next != 0 : obs_dev[step + 1] != 0; }
     int finalize_only;
     int book_inline;  // the column's bookkeeping is done by its last step workgroup (after its own work) instead of an

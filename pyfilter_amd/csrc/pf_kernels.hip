@@ -1900,6 +1900,9 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
 #endif
     // neither flag array given: the flags are derived from y on the device, into the workspace (runs of <= PF_AUTO_FLAGS steps)
     const bool auto_flags = !A->observed && !A->observed_dev && n_steps > 0;
+    // ... of ONE step on a shared observation row (the online move): every kernel looks at the row itself (FusedArgs::is_obs, -2) -
+    // no launch that derives a flag byte
+    const bool inline_flag = auto_flags && n_steps == 1 && A->y_rows == 1;
     uint8_t* const auto_fl = (uint8_t*)A->ws + wl.off_ctr + 64;
     const int64_t auto_row = A->y_rows * (int64_t)A->model.obs_dim;
     if (t0 == 0) {
@@ -1909,7 +1912,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         // tools/graph_replays.py)
         const size_t words = (wl.off_ctr - wl.off_stat) / sizeof(uint32_t);  // (256-byte aligned regions)
         const unsigned zb = (unsigned)((words + PF_BLOCK - 1) / PF_BLOCK);
-        if (auto_flags)  // (the flags ride along: one launch)
+        if (auto_flags && !inline_flag)  // (the flags ride along: one launch)
             hipLaunchKernelGGL((k_zero_and_flags<T>), dim3(zb + (unsigned)n_steps), dim3(PF_BLOCK), 0, st,
                                (uint32_t*)((char*)A->ws + wl.off_stat), words, zb, (const T*)A->y + t0 * auto_row, auto_row, auto_fl);
         else
@@ -1932,12 +1935,13 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     a.step = (int)t0;
     const bool dev_flags = A->observed_dev != nullptr || auto_flags;  // the kernels read the flags themselves
     a.obs_dev = A->observed_dev;
-    if (auto_flags) {
+    if (auto_flags && !inline_flag) {
         if (t0 != 0)
             hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * auto_row, auto_row, auto_fl);
         a.obs_dev = auto_fl - t0;  // (indexed by the absolute step)
     }
-    a.obs = n_steps > 0 ? (dev_flags ? -1 : (observed[t0] != 0)) : 0;
+    const int flag_mode = inline_flag ? -2 : -1;
+    a.obs = n_steps > 0 ? (dev_flags ? flag_mode : (observed[t0] != 0)) : 0;
     a.obs_next = 0;
     // (pf_run_hints.resume: the previous call on this argument block ended with a SISR step that left the partials and local
     // scans of exactly this state in the workspace - the pass is redundant)
@@ -2034,7 +2038,7 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         const int64_t t = t0 + s;
         a.step = (int)t;
         place(t);
-        a.obs = dev_flags ? -1 : (observed[t] != 0);
+        a.obs = dev_flags ? flag_mode : (observed[t] != 0);
         a.obs_next = (s + 1 < n_steps) ? (dev_flags ? -1 : (observed[t + 1] != 0)) : (prepare_next ? 1 : 0);
 #ifdef PF_DEVTOOLS
         // stage cuts on ONE launch (the last but one step) when PF_DEBUG_CUT_AT_END is set: the state entering it is

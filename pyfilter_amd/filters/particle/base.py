@@ -375,7 +375,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         # through pf_theta_step into the host slot it polls).  Everybody else's moves of that size stay on the per-step route.
         verified = self._online_cluster and HINTS.kernel_route() == 3 and HINTS.cluster_takes(n, b, rs_kind == L.RESAMPLE_SYSTEMATIC)
         hk = (HINTS.key(), verified)
-        if plan.hints_key != hk or a.hints.resume or a.hints.prepare_next:
+        if plan.hints_key != hk or a.hints.prepare_next:
             HINTS.fill(a)
             if a.hints.route == 3 and not verified:
                 a.hints.route = 0  # PF_ROUTE_AUTO
@@ -395,15 +395,33 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                       percol if percol is not None else ops.to_soa(scale.to(dtype).expand(full), batched, has_event).contiguous())
             a.user_loc, a.user_scale = planes[0].data_ptr(), planes[1].data_ptr()
             a.user_scale_per_column = 0 if percol is None else 1
-        a.y, a.y_rows = y_dev.data_ptr(), rows
+        # ---- the resume token (include/pf_amd.h: a run issued in pieces on ONE argument block) --------------------------------------
+        # A move on the per-step route is piece m of a run whose pieces the workspace connects: when the incoming state is exactly what
+        # this plan's previous move wrote - the same tensors, untouched since (their in-place version counters) - the move is issued
+        # as piece m + 1: no launch that clears the per-filter records, and for SISR no launch that re-reduces the incoming state (its
+        # partials and local scans are what the previous step kernel left: pf_run_hints.resume; an APF's first stage weighs with the
+        # NEW observation, so its reduce pass stays).  Rows are addressed relative to piece m: the pointers below are offset so that
+        # row m is this move's.  Anything else - a state somebody replaced or edited, another plan's, a rejuvenated filter set -
+        # starts a fresh run at piece 0.
+        m = 0
+        per_step_route = (not verified) and (HINTS.route == 1 or (a.hints.route == 0 and n > (HINTS.column_max_n or 2048)))
+        chain = plan.chain
+        if (per_step_route and chain is not None and chain[1] is x_in and chain[2] is lw_in and chain[3] == x_in._version
+                and chain[4] == lw_in._version and chain[5] == hk):
+            m = chain[0] + 1
+        plan.chain = None
+        resume = 1 if (m > 0 and not apf) else 0
+        if a.hints.resume != resume:
+            a.hints.resume = resume
+        a.y, a.y_rows = y_dev.data_ptr() - m * rows * o * es, rows
         a.observed, a.observed_dev, a.step_counter = None, None, None  # (the block route shares this argument block)
         a.seed = self._next_draw_seed()  # fresh Philox draws per move
-        a.x[0], a.x[1] = x_in.data_ptr(), x_out.data_ptr()
-        a.logw[0], a.logw[1] = lw_in.data_ptr(), lw_out.data_ptr()
+        a.x[m & 1], a.x[(m + 1) & 1] = x_in.data_ptr(), x_out.data_ptr()
+        a.logw[m & 1], a.logw[(m + 1) & 1] = lw_in.data_ptr(), lw_out.data_ptr()
         a.anc = anc.data_ptr()
         db = d * b * es
-        a.means, a.vars = stats_ptr, stats_ptr + 2 * db
-        a.ll_steps = stats_ptr + 4 * db
+        a.means, a.vars = stats_ptr - m * db, stats_ptr + 2 * db - m * db
+        a.ll_steps = stats_ptr + 4 * db - m * b * es
         self._ll_accumulated = (ll_into is not None and ll_into.device == device and ll_into.dtype == dtype and ll_into.numel() == b
                                 and ll_into.is_contiguous())
         a.ll_total = ll_into.data_ptr() if self._ll_accumulated else stats_ptr + 4 * db + b * es
@@ -413,9 +431,13 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             assert z_tape.shape[0] == 1, "z tape shorter than the number of steps"
         if ctx.u_tape is not None:
             u_tape = ctx.u_tape[t_start:t_start + 1].contiguous()
-        a.z_tape, a.u_tape = L.ptr(z_tape), L.ptr(u_tape)  # no uniform tape: every workgroup draws its column's u (Philox)
-        L.check(plan.run(plan.args_ref, 0, 1, 1, L.stream_ptr()), "pf_filter_run")
-        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed,
+        # no uniform tape: every workgroup draws its column's u (Philox)
+        a.z_tape = None if z_tape is None else z_tape.data_ptr() - m * d * b * n * es
+        a.u_tape = None if u_tape is None else u_tape.data_ptr() - m * b * es
+        L.check(plan.run(plan.args_ref, m, 1, 1, L.stream_ptr()), "pf_filter_run")
+        if per_step_route:
+            plan.chain = (m, x_out, lw_out, x_out._version, lw_out._version, hk)
+        self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed, piece=m,
                               keep=(x_in, lw_in, y_dev, ctx.params, planes))
         self._watched_move = None
         if verified:
@@ -598,6 +620,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         plan = self._single_plans.get(key)
         if plan is None:
             plan = self._single_plans[key] = _SingleStepPlan(self, kind, n, b, d, o, rows, dtype, device)
+        plan.chain = None  # (the block's run rewrites the workspace an online move's resume token points into)
         if plan.xl is None:  # the run's other state slot (the kernels alternate between two)
             plan.xl = torch.empty((d + 1, b, n), device=device, dtype=dtype)
         t_start = int(ts_in.time_index)
@@ -1055,6 +1078,7 @@ class _SingleStepPlan:
         self._pool = None
         self._pool_next = 0
         self._view_geo = None
+        self.chain = None  # the resume token: (piece, x_out, lw_out, their versions, hints) of the latest per-step-route online move
 
     _STATS_POOL = 64
 

@@ -1030,3 +1030,45 @@ def test_randomised_parity_sweep(monkeypatch, kernel_route):
         assert mod.main() == 0
     finally:
         HINTS.tile_target, HINTS.column_max_n = saved
+
+
+@pytest.mark.parametrize("name", ["lg1d_sisr_boot", "sine_apf_lgo", "lorenz_sisr_boot", "sine_sisr_boot_nan"])
+def test_online_moves_resume_from_the_previous_move_and_notice_a_replaced_state(name, monkeypatch):
+    """``filter()`` on the per-step route issues a move as piece m + 1 of the run the previous move was piece m of when the incoming
+    state is exactly what that move wrote (the resume token: no record fill, no re-reduction for SISR - ``pf_run_hints.resume``).
+    A state whose tensors were REPLACED from outside (``state["_w"] = ...``), EDITED in place, or produced two moves ago invalidates
+    the token - a fresh piece 0.  Either way every move lands on the reference's numbers (float64, identical draws)."""
+    monkeypatch.setattr(HINTS, "route", 1)
+    case = CASE_BY_NAME[name]
+    g = load_golden(name, "f64")
+    y = g["y"].cuda()
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    state = filt.initialize()
+    res = filt.initialize_with_result(state)
+    tol = dict(rtol=1e-9, atol=1e-11)
+    pieces, older = [], None
+    for t in range(y.shape[0]):
+        if t == 4:    # the same values in a NEW tensor: not the buffer the previous move wrote
+            state["_w"] = state["_w"].clone()
+        elif t == 7:  # edited in place: the buffer's version counter moved
+            state.weights.add_(0.0)
+        elif t == 10:  # a state from two moves ago
+            state = older
+        if t == 8:
+            older = state
+        if t == 10:
+            # (the golden run continues from move 9's state: replay moves 8, 9 from `older` to stay on the reference's path)
+            s2 = filt.filter(y[8], older)
+            assert filt._last_run["piece"] == 0
+            state = filt.filter(y[9], s2)
+            assert filt._last_run["piece"] == 1
+        new = filt.filter(y[t], state)
+        pieces.append(filt._last_run["piece"])
+        torch.testing.assert_close(new.timeseries_state.value.cpu(), g["step_x"][t], **tol)
+        torch.testing.assert_close(new.weights.cpu(), g["step_w"][t], equal_nan=True, **tol)
+        torch.testing.assert_close(new.get_loglikelihood().cpu(), g["step_ll"][t], rtol=1e-9, atol=1e-9)
+        assert torch.equal(new.previous_indices.cpu(), g["step_idx"][t]), f"ancestors differ at move {t}"
+        torch.testing.assert_close(new.get_mean().cpu().reshape(-1), g["filter_means"][t + 1].reshape(-1), **tol)
+        state = new
+    assert pieces[:4] == [0, 1, 2, 3] and pieces[4] == 0 and pieces[5:7] == [1, 2] and pieces[7] == 0 and pieces[8:10] == [1, 2], pieces
+    assert pieces[10] == 2 and pieces[11] == 3, pieces  # (behind the replayed moves 8, 9: pieces 0, 1)
