@@ -350,9 +350,6 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
                     break;
                 }
                 if (__ballot(ok) == ~0ull) break;
-#ifdef PFK_NOWAIT  // (timing experiments: nobody waits - garbage results, the price of the compute and the memory traffic alone)
-                break;
-#endif
                 if (++spins > limit) {
                     dead = true;
                     if (lane == 0) {
@@ -461,7 +458,6 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
     cc.set_obs(cp);
     publish(0, apf && obs_nx, false);
 
-    ProbeState probe{0, PF_PROBE_BACKOFF};  // (sorted_lower_bound's wave-uniform back-off state)
     T ll_tot = T(0);
     double base_prev = 0.0;
     bool obs_prev = false, prepoison_prev = false;
@@ -622,10 +618,8 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
                 // unrolled with the positions as BYTE offsets, so a probe is one ds_read with an immediate offset and a round costs
                 // compare + select + add per position (as a run-time loop over element indices: 21 VALU per round for four positions,
                 // a third of the kernel's instructions); rounds above the staged length are skipped (uniform) ------------------------
-                // (round 5, late: the lane's first position by the search, the other three by a probe of the eight entries from its
-                // answer on - sorted_lower_bound, pf_device.hpp)
                 int q[VEC];
-                sorted_lower_bound<T, VEC, PFK_WIN_P2>(cdfs, np2, pp, q, probe);
+                sorted_lower_bound<T, VEC, PFK_WIN_P2>(cdfs, np2, pp, q);
                 PFK_MARK(60_search_loop_done);
                 const bool col_end = wb == nchunks - 1;
 #pragma unroll

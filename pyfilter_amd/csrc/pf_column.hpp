@@ -22,9 +22,6 @@
 
 namespace pf {
 
-#ifndef PFC_EXP
-#define PFC_EXP 0  // development: compile-time ablations that price the stages of a column step (tools/column_ablation.sh)
-#endif
 #define PFC_MAXW 16       // waves per workgroup (1024 threads)
 #define PFC_OBS_WORDS 64  // observed flags of a launch as kernel arguments: 2048 steps per launch (longer runs: several)
 
@@ -114,9 +111,9 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     // LDS carve-up: cdf (np2 Ts, +inf beyond N) | x planes (D x N Ts) | wave records
     constexpr int KB = 4 + 2 * D;  // the state's record: max, sum e, sum e^2, poison, sum e (x - c)[D], sum e (x - c)^2[D]
     T* const cdfs = reinterpret_cast<T*>(pfc_lds);
-    T* const xs = cdfs + np2 + PF_PROBE;  // (PF_PROBE readable +inf entries behind the cdf: sorted_lower_bound's probe)
+    T* const xs = cdfs + np2 + PF_LB_PAD;  // (PF_LB_PAD readable +inf entries behind the cdf: sorted_lower_bound's last read)
     const int NP = ((N + VEC - 1) / VEC) * VEC;  // stride of a particle plane in LDS: N rounded up to the lanes' VEC particles
-    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + PF_PROBE + (size_t)D * NP) * sizeof(T) + 15) & ~(size_t)15));
+    double* const recA = reinterpret_cast<double*>(pfc_lds + (((size_t)(np2 + PF_LB_PAD + (size_t)D * NP) * sizeof(T) + 15) & ~(size_t)15));
     double* const recB = recA + 2 * PFC_MAXW;  // [2][PFC_MAXW][KB]: double buffered by step parity
 
     const bool apf = FILT >= 0 ? (FILT == PF_FILTER_APF) : (a.filter == PF_FILTER_APF);
@@ -175,7 +172,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             }
         }
     }
-    for (int q = N + tid; q < np2 + PF_PROBE; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
+    for (int q = N + tid; q < np2 + PF_LB_PAD; q += blockDim.x) cdfs[q] = Lim<T>::inf();  // (never overwritten)
 
     // the column's parameters and everything derived from them alone: once per run
     ColParams<T, D> cp;
@@ -229,17 +226,15 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             e1[j] = ej;
             v[0] += ej;
             if constexpr (FILT != PF_FILTER_APF) v[1] += ej * ej;  // (an APF never looks at the weights' ESS: FILT known -> not formed)
-#if !(PFC_EXP & 8)
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const T xd = x[d][j] - piv[d];
                 v[2 + d] += ej * xd;
                 v[2 + D + d] += ej * xd * xd;
             }
-#endif
         }
 #pragma unroll
-        for (int k = 0; k < ((PFC_EXP & 8) ? 2 : 2 + 2 * D); ++k)
+        for (int k = 0; k < 2 + 2 * D; ++k)
             if (FILT != PF_FILTER_APF || k != 1) v[k] = wave_sum<T>(v[k]);
         bool any = __ballot(poison) != 0ull;
         if (nw == 1) {
@@ -342,7 +337,6 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
     request_inputs(0);
     uint32_t bits = 0u;
 
-    ProbeState probe{0, PF_PROBE_BACKOFF};  // (sorted_lower_bound's wave-uniform back-off state)
     for (int s = 0; s < run.n_steps; ++s) {
         const int t = run.t0 + s;
         if ((s & 31) == 0) bits = run.obs_bits[s >> 5];  // (one scalar load per 32 steps)
@@ -483,20 +477,9 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             int q[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) q[j] = 0;
-#if PFC_EXP & 1
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) q[j] = (int)(pp[j] * nT);
-            if (false)
-#endif
-            {
-                // (round 5: the rounds unrolled with the positions as BYTE offsets - 16 VALU per round of four positions against 21 for a
-                // run-time loop over element indices - and, for systematic grids, only the lane's FIRST position searched: the other
-                // three by a probe of the eight entries from its answer on; sorted_lower_bound, pf_device.hpp.  The sorted
-                // positions of the multinomial resampler are Exp(1) spacings apart - more than eight entries often enough - and
-                // keep the search)
-                if (multinomial) probe.skip = 1 << 30;
-                sorted_lower_bound<T, VEC, 4096>(cdfs, np2, pp, q, probe);
-            }
+            // (the rounds unrolled with the positions as BYTE offsets - 16 VALU per round of four positions against 21 for a run-time
+            // loop over element indices: sorted_lower_bound, pf_device.hpp)
+            sorted_lower_bound<T, VEC, 4096>(cdfs, np2, pp, q);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 idx[j] = q[j] > N - 1 ? N - 1 : q[j];
@@ -535,15 +518,8 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
                     for (int j = 0; j < VEC; ++j) z[j][d] = zr[j];
                 }
             } else {
-#if PFC_EXP & 2
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-#pragma unroll
-                    for (int d = 0; d < D; ++d) z[j][d] = T(0.25) * T(j + d) - T(0.3) + T(1e-3) * T(lane);
-#else
                 if (!ragged) draw_normals<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
                 else draw_normals_ragged<T, D, VEC>(seed, PF_STREAM_NORMAL, (uint32_t)t, (uint64_t)((int64_t)b * N + i0), z);
-#endif
             }
         }
         T lw_new[VEC];
@@ -558,11 +534,7 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
             if (obs) {
                 const T wi = sample_and_weight<T, D>(md, proposal, cp, cc, xr[j], z[j], xn, um);
                 if (apf) {
-#if PFC_EXP & 4
-                    w_new = wi;
-#else
                     w_new = wi - pre_weight<T, D>(md, proposal, cp, cc, xr[j], false, um);  // apf.py:43
-#endif
                     if (ok[j] && is_nan_or_posinf(w_new)) poison = true;
                 } else {
                     if (ok[j] && is_nan_or_posinf(wi)) poison = true;

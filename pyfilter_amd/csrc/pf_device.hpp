@@ -67,14 +67,10 @@ __device__ __forceinline__ double pf_sin(double x) { return sin(x); }
 // error <= 2^-21.4 = 3.6e-7 on [-pi, pi] plus the reduction's |x| * 6e-8 - the one-step mean x + sin(x - gamma) dt carries a
 // tenth of that, two orders below the 1e-5 bar of the teacher-forced tests; valid for |x / 2 pi| <= 256).  Larger arguments -
 // a diverged particle - take the Cody-Waite form.  The float64 parity path never comes here.
-#ifndef PF_NO_NATIVE_SIN
 __device__ __forceinline__ float pf_sin_fast(float x) {
     if (!(fabsf(x) < 1.0e3f)) return pf_sin(x);
     return __builtin_amdgcn_sinf(x * 0.159154943091895335769f);
 }
-#else
-__device__ __forceinline__ float pf_sin_fast(float x) { return pf_sin(x); }
-#endif
 __device__ __forceinline__ double pf_sin_fast(double x) { return sin(x); }
 // exp for importance weights: float -> the bare v_exp_f32 (2^x) on x * log2(e): two instructions (clang's __expf
 // expands to 13 with its range handling).  Relative error ~|x| * 6e-8, irrelevant next to the fp32 rounding of the
@@ -161,14 +157,13 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     v += dpp_get0<PF_DPP_ROW_MIRROR>(v);
     return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
-#ifndef PF_NO_FMAX_WAVE_MAX
 // float: v_max_f32 takes the DPP operand directly - ONE instruction per exchange.  Written as inline asm since round 5: from
 // `fmaxf(v, dpp(v))` the compiler emits v_mov_b32 + v_mov_b32_dpp + a canonicalising v_max_f32 v, v, v + the v_max_f32 (IEEE
 // mode: the DPP move's result is not known to be quiet), i.e. four VALU instructions per exchange - 30 such canonicalisations
 // in the headline step kernel alone.  `s_nop 1`: a DPP operand must not be read within two wait states of the VALU write that
 // produced it (the compiler pads its own DPP instructions; inside asm nobody does).  Inputs are NaN-free maxima of sanitised
-// log-weights; -inf is an ordinary operand of v_max.  PF_WAVE_MAX_BUILTIN restores the compiler's form (A/B).
-#ifndef PF_WAVE_MAX_BUILTIN
+// log-weights; -inf is an ordinary operand of v_max.  PRECONDITION: all 64 lanes active (every caller reduces in uniform control
+// flow) - a lane whose DPP source lane is inactive is not written (no bound_ctrl) and would keep whatever the register held.
 #define PF_DPP_MAX_F32(r, v, CTRL) asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v))
 __device__ __forceinline__ float wave_max_f32(float v) {
     float a, b, c, d;
@@ -178,20 +173,8 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     PF_DPP_MAX_F32(d, c, "row_mirror");
     return __builtin_fmaxf(__builtin_fmaxf(lane_get(d, 0), lane_get(d, 16)), __builtin_fmaxf(lane_get(d, 32), lane_get(d, 48)));
 }
-#else
-__device__ __forceinline__ float wave_max_f32(float v) {
-    v = __builtin_fmaxf(v, dpp_get<PF_DPP_QUAD_XOR1>(v, v));
-    v = __builtin_fmaxf(v, dpp_get<PF_DPP_QUAD_XOR2>(v, v));
-    v = __builtin_fmaxf(v, dpp_get<PF_DPP_ROW_HALF_MIRROR>(v, v));
-    v = __builtin_fmaxf(v, dpp_get<PF_DPP_ROW_MIRROR>(v, v));
-    return __builtin_fmaxf(__builtin_fmaxf(lane_get(v, 0), lane_get(v, 16)), __builtin_fmaxf(lane_get(v, 32), lane_get(v, 48)));
-}
-#endif
-#endif
 template <typename T> __device__ __forceinline__ T wave_max(T v) {
-#ifndef PF_NO_FMAX_WAVE_MAX
     if constexpr (sizeof(T) == 4) return wave_max_f32(v);
-#endif
     // NaN-free inputs (maxima of sanitised log-weights); the comparison form keeps -inf working
     T o = dpp_get<PF_DPP_QUAD_XOR1>(v, v);
     v = (o > v) ? o : v;
@@ -385,29 +368,18 @@ template <typename T> __device__ __forceinline__ T ld1_sc1(const T* base, int el
 // positions are consecutive points of the systematic grid).
 //   lb_search     the branch-free binary search, rounds unrolled with BYTE offsets (a probe is one ds_read with an immediate
 //                 offset; compare + select + add per target and round), rounds above the power of two `np2` skipped (uniform).
-//   sorted_lower_bound   all targets by lb_search, side by side (one chain of dependent LDS round trips).  With -DPF_SEARCH_PROBE
-//                 (A/B builds) only the first target is searched and the others come from a PROBE of the PF_PROBE entries from its
-//                 answer on - with c_k the entries at q_0 + k, target j lies at q_0 + #{k : c_k < p_j} whenever that count is below
-//                 PF_PROBE; a wave in which any lane's count overflows searches targets 1 .. VEC - 1 the long way and stops probing
-//                 for a while (ProbeState: 8 calls after a first failure, doubled at every further one).  Identical answers, ~100 of
-//                 ~1 000 VALU per wave and step fewer - and NOT faster: the probe hangs a second dependent LDS round trip and the
-//                 counting behind the first target's eleven rounds (same-box A/B, profiles/r05_search_probe_ab.txt: column route
-//                 4.81 -> 5.04 us per step at 1 024 x 512, cluster route 8.34 -> 8.38 APF + LGO, 7.66 -> 8.25 SISR).  Entries
-//                 [0, np2 + PF_PROBE) must be readable, +inf behind the data.
+//   sorted_lower_bound   all targets by lb_search, side by side (one chain of dependent LDS round trips).  (Two restructurings were
+//                 built and measured in round 5 and are not in the source any more - a probe of the eight entries behind the first
+//                 target's answer for the lane's other targets, and two binary levels per LDS round trip: identical answers, 0 .. 7 %
+//                 slower, profiles/r05_search_probe_ab.txt.)  Entries [0, np2 + PF_LB_PAD) must be readable, +inf behind the data:
+//                 the last round reads the entry AT the answer, which may be entry np2.
 // ---------------------------------------------------------------------------------------------------------------
-#define PF_PROBE 8
-#define PF_PROBE_BACKOFF 8
-// wave-uniform state a caller keeps across steps: calls left without probing, and how many a failed probe costs next time (doubled
-// at every failure up to 512, reset by a success: a run whose weights stay degenerate pays for a wasted probe ever more rarely)
-struct ProbeState {
-    int skip, backoff;
-};
+#define PF_LB_PAD 8
 template <typename T, int NP, int MAXP2>
 __device__ __forceinline__ void lb_search(const unsigned char* cb, int np2, const T* __restrict__ p, int* __restrict__ qb) {
     constexpr int SZ = (int)sizeof(T);
 #pragma unroll
     for (int j = 0; j < NP; ++j) qb[j] = 0;
-#ifndef PF_SEARCH_TWO_LEVELS
 #pragma unroll
     for (int st = MAXP2 / 2; st >= 1; st >>= 1) {
         if (st < np2) {
@@ -418,91 +390,13 @@ __device__ __forceinline__ void lb_search(const unsigned char* cb, int np2, cons
             for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? st * SZ : 0;
         }
     }
-#else
-    // (A/B builds, -DPF_SEARCH_TWO_LEVELS: measured, not adopted) TWO levels of the binary search per LDS round trip: the three
-    // pivots q + s/2 - 1, q + s - 1, q + 3s/2 - 1 are read together, the middle one decides the upper level and which of the other
-    // two decides the lower one - half the dependent round trips for about the same VALU count, but half as many LDS reads again
-    // and twelve values in flight per lane: cluster route 8.35 -> 8.88 us per step, column route +- 0 .. + 4 %
-    // (profiles/r05_search_probe_ab.txt)
-    static_assert((MAXP2 & (MAXP2 - 1)) == 0 && MAXP2 >= 4, "power-of-two bound");
-    constexpr int TOP = MAXP2 / 2;
-    // (levels st = TOP, TOP / 2, .., 1 are paired from the top; with an odd number of levels the LAST one stands alone)
-    constexpr int LEVELS = __builtin_ctz(MAXP2);
-#pragma unroll
-    for (int l = 0; l + 1 < LEVELS; l += 2) {
-        const int s = TOP >> l, h = s >> 1;  // the pair's steps
-        if (s < np2) {
-            T v1[NP], v2[NP], v3[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                v1[j] = *reinterpret_cast<const T*>(cb + qb[j] + (h - 1) * SZ);
-                v2[j] = *reinterpret_cast<const T*>(cb + qb[j] + (s - 1) * SZ);
-                v3[j] = *reinterpret_cast<const T*>(cb + qb[j] + (s + h - 1) * SZ);
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const bool up = v2[j] < p[j];
-                const T second = up ? v3[j] : v1[j];
-                qb[j] += (up ? s * SZ : 0) + ((second < p[j]) ? h * SZ : 0);
-            }
-        } else if (h < np2) {
-            T v[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const T*>(cb + qb[j] + (h - 1) * SZ);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? h * SZ : 0;
-        }
-    }
-    if constexpr (LEVELS % 2 == 1) {  // the unpaired last level: st = 1
-        if (1 < np2) {
-            T v[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) v[j] = *reinterpret_cast<const T*>(cb + qb[j]);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) qb[j] += (v[j] < p[j]) ? SZ : 0;
-        }
-    }
-#endif
 #pragma unroll
     for (int j = 0; j < NP; ++j) qb[j] += (*reinterpret_cast<const T*>(cb + qb[j]) < p[j]) ? SZ : 0;
 }
 template <typename T, int VEC, int MAXP2>
-__device__ __forceinline__ void sorted_lower_bound(const T* win, int np2, const T (&p)[VEC], int (&out)[VEC], ProbeState& ps) {
+__device__ __forceinline__ void sorted_lower_bound(const T* win, int np2, const T (&p)[VEC], int (&out)[VEC]) {
     constexpr int SZ = (int)sizeof(T);
     const unsigned char* const cb = reinterpret_cast<const unsigned char*>(win);
-#ifdef PF_SEARCH_PROBE  // (measured, not adopted: see the note above)
-    if constexpr (VEC > 1) {
-        if (ps.skip == 0) {
-            int q0b[1];
-            lb_search<T, 1, MAXP2>(cb, np2, &p[0], q0b);
-            out[0] = q0b[0] / SZ;
-            T c[PF_PROBE];
-#pragma unroll
-            for (int k = 0; k < PF_PROBE; ++k) c[k] = *reinterpret_cast<const T*>(cb + q0b[0] + k * SZ);
-            int cnt[VEC];
-#pragma unroll
-            for (int j = 1; j < VEC; ++j) {
-                cnt[j] = 0;
-#pragma unroll
-                for (int k = 0; k < PF_PROBE; ++k) cnt[j] += (c[k] < p[j]) ? 1 : 0;
-                out[j] = out[0] + cnt[j];
-            }
-            // (targets are non-decreasing, so are the counts: the last one says whether any target lies beyond the probe)
-            if (__ballot(cnt[VEC - 1] == PF_PROBE) == 0ull) {
-                ps.backoff = PF_PROBE_BACKOFF;
-                return;
-            }
-            ps.skip = ps.backoff;
-            ps.backoff = ps.backoff < 512 ? 2 * ps.backoff : 512;
-            int qb[VEC - 1];
-            lb_search<T, VEC - 1, MAXP2>(cb, np2, &p[1], qb);
-#pragma unroll
-            for (int j = 1; j < VEC; ++j) out[j] = qb[j - 1] / SZ;
-            return;
-        }
-        --ps.skip;
-    }
-#endif
     // every target by the search, side by side (ONE chain of dependent LDS round trips)
     int qb[VEC];
     lb_search<T, VEC, MAXP2>(cb, np2, &p[0], qb);

@@ -28,13 +28,8 @@
 namespace pf {
 
 // the step kernel's grid axes: x = column, y = tile (bookkeepers last in dispatch order); A/B builds can restore (tiles + 1, B)
-#ifdef PF_STEP_GRID_TILES_FIRST
-#define PF_STEP_B blockIdx.y
-#define PF_STEP_K blockIdx.x
-#else
 #define PF_STEP_B blockIdx.x
 #define PF_STEP_K blockIdx.y
-#endif
 
 // Development instrumentation (cycle stamps, early-exit cuts for per-stage PMC profiles) is compiled in only with
 // -DPF_DEVTOOLS (tools/pmc_stages.py builds that variant); the production kernels carry none of it.
@@ -271,7 +266,6 @@ template <typename T, int D, bool WQ = true> struct PartialAcc {
         }
         if (poison) atomicOr(poison_slot, 1);
         __syncthreads();
-#ifndef PF_NO_LANE_TAIL
         // the tile's record: lane q of wave 0 adds the four waves' sums of quantity q (same order as a single thread would:
         // identical values) and stores it to its row - one pass of ~10 instructions instead of thread 0 walking NS + 1
         // quantities and 6 + 2 D stores one after the other at the very end of the workgroup's critical path
@@ -293,34 +287,6 @@ template <typename T, int D, bool WQ = true> struct PartialAcc {
                 part[PQ_M2 * stride + o] = pre_on ? (double)M2 : -__builtin_huge_val();
             }
         }
-#else
-        if (threadIdx.x == 0) {
-            double tot[NS + 1];
-#pragma unroll
-            for (int q = 0; q < NS + 1; ++q) {
-                double r = 0.0;
-                if (q < NS || WITH_ES) {
-                    r = red[q * PF_NWAVES];
-#pragma unroll
-                    for (int w = 1; w < PF_NWAVES; ++w) r += red[q * PF_NWAVES + w];
-                }
-                tot[q] = r;
-            }
-            const int64_t stride = (int64_t)B * tiles;
-            const int64_t o = (int64_t)b * tiles + k;
-            part[PQ_M1 * stride + o] = (double)M1;
-            part[PQ_S1 * stride + o] = tot[0];
-            part[PQ_Q1 * stride + o] = tot[1];
-            part[PQ_M2 * stride + o] = pre_on ? (double)M2 : -__builtin_huge_val();
-            part[PQ_S2 * stride + o] = tot[2];
-            part[PQ_E * stride + o] = tot[NS];
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                part[(PQ_MX + d) * stride + o] = tot[3 + d];
-                part[(PQ_MX + D + d) * stride + o] = tot[3 + D + d];
-            }
-        }
-#endif
     }
 };
 
@@ -611,14 +577,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_reduce(FusedArgs<T> a) {
 // double - 2^-29 of a float ulp of any cdf value; every workgroup of a column performs the same operations on the same sums,
 // so they still agree bit for bit)
 template <typename T> __device__ __forceinline__ double pf_rcp_tot(double tot) {
-#ifndef PF_NO_FAST_RCP_TOT
     if constexpr (sizeof(T) == 4) {
         double r = __builtin_amdgcn_rcp(tot);
         r = __builtin_fma(__builtin_fma(-tot, r, 1.0), r, r);
         r = __builtin_fma(__builtin_fma(-tot, r, 1.0), r, r);
         return r;
     }
-#endif
     return 1.0 / tot;
 }
 #define PF_PROBE_STEP 8  // spacing of the prologue's window-start probes (entries)
@@ -637,7 +601,6 @@ template <bool WITH_Q, int NX = 0>
 __device__ __forceinline__ void load_col_partials(const double* part, int64_t stride, int64_t cb, int tiles, int slot_m,
                                                   int slot_s, int slot_x, ColPartials<WITH_Q, NX>& r) {
     const int IT = (tiles + PF_BLOCK - 1) / PF_BLOCK;
-#ifndef PF_NO_VEC_PARTIALS
     if constexpr (PF_COMBINE_ITERS == 4 && NX == 0) {
         // a full table (IT = 4, tiles a multiple of four: 2^20 x 1 and every column of >= 769 tiles): a thread's four records
         // are 32 contiguous, 32-byte aligned bytes of each row - two 16-byte loads per row instead of four 8-byte ones with
@@ -666,7 +629,6 @@ __device__ __forceinline__ void load_col_partials(const double* part, int64_t st
             return;
         }
     }
-#endif
 #pragma unroll
     for (int q = 0; q < PF_COMBINE_ITERS; ++q) {
         const int t = threadIdx.x * IT + q;
@@ -915,18 +877,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fused_book(FusedArgs<T> a) {
 // For D > 1 the optimal proposal's 3x3 inverse + Cholesky would otherwise set the register budget of Bootstrap runs too.
 // FAST: the scalar closed-form path (ColConsts::fast) is known on the host - as a compile-time constant it removes the
 // generic per-particle arithmetic (and its registers) from the fast instantiation and vice versa.
-#ifndef PF_WAVES_D1_GENERIC
 #define PF_WAVES_D1_GENERIC 4
-#endif
-#ifndef PF_WAVES_D1_MN
 // scalar-state multinomial kernels of multi-round tiles (the spacing scan's registers on top of the search's): at 4 waves
 // they spill 130 - 250 B / lane; at 3 (<= 168 VGPRs) none - 60.6 -> 56.6 us per step at 2^22 x 1, 75.8 -> 60.1 at 64 x 65 536
 // (profiles/r03_multinomial_scalar_waves.txt).  Single-round tiles stay at 4: 2^20 x 1 APF ran 20.4 -> 25.2 us at 3.
 #define PF_WAVES_D1_MN 3
-#endif
-#ifndef PF_WAVES_DN_A
 #define PF_WAVES_DN_A 3  // (4 waves = 128 VGPRs spill 128 B / lane once the prologue lives in this kernel: measured slower)
-#endif
 // resident waves per SIMD the register allocation is tuned for (float; measured per variant, tools/kbench.py)
 template <typename T, int D, int MODE, int PROP, bool FAST, int SPEC, bool MULTI> struct StepWaves {
     static constexpr int value = sizeof(T) != 4 ? 1
@@ -1229,11 +1185,7 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
     const T* cdf_col = ((step & 1) ? a.pos : a.cdf) + (int64_t)b * g.N;  // the local scans of this step's parity
     const int64_t base = (int64_t)k * g.tile_elems;
     const T nT = T(N);
-#ifdef PF_NO_HOST_RCN
-    const T rcN = T(1) / nT;
-#else
     const T rcN = a.rcN;
-#endif
     const bool pow2 = (N & (N - 1)) == 0;                  // then the grid division is an exact multiplication
 
     bool poison = false;
@@ -1394,11 +1346,6 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                     for (int j = 0; j < V1; ++j)
                         m1[j] = winb ? cdf_from_local<T>(m1[j], Cb, gb, tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
                 } else {
-#ifdef PF_NO_TILE_LAST_SPLIT
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j)
-                        m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, wja + j == la, wja + j == N - 1) : Lim<T>::inf();
-#else
                     // a tile's (and the column's) last element is the LAST element of its staged vector (tile_elems % VEC == 0,
                     // N % VEC == 0 for VEC > 1): the pinned value T(P_{k+1}) / 1 is selected for that one element only
 #pragma unroll
@@ -1406,7 +1353,6 @@ __device__ __forceinline__ void step_body(const FusedArgs<T>& a, const StepShare
                         const bool tl = (j == VEC - 1) && (wja + j == la);
                         m0[j] = wina ? cdf_from_local<T>(m0[j], tPa, tFa, tNa, tl, tl && (wja + j == N - 1)) : Lim<T>::inf();
                     }
-#endif
 #pragma unroll
                     for (int j = 0; j < V1; ++j)
                         m1[j] = winb ? cdf_from_local<T>(m1[j], tPb, tFb, tNb, wjb + j == lb, wjb + j == N - 1) : Lim<T>::inf();
@@ -1688,7 +1634,7 @@ __global__ __launch_bounds__(PF_BLOCK, (StepWaves<T, D, MODE, PROP, FAST, SPEC, 
     __shared__ double redb[PF_NWAVES];
     // Grid (B, tiles + 1): x = the column, y = the tile - and y == tiles the column's bookkeeper (scratch: 2 + 2 D rows of `red`).
     // Workgroups are dispatched in linear order (x fastest), so every column's bookkeeper comes AFTER all step workgroups: see
-    // filter_run_impl.  PF_STEP_GRID_TILES_FIRST (A/B builds): the round-2 layout (tiles + 1, B) with its interleaved bookkeepers.
+    // filter_run_impl.  (The round-2 layout (tiles + 1, B) interleaved the bookkeepers with the columns: 2 - 3 us per step slower.)
     if (!a.book_inline && PF_STEP_K == (unsigned)a.g.tiles) {
         column_bookkeeping<T, D>(a, PF_STEP_B, red, redb);
         return;

@@ -326,20 +326,6 @@ template <typename T, int VEC> struct SearchWin {
 template <typename T, int WIN, int VEC>
 __device__ __forceinline__ void window_lower_bound_flat(const T* win, const T (&p)[VEC], int (&out)[VEC]) {
     static_assert((WIN & (WIN - 1)) == 0, "window size must be a power of two");
-#ifdef PF_SEARCH_BY_INDEX
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) out[j] = 0;
-#pragma unroll
-    for (int step = WIN / 2; step >= 1; step >>= 1) {
-        T v[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = win[out[j] + step - 1];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) out[j] += (v[j] < p[j]) ? step : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) out[j] += (win[out[j]] < p[j]) ? 1 : 0;
-#else
     // positions as BYTE offsets: a probe is one ds_read with an immediate offset, a round compare + select + add per position
     // (element indices cost a shift and an add more per probe: 21 against 16 VALU per round of four positions)
     const unsigned char* const wb = reinterpret_cast<const unsigned char*>(win);
@@ -358,7 +344,6 @@ __device__ __forceinline__ void window_lower_bound_flat(const T* win, const T (&
         out[j] += (*reinterpret_cast<const T*>(wb + out[j]) < p[j]) ? (int)sizeof(T) : 0;
         out[j] /= (int)sizeof(T);
     }
-#endif
 }
 
 template <typename T, int VEC>
@@ -582,12 +567,10 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
         const bool on = i0 < g.N;
         T v[VEC];
         double e[VEC];
-#ifndef PF_SCAN_NO_PREFETCH
         if (r == 0) {  // (loaded by the caller BEFORE it combined the tile records: one round trip to memory instead of two in a row)
 #pragma unroll
             for (int j = 0; j < VEC; ++j) v[j] = v_first[j];
         } else
-#endif
         if (on) {
             if (VEC == 1) v[0] = src_col[i0]; else load_vec<T, VEC>(src_col + i0, v);
         }
@@ -625,7 +608,6 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
     T v_first[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v_first[j] = T(0);
-#ifndef PF_SCAN_NO_PREFETCH
     {
         const int64_t i0 = (int64_t)k * g.tile_elems + threadIdx.x * VEC;
         if (i0 < g.N) {
@@ -633,7 +615,6 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
             if (VEC == 1) v_first[0] = sc[i0]; else load_vec<T, VEC>(sc + i0, v_first);
         }
     }
-#endif
     ColLse c;
     if constexpr (FROM_W) {
         // normalised weights: every tile record is (max 0, plain sum) - the prefix is the plain sum of the tile sums before k, in
@@ -1864,9 +1845,7 @@ static FusedArgs<T> make_fused_args(const pf_filter_args* A, const Geom& g, cons
 // the bookkeepers are dispatched LAST (the grid's slowest axis is the tile index, see below) they cost nothing on the critical path and inline lost at every
 // shape measured, single-tile columns included (1 024 x 8 192: 65.5 -> 59.1 us per step; 256 x 8 192 27.3 -> 22.1;
 // profiles/r04c_step_kernel_book_inline_threshold_ab.txt): 1 = never.  (Round 2's rule was 8.)
-#ifndef PF_BOOK_INLINE_TILES
 #define PF_BOOK_INLINE_TILES 1
-#endif
 template <typename T, int D, int VEC, bool MULTI>
 static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayout& wl, int64_t t0, int64_t n_steps,
                            int finalize, hipStream_t st, float* kernel_ms) {
@@ -1886,18 +1865,12 @@ static int filter_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     // they sat between the columns, took slots first, and the last columns' step workgroups started 2 - 3 us late
     // (profiles/r04c_step_kernel_bookkeepers_last_ab.txt).  B = 1 is the same linear order either way.
     a.kmap = 0u;
-#ifndef PF_NO_XCD_TILE_MAP
     if (g.B == 1 && g.tiles >= 16 && (g.tiles & (g.tiles - 1)) == 0) {  // one column of 2^q tiles: an eighth of it per XCD
         unsigned q = 0;
         while ((1 << q) < g.tiles) ++q;
         a.kmap = 7u | ((q - 3u) << 8) | (3u << 16);
     }
-#endif
-#ifdef PF_STEP_GRID_TILES_FIRST
-    const dim3 grid(g.tiles + (a.book_inline ? 0 : 1), g.B);
-#else
     const dim3 grid(g.B, g.tiles + (a.book_inline ? 0 : 1));
-#endif
     // neither flag array given: the flags are derived from y on the device, into the workspace (runs of <= PF_AUTO_FLAGS steps)
     const bool auto_flags = !A->observed && !A->observed_dev && n_steps > 0;
     // ... of ONE step on a shared observation row (the online move): every kernel looks at the row itself (FusedArgs::is_obs, -2) -
@@ -2092,16 +2065,14 @@ static inline size_t column_lds_bytes(int64_t N, int D, size_t tsize, int vec) {
     int64_t np2 = 64;
     while (np2 < N) np2 <<= 1;
     const int64_t NP = ((N + vec - 1) / vec) * vec;  // (the kernel's padded plane stride)
-    const size_t planes = (((size_t)(np2 + PF_PROBE + (int64_t)D * NP) * tsize) + 15) & ~(size_t)15;  // (cdf + the probe's pad | particle planes)
+    const size_t planes = (((size_t)(np2 + PF_LB_PAD + (int64_t)D * NP) * tsize) + 15) & ~(size_t)15;  // (cdf + the search's pad | particle planes)
     return planes + sizeof(double) * (2 + 2 * (4 + 2 * D)) * PFC_MAXW + 16;  // scan records + the state's records (x 2)
 }
 // (measured, profiles/r03_column_route.txt: 1024 x 2048 runs 21 us per step here against 29 on the per-step route, 1024 x
 // 4096 56 against 42 - sixteen waves of one workgroup issue-bound on one CU)
-#ifndef PF_COLUMN_MAX_N
 #define PF_COLUMN_MAX_N 2048
-#endif
 // Which runs take it: self-contained runs (finalize: the last state's row is flushed by the same call), no state history,
-// a column that fits one workgroup.  PF_NO_COLUMN=1 keeps everything on the per-step route (tests compare the two).
+// a column that fits one workgroup.  pf_run_hints.route = PF_ROUTE_PER_STEP keeps everything on the per-step route (tests compare the two).
 static inline bool column_eligible(const pf_filter_args* A, const Geom& g, int64_t n_steps, int finalize) {
     if (!finalize || n_steps < 1 || A->ring >= 3) return false;
     if (A->hints.route == PF_ROUTE_PER_STEP) return false;
@@ -2265,9 +2236,7 @@ PF_DEFINE_COLUMN(pf_run_column_f64, double)
 
 // ---- the column-cluster route (pf_cluster.hpp): filters of 2 049 .. 16 384 particles, c workgroups per filter, one launch per
 // run and group of columns -------------------------------------------------------------------------------------------------------
-#ifndef PFK_HOST_VEC
-#define PFK_HOST_VEC 4  // particles per lane of the cluster kernels (a build-time choice: -DPFK_HOST_VEC=8 for A/B builds)
-#endif
+#define PFK_HOST_VEC 4  // particles per lane of the cluster kernels 
 #define PF_CLUSTER_INFEASIBLE (-1000)  // internal: the cluster kernel cannot be launched here (no launch was issued)
 static inline size_t cluster_lds_bytes(int D, size_t tsize) {
     return (size_t)(PFK_WIN_P2 + D * PFK_WIN) * tsize + 2 * PFK_FOLD * sizeof(double);  // window planes | the folds of two states

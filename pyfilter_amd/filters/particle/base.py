@@ -71,6 +71,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         self._draws = 0          # draw epoch: every new stream of random numbers (initial sample, fused run, online
                                  # move, step-by-step run) takes the next one - repeated calls are independent runs
         self._copies = 0
+        self._defer_status_once = False  # the next batch_filter leaves a cluster run's verification to its caller
+        self._per_step_once = False   # the next lean batch_filter takes the per-step route (see _batch_filter_lean)
         self._online_cluster = False  # set by a caller that verifies its online moves (SMC2.step): see _filter_fused_single
         self._watched_move = None     # (status word, redo) of the latest online move when it took the column-cluster kernel
         self._obs_cache = None   # (identity of y, host copy of its observed flags): re-filtering the same data costs no sync
@@ -461,7 +463,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         return new
 
     def batch_filter(self, y, bar=True, init_state=None) -> FilterResult:
+        """``self._defer_status_once`` (set by callers inside this package that never wait for a run by itself - PMMH moves): a run
+        that took the column-cluster kernel is NOT verified before it is handed back; ``result._cluster_watch = (status word,
+        plan)`` lets the caller look where it next waits for the device (a launch that gave up leaves NaN log-likelihoods: a
+        rejected proposal)."""
         assert self._model is not None, "Model has not been initialized!"
+        _defer_status, self._defer_status_once = self._defer_status_once, False
         device, _ = self._device_dtype()
         if (not self._fused_capable(device) or not isinstance(y, torch.Tensor)
                 or not HINTS.fused_batch
@@ -469,7 +476,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
             # (a user-defined affine process with recorded states: the driver's loop over fused single steps)
             return super().batch_filter(y, bar=bar, init_state=init_state)
         if self._single_launch_run(y):
-            return self._batch_filter_lean(y, init_state)
+            return self._batch_filter_lean(y, init_state, defer_status=_defer_status)
         return self._batch_filter_fused(y, init_state)
 
     def _single_launch_run(self, y) -> bool:
@@ -485,10 +492,12 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                                             self._resampler_kind() == L.RESAMPLE_SYSTEMATIC))
                 and self._ctx_tapes_none())
 
-    def _batch_filter_lean(self, y: torch.Tensor, init_state=None) -> FilterResult:
+    def _batch_filter_lean(self, y: torch.Tensor, init_state=None, defer_status: bool = False) -> FilterResult:
         state = init_state if init_state is not None else self.initialize()
         result = FilterResult(state, self.record_states, self.record_moments, _defer_moments=True)
-        blk, _, _ = self._filter_block_lean(y, state, None, None, host_u=True)
+        per_step, self._per_step_once = self._per_step_once, False  # (a caller repeating a run whose cluster launch gave up)
+        blk, _, _ = self._filter_block_lean(y, state, None, None, host_u=True, defer_status=defer_status, per_step=per_step)
+        result._cluster_watch = (blk.status, blk.plan) if blk.status is not None else None
         result._extend_fused(blk.filter_means, blk.filter_variance, blk.loglikelihood, blk.latest_state)
         self._last_run["rows"] = (blk.filter_means, blk.filter_variance)
         return result

@@ -148,6 +148,34 @@ def _uniforms(like: torch.Tensor, shard, draws):
     return _to_device(u, like)
 
 
+def _refilter(proposal_filter, y, stats):
+    """The proposals' filters over the data.  A run on the column-cluster kernel reports through a status word when a launch could
+    not make progress (its log-likelihoods are NaN then: the acceptance step rejects those proposals); verifying it here would
+    make every move wait for its own re-filter, so the word goes to the caller (``stats["cluster_watch"]``), who reads it where
+    it next waits for the device - ``watch_refilters`` - and without a ``stats`` dictionary the run is verified on the spot."""
+    if stats is None or not hasattr(proposal_filter, "_cluster_gave_up"):
+        return proposal_filter.batch_filter(y, bar=False)
+    proposal_filter._defer_status_once = True
+    res = proposal_filter.batch_filter(y, bar=False)
+    proposal_filter._defer_status_once = False  # (a subclass that does not pass through ParticleFilter.batch_filter)
+    watch = getattr(res, "_cluster_watch", None)
+    if watch is not None:
+        stats.setdefault("cluster_watch", []).append((watch[0], watch[1], proposal_filter))
+    return res
+
+
+def watch_refilters(stats) -> int:
+    """Call where the host has just waited for the device: how many of the re-filters noted in ``stats`` had a column-cluster launch
+    give up (their proposals were rejected: NaN log-likelihoods) - the status words are cleared and the filters told, so that
+    the caller can repeat the move (SMC^2) or count it (PMMH)."""
+    gave_up = 0
+    for status, plan, filt in (stats or {}).pop("cluster_watch", []):
+        if int(status.item()) != 0:
+            filt._cluster_gave_up(plan)
+            gave_up += 1
+    return gave_up
+
+
 def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_filter, proposal_theta, y, draws, trace, stats,
                      overlap=None):
     """``run_pmmh`` for a Gaussian kernel shared by all theta-particles and scalar priors of the standard families: the
@@ -172,7 +200,7 @@ def _run_pmmh_native(theta, state, proposal, kernel: "GaussianKernel", proposal_
     mark("  theta* proposed")
     proposal_filter.initialize_model(proposal_theta)  # (rebuilt from theta*: see run_pmmh)
     mark("  model rebuilt")
-    new_res = proposal_filter.batch_filter(y, bar=False)
+    new_res = _refilter(proposal_filter, y, stats)
     mark("  re-filter issued")
     if overlap is not None:
         overlap()
@@ -214,7 +242,7 @@ def run_pmmh(theta, state, proposal, proposal_kernel: Distribution, proposal_fil
     # the model is REBUILT from theta* (mcmc/utils.py:52-53): whatever the builder derives from the parameters - e.g. the
     # stationary initial distribution of an Ornstein-Uhlenbeck process - belongs to the proposed values, not the old ones
     proposal_filter.initialize_model(proposal_theta)
-    new_res = proposal_filter.batch_filter(y, bar=False)
+    new_res = _refilter(proposal_filter, y, stats)
     if overlap is not None:
         overlap()
 
@@ -314,8 +342,13 @@ class PMMH:
         proposal_theta = self.theta.like()
         proposal_filter = self.filter.copy()
         proposal_filter.initialize_model(proposal_theta)
+        stats = {}
         for _ in range(self.num_samples):
             accepted = run_pmmh(self.theta, state, self._proposal, kernel, proposal_filter, proposal_theta, y,
-                                self.filter.batch_shape, mutate_kernel=True, generator=self._gen)
+                                self.filter.batch_shape, mutate_kernel=True, generator=self._gen, stats=stats)
             state.update_chain(self.theta.stack_parameters(True), accepted)
+            if len(stats.get("cluster_watch", ())) >= 64:  # (the words are sticky per plan: looked at every 64 moves and at the end)
+                self.unfinished_moves = getattr(self, "unfinished_moves", 0) + watch_refilters(stats)
+        # moves whose re-filter was cut short by a column-cluster launch that gave up count as rejections (pf_amd.h: PF_ROUTE_CLUSTER)
+        self.unfinished_moves = getattr(self, "unfinished_moves", 0) + watch_refilters(stats)
         return state

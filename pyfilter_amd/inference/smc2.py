@@ -19,7 +19,7 @@ import torch
 from ..distributed import Shard
 from ..filters.result import FilterResult
 from .parameters import ThetaParticles
-from .pmmh import SymmetricMH, as_draws, run_pmmh
+from .pmmh import SymmetricMH, as_draws, run_pmmh, watch_refilters
 from .. import ops as _ops
 from ..hints import HINTS
 from ..hints import HINTS as _HINTS
@@ -253,6 +253,9 @@ class ParticleMetropolisHastings:
         previous_distance, acceptance_rate = 0.0, 0.0
         for i in range(self._n_steps):
             stats = {"mark": mark} if self.timeline is not None else {}
+            # (what a repeated move starts from again: the theta-level stream and the proposals' filter draw epoch)
+            gen = getattr(draws, "generator", None)
+            rewind = (gen.get_state() if isinstance(gen, torch.Generator) else None, getattr(proposal_filter, "_draws", None))
             accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, data,
                                 shape, mutate_kernel=False, generator=draws, trace=self.trace, stats=stats, overlap=move_filters)
             if "rate" in stats:  # (the native theta route: the acceptance kernel counted this rank's share)
@@ -263,7 +266,23 @@ class ParticleMetropolisHastings:
                 rate = accepted.float().sum()
                 rate = shard.all_mean(rate, accepted.numel()) if sharded else rate / accepted.numel()
             mark("move issued")
-            acceptance_rate = (float(rate) + i * acceptance_rate) / (i + 1)  # the kernel's one host decision per move
+            rate_now = float(rate)  # the kernel's one host decision per move
+            if watch_refilters(stats):
+                # the move's re-filter ran on the column-cluster kernel and a launch gave up (its proposals were rejected, nothing
+                # else happened): the move again - the filter now re-issues on the per-step route itself (its plan was told)
+                proposal_filter._per_step_once = True
+                if rewind[0] is not None:
+                    gen.set_state(rewind[0])  # the same proposals, the same acceptance uniforms ...
+                if rewind[1] is not None:
+                    proposal_filter._draws = rewind[1]  # ... the same particle draws: the move the launch cut short, not another one
+                stats.pop("rate", None)
+                accepted = run_pmmh(theta, state, self._proposal, dist, proposal_filter, proposal_theta, data,
+                                    shape, mutate_kernel=False, generator=draws, trace=self.trace, stats=stats, overlap=move_filters)
+                rate = stats["rate"] if "rate" in stats else accepted.float().mean()
+                if sharded:
+                    rate = shard.all_mean(rate * accepted.numel(), accepted.numel())
+                rate_now = float(rate)
+            acceptance_rate = (rate_now + i * acceptance_rate) / (i + 1)
             mark("move done on the device")
             self.acceptance_history.append(acceptance_rate)
             if acceptance_rate < self._acceptance_threshold:  # abort early: more state particles are needed

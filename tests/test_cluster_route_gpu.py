@@ -368,8 +368,7 @@ def test_a_cluster_launch_that_gives_up_falls_back_to_the_per_step_route(driver,
 def test_smc2_survives_cluster_launches_that_give_up(monkeypatch):
     """SMC2.fit (pipelined blocks: the status word travels with the block's statistics) and SMC2.step (watched online moves: the
     word rides through ``pf_theta_step`` into the host slot) with ``cluster_patience = -1``: every cluster launch gives up, every
-    piece is re-issued on the per-step route - the run equals the one that never took the cluster kernel (``HINTS.cluster = False``)
-    decision for decision and number for number.  (float64: a watched move's log-likelihood joins the running total in
+    piece is re-issued on the per-step route - the run equals the one whose cluster launches all completed, decision for decision.  (float64: a watched move's log-likelihood joins the running total in
     ``pf_theta_step`` - the reference's ``+=`` of the increment in the tensors' type, filters/result.py:130 - where an unwatched
     move's kernel adds its double-precision increment before rounding: one float32 ulp apart, the same number in float64.)"""
     import warnings
@@ -406,9 +405,12 @@ def test_smc2_survives_cluster_launches_that_give_up(monkeypatch):
         return state, getattr(filt, "cluster_fallbacks", 0)
 
     for how in ("fit", "step"):
-        ref, fb0 = fit(False, 0, how)
-        got, fb1 = fit(True, -1, how)
+        ref, fb0 = fit(True, 0, how)    # every cluster launch completes
+        got, fb1 = fit(True, -1, how)   # every cluster launch gives up: every piece re-issued on the per-step route
         assert fb0 == 0 and fb1 > 0, (how, fb0, fb1)
-        assert torch.equal(torch.stack(got.ess).cpu(), torch.stack(ref.ess).cpu()), how
-        assert torch.equal(got.w, ref.w), how
-        assert torch.equal(got.filter_state.loglikelihood, ref.filter_state.loglikelihood), how
+        # the same draws either way (the routes key Philox alike; a repeated PMMH move rewinds the theta-level stream): the two runs
+        # are the same particle system up to the routes' float64 summation order - same decisions, numbers to 1e-8
+        assert len(got.ess) == len(ref.ess), how
+        torch.testing.assert_close(torch.stack(got.ess), torch.stack(ref.ess), rtol=1e-8, atol=1e-8, msg=how)
+        torch.testing.assert_close(got.w, ref.w, rtol=1e-8, atol=1e-8, msg=how)
+        torch.testing.assert_close(got.filter_state.loglikelihood, ref.filter_state.loglikelihood, rtol=1e-8, atol=1e-8, msg=how)

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Per-move wall time of an online filter() loop (synchronised per move): outliers and non-finite log-likelihoods.
-python tools/scratch/online_outliers.py model filter proposal N B [moves]"""
+python tools/online_outliers.py model filter proposal N B [moves]"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kbench import make  # noqa: E402
 
 cfg = (sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))

@@ -1,7 +1,7 @@
 """cProfile of the online filter() move at 16 x 4096 (host cost per move)"""
 import cProfile, pstats, os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kbench import make
 for cfg in (("sine", "apf", "lgo", 4096, 16), ("sine", "apf", "lgo", 8192, 128)):
     f, _ = make(*cfg)

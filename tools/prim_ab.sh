@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-kernel rocprofv3 averages of the stand-alone primitives for several variant libraries (tools/build_variant.sh):
-# tools/scratch/prim_ab.sh name1 name2 ...   (shapes: 2^20 x 1, 65536 x 64, 4M x 1)
+# tools/prim_ab.sh name1 name2 ...   (shapes: 2^20 x 1, 65536 x 64, 4M x 1)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   for shape in "1048576 1" "65536 64" "4194304 1"; do

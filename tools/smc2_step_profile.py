@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """cProfile of the reference-style SMC2.step() loop (one observation per call, host ESS test per observation):
-python tools/scratch/smc2_step_profile.py [n_theta] [n_state] [T]"""
+python tools/smc2_step_profile.py [n_theta] [n_state] [T]"""
 import cProfile
 import math
 import os
@@ -10,8 +10,8 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _env  # noqa: E402
 
 _env.setup()

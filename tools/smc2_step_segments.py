@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Wall time of the segments of one SMC2.step() observation (perf_counter around them, no profiler):
-python tools/scratch/smc2_step_segments.py [n_theta] [n_state] [T]"""
+python tools/smc2_step_segments.py [n_theta] [n_state] [T]"""
 import math
 import os
 import sys
@@ -8,8 +8,8 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import _env  # noqa: E402
 
 _env.setup()
