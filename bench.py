@@ -136,6 +136,18 @@ def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None, solo
 
 
 
+def _rccl_version(world):
+    """The RCCL the collectives ran on - None for one rank, and None when the ranks talk over gloo (a development run of several
+    ranks on ONE GPU, PF_BENCH_SHARE_GPU=1: no RCCL involved)."""
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_backend() != "nccl":
+        return None
+    return ".".join(str(v) for v in torch.cuda.nccl.version())
+
+
 def smc2_step_kernel_roofline(w, b_local, dtype, device, t_len=64):
     """The dominant kernel of the SMC^2 job - ``k_fused_step`` at the PER-RANK shape (``b_local`` filters x 8 192 particles,
     APF + optimal proposal on the OU model: what every online move and every PMMH re-filter launches) - timed with HIP events
@@ -268,7 +280,7 @@ def smc2_line(args, dtype, device, world, rank, scaling, attach=False):
         "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic", "world_size": world,
-        "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+        "rccl_version": _rccl_version(world),
         "config": {"workload": f"smc2: SMC^2, APF + lgo, {w['B']} theta-particles (sharded {info['theta_per_rank']} per GPU) x "
                                f"{w['N']} state particles, T={info['T']}, theta-weights all-gathered per block of 16 observations",
                    "parallelism": f"theta-particles block-sharded over {world} GPU(s)", **info},
@@ -735,7 +747,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "world_size": world,
-            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+            "rccl_version": _rccl_version(world),
             "config": {
                 "workload": f"{args.workload}: {w['filter'].upper()} + {w['proposal']} proposal, {w['resampler']} "
                             f"resampling, N={w['N']} particles x B={w['B']} filters per GPU, T={w['T']}, state dim {w['D']}",

@@ -1278,11 +1278,13 @@ extern "C" const char* pf_error_string(int code) {
 
 
 
+#ifdef PF_DEVTOOLS  // (the instrumented build only - tools/pmc_stages.py --build: where the workspace keeps the development timestamps)
 extern "C" int pf_debug_offset(int64_t N, int64_t B, size_t* off) {
     if (!off || bad_shape(N, B)) return PF_EINVAL;
     *off = make_ws(make_geom(N, B), PF_MAXD).off_dbg;
     return PF_OK;
 }
+#endif
 
 extern "C" int pf_workspace_bytes(int64_t N, int64_t B, int64_t D, size_t* bytes) {
     if (!bytes || bad_shape(N, B) || D < 1 || D > PF_MAXD) return PF_EINVAL;

@@ -257,3 +257,16 @@ def test_rccl_world_of_one_runs_every_exchange_of_the_sharded_driver(tmp_path):
     for k in ("w", "mean", "ll"):  # (the sharded branches evaluate the theta-level arithmetic with torch ops where the one-rank
         # route takes one kernel: same numbers to rounding)
         torch.testing.assert_close(got[k][0], got[k][1], rtol=1e-5, atol=1e-6, msg=k)
+
+
+def test_scale_preflight_quick():
+    """``tools/scale_preflight.py --quick``: the one command that rehearses the driver's N > 1 bench on a one-GPU box (JSON contract of
+    both lines, per-rank kernel routes, sharded == unsharded) - at full length it is what a round runs before its SCALE record."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "scale_preflight.py"), "--quick"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0 and "scale preflight: ok" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -16,14 +16,14 @@ def main():
     objdir = os.path.join(ROOT, "build", "obj")
     units = ge.build_units(objdir)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(ge.CSRC, "pf_kernels.hip"),
+    common = [hipcc, "--offload-arch=gfx950"] + ge.COMPRESS + ["-O3", "-std=c++17", "-fPIC", "-c", os.path.join(ge.CSRC, "pf_kernels.hip"),
               f'-DPF_SOURCE_SHA256="{ge.source_digest()}"']
     procs = [subprocess.Popen(common + flags + ["-o", obj], cwd=ge.CSRC) for flags, obj in units
              if os.path.basename(obj)[:-2] in want]
     assert len(procs) == len(want), "unknown unit name"
     if any(p.wait() for p in procs):
         raise SystemExit("compile failed")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _, obj in units] + ["-o", ge.LIB], cwd=ge.CSRC)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950"] + ge.COMPRESS + ["-shared", "-fPIC"] + [obj for _, obj in units] + ["-o", ge.LIB], cwd=ge.CSRC)
     print("relinked; matches sources:", ge.binary_matches_sources())
 
 

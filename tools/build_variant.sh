@@ -18,7 +18,7 @@ declare -A FLAGS=(
   [f64_m0]="-DPF_TU_F64_ONLY -DPF_TU_MULTI=0" [f64_m1]="-DPF_TU_F64_ONLY -DPF_TU_MULTI=1")
 pids=()
 for u in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $ROOT/pyfilter_amd/csrc/pf_kernels.hip ${FLAGS[$u]} $EXTRA -o $OUT/pf_$u.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 --offload-compress -O3 -std=c++17 -fPIC -c $ROOT/pyfilter_amd/csrc/pf_kernels.hip ${FLAGS[$u]} $EXTRA -o $OUT/pf_$u.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
@@ -26,5 +26,5 @@ objs=()
 for u in "${!FLAGS[@]}"; do
   if [ -f $OUT/pf_$u.o ] && [[ " $* " == *" $u "* ]]; then objs+=($OUT/pf_$u.o); else objs+=($OBJ/pf_$u.o); fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o $ROOT/pyfilter_amd/libpfamd_$NAME.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 --offload-compress -shared -fPIC "${objs[@]}" -o $ROOT/pyfilter_amd/libpfamd_$NAME.so
 echo $ROOT/pyfilter_amd/libpfamd_$NAME.so
