@@ -301,6 +301,12 @@ typedef struct pf_run_hints {
                               * and user_scale_per_column: the optimal proposal's first-stage weight (linear.py:57-86) needs
                               * the particle and its transition scale - not the caller's one-step mean, which does not exist
                               * yet for the new particles */
+    int32_t cluster_generation; /* 0: every column-cluster launch first clears its records (one small launch more).  != 0 (needs
+                               * pf_filter_args.status, runs of <= 2 048 steps, not under stream capture): the caller NUMBERS its
+                               * cluster launches on this workspace - any value in [1, 2^20) that differs from those of the
+                               * previous 2^20 - 1 launches on it, e.g. a counter; the records then carry it in their tags, stale
+                               * ones never match and nothing is cleared: an online move of 2 049 .. 16 384 particles is ONE launch.
+                               * The workspace must have been zero-filled once before its first such launch */
     int32_t cluster_patience; /* polls a workgroup of the column-cluster kernel spends on one wait for its siblings before it
                                * gives up (see PF_ROUTE_CLUSTER); 0 = the default, 2^21 (seconds).  -1 (tests): every workgroup
                                * gives up at its first wait whatever it finds - the give-up path, deterministically */

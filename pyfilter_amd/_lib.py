@@ -53,7 +53,7 @@ ABI_VERSION = 4  # include/pf_amd.h: PF_ABI_VERSION
 
 class PfRunHints(C.Structure):
     _fields_ = [("route", C.c_int32), ("column_max_n", C.c_int32), ("tile_target", C.c_int32), ("ancestor_search", C.c_int32),
-                ("resume", C.c_int32), ("prepare_next", C.c_int32), ("cluster_patience", C.c_int32)]
+                ("resume", C.c_int32), ("prepare_next", C.c_int32), ("cluster_generation", C.c_int32), ("cluster_patience", C.c_int32)]
 
 
 class PfFilterArgs(C.Structure):

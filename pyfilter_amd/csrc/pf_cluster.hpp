@@ -11,7 +11,8 @@
 //              the new log-weights and (max, total) of the next step's resampling weights, next to the chunk-local inclusive
 //              scan L_i of those weights and the particles themselves (write-through `sc1` stores into the state buffer the
 //              per-step route would have written, and into the scan planes), as 16-byte {3 words, tag} granules - tag = state
-//              index + 1, written by one `sc1` store each, so a record needs no flag and no second drain;
+//              index + 1 (+ the launch's generation x 4096 when the caller numbers its launches: nothing to clear between them),
+//              written by one `sc1` store each, so a record needs no flag and no second drain;
 //              wave 0 of every member polls the column's <= 64 records (lane l <-> chunk l, `sc1` loads: L1 bypassed - one poller
 //              per workgroup: what a hand-off costs is set by the traffic in the consumer CU's own memory queue), folds them with
 //              wave-level DPP operations and broadcasts the fold through LDS: identical arithmetic in every member, so all take
@@ -69,6 +70,9 @@ struct ClusterRun {
     int* err;            // |= 1: a poll ran out of patience, |= 2: an ancestor fell outside the staged chunks
     int* status;         // pf_filter_args.status (or null): the same bits, never cleared by the library
     int patience;        // polls of one wait before a member gives up
+    unsigned tag_base;   // the record of state s carries tag_base + s + 1.  0: the records were cleared for this launch.  Else the
+                         // caller numbers its launches on this workspace (pf_run_hints.cluster_generation) and tag_base =
+                         // generation * 4096: records of earlier launches never match, nothing is cleared
     int spread;          // != 0 (PF_ROUTE_CLUSTER_SPREAD, tests): the members of a column get CONSECUTIVE ids - one per XCD under
                          // the id % 8 placement - so the exchange runs on its placement-independent form (agent-scope `sc1` on both
                          // sides, never the same-XCD fast path)
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
             for (int i = 0; i < 2 * D; ++i) PfkWords<T>::put(w + (4 + i) * NWT, v[2 + i]);
             PfkWords<T>::put(w + (4 + 2 * D) * NWT, mw2);
             PfkWords<double>::put(w + NT * NWT, tw);
-            pfk_u4 gv = {0u, 0u, 0u, (unsigned)(s + 1)};
+            pfk_u4 gv = {0u, 0u, 0u, cr.tag_base + (unsigned)(s + 1)};
 #pragma unroll
             for (int gi = 0; gi < NG; ++gi) {
                 if (lane == gi) {
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
         if (wid == 0) {
             const unsigned char* base = cr.rec + ((size_t)((s & 1) * cr.nb + bl) * NG) * (64 * 16);
             pfk_u4 gr[NG];
-            const unsigned want = (unsigned)(s + 1);
+            const unsigned want = cr.tag_base + (unsigned)(s + 1);
             // (the first records of a run may have to wait for a sibling's SLOT - behind whatever else occupies the device -
             // not only for its arithmetic: that wait is given time in proportion to the run)
             const int limit = (s == 0) ? cr.patience + ((run.n_steps < (1 << 19) ? run.n_steps : (1 << 19)) << 10) : cr.patience;
@@ -445,7 +449,14 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
     // ---- observed flags / observations, one step ahead ---------------------------------------------------------------------------
     auto obs_flag = [&](int s) -> bool {
         if (s >= run.n_steps) return false;
-        return run.use_bits ? ((run.obs_bits[s >> 5] >> (s & 31)) & 1u) != 0 : a.obs_dev[run.t0 + s] != 0;
+        if (run.use_bits) return ((run.obs_bits[s >> 5] >> (s & 31)) & 1u) != 0;
+        if (run.inline_y) {  // (one-step run, shared row)
+            const T* yr = a.y + (int64_t)(run.t0 + s) * O;
+            bool any = false;
+            for (int o = 0; o < O; ++o) any = any || !(yr[o] != yr[o]);
+            return any;
+        }
+        return a.obs_dev[run.t0 + s] != 0;
     };
     auto load_yn = [&](int s, bool obs) {  // cp.yn <- the observation of local step s (0 when it carries none)
         const T* yr = y_row(run.t0 + (s < run.n_steps ? s : run.n_steps - 1));

@@ -28,6 +28,8 @@ namespace pf {
 struct ColumnRun {
     int t0, n_steps;
     int use_bits;                      // 1: obs_bits (the host's flags, baked into the launch); 0: FusedArgs::obs_dev[t]
+    int inline_y;                      // (cluster kernel, one-step runs on a shared observation row, use_bits == 0) the flag is read off
+                                       // y[t0] itself - "not all-NaN" of its <= 3 values - instead of a byte a launch of its own derived
     uint32_t obs_bits[PFC_OBS_WORDS];  // bit s = step t0 + s weighs against y[t0 + s]
 };
 

@@ -2109,6 +2109,7 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         r.t0 = (int)(t0 + done);
         r.n_steps = (int)((n_steps - done < 32 * PFC_OBS_WORDS) ? n_steps - done : 32 * PFC_OBS_WORDS);
         r.use_bits = (a.obs_dev == nullptr) ? 1 : 0;
+        r.inline_y = 0;
         for (int w = 0; w < PFC_OBS_WORDS; ++w) r.obs_bits[w] = 0u;
         if (r.use_bits)
             for (int q = 0; q < r.n_steps; ++q)
@@ -2295,8 +2296,17 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
     a.obs_dev = A->observed_dev;
     uint8_t* const auto_fl = (uint8_t*)A->ws + wl.off_ctr + 64;
     const int64_t auto_row = A->y_rows * (int64_t)A->model.obs_dim;
-    bool flags_pending = auto_flags;  // (derived by the launch that clears the first piece's records: k_zero_and_flags)
-    if (auto_flags) a.obs_dev = auto_fl - t0;
+    // one-step runs on a shared observation row: the kernel reads the flag off y itself (ColumnRun::inline_y)
+    const bool inline_y = auto_flags && n_steps == 1 && A->y_rows == 1;
+    bool flags_pending = auto_flags && !inline_y;  // (derived by the launch that clears the first piece's records: k_zero_and_flags)
+    if (auto_flags && !inline_y) a.obs_dev = auto_fl - t0;
+    // the caller numbers its launches (pf_run_hints.cluster_generation): tagged records, nothing to clear
+    bool numbered = A->hints.cluster_generation != 0 && A->status != nullptr && n_steps <= 32 * PFC_OBS_WORDS;
+    if (numbered) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) numbered = false;  // (a replay repeats the number)
+        (void)hipGetLastError();
+    }
     const int c = (int)((A->N + PFK_TPB * VEC - 1) / (PFK_TPB * VEC));
     const int nchunks = (int)((A->N + 64 * VEC - 1) / (64 * VEC));
     // which instantiation: float runs of the built-in scalar closed-form models on Philox normals take KIND / FILT / PROP folded
@@ -2356,7 +2366,8 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
             ColumnRun r;
             r.t0 = (int)(t0 + done);
             r.n_steps = (int)((n_steps - done < 32 * PFC_OBS_WORDS) ? n_steps - done : 32 * PFC_OBS_WORDS);
-            r.use_bits = (a.obs_dev == nullptr) ? 1 : 0;
+            r.use_bits = (a.obs_dev == nullptr && !inline_y) ? 1 : 0;
+            r.inline_y = inline_y ? 1 : 0;
             for (int w = 0; w < PFC_OBS_WORDS; ++w) r.obs_bits[w] = 0u;
             if (r.use_bits)
                 for (int q = 0; q < r.n_steps; ++q)
@@ -2371,7 +2382,7 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
             if (flags_pending)
                 hipLaunchKernelGGL((k_zero_and_flags<T>), dim3(zb + (unsigned)n_steps), dim3(PF_BLOCK), 0, st, (uint32_t*)clu, words, zb,
                                    (const T*)A->y + t0 * auto_row, auto_row, auto_fl);
-            else
+            else if (!numbered)
                 hipLaunchKernelGGL((k_zero_words<uint32_t>), dim3(zb), dim3(PF_BLOCK), 0, st, (uint32_t*)clu, words);
             flags_pending = false;
             trace_launch(r.t0, (int)sizeof(T), D, VEC, 0, A->proposal, spec_ok ? 1 : 0, /*SPEC*/ 10, spec_ok ? A->model.hid_kind : 0, c);
@@ -2382,8 +2393,10 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
                 cr.nbp = (cr.nb + 7) & ~7;
                 cr.c = c;
                 cr.nchunks = nchunks;
-                cr.err = (int*)clu;
-                cr.status = A->status;
+                // (numbered launches: the workspace's error word is never cleared - the caller's status word, which it clears itself, is both)
+                cr.err = numbered ? A->status : (int*)clu;
+                cr.status = numbered ? nullptr : A->status;
+                cr.tag_base = numbered ? (unsigned)(A->hints.cluster_generation & 0xFFFFF) * 4096u : 0u;
                 cr.patience = A->hints.cluster_patience != 0 ? A->hints.cluster_patience : PFK_SPIN_LIMIT;
                 cr.spread = A->hints.route == PF_ROUTE_CLUSTER_SPREAD ? 1 : 0;
                 cr.rec = clu + 256 + (size_t)b0 * 2 * PF_CLUSTER_NG * 64 * 16;  // (this group's [2][nb][NG][64] block)
@@ -2574,7 +2587,7 @@ static int filter_run_checked(const pf_filter_args* A, int64_t t0, int64_t n_ste
                               float* kernel_ms) {
     if (!A || A->struct_size != sizeof(pf_filter_args)) return PF_EINVAL;  // (another ABI version: include/pf_amd.h)
     if (A->hints.route < 0 || A->hints.route > PF_ROUTE_CLUSTER_SPREAD || A->hints.column_max_n < 0 || A->hints.tile_target < 0 ||
-        A->hints.cluster_patience < -1 || A->hints.cluster_patience > (1 << 30))
+        A->hints.cluster_patience < -1 || A->hints.cluster_patience > (1 << 30) || A->hints.cluster_generation < 0)
         return PF_EINVAL;
     int rc = check_model(&A->model, true);
     if (rc) return rc;

@@ -436,6 +436,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         # no uniform tape: every workgroup draws its column's u (Philox)
         a.z_tape = None if z_tape is None else z_tape.data_ptr() - m * d * b * n * es
         a.u_tape = None if u_tape is None else u_tape.data_ptr() - m * b * es
+        plan.generation = g_ = plan.generation % 0xFFFFF + 1  # (numbered cluster launches: tagged records, no clearing launch)
+        a.hints.cluster_generation = g_
         L.check(plan.run(plan.args_ref, m, 1, 1, L.stream_ptr()), "pf_filter_run")
         if per_step_route:
             plan.chain = (m, x_out, lw_out, x_out._version, lw_out._version, hk)
@@ -679,6 +681,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.anc = anc.data_ptr()
         a.means, a.vars = rows_buf[0].data_ptr(), rows_buf[1].data_ptr()
         a.ll_steps, a.ll_total = ll.data_ptr(), ll[steps].data_ptr()
+        plan.generation = a.hints.cluster_generation = plan.generation % 0xFFFFF + 1
         L.check(L.load().pf_filter_run(C.byref(a), 0, steps, 1, L.stream_ptr()), "pf_filter_run")
         # A column-cluster launch reports through the plan's status word when it could not make progress (include/pf_amd.h:
         # PF_ROUTE_CLUSTER).  ``batch_filter`` looks at it here (one small device -> host read per run); a caller that pipelines
@@ -1087,6 +1090,7 @@ class _SingleStepPlan:
         self._pool = None
         self._pool_next = 0
         self._view_geo = None
+        self.generation = 0  # pf_run_hints.cluster_generation of the latest cluster launch on self.ws (zero-filled: new_workspace)
         self.chain = None  # the resume token: (piece, x_out, lw_out, their versions, hints) of the latest per-step-route online move
 
     _STATS_POOL = 64

@@ -59,6 +59,7 @@ class RunHints:
         h = args.hints
         h.route, h.column_max_n, h.tile_target, h.ancestor_search = self.kernel_route(), self.column_max_n, self.tile_target, self.ancestor_search
         h.cluster_patience = self.cluster_patience
+        h.cluster_generation = 0  # (per launch: the drivers that own a zero-filled workspace number their cluster launches)
         h.resume = h.prepare_next = 0  # (per-call facts, set by the move loops that know them)
 
     def apply_mapping(self, m):
