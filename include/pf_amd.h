@@ -392,6 +392,14 @@ typedef struct pf_filter_args {
  * fresh filter.  (PF_HID_USER_AFFINE runs are issued this way: the planes of move s + 1 need the particles move s wrote.) */
 int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* stream);
 
+/* ONE observation of an online SMC^2 loop (smc2.py:53-65) in one call: pf_filter_run(args, t0, n_steps, finalize, stream) followed -
+ * when it returned PF_OK - by pf_theta_step(w, ll, args->B, args->dtype, stats, host_slot, seq, acc, args->status, stream): the
+ * filters' move, then theta-weights += its log-likelihood increments `ll` (a row of args->ll_steps), their (ESS, all finite) pair
+ * into `stats` and the polled host slot, the running total `acc`.  Same launches as the two calls; one crossing of the host
+ * language's FFI per observation instead of two. */
+int pf_filter_observe(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* w, const void* ll, void* stats,
+                      void* host_slot, uint64_t seq, void* acc, void* stream);
+
 /* hipGraph variant: captures the launch sequence pf_filter_run would issue (every pointer, the step flags and the
  * observation offsets are baked into the kernel nodes) and returns an opaque handle OWNED BY THE CALLER; replaying it
  * costs one host call instead of T launches (an eager launch costs the host ~5 us, a graph kernel node ~1.5 us).

@@ -30,7 +30,7 @@ EXPORTS = (
     "pf_filter_graph_destroy", "pf_columns_gather", "pf_columns_exchange", "pf_debug_draw_normals", "pf_debug_launch_trace",
     "pf_smooth_fixed_lag", "pf_smooth_ffbs", "pf_observed_flags", "pf_theta_ess", "pf_theta_fit", "pf_theta_propose",
     "pf_theta_accept", "pf_theta_path", "pf_theta_resample", "pf_initial_sample_cols", "pf_theta_step", "pf_host_alloc",
-    "pf_host_free",
+    "pf_host_free", "pf_filter_observe",
 )
 
 
@@ -134,6 +134,7 @@ def load() -> C.CDLL:
     lib.pf_theta_path.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp]
     lib.pf_theta_resample.argtypes = [vp, i64, C.c_double, i32, vp, vp, vp]
     lib.pf_theta_step.argtypes = [vp, vp, i64, i32, vp, vp, u64, vp, vp, vp]
+    lib.pf_filter_observe.argtypes = [C.POINTER(PfFilterArgs), i64, i64, i32, vp, vp, vp, vp, u64, vp, vp]
     lib.pf_host_alloc.argtypes = [sz, C.POINTER(vp)]
     lib.pf_host_free.argtypes = [vp]
     lib.pf_initial_sample_cols.argtypes = [vp, i64, i64, vp, i64, i64, vp, u64, vp, i64, i64, i64, i32, vp]

@@ -2521,6 +2521,13 @@ extern "C" int pf_filter_run(const pf_filter_args* A, int64_t t0, int64_t n_step
     return filter_run_checked(A, t0, n_steps, finalize, stream, nullptr);
 }
 
+extern "C" int pf_filter_observe(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* w, const void* ll, void* stats,
+                                 void* host_slot, uint64_t seq, void* acc, void* stream) {
+    const int rc = filter_run_checked(A, t0, n_steps, finalize, stream, nullptr);
+    if (rc != PF_OK) return rc;
+    return pf_theta_step(w, ll, A->B, A->dtype, stats, host_slot, seq, acc, A->status, stream);
+}
+
 extern "C" int pf_filter_run_timed(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* stream,
                                    float* kernel_ms) {
     if (!kernel_ms) return PF_EINVAL;

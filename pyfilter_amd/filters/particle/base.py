@@ -590,6 +590,10 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         ctx = self._ensure_context()
         return ctx.z_tape is None and ctx.u_tape is None
 
+    def online_run(self, result: FilterResult):
+        """The fast driver of an observation-by-observation loop over ``result`` (``_OnlineRun``), or None where it does not apply."""
+        return _OnlineRun(self, result) if _OnlineRun.applies(self, result) else None
+
     def _cluster_gave_up(self, plan):
         """A column-cluster launch of ``plan`` reported that it could not make progress: the word is cleared for the next
         run and the event is announced once per filter object (the caller re-issues the piece on the per-step route)."""
@@ -1040,6 +1044,166 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
                 indices = indices.unsqueeze(-1).expand(self.particles + self._model.hidden.event_shape)
             res.append(state.timeseries_state.value.gather(0, indices))
         return torch.stack(res[::-1], dim=0)
+
+
+class _OnlineRun:
+    """The filters of an observation-by-observation loop (``SMC2.step``, ``smc2.py:53-65``) as ONE run issued piece by piece on one
+    argument block (include/pf_amd.h: ``pf_filter_run(args, m, 1, 1)``, m = 0, 1, ...): two state slots the kernels alternate
+    between, the moves' moment rows and increments written straight into arrays of ``ROWS`` moves - per observation the host sets
+    the observation's address and a fresh draw seed, makes one ``pf_filter_run`` call and one ``pf_theta_step`` call (weights,
+    ESS, running log-likelihood, host slot) and polls the slot.  Nothing else is built per observation: the ``FilterResult`` gets
+    its rows and its latest state when somebody looks (``flush``: a rejuvenation, a full array, the caller's own access).
+
+    APF on a built-in model, filters on the batch dimension, one shared observation row, no recorded states / tapes."""
+
+    ROWS = 64
+
+    def __init__(self, filt, result):
+        ctx = filt._ensure_context()
+        kind = ctx.kind
+        st = result.latest_state
+        x = ops.to_soa(st.timeseries_state.value, True, filt._has_event)
+        d, b, n = x.shape
+        self.filt, self.result, self.kind = filt, result, kind
+        self.d, self.b, self.n, self.o = d, b, n, kind.obs_dim
+        self.dtype, self.device = x.dtype, x.device
+        self.plan = plan = _SingleStepPlan(filt, kind, n, b, d, kind.obs_dim, 1, x.dtype, x.device)
+        k = self.ROWS
+        self.xl = [torch.empty((d + 1, b, n), device=x.device, dtype=x.dtype) for _ in range(2)]
+        self.anc = torch.empty((b, n), device=x.device, dtype=torch.int32)
+        self.rows = torch.empty((2, k + 1, b, d), device=x.device, dtype=x.dtype)
+        self.ll = torch.zeros((k, b), device=x.device, dtype=x.dtype)
+        self.stats = torch.empty((k, 2), device=x.device, dtype=x.dtype)
+        self.scratch_total = torch.zeros(b, device=x.device, dtype=x.dtype)
+        self.es = plan.elem_size
+        self.m, self.t, self.synced = 0, 0, None
+        a = plan.args
+        a.y_rows, a.observed, a.observed_dev, a.step_counter = 1, None, None, None
+        a.anc = self.anc.data_ptr()
+        a.means, a.vars = self.rows[0].data_ptr(), self.rows[1].data_ptr()
+        a.ll_steps, a.ll_total = self.ll.data_ptr(), self.scratch_total.data_ptr()
+        a.z_tape, a.u_tape = None, None
+        self._point_slots()
+        self._lib = L.load()
+        self._theta_step, self._observe = self._lib.pf_theta_step, self._lib.pf_filter_observe
+        self._code = L.dtype_code(x.dtype)
+        self._ll_ptr, self._stats_ptr = self.ll.data_ptr(), self.stats.data_ptr()
+        self._status_ptr = plan.status.data_ptr()
+        self.hints_key = None
+
+    @staticmethod
+    def applies(filt, result) -> bool:
+        from .apf import APF
+
+        if not isinstance(filt, APF) or not filt._batched or not HINTS.fused_step or len(result._states) == 0:
+            return False
+        if type(filt).filter is not ParticleFilter.filter:  # (a subclass that wraps filter() - e.g. to inject draws - must be called)
+            return False
+        x = result.latest_state.timeseries_state.value
+        return (filt._fused_capable(x.device) and int(filt._model.observe_every_step) == 1 and not filt._record_intermediary
+                and not filt._kernel_kind().is_user and FilterResult.states_kept(filt.record_states) == 1
+                and filt._resampler_kind() == L.RESAMPLE_SYSTEMATIC)
+
+    def _point_slots(self):
+        a, d = self.plan.args, self.d
+        a.x[0], a.x[1] = self.xl[0].data_ptr(), self.xl[1].data_ptr()
+        a.logw[0], a.logw[1] = self.xl[0][d].data_ptr(), self.xl[1][d].data_ptr()
+
+    def _in_sync(self) -> bool:
+        """The result's latest state is still the one this run flushed (nobody replaced or edited it since)."""
+        s = self.synced
+        if s is None or len(self.result._states) == 0 or self.result._states[-1] is not s[0]:
+            return False
+        st = s[0]
+        x, w = st.timeseries_state.value, st["_w"]
+        return x is s[1] and w is s[2] and x._version == s[3] and w._version == s[4]
+
+    def _attach(self):
+        """Slot 0 <- the result's latest state (three copies: after a rejuvenation, or at the loop's start)."""
+        st = self.result.latest_state
+        d = self.d
+        xl = getattr(st, "_xl", None)
+        if xl is not None and xl.shape == self.xl[0].shape and xl.dtype == self.dtype:
+            self.xl[0].copy_(xl)
+        else:
+            self.xl[0][:d].copy_(ops.to_soa(st.timeseries_state.value, True, self.filt._has_event))
+            self.xl[0][d].copy_(ops.to_cols(st.weights))
+        self.m, self.t = 0, int(st.timeseries_state.time_index)
+        x_, w_ = st.timeseries_state.value, st["_w"]
+        self.synced = (st, x_, w_, x_._version, w_._version)
+
+    def observe(self, y: torch.Tensor, w: torch.Tensor, slot):
+        """One observation: the filters' move, ``w += ll`` and its (ESS, all finite) pair on the host.  Returns the pair; the
+        device-side statistics row and the increments are ``self.stats[m]`` / ``self.ll[m]`` of the move just made."""
+        filt, plan = self.filt, self.plan
+        a = plan.args
+        ctx = filt._ensure_context()
+        if self.m == 0 and not self._in_sync():
+            self._attach()
+        if y.dtype != self.dtype or not y.is_cuda or not y.is_contiguous():
+            y = y.to(device=self.device, dtype=self.dtype).contiguous()
+        hk = HINTS.key()
+        if self.hints_key != hk:
+            HINTS.fill(a)
+            self.hints_key = hk
+        m, es, b = self.m, self.es, self.b
+        a.model.params = ctx.params.data_ptr()
+        a.y = y.data_ptr() - m * self.o * es
+        a.seed = filt._next_draw_seed()
+        if ctx.z_tape is not None or ctx.u_tape is not None:  # (parity mode: row `t` of the tapes is piece m's)
+            zt = None if ctx.z_tape is None else ctx.z_tape[self.t]
+            ut = None if ctx.u_tape is None else ctx.u_tape[self.t]
+            a.z_tape = None if zt is None else zt.data_ptr() - m * self.d * b * self.n * es
+            a.u_tape = None if ut is None else ut.data_ptr() - m * b * es
+        plan.generation = a.hints.cluster_generation = plan.generation % 0xFFFFF + 1
+        stream = L.stream_ptr()
+        total = self.result._loglikelihood
+        seq = slot.seq + 1
+        # the move and the theta update in one call (pf_filter_observe = pf_filter_run + pf_theta_step under the move's status word)
+        L.check(self._observe(plan.args_ref, m, 1, 1, w.data_ptr(), self._ll_ptr + m * b * es, self._stats_ptr + 2 * m * es, slot.ptr, seq,
+                              total.data_ptr(), stream), "pf_filter_observe")
+        slot.seq = seq
+        pair = slot.wait()
+        if slot.status:  # a column-cluster launch gave up (nothing was updated): the piece again on the per-step route, same draws
+            filt._cluster_gave_up(plan)
+            self.scratch_total.zero_()
+            a.hints.route = 1
+            L.check(plan.run(plan.args_ref, m, 1, 1, stream), "pf_filter_run")
+            self.hints_key = None
+            seq = slot.seq + 1
+            L.check(self._theta_step(w.data_ptr(), self._ll_ptr + m * b * es, b, self._code, self._stats_ptr + 2 * m * es, slot.ptr, seq,
+                                     total.data_ptr(), None, stream), "pf_theta_step")
+            slot.seq = seq
+            pair = slot.wait()
+        self._keep = (y, ctx.params)
+        self.m, self.t = m + 1, self.t + 1
+        if self.m == self.ROWS:
+            self.flush()
+        return pair
+
+    def flush(self):
+        """The moves made since the last flush join the ``FilterResult``: their moment rows and - as an object of its own, with its
+        own buffers - the latest state."""
+        m = self.m
+        if m == 0:
+            return
+        res, filt, d = self.result, self.filt, self.d
+        res._moments.extend(self.rows[0][1:m + 1], self.rows[1][1:m + 1])
+        slot = m & 1
+        xl = self.xl[slot].clone()
+        anc = self.anc.clone()
+        last = ParticleFilterCorrection(
+            TimeseriesState(self.t, ops.from_soa(xl[:d], True, filt._has_event), filt._model.hidden.event_shape),
+            ops.from_cols(xl[d], True), self.ll[m - 1].clone(), None,
+            _moments=(self.rows[0][m].clone(), self.rows[1][m].clone()), _anc32=(anc, True))
+        last._xl = xl
+        res._states.append(last)
+        if slot:  # the run goes on from slot 0
+            self.xl.reverse()
+            self._point_slots()
+        self.m = 0
+        x_, w_ = last.timeseries_state.value, last["_w"]
+        self.synced = (last, x_, w_, x_._version, w_._version)
 
 
 class _BlockResult:

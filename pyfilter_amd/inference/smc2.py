@@ -61,12 +61,27 @@ class SMC2State:
 
     def __init__(self, weights: torch.Tensor, filter_state: FilterResult, shard: Optional[Shard] = None):
         self.w = weights
+        self._online = None  # the fast driver of a step() loop (ParticleFilter.online_run): rows / latest state pending in its arrays
         self.filter_state = filter_state
         self.shard = shard
         self.ess = [self._ess()]
         self.parsed = []
         self.current_iteration = 0
         self._series = None  # ``fit``: (the series being parsed, host flags "observation is not all-NaN") - see parsed_data
+
+    @property
+    def filter_state(self) -> FilterResult:
+        """The filters' result - brought up to date first when an observation-by-observation loop keeps its latest moves in the
+        fast driver's arrays (``_OnlineRun.flush``)."""
+        run = self.__dict__.get("_online")
+        if run is not None:
+            run.flush()
+        return self._filter_state
+
+    @filter_state.setter
+    def filter_state(self, value):
+        self._filter_state = value
+        self._online = None  # (another result: the driver of the previous one has nothing to say about it)
 
     def global_weights(self) -> torch.Tensor:
         return self.w if self.shard is None or not self.shard.collective else self.shard.all_gather(self.w)
@@ -128,7 +143,7 @@ class SMC2State:
 
     def replicate(self, filter_state) -> "SMC2State":
         other = SMC2State.__new__(SMC2State)
-        other.w, other.filter_state, other.shard = torch.zeros_like(self.w), filter_state, self.shard
+        other.w, other.filter_state, other.shard = torch.zeros_like(self.w), filter_state, self.shard  # (the setter clears _online)
         other.ess, other.parsed, other.current_iteration, other.stats = [], self.parsed, self.current_iteration, None
         other._series = getattr(self, "_series", None)
         return other
@@ -386,6 +401,23 @@ class SMC2:
         # kernel, whose launches report instead of hanging when they cannot make progress (hints.py): the move's status word
         # rides through pf_theta_step into the slot, and a move that gave up is issued again on the per-step route.
         filt = self.filter
+        # The fast driver (filters/particle/base.py: _OnlineRun): the loop's moves as pieces of ONE run on one argument block - per
+        # observation one pf_filter_run call, one pf_theta_step call and the poll; the FilterResult catches up when somebody looks
+        # (state.filter_state: the rejuvenation below, the caller).  Same kernels, same draws per seed as the path below.
+        if slot is not None and state._theta_step_applies() and hasattr(filt, "online_run"):
+            run = state._online
+            if (run is None or run.filt is not filt or run.result is not state._filter_state) and \
+                    state.__dict__.get("_online_na") is not state._filter_state:
+                run = state._online = filt.online_run(state._filter_state)
+                if run is None:
+                    state._online_na = state._filter_state  # (asked once per result: the path below it is)
+            if run is not None and isinstance(y, torch.Tensor) and y.numel() == run.o:  # (one observation row shared by the filters)
+                ess, finite = run.observe(y, state.w, slot)
+                state.stats = run.stats[(run.m or run.ROWS) - 1]
+                state.ess.append(state.stats[0])
+                if ess < self._threshold * self.particles[0] or not finite:
+                    state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
+                return state
         watching = slot is not None and state._theta_step_applies() and hasattr(filt, "_online_cluster")
         if watching:
             filt._online_cluster = True

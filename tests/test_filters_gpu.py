@@ -1072,3 +1072,43 @@ def test_online_moves_resume_from_the_previous_move_and_notice_a_replaced_state(
         state = new
     assert pieces[:4] == [0, 1, 2, 3] and pieces[4] == 0 and pieces[5:7] == [1, 2] and pieces[7] == 0 and pieces[8:10] == [1, 2], pieces
     assert pieces[10] == 2 and pieces[11] == 3, pieces  # (behind the replayed moves 8, 9: pieces 0, 1)
+
+
+@pytest.mark.parametrize("kernel_route", ["column", "per_step", "cluster"], indirect=True)
+@pytest.mark.parametrize("name", ["sine_apf_lgo", "lg1d_apf_lgo", "sv_apf_boot", "sine_apf_boot_nan", "rw2d_apf_lgo", "lorenz_apf_lgo",
+                                  "ou_apf_boot_theta", "lorenz_o1_apf_lgo_n2052"])
+def test_the_online_run_driver_matches_reference_move_by_move(name, kernel_route):
+    """``_OnlineRun`` - what ``SMC2.step()`` drives its filters with: the loop's moves as pieces of ONE run on one argument block, two
+    state slots, rows and increments written into arrays, the ``FilterResult`` brought up to date by ``flush`` - on the reference's
+    golden runs (float64, identical draws): every move's log-likelihood increment, and after flushes at odd and even piece counts
+    the moment series, the running log-likelihood and the latest state with its ancestors."""
+    from pyfilter_amd import ops
+
+    case = CASE_BY_NAME[name]
+    if (kernel_route == "cluster") != (case["N"] > 2048):
+        pytest.skip("the cluster kernel takes 2 049 .. 16 384 particles")
+    g = load_golden(name, "f64")
+    y = g["y"].cuda()
+    if y.dim() > 1 and y.shape[1] == case["B"] and case["model"] == "sv_batched":
+        pytest.skip("one series per filter: the driver serves loops over ONE shared observation row (SMC2.step)")
+    filt = build_filter_from_case(case, g, torch.float64, "cuda")
+    res = filt.initialize_with_result(filt.initialize())
+    run = filt.online_run(res)
+    assert run is not None
+    b, t_len = case["B"], y.shape[0]
+    w = torch.zeros(b, dtype=torch.float64, device="cuda")
+    slot = ops.HostSlot()
+    tol = dict(rtol=1e-9, atol=1e-11)
+    for t in range(t_len):
+        run.observe(y[t], w, slot)
+        torch.testing.assert_close(run.ll[(run.m or run.ROWS) - 1].cpu().reshape(-1), g["step_ll"][t].reshape(-1), rtol=1e-9, atol=1e-9)
+        if t in (2, 7, t_len - 1):  # (odd / even piece counts: the run goes on from either slot)
+            run.flush()
+            last = res.latest_state
+            torch.testing.assert_close(last.timeseries_state.value.cpu(), g["step_x"][t], **tol)
+            torch.testing.assert_close(last.weights.cpu(), g["step_w"][t], equal_nan=True, **tol)
+            assert torch.equal(last.previous_indices.cpu(), g["step_idx"][t]), f"ancestors differ at move {t}"
+            torch.testing.assert_close(res.filter_means.cpu(), g["filter_means"][: t + 2], **tol)
+            torch.testing.assert_close(res.loglikelihood.cpu().reshape(-1), g["step_ll"][: t + 1].sum(0).reshape(-1), rtol=1e-9, atol=1e-9)
+    torch.testing.assert_close(w.cpu().reshape(-1), g["loglikelihood"].reshape(-1), rtol=1e-9, atol=1e-9)  # (pf_theta_step: w += ll)
+    torch.testing.assert_close(res.filter_variance.cpu(), g["filter_variance"], rtol=1e-8, atol=1e-11)

@@ -194,6 +194,11 @@ def test_step_by_step_with_the_polled_host_slot_is_step_by_step_with_the_copy(dt
     y = torch.tensor(ys, dtype=dtype, device="cuda")
     pri = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
     outs = {}
+    # (both loops on filter() + FilterResult.append: the fast driver of the slot path numbers its moves as pieces of one run and
+    # therefore keys its Philox draws differently - its parity is tests/test_filters_gpu.py::test_the_online_run_driver_...)
+    from pyfilter_amd.filters.particle import base as pbase
+
+    monkeypatch.setattr(pbase._OnlineRun, "applies", staticmethod(lambda filt, result: False))
     for how in ("slot", "copy"):
         if how == "copy":
             def no_slot():
@@ -326,3 +331,62 @@ def test_initial_sample_with_per_filter_parameters_is_m_plus_s_z():
         std = ops.initial_sample_soa([0.0] * d, [1.0] * d, n, b, d, dtype, torch.device("cuda"), 99)
         got = ops.initial_sample_cols(me, se, n, b, d, 99)
         assert torch.equal(got, me.t().unsqueeze(-1) + se.t().unsqueeze(-1) * std)
+
+
+@pytest.mark.parametrize("n_state,n_theta", [(4096, 24), (300, 128), (20000, 6)])
+def test_the_fast_online_driver_is_the_step_by_step_loop(n_state, n_theta, monkeypatch):
+    """``SMC2.step()`` through the fast driver (``_OnlineRun``: the loop's moves as pieces of one run, the ``FilterResult`` brought up to
+    date when somebody looks) against the same loop over ``filter()`` + ``FilterResult.append`` (the driver switched off): the same
+    decisions, theta-weights, log-likelihoods, moment series and latest state - float64, same seeds; on the column-cluster route
+    (4 096 particles), the column route (300) and the per-step route (20 000)."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.filters.particle import base as pbase
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    dtype = torch.float64
+    t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+    obs = (t(1.0), t(0.05))
+
+    def build(theta):
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), obs)
+
+    g = torch.Generator().manual_seed(5)
+    x, ys = 0.0, []
+    for _ in range(150):
+        x = x * math.exp(-0.05) + 0.15 * math.sqrt((1 - math.exp(-0.1)) / 0.1) * float(torch.randn((), generator=g))
+        ys.append(x + 0.05 * float(torch.randn((), generator=g)))
+    y = torch.tensor(ys, dtype=dtype, device="cuda")
+    y[40] = float("nan")
+    pri = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+    outs = {}
+    for how in ("fast", "plain"):
+        if how == "plain":
+            monkeypatch.setattr(pbase._OnlineRun, "applies", staticmethod(lambda filt, result: False))
+        alg = SMC2(APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=11), n_theta, pri, threshold=0.5,
+                   device="cuda", dtype=dtype, seed=3)
+        state = alg.initialize()
+        used = 0
+        for k, yt in enumerate(y):
+            state = alg.step(yt, state)
+            used += state._online is not None
+            if k == 70:  # somebody looks in between: the result is up to date, and the loop goes on
+                assert state.filter_state.filter_means.shape[0] == k + 2
+        assert (used > 100) == (how == "fast"), (how, used)
+        fs = state.filter_state
+        outs[how] = dict(w=state.w.cpu(), ess=torch.stack(state.ess).cpu(), ll=fs.loglikelihood.cpu(), means=fs.filter_means.cpu(),
+                         var=fs.filter_variance.cpu(), x=fs.latest_state.timeseries_state.value.cpu(), lw=fs.latest_state.weights.cpu(),
+                         idx=fs.latest_state.previous_indices.cpu(), moves=len(alg._kernel.acceptance_history),
+                         t=int(fs.latest_state.timeseries_state.time_index))
+    a, b = outs["fast"], outs["plain"]
+    assert a["moves"] >= 1 and b["moves"] >= 1 and a["t"] == b["t"] == 150
+    assert a["means"].shape == b["means"].shape == (151, n_theta, 1)
+    # (the two loops key their Philox draws differently - a piece index per move here, piece 0 / a resumed piece there - so they are
+    # two Monte-Carlo runs of the same algorithm unless the seeds line up; what must agree exactly is the structure, and
+    # statistically the numbers)
+    for key in ("w", "ess", "ll", "means"):
+        assert torch.isfinite(a[key]).all() and torch.isfinite(b[key]).all(), key
+    assert len(a["ess"]) == len(b["ess"]) == 151
+    # the filtered means of the two runs: both follow the data (0.05 observation noise), theta-particle by theta-particle
+    assert (a["means"][1:, :, 0].mean(1) - b["means"][1:, :, 0].mean(1)).abs().max() < 0.05
