@@ -16,6 +16,11 @@ from ..state import Correction, Prediction
 from .utils import get_filter_mean_and_variance
 
 
+def _rows_mask(mask: Tensor, like: Tensor) -> Tensor:
+    """``mask (B,)`` shaped to select whole rows of ``like (B, ...)``."""
+    return mask.reshape(mask.shape + (1,) * (like.dim() - mask.dim()))
+
+
 def _masked_assign(dst: Tensor, src: Tensor, mask: Tensor):
     """``dst[mask] = src[mask]`` along dim 0, in place.  A boolean mask of the right length goes through ``torch.where`` -
     indexing with it would first count its set entries on the host (a device round trip per call; PMMH does this for every
@@ -221,8 +226,15 @@ class ParticleFilterCorrection(Correction):
             dict.pop(self, "_prev_inds", None)
         else:
             self["_prev_inds"] = ops.exchange_filters(self["_prev_inds"], other.previous_indices, mask)
-        _masked_assign(self["_mean"], other["_mean"], mask)
-        _masked_assign(self["_var"], other["_var"], mask)
+        # (NEW tensors, not writes into the old ones: a FilterResult's moment log may still remember this state's rows by
+        # reference - MomentLog.append - and its history must not change with the state)
+        for k in ("_mean", "_var"):
+            if mask.dtype == torch.bool and mask.dim() == 1 and self[k].shape == other[k].shape:
+                self[k] = torch.where(_rows_mask(mask, self[k]), other[k], self[k])
+            else:
+                fresh = self[k].clone()
+                fresh[mask] = other[k][mask]
+                self[k] = fresh
 
     def state_dict(self) -> Dict[str, Any]:
         self._ensure_moments()

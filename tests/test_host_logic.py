@@ -574,3 +574,4 @@ def test_moment_log_remembers_single_rows_and_writes_them_when_somebody_looks(ma
     assert log.rows == len(ref)
     assert torch.equal(log.means(), torch.stack([m for m, _ in ref]))
     assert torch.equal(log.variances(), torch.stack([v for _, v in ref]))
+
