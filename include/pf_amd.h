@@ -395,8 +395,9 @@ int pf_filter_run(const pf_filter_args* args, int64_t t0, int64_t n_steps, int f
 /* ONE observation of an online SMC^2 loop (smc2.py:53-65) in one call: pf_filter_run(args, t0, n_steps, finalize, stream) followed -
  * when it returned PF_OK - by pf_theta_step(w, ll, args->B, args->dtype, stats, host_slot, seq, acc, args->status, stream): the
  * filters' move, then theta-weights += its log-likelihood increments `ll` (a row of args->ll_steps), their (ESS, all finite) pair
- * into `stats` and the polled host slot, the running total `acc`.  Same launches as the two calls; one crossing of the host
- * language's FFI per observation instead of two. */
+ * into `stats` and the polled host slot, the running total `acc`.  `ll` must be the row of args->ll_steps the run's LAST step
+ * writes.  The same results as the two calls; one crossing of the host language's FFI per observation instead of two - and on the
+ * column-cluster route ONE launch: the last filter to finish does the theta update inside the run's kernel. */
 int pf_filter_observe(const pf_filter_args* args, int64_t t0, int64_t n_steps, int finalize, void* w, const void* ll, void* stats,
                       void* host_slot, uint64_t seq, void* acc, void* stream);
 

@@ -62,6 +62,20 @@ namespace pf {
 #endif
 #define PFK_FOLD (16 + 3 * 64)  // scalars | per chunk: inclusive prefix, exclusive prefix, factor
 
+// pf_filter_observe: the theta update of an SMC^2 observation (pf_theta_step: w += ll, the running total, the (ESS, all finite) pair
+// on the device and in the polled host slot) folded into the run's tail - every column's bookkeeper writes its increment through and
+// counts itself in; member 0 of the LAST column to arrive does the update for all B columns.  One launch per observation.
+struct ClusterTheta {
+    int enabled;
+    void* w;           // (B) theta log-weights, updated in place
+    const void* ll;    // (B) the row of pf_filter_args.ll_steps the run's LAST step writes
+    void* stats;       // (2)
+    double* slot;      // pf_host_alloc memory or null: {ESS, all finite, seq, status}
+    unsigned long long seq;
+    void* acc;         // (B) running log-likelihood or null
+    unsigned* arrive;  // columns whose bookkeeper is done (workspace; left at zero)
+};
+
 struct ClusterRun {
     unsigned char* rec;  // granule records of this launch's columns: [2 (state parity)][nb][NG][64] x 16 B
     int b0, nb, nbp;     // first column, columns of this launch, nb rounded up to a multiple of 8 (grid = nbp * c)
@@ -70,6 +84,7 @@ struct ClusterRun {
     int* err;            // |= 1: a poll ran out of patience, |= 2: an ancestor fell outside the staged chunks
     int* status;         // pf_filter_args.status (or null): the same bits, never cleared by the library
     int patience;        // polls of one wait before a member gives up
+    ClusterTheta th;
     unsigned tag_base;   // the record of state s carries tag_base + s + 1.  0: the records were cleared for this launch.  Else the
                          // caller numbers its launches on this workspace (pf_run_hints.cluster_generation) and tag_base =
                          // generation * 4096: records of earlier launches never match, nothing is cleared
@@ -716,7 +731,8 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
                 ll = lse_w - base_prev;
                 if (f.poison_w || prepoison_prev) ll = __builtin_nan("");
             }
-            a.ll_steps[(int64_t)(q_out - 1) * g.B + b] = (T)ll;
+            if (cr.th.enabled) st1_sc1<T>(a.ll_steps, (int)((int64_t)(q_out - 1) * g.B + b), (T)ll);  // (read by another column's workgroup)
+            else a.ll_steps[(int64_t)(q_out - 1) * g.B + b] = (T)ll;
             ll_tot = (T)((double)ll_tot + ll);
             if (dead || *(volatile int*)cr.err) ll_tot = (T)__builtin_nan("");
             a.ll_total[b] = ll_tot;
@@ -726,6 +742,47 @@ __global__ __launch_bounds__(PFK_TPB, (sizeof(T) == 4 && D == 1) ? (VEC == 4 ? 4
             a.stat[b] = st;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) a.poison[qq * g.B + b] = 0;
+        }
+        if (cr.th.enabled) {
+            int* const lastf = reinterpret_cast<int*>(pfk_lds);  // (the window planes are free: every reader passed the fold's barrier)
+            if (book) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the increment has left before the arrival can be seen
+                const unsigned old = __hip_atomic_fetch_add(cr.th.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *lastf = (old == (unsigned)g.B - 1u) ? 1 : 0;
+            }
+            __syncthreads();
+            if (*lastf) {
+                __syncthreads();
+                const int B = g.B;
+                T* const w = reinterpret_cast<T*>(cr.th.w);
+                T* const acc = reinterpret_cast<T*>(cr.th.acc);
+                const T* const llr = reinterpret_cast<const T*>(cr.th.ll);
+                T* const stats = reinterpret_cast<T*>(cr.th.stats);
+                T* const redm = reinterpret_cast<T*>(pfk_lds + 64);
+                double* const red = reinterpret_cast<double*>(pfk_lds + 128);
+                const int err = __hip_atomic_load(cr.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (err == 0) {  // (pf_theta_step's arithmetic: k_theta_path, row 0)
+                    for (int i = tid; i < B; i += PFK_TPB) {
+                        const T v = ld1_sc1<T>(llr, i);
+                        w[i] = w[i] + v;
+                        if (acc) acc[i] = acc[i] + v;
+                    }
+                    theta_ess_row<T>(w, (int64_t)B, stats, redm, red);
+                } else if (tid == 0) {  // a launch that gave up: nothing is updated, the slot says so
+                    stats[0] = T(__builtin_nan(""));
+                    stats[1] = T(0);
+                }
+                if (tid == 0) {
+                    __hip_atomic_store(cr.th.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (cr.th.slot != nullptr) {
+                        cr.th.slot[0] = err == 0 ? (double)stats[0] : __builtin_nan("");
+                        cr.th.slot[1] = err == 0 ? (double)stats[1] : 0.0;
+                        reinterpret_cast<unsigned long long*>(cr.th.slot)[3] = (unsigned long long)(unsigned)err;
+                        __threadfence_system();
+                        __hip_atomic_store((unsigned long long*)(cr.th.slot + 2), cr.th.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
         }
     }
 }

@@ -346,6 +346,20 @@ __device__ __forceinline__ void st16_sc1(void* base, int byte_off, pf_u4 v) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
     __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, byte_off, 0, /*sc1*/ 16);
 }
+// one element written through to the memory side (a scalar `sc1` store is one fabric write: for single values only)
+template <typename T> __device__ __forceinline__ void st1_sc1(T* base, int elem, T v) {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+    if constexpr (sizeof(T) == 4) {
+        unsigned w;
+        __builtin_memcpy(&w, &v, 4);
+        __builtin_amdgcn_raw_buffer_store_b32(w, rsrc, elem * 4, 0, /*sc1*/ 16);
+    } else {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        u2 w;
+        __builtin_memcpy(&w, &v, 8);
+        __builtin_amdgcn_raw_buffer_store_b64(w, rsrc, elem * 8, 0, /*sc1*/ 16);
+    }
+}
 // one element of a plane another workgroup wrote with write-through stores (L1 bypassed); `base` wave-uniform
 template <typename T> __device__ __forceinline__ T ld1_sc1(const T* base, int elem) {
     const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, 0x7FFFFFFF, 0x00020000);

@@ -1199,6 +1199,21 @@ __global__ __launch_bounds__(PF_BLOCK) void k_ffbs(ModelDesc md, const T* __rest
 #include "pf_column.hpp"
 #include "pf_cluster.hpp"
 
+namespace pf {
+// pf_filter_observe -> the route that carries the run: what the theta update needs, for the length of that one call on that one
+// thread (the cluster route folds it into its launch and says so; every other route leaves it to a pf_theta_step launch)
+struct ThetaFold {
+    void* w;
+    const void* ll;
+    void* stats;
+    void* slot;
+    uint64_t seq;
+    void* acc;
+    int folded;
+};
+extern thread_local ThetaFold* tls_theta_fold;
+}  // namespace pf
+
 // =================================================================================================================
 // C ABI
 // =================================================================================================================
@@ -1263,6 +1278,7 @@ static inline ModelDesc to_desc(const pf_model* m) {
 #endif
 #define PF_STR2(x) #x
 #define PF_STR(x) PF_STR2(x)
+namespace pf { thread_local ThetaFold* tls_theta_fold = nullptr; }
 extern "C" const char* pf_version(void) { return "pfamd 0.2.0 (gfx950) abi " PF_STR(PF_ABI_VERSION) " src:" PF_SOURCE_SHA256; }
 extern "C" int pf_abi_version(void) { return PF_ABI_VERSION; }
 
@@ -2399,6 +2415,20 @@ static int cluster_run_impl(const pf_filter_args* A, const Geom& g, const WsLayo
                 cr.tag_base = numbered ? (unsigned)(A->hints.cluster_generation & 0xFFFFF) * 4096u : 0u;
                 cr.patience = A->hints.cluster_patience != 0 ? A->hints.cluster_patience : PFK_SPIN_LIMIT;
                 cr.spread = A->hints.route == PF_ROUTE_CLUSTER_SPREAD ? 1 : 0;
+                cr.th = ClusterTheta{};
+                if (tls_theta_fold != nullptr && g.B <= per_launch && done + r.n_steps == n_steps && done == 0) {
+                    // (one launch carries the whole run and every column: its last column to finish does the theta update)
+                    ThetaFold* tf = tls_theta_fold;
+                    cr.th.enabled = 1;
+                    cr.th.w = tf->w;
+                    cr.th.ll = tf->ll;
+                    cr.th.stats = tf->stats;
+                    cr.th.slot = (double*)tf->slot;
+                    cr.th.seq = (unsigned long long)tf->seq;
+                    cr.th.acc = tf->acc;
+                    cr.th.arrive = (unsigned*)clu + 16;
+                    tf->folded = 1;
+                }
                 cr.rec = clu + 256 + (size_t)b0 * 2 * PF_CLUSTER_NG * 64 * 16;  // (this group's [2][nb][NG][64] block)
                 hipLaunchKernelGGL(kernel, dim3((unsigned)(cr.nbp * c)), dim3(PFK_TPB), lds, st, a, r, cr);
             }
@@ -2523,8 +2553,13 @@ extern "C" int pf_filter_run(const pf_filter_args* A, int64_t t0, int64_t n_step
 
 extern "C" int pf_filter_observe(const pf_filter_args* A, int64_t t0, int64_t n_steps, int finalize, void* w, const void* ll, void* stats,
                                  void* host_slot, uint64_t seq, void* acc, void* stream) {
+    if (!A || !w || !ll || !stats || ((uintptr_t)host_slot & 7) != 0) return PF_EINVAL;
+    ThetaFold tf{w, ll, stats, host_slot, seq, acc, 0};
+    tls_theta_fold = &tf;
     const int rc = filter_run_checked(A, t0, n_steps, finalize, stream, nullptr);
+    tls_theta_fold = nullptr;
     if (rc != PF_OK) return rc;
+    if (tf.folded) return PF_OK;  // (the column-cluster launch did the update itself)
     return pf_theta_step(w, ll, A->B, A->dtype, stats, host_slot, seq, acc, A->status, stream);
 }
 
