@@ -28,7 +28,7 @@ namespace pf {
 struct ColumnRun {
     int t0, n_steps;
     int use_bits;                      // 1: obs_bits (the host's flags, baked into the launch); 0: FusedArgs::obs_dev[t]
-    int inline_y;                      // (cluster kernel, one-step runs on a shared observation row, use_bits == 0) the flag is read off
+    int inline_y;                      // (one-step runs on a shared observation row, use_bits == 0) the flag is read off
                                        // y[t0] itself - "not all-NaN" of its <= 3 values - instead of a byte a launch of its own derived
     uint32_t obs_bits[PFC_OBS_WORDS];  // bit s = step t0 + s weighs against y[t0 + s]
 };
@@ -334,7 +334,14 @@ __global__ __launch_bounds__(TPB) void k_fused_column(FusedArgs<T> a, ColumnRun 
 #pragma unroll
         for (int o = 0; o < ColParams<T, D>::MAXO; ++o) y_nx[o] = yr[o < O ? o : 0];
         if (a.u_tape) u_nx = a.u_tape[(int64_t)t * g.B + b];
-        if (!run.use_bits) flag_nx = a.obs_dev[t];
+        if (run.inline_y) {  // (one-step run on a shared row: "not all-NaN" read off the row itself)
+            bool any = false;
+#pragma unroll
+            for (int o = 0; o < ColParams<T, D>::MAXO; ++o) any = any || (o < O && !(y_nx[o] != y_nx[o]));
+            flag_nx = any ? 1 : 0;
+        } else if (!run.use_bits) {
+            flag_nx = a.obs_dev[t];
+        }
     };
     request_inputs(0);
     uint32_t bits = 0u;

@@ -2107,8 +2107,9 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
     const size_t lds = column_lds_bytes(A->N, D, sizeof(T), VEC);
     // observed flags: the host's (baked into the launch arguments), the caller's device array, or derived from y here
     const bool auto_flags = !A->observed && !A->observed_dev;
+    const bool inline_y = auto_flags && n_steps == 1 && A->y_rows == 1;  // (the online move: the kernel looks at y itself)
     a.obs_dev = A->observed_dev;
-    if (auto_flags) {
+    if (auto_flags && !inline_y) {
         uint8_t* fl = (uint8_t*)A->ws + wl.off_ctr + 64;
         const int64_t row = A->y_rows * (int64_t)A->model.obs_dim;
         hipLaunchKernelGGL((k_observed_flags<T>), dim3((unsigned)n_steps), dim3(PF_WAVE), 0, st, (const T*)A->y + t0 * row, row, fl);
@@ -2124,8 +2125,8 @@ static int column_run_impl(const pf_filter_args* A, const Geom& g, const WsLayou
         ColumnRun r;
         r.t0 = (int)(t0 + done);
         r.n_steps = (int)((n_steps - done < 32 * PFC_OBS_WORDS) ? n_steps - done : 32 * PFC_OBS_WORDS);
-        r.use_bits = (a.obs_dev == nullptr) ? 1 : 0;
-        r.inline_y = 0;
+        r.use_bits = (a.obs_dev == nullptr && !inline_y) ? 1 : 0;
+        r.inline_y = inline_y ? 1 : 0;
         for (int w = 0; w < PFC_OBS_WORDS; ++w) r.obs_bits[w] = 0u;
         if (r.use_bits)
             for (int q = 0; q < r.n_steps; ++q)

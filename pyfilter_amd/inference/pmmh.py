@@ -156,8 +156,10 @@ def _refilter(proposal_filter, y, stats):
     if stats is None or not hasattr(proposal_filter, "_cluster_gave_up"):
         return proposal_filter.batch_filter(y, bar=False)
     proposal_filter._defer_status_once = True
-    res = proposal_filter.batch_filter(y, bar=False)
-    proposal_filter._defer_status_once = False  # (a subclass that does not pass through ParticleFilter.batch_filter)
+    try:
+        res = proposal_filter.batch_filter(y, bar=False)
+    finally:
+        proposal_filter._defer_status_once = False  # (a subclass that does not pass through ParticleFilter.batch_filter; an error)
     watch = getattr(res, "_cluster_watch", None)
     if watch is not None:
         stats.setdefault("cluster_watch", []).append((watch[0], watch[1], proposal_filter))

@@ -83,6 +83,16 @@ class SMC2State:
         self._filter_state = value
         self._online = None  # (another result: the driver of the previous one has nothing to say about it)
 
+    def __getstate__(self):
+        """Copies / pickles carry the result, not the driver's launch arguments (raw device addresses of this process)."""
+        state = dict(self.__dict__)
+        run = state.pop("_online", None)
+        if run is not None:
+            run.flush()
+        state["_online"] = None
+        state.pop("_online_na", None)
+        return state
+
     def global_weights(self) -> torch.Tensor:
         return self.w if self.shard is None or not self.shard.collective else self.shard.all_gather(self.w)
 

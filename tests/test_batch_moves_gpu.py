@@ -372,7 +372,7 @@ def test_a_remembered_moment_row_does_not_change_with_the_state():
     def state(v):
         x = torch.full((5, 3), float(v), device="cuda")
         return ParticleFilterCorrection(TimeseriesState(0, x, torch.Size([])), torch.zeros(5, 3, device="cuda"), torch.zeros(3, device="cuda"),
-                                        torch.arange(5, device="cuda").unsqueeze(-1).expand(5, 3),
+                                        torch.arange(5, device="cuda").unsqueeze(-1).expand(5, 3).contiguous(),
                                         _moments=(torch.full((3, 1), float(v), device="cuda"), torch.full((3, 1), 0.5 * v, device="cuda")))
 
     a, b = state(1.0), state(2.0)
