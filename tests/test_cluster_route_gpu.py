@@ -414,3 +414,36 @@ def test_smc2_survives_cluster_launches_that_give_up(monkeypatch):
         torch.testing.assert_close(torch.stack(got.ess), torch.stack(ref.ess), rtol=1e-8, atol=1e-8, msg=how)
         torch.testing.assert_close(got.w, ref.w, rtol=1e-8, atol=1e-8, msg=how)
         torch.testing.assert_close(got.filter_state.loglikelihood, ref.filter_state.loglikelihood, rtol=1e-8, atol=1e-8, msg=how)
+
+
+def test_four_streams_of_cluster_launches_from_one_thread():
+    """Four HIP streams, one host thread: twelve cluster launches (filters of different sizes, each launch sized to the chip's resident
+    slots) issued round robin without waiting - whatever the hardware interleaves, the grouped workgroup ids keep whole filters
+    resident: every run finite, equal to the same filter run alone, nothing gives up."""
+    from pyfilter_amd.hints import HINTS
+
+    assert HINTS.kernel_route() == 3
+    g = torch.Generator().manual_seed(29)
+    y = (0.1 * torch.randn(60, generator=g)).cumsum(0).to(DEV)
+    shapes = [(128, 8192), (200, 4096), (64, 16384), (256, 4100)]
+    alone = []
+    for i, (b, n) in enumerate(shapes):
+        f = _concurrent_filter(70 + i, b=b, n=n)
+        alone.append(f.batch_filter(y, bar=False).loglikelihood.cpu())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in shapes]
+    filters = [_concurrent_filter(70 + i, b=b, n=n) for i, (b, n) in enumerate(shapes)]
+    outs = [[] for _ in shapes]
+    for rep in range(3):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                filters[i]._defer_status_once = True  # (no wait between the launches: the status words are read at the end)
+                outs[i].append(filters[i].batch_filter(y, bar=False))
+    torch.cuda.synchronize()
+    for i in range(len(shapes)):
+        assert getattr(filters[i], "cluster_fallbacks", 0) == 0
+        for r in outs[i]:
+            watch = getattr(r, "_cluster_watch", None)
+            assert watch is not None and int(watch[0].item()) == 0, "a launch gave up"
+            assert torch.isfinite(r.loglikelihood).all()
+        assert torch.equal(outs[i][0].loglikelihood.cpu(), alone[i]), shapes[i]
