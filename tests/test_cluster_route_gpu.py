@@ -447,3 +447,45 @@ def test_four_streams_of_cluster_launches_from_one_thread():
             assert watch is not None and int(watch[0].item()) == 0, "a launch gave up"
             assert torch.isfinite(r.loglikelihood).all()
         assert torch.equal(outs[i][0].loglikelihood.cpu(), alone[i]), shapes[i]
+
+
+def _process_worker(rank, barrier, out_dir, seed):
+    import os
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    g = torch.Generator().manual_seed(17)
+    y = (0.1 * torch.randn(200, generator=g)).cumsum(0).to(DEV)
+    f = _concurrent_filter(seed + rank)
+    f.batch_filter(y[:4], bar=False)  # (load the library, build the plan)
+    torch.cuda.synchronize()
+    f = _concurrent_filter(seed + rank)
+    barrier.wait()
+    reps = [f.batch_filter(y, bar=False).loglikelihood.cpu() for _ in range(3)]
+    torch.cuda.synchronize()
+    torch.save({"ll": reps, "fallbacks": getattr(f, "cluster_fallbacks", 0)}, os.path.join(out_dir, f"r{rank}.pt"))
+
+
+def test_two_processes_share_the_gpu_on_the_cluster_route(tmp_path):
+    """Two PROCESSES on the one GPU, each filtering 128 x 8 192 x T = 200 on the default hints at the same time - two tenants whose
+    cluster launches each fill the chip's resident slots and know nothing of each other (the residency query cannot): both finish,
+    finite, equal to the same filters run alone, without a fallback."""
+    import torch.multiprocessing as mp
+
+    g = torch.Generator().manual_seed(17)
+    y = (0.1 * torch.randn(200, generator=g)).cumsum(0).to(DEV)
+    alone = [_concurrent_filter(90 + r).batch_filter(y, bar=False).loglikelihood.cpu() for r in range(2)]
+    torch.cuda.synchronize()
+    ctx = mp.get_context("spawn")
+    barrier = ctx.Barrier(2)
+    procs = [ctx.Process(target=_process_worker, args=(r, barrier, str(tmp_path), 90)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    for r in range(2):
+        got = torch.load(str(tmp_path / f"r{r}.pt"))
+        assert got["fallbacks"] == 0
+        for ll in got["ll"]:
+            assert torch.isfinite(ll).all()
+        assert torch.equal(got["ll"][0], alone[r])
