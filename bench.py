@@ -131,7 +131,7 @@ def run_smc2(w, dtype, device, world, rank, steps, warmup, t_override=None, solo
     elapsed = time.perf_counter() - t0
     info = {"rejuvenations": len(alg._kernel.acceptance_history), "particle_increases": alg._kernel._increases,
             "state_particles_at_end": int(alg.filter.particles[0]), "posterior_mean": alg.posterior_mean(state).tolist(),
-            "theta_per_rank": alg.shard.local, "T": t_len}
+            "theta_per_rank": alg.shard.local, "T": t_len, "block": alg._block}
     return elapsed, info, state.global_weights()
 
 
@@ -282,7 +282,7 @@ def smc2_line(args, dtype, device, world, rank, scaling, attach=False):
         "dtype": args.dtype, "data": "synthetic", "world_size": world,
         "rccl_version": _rccl_version(world),
         "config": {"workload": f"smc2: SMC^2, APF + lgo, {w['B']} theta-particles (sharded {info['theta_per_rank']} per GPU) x "
-                               f"{w['N']} state particles, T={info['T']}, theta-weights all-gathered per block of 16 observations",
+                               f"{w['N']} state particles, T={info['T']}, theta-weights all-gathered per block of {info.get('block', 16)} observations",
                    "parallelism": f"theta-particles block-sharded over {world} GPU(s)", **info},
         "single_gpu_same_workload": solo, "roofline": roof, "cpu_baseline": cpu}
     if cpu:

@@ -365,7 +365,11 @@ class SMC2:
         # should hold about that much device time: 32 moves of a few hundred thousand particles (1 000 theta x 400: 5 us per
         # move), 16 of more (128 x 8 192: 12 us per move; profiles/r04_smc2_block_sweep.txt)
         if block is None:
-            block = 32 if self.shard.local * int(filter_.particles[0]) < (3 << 18) else 16
+            work = self.shard.local * int(filter_.particles[0])
+            # (2^23 particles and more - 1 024 theta x 8 192 on one GPU: a move is ~53 us of kernel, and what a rejuvenation inside a
+            # block costs - the cut replay, the dropped speculative successor - outweighs the host time a longer block saves:
+            # tools/smc2_timeline.py, 8: 53.5 ms, 16: 56.7, 32: 62.4)
+            block = 32 if work < (3 << 18) else (16 if work < (1 << 23) else 8)
         self._block = max(1, int(block))
         self._kernel = ParticleMetropolisHastings(proposal=kernel, max_increases=max_increases, **kwargs)
         self._gen = torch.Generator().manual_seed(seed)  # CPU: the same stream on every rank (theta-level draws)
