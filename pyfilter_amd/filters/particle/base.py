@@ -1201,6 +1201,9 @@ class _OnlineRun:
         if slot:  # the run goes on from slot 0
             self.xl.reverse()
             self._point_slots()
+        # (the caller keeps VIEWS of the statistics rows - SMC2State.ess -: a used array is replaced, never rewritten)
+        self.stats = torch.empty_like(self.stats)
+        self._stats_ptr = self.stats.data_ptr()
         self.m = 0
         x_, w_ = last.timeseries_state.value, last["_w"]
         self.synced = (last, x_, w_, x_._version, w_._version)

@@ -367,13 +367,16 @@ def test_the_fast_online_driver_is_the_step_by_step_loop(n_state, n_theta, monke
         alg = SMC2(APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=11), n_theta, pri, threshold=0.5,
                    device="cuda", dtype=dtype, seed=3)
         state = alg.initialize()
-        used = 0
+        used, seen = 0, []
         for k, yt in enumerate(y):
             state = alg.step(yt, state)
             used += state._online is not None
+            seen.append(float(state.ess[-1]))
             if k == 70:  # somebody looks in between: the result is up to date, and the loop goes on
                 assert state.filter_state.filter_means.shape[0] == k + 2
         assert (used > 100) == (how == "fast"), (how, used)
+        # (the ESS history holds what each observation reported - not a later observation's row of a reused statistics array)
+        assert [float(e) for e in state.ess[1:]] == seen
         fs = state.filter_state
         outs[how] = dict(w=state.w.cpu(), ess=torch.stack(state.ess).cpu(), ll=fs.loglikelihood.cpu(), means=fs.filter_means.cpu(),
                          var=fs.filter_variance.cpu(), x=fs.latest_state.timeseries_state.value.cpu(), lw=fs.latest_state.weights.cpu(),
