@@ -1134,7 +1134,7 @@ class _OnlineRun:
 
     def observe(self, y: torch.Tensor, w: torch.Tensor, slot):
         """One observation: the filters' move, ``w += ll`` and its (ESS, all finite) pair on the host.  Returns the pair; the
-        device-side statistics row and the increments are ``self.stats[m]`` / ``self.ll[m]`` of the move just made."""
+        device-side statistics row of the move just made is ``self.last_stats`` (array, row)."""
         filt, plan = self.filt, self.plan
         a = plan.args
         ctx = filt._ensure_context()
@@ -1176,6 +1176,7 @@ class _OnlineRun:
             slot.seq = seq
             pair = slot.wait()
         self._keep = (y, ctx.params)
+        self.last_stats = (self.stats, m)  # (the move's statistics row: a flush replaces self.stats)
         self.m, self.t = m + 1, self.t + 1
         if self.m == self.ROWS:
             self.flush()

@@ -427,7 +427,8 @@ class SMC2:
                     state._online_na = state._filter_state  # (asked once per result: the path below it is)
             if run is not None and isinstance(y, torch.Tensor) and y.numel() == run.o:  # (one observation row shared by the filters)
                 ess, finite = run.observe(y, state.w, slot)
-                state.stats = run.stats[(run.m or run.ROWS) - 1]
+                stats, row = run.last_stats
+                state.stats = stats[row]
                 state.ess.append(state.stats[0])
                 if ess < self._threshold * self.particles[0] or not finite:
                     state = self._kernel.update(self.theta, self.filter, state, generator=self._gen)
