@@ -376,7 +376,8 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         # that reads the move's status word with the next thing it waits for: SMC2.step() (``_online_cluster``; the word travels
         # through pf_theta_step into the host slot it polls).  Everybody else's moves of that size stay on the per-step route.
         verified = self._online_cluster and HINTS.kernel_route() == 3 and HINTS.cluster_takes(n, b, rs_kind == L.RESAMPLE_SYSTEMATIC)
-        hk = (HINTS.key(), verified)
+        stream = L.stream_ptr()
+        hk = (HINTS.key(), verified, stream)  # (the stream: a resumed piece relies on stream order behind the previous one)
         if plan.hints_key != hk or a.hints.prepare_next:
             HINTS.fill(a)
             if a.hints.route == 3 and not verified:
@@ -438,7 +439,7 @@ class ParticleFilter(BaseFilter[ParticleFilterCorrection, ParticleFilterPredicti
         a.u_tape = None if u_tape is None else u_tape.data_ptr() - m * b * es
         plan.generation = g_ = plan.generation % 0xFFFFF + 1  # (numbered cluster launches: tagged records, no clearing launch)
         a.hints.cluster_generation = g_
-        L.check(plan.run(plan.args_ref, m, 1, 1, L.stream_ptr()), "pf_filter_run")
+        L.check(plan.run(plan.args_ref, m, 1, 1, stream), "pf_filter_run")
         if per_step_route:
             plan.chain = (m, x_out, lw_out, x_out._version, lw_out._version, hk)
         self._last_run = dict(plan=plan, z=z_tape, u=u_tape, ws=plan.ws, seed_eff=a.seed, piece=m,
@@ -1089,7 +1090,7 @@ class _OnlineRun:
         self._code = L.dtype_code(x.dtype)
         self._ll_ptr, self._stats_ptr = self.ll.data_ptr(), self.stats.data_ptr()
         self._status_ptr = plan.status.data_ptr()
-        self.hints_key = None
+        self.hints_key, self._stream = None, None
 
     @staticmethod
     def applies(filt, result) -> bool:
@@ -1138,6 +1139,10 @@ class _OnlineRun:
         filt, plan = self.filt, self.plan
         a = plan.args
         ctx = filt._ensure_context()
+        stream = L.stream_ptr()
+        if stream != self._stream:  # (pieces m > 0 rely on stream order behind piece m - 1: another stream starts another run)
+            self.flush()
+            self._stream = stream
         if self.m == 0 and not self._in_sync():
             self._attach()
         if y.dtype != self.dtype or not y.is_cuda or not y.is_contiguous():
@@ -1156,7 +1161,6 @@ class _OnlineRun:
             a.z_tape = None if zt is None else zt.data_ptr() - m * self.d * b * self.n * es
             a.u_tape = None if ut is None else ut.data_ptr() - m * b * es
         plan.generation = a.hints.cluster_generation = plan.generation % 0xFFFFF + 1
-        stream = L.stream_ptr()
         total = self.result._loglikelihood
         seq = slot.seq + 1
         # the move and the theta update in one call (pf_filter_observe = pf_filter_run + pf_theta_step under the move's status word)
