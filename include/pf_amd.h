@@ -112,9 +112,16 @@ int pf_normalize(void* logw, void* W, void* lse, void* ess, int64_t N, int64_t B
  * position, the arrangement of the reference's own known-answer test (tests/test_resampling.py:39-47);
  * colmask (B) uint8 or NULL: only columns with colmask != 0 are
  * resampled, the others' idx are left untouched (SISR's masked resampling, sisr.py:29-31);
- * cdf (B,N) scratch/out; idx (B,N) int32 out. */
+ * cdf (B,N) scratch/out; idx (B,N) int32 out.
+ * cdf == NULL (where pf_systematic_cdf_free says yes, PF_EINVAL elsewhere): the ancestors only, in TWO launches instead of three
+ * on columns of several tiles - the cdf values are rebuilt from the weights where they are used (same definition, same rounding per
+ * element; the fp64 sum under it is associated per 256-particle chunk, which float weights do not see). */
 int pf_systematic(const void* W, const void* u, int u_per_element, const uint8_t* colmask, void* cdf, int32_t* idx,
                   int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* *yes <- 1 when pf_systematic(N, B, dtype, u_per_element) takes cdf == NULL (columns of more than one tile, N % 4 == 0, one u per
+ * column, float: N <= 2^22), else 0. */
+int pf_systematic_cdf_free(int64_t N, int64_t B, int dtype, int u_per_element, int* yes);
 
 /* systematic with normalized=False (resampling.py:8-21 then :24-52): logw is sanitised in place, the softmax is
  * never materialised (cdf is built from exp(logw - tile max) with an fp64 carry). */

@@ -24,7 +24,7 @@ MAX_D = 3
 MAX_O = 3
 
 EXPORTS = (
-    "pf_version", "pf_abi_version", "pf_error_string", "pf_workspace_bytes", "pf_normalize", "pf_systematic", "pf_systematic_logw",
+    "pf_version", "pf_abi_version", "pf_error_string", "pf_workspace_bytes", "pf_normalize", "pf_systematic", "pf_systematic_cdf_free", "pf_systematic_logw",
     "pf_multinomial", "pf_gather", "pf_loglik", "pf_moments", "pf_pre_weight", "pf_sample_and_weight",
     "pf_initial_sample", "pf_filter_run", "pf_filter_run_timed", "pf_filter_graph_create", "pf_filter_graph_launch",
     "pf_filter_graph_destroy", "pf_columns_gather", "pf_columns_exchange", "pf_debug_draw_normals", "pf_debug_launch_trace",
@@ -113,6 +113,7 @@ def load() -> C.CDLL:
     lib.pf_normalize.argtypes = [vp, vp, vp, vp, i64, i64, i32, vp, sz, vp]
     lib.pf_systematic.argtypes = [vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, sz, vp]
     lib.pf_systematic_logw.argtypes = [vp, vp, i32, vp, vp, vp, i64, i64, i32, vp, sz, vp]
+    lib.pf_systematic_cdf_free.argtypes = [i64, i64, i32, i32, C.POINTER(C.c_int)]
     lib.pf_multinomial.argtypes = [vp, vp, u64, u32, vp, vp, vp, i64, i64, i32, vp, sz, vp]
     lib.pf_gather.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     lib.pf_loglik.argtypes = [vp, vp, vp, i64, i64, i32, vp, sz, vp]

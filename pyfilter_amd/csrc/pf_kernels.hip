@@ -773,6 +773,257 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
                                                      Geom g, int force_search) {
     search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, force_search, blockIdx.y, blockIdx.x);
 }
+// ---------------------------------------------------------------------------------------------------------------
+// systematic(W) WITHOUT a materialised cdf (pf_systematic with cdf == NULL): two launches instead of three, 12 bytes per particle
+// instead of 21.  The three-launch form is a chain tile sums -> cdf in memory -> search; here the cdf values a workgroup needs
+// are rebuilt where they are used, from the weights themselves:
+//   k_chunk_scan   every tile scans its weights once (fp64) and leaves, per CHUNK of 256 particles (one wave x 4), the sum of the
+//                  tile's weights before the chunk (`cb`), and the tile's sum;
+//   k_chunk_search every workgroup (a tile of grid positions) builds the column's tile-prefix table in LDS (<= 1 024 tile sums),
+//                  finds the chunk its first position falls into - a count over the table, a count over that tile's `cb` -,
+//                  and then per round stages FIVE chunks of WEIGHTS from there: a wave re-scans its chunk (the same DPP scan in the
+//                  same lanes as k_chunk_scan) and has its 256 cdf values in registers,
+//                         cdf_j = T( P_tile + ( cb_chunk + ( lanes before + own elements up to j ) ) ),   cdf_{N-1} = 1,
+//                  one rounding to T per element like k_scan's; the ancestors come from the inverted systematic grid
+//                  (grid_count: every entry's offspring range in closed form, heads scattered into LDS, a running maximum) as in
+//                  k_search.  A stretch the five chunks do not cover walks on; a window that brings no progress (a long stretch of
+//                  weightless particles) JUMPS: the chunk of the first position not yet covered is found like the first one.
+// A cdf value is a deterministic function of (column, j) - whichever workgroup evaluates it gets the same bits -, so ancestors are
+// consistent across tiles; against k_scan's values they differ in the association of the fp64 sum only (exact for float weights
+// of ordinary dynamic range: tests/test_primitives_gpu.py).
+// ---------------------------------------------------------------------------------------------------------------
+#define PF_CHUNK (PF_WAVE * 4)
+#define PF_CHUNK_WINDOW 5  // chunks staged per window: 256 (alignment slack) + 1 024 positions + 1 <= 1 280 entries
+
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_chunk_scan(const T* __restrict__ W, const uint8_t* colmask, double* __restrict__ part,
+                                                         double* __restrict__ cb, Geom g, int nchunks) {
+    __shared__ double red[PF_NWAVES];
+    const int b = blockIdx.y, k = blockIdx.x;
+    if (colmask && !colmask[b]) return;
+    const T* col = W + (int64_t)b * g.N;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double carry = 0.0;
+    const int64_t base = (int64_t)k * g.tile_elems;
+    for (int r = 0; r < g.rounds_per_tile; ++r) {
+        const int64_t r0 = base + (int64_t)r * g.round_elems;
+        if (r0 >= g.N) break;
+        const int64_t i0 = r0 + threadIdx.x * 4;
+        T v[4] = {T(0), T(0), T(0), T(0)};
+        if (i0 < g.N) load_vec<T, 4>(col + i0, v);
+        double run = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) run += (double)v[j];
+        double total;
+        const double excl = block_scan_excl(run, red, total);
+        const int64_t c = r0 / PF_CHUNK + wid;
+        if (lane == 0 && c < nchunks) cb[(int64_t)b * nchunks + c] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        const int64_t stride = (int64_t)g.B * g.tiles;
+        part[PQ_M1 * stride + (int64_t)b * g.tiles + k] = 0.0;
+        part[PQ_S1 * stride + (int64_t)b * g.tiles + k] = carry;
+    }
+}
+
+// the 4 cdf values lane `lane` holds of chunk c (entries c * 256 + lane * 4 + j); +inf beyond the column.  All 64 lanes call.
+// Two phases so that a wave with two chunks to rebuild (the window's fifth) has both loads in flight before it scans the first.
+template <typename T> struct ChunkLoad {
+    T v[4];
+    double basec;
+    bool live, in;
+    int j0;
+};
+template <typename T>
+__device__ __forceinline__ ChunkLoad<T> chunk_load(const T* __restrict__ col, const double* __restrict__ cbcol, int c, int nchunks, int N,
+                                                   int lane) {
+    ChunkLoad<T> q;
+    q.j0 = c * PF_CHUNK + lane * 4;
+    q.live = c < nchunks;  // wave-uniform
+    q.in = q.live && q.j0 < N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q.v[j] = T(0);
+    if (q.in) load_vec<T, 4>(col + q.j0, q.v);
+    q.basec = q.live ? cbcol[c] : 0.0;
+    return q;
+}
+template <typename T>
+__device__ __forceinline__ void chunk_cdf4(const ChunkLoad<T>& q, double P, int N, int lane, T (&out)[4]) {
+    double e[4];
+    double run = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        run += (double)q.v[j];
+        e[j] = run;
+    }
+    const double wex = wave_scan_incl(run, lane) - run;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double cv = P + (q.basec + (wex + e[j]));
+        out[j] = q.in ? ((q.j0 + j == N - 1) ? T(1) : (T)cv) : Lim<T>::inf();
+    }
+}
+
+#ifdef PF_DEVTOOLS  // (the instrumented build: cycle stamps of the middle workgroup of column 0, tools/chunk_search_stages.py)
+#define PF_CSTAMP_ARG , unsigned long long* dbg
+#define PF_CSTAMP(slot)                                                                                       \
+    do {                                                                                                      \
+        if (dbg && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == (unsigned)g.tiles / 2) dbg[slot] = (unsigned long long)clock64(); \
+    } while (0)
+#else
+#define PF_CSTAMP_ARG
+#define PF_CSTAMP(slot) do { } while (0)
+#endif
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void k_chunk_search(const T* __restrict__ W, const T* __restrict__ u, const uint8_t* colmask,
+                                                           const double* __restrict__ part, const double* __restrict__ cb,
+                                                           int32_t* __restrict__ idx, Geom g, int nchunks PF_CSTAMP_ARG) {
+    __shared__ double ptab[PF_MAX_TILES];
+    __shared__ double red[PF_NWAVES];
+    __shared__ int hd[PF_BLOCK * 4 + PF_WAVE];
+    __shared__ __attribute__((aligned(32))) T c1buf[PF_CHUNK];
+    __shared__ int sh_cl[2 * PF_NWAVES], sh_wm[PF_NWAVES], sh_cnt[PF_NWAVES], sh_j0;
+    const int b = blockIdx.y, k = blockIdx.x;
+    if (colmask && !colmask[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int N = (int)g.N, tiles = g.tiles;
+    PF_CSTAMP(0);
+    const int cpt = g.rounds_per_tile * (g.round_elems / PF_CHUNK);  // chunks per tile (<= PF_BLOCK: the host checks)
+    const T* col = W + (int64_t)b * g.N;
+    const double* cbcol = cb + (int64_t)b * nchunks;
+    int32_t* out = idx + (int64_t)b * g.N;
+    const int64_t base = (int64_t)k * g.tile_elems;
+    // ---- the column's tile-prefix table: P_t = sum of the tile sums before t (the same bits in every workgroup) ----
+    {
+        const double* ps = part + PQ_S1 * ((int64_t)g.B * tiles) + (int64_t)b * tiles;
+        double s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = (tid * 4 + j < tiles) ? ps[tid * 4 + j] : 0.0;
+        double total;
+        const double excl = block_scan_excl((s[0] + s[1]) + (s[2] + s[3]), red, total);
+        ptab[tid * 4 + 0] = excl;
+        ptab[tid * 4 + 1] = excl + s[0];
+        ptab[tid * 4 + 2] = excl + (s[0] + s[1]);
+        ptab[tid * 4 + 3] = excl + ((s[0] + s[1]) + s[2]);
+    }
+    __syncthreads();
+    PF_CSTAMP(1);
+    const T ub = u[b];
+    const T nT = T(N), rcN = T(1) / nT;
+    const bool pow2 = (N & (N - 1)) == 0;
+    // workgroup-wide count of up to four predicates per thread (uniform result; ballots, no cross-lane data movement)
+    auto block_count = [&](bool p0, bool p1, bool p2, bool p3) -> int {
+        const int w = (__popcll(__ballot(p0)) + __popcll(__ballot(p1))) + (__popcll(__ballot(p2)) + __popcll(__ballot(p3)));
+        __syncthreads();  // (sh_cnt's previous readers)
+        if (lane == 0) sh_cnt[wid] = w;
+        __syncthreads();
+        return (sh_cnt[0] + sh_cnt[1]) + (sh_cnt[2] + sh_cnt[3]);
+    };
+    // the chunk holding the first entry with cdf >= p: the last tile, then the last chunk of it, that starts below p
+    auto find_chunk = [&](T p) -> int {
+        bool below[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) below[j] = tid * 4 + j < tiles && (T)ptab[tid * 4 + j] < p;
+        int t = block_count(below[0], below[1], below[2], below[3]) - 1;
+        t = t < 0 ? 0 : t;
+        const int c = t * cpt + tid;
+        const bool in = tid < cpt && c < nchunks;
+        const double v = in ? cbcol[c] : 0.0;
+        int cc = block_count(in && (T)(ptab[t] + v) < p, false, false, false) - 1;
+        cc = cc < 0 ? 0 : cc;
+        return t * cpt + cc;
+    };
+    const int RE = g.round_elems;
+    for (int r = 0; r < g.rounds_per_tile; ++r) {
+        const int64_t r0 = base + (int64_t)r * RE;
+        if (r0 >= g.N) break;
+        const int64_t i0 = r0 + tid * 4;
+        const int need = (g.N - r0 < RE) ? (int)(g.N - r0) : RE;
+        int chunk = (r == 0) ? find_chunk(grid_position<T>(r0, ub, nT)) : sh_j0 / PF_CHUNK;
+        PF_CSTAMP(2);
+        {
+            const int zero[4] = {0, 0, 0, 0};
+            store_vec<int, 4>(hd + tid * 4, zero);
+        }
+        const int dump = RE + lane;
+        int covered = 0, stalled = 0;
+        for (;;) {  // every branch below is workgroup-uniform
+            T c0[4], c1[4];
+            // (a window of five chunks from offset `off` in tile t0 reaches at most into tile t0 + 1: off + 4 < 2 cpt, cpt >= 4)
+            const int t0 = chunk / cpt, off = chunk - t0 * cpt;
+            const ChunkLoad<T> la = chunk_load<T>(col, cbcol, chunk + wid, nchunks, N, lane);
+            ChunkLoad<T> lb;
+            if (wid == 0) lb = chunk_load<T>(col, cbcol, chunk + 4, nchunks, N, lane);
+            chunk_cdf4<T>(la, la.live ? ptab[t0 + (off + wid >= cpt ? 1 : 0)] : 0.0, N, lane, c0);
+            if (wid == 0) {
+                chunk_cdf4<T>(lb, lb.live ? ptab[t0 + (off + 4 >= cpt ? 1 : 0)] : 0.0, N, lane, c1);
+                store_vec<T, 4>(c1buf + lane * 4, c1);
+            }
+            __syncthreads();  // c1buf is written (and, first window: hd is zeroed)
+            PF_CSTAMP(3);
+            T d1[1] = {c1buf[tid]};
+            int cn0[4], cn1[1];
+            if (pow2) {
+                grid_counts_local<T, 4, true>(c0, ub, nT, rcN, N, (int)r0, RE, cn0);
+                grid_counts_local<T, 1, true>(d1, ub, nT, rcN, N, (int)r0, RE, cn1);
+            } else {
+                grid_counts_local<T, 4, false>(c0, ub, nT, rcN, N, (int)r0, RE, cn0);
+                grid_counts_local<T, 1, false>(d1, ub, nT, rcN, N, (int)r0, RE, cn1);
+            }
+            if (lane == 63) {
+                sh_cl[wid] = cn0[3];
+                sh_cl[PF_NWAVES + wid] = cn1[0];
+            }
+            __syncthreads();
+            int pv0 = wave_prev(cn0[3], 0), pv1 = wave_prev(cn1[0], 0);
+            if (lane == 0) {
+                pv0 = wid ? sh_cl[wid - 1] : covered;  // entries before the window own no position not covered yet
+                pv1 = sh_cl[PF_NWAVES + wid - 1];      // (wave 0: the first part's last entry)
+            }
+            const int covered_now = sh_cl[2 * PF_NWAVES - 1];
+            const int q0 = chunk * PF_CHUNK + tid * 4 + 1, q1 = (chunk + 4) * PF_CHUNK + tid + 1;  // entry index + 1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int lo = j ? cn0[j - 1] : pv0;
+                hd[(cn0[j] > lo) ? lo : dump] = q0 + j;
+            }
+            hd[(cn1[0] > pv1) ? pv1 : dump] = q1;
+            stalled = (covered_now > covered) ? 0 : stalled + 1;
+            covered = covered_now > covered ? covered_now : covered;
+            PF_CSTAMP(4);
+            if (covered >= need || stalled >= 2 || (int64_t)(chunk + PF_CHUNK_WINDOW) * PF_CHUNK >= g.N) break;
+            __syncthreads();  // everyone has read sh_cl / c1buf
+            // no progress: the next entry that owns a position is far away - look it up; else walk on
+            chunk = stalled ? find_chunk(grid_position<T>(r0 + covered, ub, nT)) : chunk + PF_CHUNK_WINDOW;
+        }
+        __syncthreads();
+        int h[4];
+        load_vec<int, 4>(hd + tid * 4, h);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) h[j] = imax(h[j], h[j - 1]);
+        const int inc = wave_scan_max(h[3]);
+        if (lane == 63) sh_wm[wid] = inc;
+        __syncthreads();
+        int carry = wave_prev(inc, 0);
+#pragma unroll
+        for (int w = 0; w < PF_NWAVES - 1; ++w) carry = (w < wid) ? imax(carry, sh_wm[w]) : carry;
+        int res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = imax(carry, h[j]);
+            const bool ok = (tid * 4 + j < covered) && q > 0 && q <= N;  // (not covered: NaN weights - the clamp searchsorted gives)
+            res[j] = ok ? q - 1 : N - 1;
+        }
+        if (i0 < g.N) store_vec<int, 4>(out + i0, res);
+        if (tid == PF_BLOCK - 1) sh_j0 = res[3];  // the next round's window starts at this round's last ancestor
+        __syncthreads();
+        PF_CSTAMP(5);
+    }
+}
+#undef PF_CSTAMP
+#undef PF_CSTAMP_ARG
+
 // systematic / multinomial resampling of columns of ONE tile (filters of up to a few thousand particles, or many filters:
 // 1 024 x 8 192 is one 8-round tile per column) in ONE launch: tile record -> scan -> ancestors, the three kernels' bodies back
 // to back in the column's workgroup (same arithmetic: identical cdf and ancestors; the cdf goes through memory between
@@ -1340,16 +1591,51 @@ extern "C" int pf_normalize(void* logw, void* W, void* lse, void* ess, int64_t N
     return PF_OK;
 }
 
+// pf_systematic without a cdf (k_chunk_scan + k_chunk_search): columns of several tiles of whole 4-vectors, one u per column, a
+// tile's chunk bases within one workgroup's reach, and a grid the closed-form inversion is exact for (float: N <= 2^22)
+static inline bool cdf_free_applies(const Geom& g, int dtype, int u_per_elem) {
+    if (dtype != PF_F32 && dtype != PF_F64) return false;
+    return g.tiles > 1 && g.vec == 4 && !u_per_elem && g.rounds_per_tile * (g.round_elems / PF_CHUNK) <= PF_BLOCK &&
+           g.N < ((int64_t)1 << 31) - 4096 && !(dtype == PF_F32 && g.N > ((int64_t)1 << 22));
+}
+extern "C" int pf_systematic_cdf_free(int64_t N, int64_t B, int dtype, int u_per_element, int* yes) {
+    if (!yes || bad_shape(N, B)) return PF_EINVAL;
+    *yes = cdf_free_applies(make_geom(N, B), dtype, u_per_element) ? 1 : 0;
+    return PF_OK;
+}
+
 static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem, const void* v, int multinomial, uint64_t seed,
                            uint32_t step, const uint8_t* colmask, void* cdf, int32_t* idx, int64_t N, int64_t B,
                            int dtype, void* ws, size_t ws_bytes, void* stream) {
-    if (!src || !cdf || !idx || !ws || bad_shape(N, B) || (!multinomial && !u)) return PF_EINVAL;
+    if (!src || !idx || !ws || bad_shape(N, B) || (!multinomial && !u)) return PF_EINVAL;
     const Geom g = make_geom(N, B);
     const WsLayout wl = make_ws(g, PF_MAXD);
     if (ws_bytes < wl.total) return PF_EWORKSPACE;
     double* part = (double*)((char*)ws + wl.off_part);
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(g.tiles, g.B);
+    if (!cdf) {  // no cdf wanted: the two-launch form where it applies (pf_systematic_cdf_free), nothing else
+        if (!from_w || multinomial || !cdf_free_applies(g, dtype, u_per_elem)) return PF_EINVAL;
+        double* cb = (double*)((char*)ws + wl.off_ctab);
+        const int nchunks = (int)((N + PF_CHUNK - 1) / PF_CHUNK);
+#ifdef PF_DEVTOOLS  // (the instrumented build: cycle stamps of the middle workgroup of column 0, tools/chunk_search_stages.py)
+#define PF_CHUNK_DBG , (unsigned long long*)((char*)ws + wl.off_dbg)
+#else
+#define PF_CHUNK_DBG
+#endif
+        if (dtype == PF_F32) {
+            hipLaunchKernelGGL((k_chunk_scan<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)src, colmask, part, cb, g, nchunks);
+            hipLaunchKernelGGL((k_chunk_search<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)src, (const float*)u, colmask,
+                               (const double*)part, (const double*)cb, idx, g, nchunks PF_CHUNK_DBG);
+        } else {
+            hipLaunchKernelGGL((k_chunk_scan<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)src, colmask, part, cb, g, nchunks);
+            hipLaunchKernelGGL((k_chunk_search<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)src, (const double*)u, colmask,
+                               (const double*)part, (const double*)cb, idx, g, nchunks PF_CHUNK_DBG);
+        }
+#undef PF_CHUNK_DBG
+        PF_CHECK_LAUNCH();
+        return PF_OK;
+    }
 #define CALL(T, V)                                                                                                   \
     if (g.tiles == 1) { /* one tile per column: record -> scan -> ancestors in one launch */                          \
         if (from_w)                                                                                                  \

@@ -192,7 +192,8 @@ def systematic_cols(w: torch.Tensor, u: torch.Tensor, normalized: bool, colmask:
         idx = torch.empty((b, n), dtype=torch.int32, device=w.device)
         if colmask is not None:
             idx.copy_(torch.arange(n, device=w.device, dtype=torch.int32).unsqueeze(0).expand(b, n))
-    cdf = torch.empty_like(w)
+    # normalised weights, several tiles per column: no cdf is materialised (two launches; include/pf_amd.h: pf_systematic, cdf == NULL)
+    cdf = None if (normalized and SYSTEMATIC_CDF_FREE and _cdf_free(n, b, w.dtype, per_elem)) else torch.empty_like(w)
     ws = L.workspace(n, b, w.device)
     fn = L.load().pf_systematic if normalized else L.load().pf_systematic_logw
     L.check(
@@ -201,6 +202,22 @@ def systematic_cols(w: torch.Tensor, u: torch.Tensor, normalized: bool, colmask:
         "pf_systematic",
     )
     return idx
+
+
+SYSTEMATIC_CDF_FREE = True  # (tests switch it off to run the three-launch form, the one a C caller that wants the cdf gets)
+_CDF_FREE = {}
+
+
+def _cdf_free(n: int, b: int, dtype, per_elem: int) -> bool:
+    key = (n, b, dtype, per_elem)
+    hit = _CDF_FREE.get(key)
+    if hit is None:
+        yes = C.c_int(0)
+        L.check(L.load().pf_systematic_cdf_free(n, b, L.dtype_code(dtype), per_elem, C.byref(yes)), "pf_systematic_cdf_free")
+        if len(_CDF_FREE) > 256:
+            _CDF_FREE.clear()
+        hit = _CDF_FREE[key] = bool(yes.value)
+    return hit
 
 
 def multinomial_cols(W: torch.Tensor, seed: int, step: int = 0, v: Optional[torch.Tensor] = None,

@@ -21,6 +21,16 @@ def pf():
     return pyfilter_amd
 
 
+@pytest.fixture(params=["cdf_free", "three_launches"])
+def sys_route(request, monkeypatch):
+    """``systematic(W)`` on columns of several tiles: without a materialised cdf (two launches, ``pf_systematic(cdf = NULL)``: the
+    default where it applies) and the three-launch form a caller that wants the cdf gets."""
+    from pyfilter_amd import ops
+
+    monkeypatch.setattr(ops, "SYSTEMATIC_CDF_FREE", request.param == "cdf_free")
+    return request.param
+
+
 def test_reference_known_answer_systematic(pf):
     """The reference's own known-answer test (tests/test_resampling.py:31-47), same inputs, same call: float64
     weights (10, 300), one uniform per grid position, indices must equal the reference's exactly."""
@@ -32,7 +42,7 @@ def test_reference_known_answer_systematic(pf):
 
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 @pytest.mark.parametrize("nm", ["a", "b", "c"])
-def test_normalize_and_systematic_vs_reference_golden(pf, dt, nm):
+def test_normalize_and_systematic_vs_reference_golden(pf, dt, nm, sys_route):
     g = load_golden("primitives", dt)
     lw = g[f"norm_{nm}_in"].clone().cuda()
     W = pf.utils.normalize(lw)
@@ -61,7 +71,7 @@ def test_normalize_and_systematic_vs_reference_golden(pf, dt, nm):
 
 @pytest.mark.parametrize("n,b", [(1 << 20, 1), (65536, 64), (1 << 22, 1), (8192, 128), (1000, 3), (4099, 2), (7, 1), (1, 2)])
 @pytest.mark.parametrize("dt", ["f32", "f64"])
-def test_systematic_bit_exact_at_benchmark_sizes(pf, n, b, dt):
+def test_systematic_bit_exact_at_benchmark_sizes(pf, n, b, dt, sys_route):
     """BASELINE.json sizes: indices bit-exact vs the oracle given identical normalised weights and uniforms."""
     dtype = DT[dt]
     gen = torch.Generator().manual_seed(n * 31 + b)
@@ -91,7 +101,7 @@ def test_systematic_bit_exact_at_benchmark_sizes(pf, n, b, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
-def test_systematic_degenerate_weights(pf, dt):
+def test_systematic_degenerate_weights(pf, dt, sys_route):
     """Edge cases: one particle holds all the mass; many zero-weight particles; unnormalised log-weight entry."""
     dtype = DT[dt]
     n = 1 << 16
@@ -118,6 +128,97 @@ def test_systematic_degenerate_weights(pf, dt):
     assert torch.equal(lw_gpu.cpu(), lw_ref)
     frac = (got != expect).double().mean().item()
     assert frac < (5e-3 if dt == "f32" else 1e-9), frac  # fp32 grid / cdf rounding: rare boundary flips only
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("n,b", [(1 << 20, 1), (1 << 18, 5), (65536, 64), (40960, 3), (4100, 300)])
+def test_systematic_sparse_and_masked_columns(pf, dt, n, b, sys_route):
+    """What the two-launch form walks and jumps over: a few heavy particles far apart among weightless ones (a round of grid
+    positions spans many 1 280-entry windows), weight only at the far end, one particle with everything - bit-exact against the
+    oracle in both dtypes (the sums are exact: weights are multiples of 2^-k); masked columns keep their ancestors."""
+    from pyfilter_amd import ops
+
+    dtype = DT[dt]
+    gen = torch.Generator().manual_seed(n + b)
+    W = torch.zeros(n, b, dtype=dtype)
+    for col in range(b):
+        kind = col % 5
+        if kind == 0:    # 64 heavy particles at random places
+            at = torch.randperm(n, generator=gen)[:64]
+            W[at, col] = 1.0 / 64
+        elif kind == 1:  # 4 096 light ones, every (n // 4096)-th ... a position every few entries, then long gaps
+            W[torch.randperm(n, generator=gen)[:4096], col] = 1.0 / 4096
+        elif kind == 2:  # everything at the far end
+            W[n - 1, col] = 1.0
+        elif kind == 3:  # a dense block in the middle, nothing else
+            W[n // 2:n // 2 + 1024, col] = 1.0 / 1024
+        else:            # two particles, far apart, unequal
+            W[3, col], W[n - 7, col] = 0.25, 0.75
+    u = torch.rand(b, 1, generator=gen, dtype=dtype)
+    expect = cpu_ref.systematic(W, normalized=True, u=u)
+    got = pf.resampling.systematic(W.cuda(), normalized=True, u=u.cuda()).cpu()
+    assert torch.equal(got, expect), f"{(got != expect).sum().item()} ancestors differ"
+    # masked columns (SISR's masked resampling): untouched
+    mask = (torch.arange(b) % 2 == 0)
+    keep = torch.full((b, n), -5, dtype=torch.int32, device="cuda")
+    idx = ops.systematic_cols(W.t().contiguous().cuda(), u.reshape(-1).cuda(), True, colmask=mask.cuda(), idx=keep.clone())
+    assert torch.equal(idx[mask.cuda()].cpu().long(), expect.t()[mask]) and bool((idx[~mask.cuda()] == -5).all())
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
+def test_systematic_with_nan_weights_terminates(pf, dt, sys_route):
+    """Garbage in: NaN weights give no meaningful ancestors (searchsorted on an unsorted cdf) - but every launch ends and every
+    index is in range."""
+    dtype = DT[dt]
+    n = 1 << 18
+    W = torch.full((n, 2), 1.0 / n, dtype=dtype)
+    W[n // 3, 0] = float("nan")
+    W[:, 1] = float("nan")
+    got = pf.resampling.systematic(W.cuda(), normalized=True, u=torch.tensor([[0.5], [0.25]], dtype=dtype).cuda()).cpu()
+    assert got.min() >= 0 and got.max() <= n - 1
+    # (well below the NaN the cdf is what it is; a round of positions whose window of entries reaches the NaN is garbage as a whole)
+    assert torch.equal(got[: n // 3 - 4096, 0], torch.arange(n // 3 - 4096))
+
+
+def test_systematic_routes_agree_and_the_query_says_where(pf):
+    """``pf_systematic_cdf_free``: several tiles, whole 4-vectors, one u per column, float up to 2^22 - and on random float64 weights
+    (where the association of the fp64 sum is visible in the last bit of a cdf value) the two forms name the same ancestors up to
+    positions within an ulp of a boundary."""
+    import ctypes as C
+
+    from pyfilter_amd import _lib as L
+    from pyfilter_amd import ops
+
+    lib = L.load()
+
+    def free(n, b, dtype, per_elem=0):
+        yes = C.c_int(-1)
+        L.check(lib.pf_systematic_cdf_free(n, b, L.dtype_code(dtype), per_elem, C.byref(yes)), "pf_systematic_cdf_free")
+        return yes.value
+
+    assert free(1 << 20, 1, torch.float32) == 1 and free(1 << 22, 1, torch.float32) == 1 and free(65536, 64, torch.float64) == 1
+    assert free(1 << 23, 1, torch.float32) == 0 and free(1 << 23, 1, torch.float64) == 1
+    assert free(8192, 1024, torch.float32) == 0     # one tile per column: already one launch
+    assert free((1 << 20) + 2, 1, torch.float32) == 0 and free(1 << 20, 1, torch.float32, 1) == 0
+    # a cdf-free call where it does not apply is refused, not mis-served
+    w = torch.rand(1, 8190, device="cuda")
+    ws = L.workspace(8190, 1, w.device)
+    idx = torch.empty((1, 8190), dtype=torch.int32, device="cuda")
+    assert free(8190, 1, torch.float32) == 0
+    rc = lib.pf_systematic(w.data_ptr(), w.data_ptr(), 0, None, None, idx.data_ptr(), 8190, 1, L.dtype_code(w.dtype), ws.data_ptr(),
+                           ws.numel(), L.stream_ptr())
+    assert rc != 0
+    gen = torch.Generator().manual_seed(77)
+    for n, b in ((1 << 20, 2), (1 << 16, 40)):
+        W = torch.softmax(3.0 * torch.randn(b, n, generator=gen, dtype=torch.float64), dim=1).cuda()
+        u = torch.rand(b, generator=gen, dtype=torch.float64).cuda()
+        ops.SYSTEMATIC_CDF_FREE = False
+        try:
+            three = ops.systematic_cols(W, u, True)
+        finally:
+            ops.SYSTEMATIC_CDF_FREE = True
+        two = ops.systematic_cols(W, u, True)
+        assert int((two != three).sum()) <= 2 and int((two - three).abs().max()) <= 1
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])

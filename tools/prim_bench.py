@@ -41,9 +41,17 @@ def main():
         e = n * b
         rows = [
             ("normalize (logw -> W, in-place sanitise)", lambda: ops.normalize_cols(lw), 4 + 4 + 4 + 4),   # read, rewrite, read again, write W
-            ("systematic(W) scan + search -> idx", lambda: ops.systematic_cols(W, u, True), 4 + 4 + 4 + 4),  # read W, write cdf, read cdf, write idx
+            ("systematic(W) -> idx (no cdf where it applies)", lambda: ops.systematic_cols(W, u, True), 4 + 4 + 4 + 4),  # (the contract: read W, write cdf, read cdf, write idx)
             ("gather x[idx]", lambda: ops.gather_soa(x, idx), 4 + 4 + 4),
         ]
+        def three_launches():
+            ops.SYSTEMATIC_CDF_FREE = False
+            try:
+                return ops.systematic_cols(W, u, True)
+            finally:
+                ops.SYSTEMATIC_CDF_FREE = True
+
+        rows.insert(2, ("systematic(W) with the cdf (tile sums, scan, search)", three_launches, 4 + 4 + 4 + 4))
         if n * b <= (1 << 24):  # the three-launch path (one offset per grid position always takes it): the A/B of the one-launch resampler
             u_exp = u.unsqueeze(1).expand(b, n).contiguous()
             rows.insert(2, ("systematic(W), three launches (u per position)", lambda: ops.systematic_cols(W, u_exp, True), 4 + 4 + 4 + 4))
