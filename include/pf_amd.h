@@ -235,8 +235,14 @@ int pf_theta_accept(const void* u_cur, const void* u_star, const void* mean_f, c
 /* The theta-weights along a block of n observations (sequential/state.py:35-44, n times): w_path (n, B) <- w0 (B) + the
  * running sum of the log-likelihood increments ll (n, B); stats (n, 2) <- (ESS, 1 if every weight is finite) per row, as
  * pf_theta_ess reports them.  n = 1: w_path may be w0 itself (the weights updated in place - one observation of the
- * reference's step(), smc2.py:53-65). */
-int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats, void* stream);
+ * reference's step(), smc2.py:53-65).
+ * host_rows != NULL: n x 32 bytes of pf_host_alloc memory - row q's two values as doubles, then the 64-bit `seq`, then the status
+ * word, written by row q's own workgroup as pf_theta_step writes its one slot: a host that decides per observation (smc2.py:59-62)
+ * polls the rows in order and has row q when it is done - no device -> host copy command behind the block, no event.
+ * status (or NULL): pf_filter_args.status of the run that produced ll - non-zero: that run gave up, the rows report NaN / 0 and
+ * the word (the caller re-issues the block, see PF_ROUTE_CLUSTER), w_path is not written. */
+int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats, void* host_rows,
+                  uint64_t seq, const int32_t* status, void* stream);
 
 /* ONE observation of the reference's SMC2.step() (smc2.py:53-65; sequential/state.py:35-44): w (B) += ll (B) in place and stats
  * (2) <- (ESS, 1 if every weight is finite) as pf_theta_ess reports them - pf_theta_path with n = 1 - and, host_slot != NULL,

@@ -132,7 +132,7 @@ def load() -> C.CDLL:
     lib.pf_smooth_ffbs.argtypes = [C.POINTER(PfModel), vp, vp, vp, vp, u64, vp, i64, i64, i64, i32, vp]
     lib.pf_observed_flags.argtypes = [vp, i64, i64, i32, vp, vp]
     lib.pf_theta_ess.argtypes = [vp, i64, i64, i32, vp, vp]
-    lib.pf_theta_path.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp]
+    lib.pf_theta_path.argtypes = [vp, vp, i64, i64, i32, vp, vp, vp, u64, vp, vp]
     lib.pf_theta_resample.argtypes = [vp, i64, C.c_double, i32, vp, vp, vp]
     lib.pf_theta_step.argtypes = [vp, vp, i64, i32, vp, vp, u64, vp, vp, vp]
     lib.pf_filter_observe.argtypes = [C.POINTER(PfFilterArgs), i64, i64, i32, vp, vp, vp, vp, u64, vp, vp]

@@ -1926,16 +1926,16 @@ extern "C" int pf_theta_accept(const void* u_cur, const void* u_star, const void
 }
 
 extern "C" int pf_theta_path(const void* w0, const void* ll, int64_t n, int64_t B, int dtype, void* w_path, void* stats,
-                             void* stream) {
-    if (!w0 || !ll || !w_path || !stats || B < 1 || n < 0 || n > 65535) return PF_EINVAL;
+                             void* host_rows, uint64_t seq, const int32_t* status, void* stream) {
+    if (!w0 || !ll || !w_path || !stats || B < 1 || n < 0 || n > 65535 || ((uintptr_t)host_rows & 7) != 0) return PF_EINVAL;
     if (n == 0) return PF_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PF_F32)
         hipLaunchKernelGGL((k_theta_path<float>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const float*)w0, (const float*)ll, B,
-                           (float*)w_path, (float*)stats, (double*)nullptr, 0ull, (float*)nullptr, (const int*)nullptr);
+                           (float*)w_path, (float*)stats, (double*)host_rows, (unsigned long long)seq, (float*)nullptr, (const int*)status, 1);
     else if (dtype == PF_F64)
         hipLaunchKernelGGL((k_theta_path<double>), dim3((unsigned)n), dim3(PF_BLOCK), 0, st, (const double*)w0, (const double*)ll, B,
-                           (double*)w_path, (double*)stats, (double*)nullptr, 0ull, (double*)nullptr, (const int*)nullptr);
+                           (double*)w_path, (double*)stats, (double*)host_rows, (unsigned long long)seq, (double*)nullptr, (const int*)status, 1);
     else return PF_EINVAL;
     PF_CHECK_LAUNCH();
     return PF_OK;

@@ -272,7 +272,7 @@ template <typename T>
 __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* __restrict__ ll, int64_t B,
                                                          T* w_path, T* __restrict__ stats,  // (n = 1: w_path may BE w0)
                                                          double* host_slot, unsigned long long seq, T* acc = nullptr,
-                                                         const int* status = nullptr) {
+                                                         const int* status = nullptr, int slot_per_row = 0) {
     __shared__ T redm[PF_NWAVES];
     __shared__ double red[3 * PF_NWAVES];
     const int r = blockIdx.x;
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* _
         if (threadIdx.x == 0) {
             stats[2 * (int64_t)r] = T(__builtin_nan(""));
             stats[2 * (int64_t)r + 1] = T(0);
-            if (host_slot != nullptr && r == (int)gridDim.x - 1) {
+            if (host_slot != nullptr && (slot_per_row || r == (int)gridDim.x - 1)) {
+                host_slot += slot_per_row ? 4 * (int64_t)r : 0;
                 host_slot[0] = __builtin_nan("");
                 host_slot[1] = 0.0;
                 reinterpret_cast<unsigned long long*>(host_slot)[3] = (unsigned long long)(unsigned)st;
@@ -311,7 +312,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_theta_path(const T* w0, const T* _
     theta_ess_row<T>(row, B, stats + 2 * (int64_t)r, redm, red);
     // pf_theta_step: the last row's statistics also go to host memory the caller polls (pf_host_alloc: coherent, mapped) - two
     // doubles, then the sequence number with system-scope release, so a host that sees `seq` sees the values
-    if (host_slot != nullptr && r == (int)gridDim.x - 1 && threadIdx.x == 0) {
+    // pf_theta_path with host rows: EVERY row reports into its own 32-byte slot (a host that polls them in order has row q as soon
+    // as row q's workgroup is done - no copy command, no event)
+    if (host_slot != nullptr && (slot_per_row || r == (int)gridDim.x - 1) && threadIdx.x == 0) {
+        host_slot += slot_per_row ? 4 * (int64_t)r : 0;
         const T* o = stats + 2 * (int64_t)r;  // (thread 0 wrote them)
         host_slot[0] = (double)o[0];
         host_slot[1] = (double)o[1];

@@ -42,15 +42,21 @@ def _theta_stats(gw: torch.Tensor) -> torch.Tensor:
     return out.reshape(gw.shape[:-1] + (2,))
 
 
-def _theta_path(w: torch.Tensor, ll: torch.Tensor, shard):
-    """The theta log-weights after each of a block's ``n`` observations, ``w + ll.cumsum(0)``, and their ``(n, 2)`` statistics
-    (``_theta_stats``) - one launch on one GPU (``pf_theta_path``); sharded, the rows are all-gathered in between."""
+def _theta_path_native(w: torch.Tensor, ll: torch.Tensor, shard) -> bool:
     from ..hints import HINTS
 
-    if ll.is_cuda and (shard is None or not shard.collective) and HINTS.theta_kernels and ll.dim() == 2 and ll.dtype == w.dtype:
+    return bool(ll.is_cuda and (shard is None or not shard.collective) and HINTS.theta_kernels and ll.dim() == 2 and ll.dtype == w.dtype)
+
+
+def _theta_path(w: torch.Tensor, ll: torch.Tensor, shard, rows=None, status=None):
+    """The theta log-weights after each of a block's ``n`` observations, ``w + ll.cumsum(0)``, and their ``(n, 2)`` statistics
+    (``_theta_stats``) - one launch on one GPU (``pf_theta_path``; ``rows`` / ``status``: the statistics also land in host memory,
+    ``ops.HostRows``); sharded, the rows are all-gathered in between."""
+    if _theta_path_native(w, ll, shard):
         from .. import ops
 
-        return ops.theta_path(w.contiguous(), ll.contiguous())
+        return ops.theta_path(w.contiguous(), ll.contiguous(), rows, status)
+    assert rows is None
     w_path = w + ll.cumsum(0)
     return w_path, _theta_stats(shard.all_gather(w_path, dim=1) if shard is not None and shard.collective else w_path)
 
@@ -477,13 +483,19 @@ class SMC2:
         if out is None:
             return None
         res, ll, token = out
-        w_path, stats = _theta_path(w, ll, shard)  # (n, B_local) theta-weights after each observation; (n, 2): ESS, all finite
-        event, status_host = None, None
-        if stats.is_cuda:  # one small asynchronous copy into pinned memory + an event: the host later waits for THIS block only
+        status = getattr(res, "status", None)  # (the block took the column-cluster kernel: its status word travels with the statistics)
+        # one GPU's own theta block: the statistics rows (and the status word) are written into host memory by the kernel that
+        # computes them - the host polls them row by row; nothing is copied, no event is recorded behind the block
+        rows = self._host_rows(slot, ll.shape[0]) if _theta_path_native(w, ll, shard) else None
+        w_path, stats = _theta_path(w, ll, shard, rows, status if rows is not None else None)
+        # (n, B_local) theta-weights after each observation; (n, 2): ESS, all finite
+        event, status_host, host = None, None, None
+        if rows is not None:
+            pass
+        elif stats.is_cuda:  # one small asynchronous copy into pinned memory + an event: the host later waits for THIS block only
             host = self._pinned(slot, stats)
             host.copy_(stats, non_blocking=True)
-            status = getattr(res, "status", None)
-            if status is not None:  # the block took the column-cluster kernel: its status word travels with the statistics
+            if status is not None:
                 status_host = self._pinned(("status", slot), status, rows=1)
                 status_host.copy_(status, non_blocking=True)
             event = torch.cuda.Event()
@@ -491,18 +503,36 @@ class SMC2:
         else:
             host = stats
         return dict(ys=ys, flags=flags, latest=latest, res=res, ll=ll, token=token, w_path=w_path, stats=stats, host=host, event=event,
-                    w0=w, slot=slot, status_host=status_host)
+                    w0=w, slot=slot, status_host=status_host, rows=rows)
+
+    def _host_rows(self, slot: int, n: int):
+        """The pipeline slot's statistics rows in host memory the device writes (``ops.HostRows``), or None where there is none to
+        be had (then the statistics travel by a copy command and an event per block)."""
+        from .. import ops
+
+        bufs = self.__dict__.setdefault("_host_row_bufs", {})
+        rows = bufs.get(slot)
+        if rows is None or rows.n < n:
+            try:
+                rows = ops.HostRows(max(n, self._block))
+            except ops.L.PfAmdError:
+                rows = False
+            bufs[slot] = rows
+        return rows or None
 
     def _verified(self, blk):
         """Waits for the block (its statistics and, for a column-cluster run, its status word).  A launch that gave up - the
         device was held by other work for seconds - is issued again on the per-step route from the same state on the same draws."""
-        if blk["event"] is not None:
-            blk["event"].synchronize()
-        if blk["status_host"] is None or int(blk["status_host"][0]) == 0:
-            return blk, False
+        if blk["rows"] is not None:
+            if blk["rows"].wait(0)[2] == 0:  # (every row carries the word: the first one's arrival is enough)
+                return blk, False
+        else:
+            if blk["event"] is not None:
+                blk["event"].synchronize()
+            if blk["status_host"] is None or int(blk["status_host"][0]) == 0:
+                return blk, False
         self.filter._cluster_gave_up(blk["res"].plan)
         again = self._issue_block(blk["ys"], blk["flags"], blk["latest"], blk["w0"], blk["slot"], token=blk["token"], per_step=True)
-        again["event"].synchronize()
         return again, True
 
     def _pinned(self, slot, like: torch.Tensor, rows: Optional[int] = None) -> torch.Tensor:
@@ -516,9 +546,16 @@ class SMC2:
 
     def _first_hit(self, blk) -> Optional[int]:
         """Waits for the block's statistics (only) and applies the reference's test to them in order."""
+        thr = self._threshold * self.particles[0]
+        if blk["rows"] is not None:  # row by row, each as soon as its workgroup is done - and no further than the first hit
+            wait = blk["rows"].wait
+            for q in range(blk["stats"].shape[0]):
+                ess, finite, _ = wait(q)
+                if ess < thr or not finite:
+                    return q
+            return None
         if blk["event"] is not None:
             blk["event"].synchronize()
-        thr = self._threshold * self.particles[0]
         return next((q for q, (ess, finite) in enumerate(blk["host"].tolist()) if ess < thr or not finite), None)
 
     def _commit(self, blk, take: int, state: SMC2State) -> SMC2State:

@@ -416,16 +416,22 @@ def theta_ess(log_w: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def theta_path(w0: torch.Tensor, ll: torch.Tensor):
+def theta_path(w0: torch.Tensor, ll: torch.Tensor, rows: Optional["HostRows"] = None, status: Optional[torch.Tensor] = None):
     """``w0 (B,)``, ``ll (n, B)`` -> ``(w0 + ll.cumsum(0) (n, B), (n, 2) ESS / all-finite rows)`` in one launch
-    (pf_theta_path; ``sequential/state.py:35-44`` for the n observations of a block)."""
+    (pf_theta_path; ``sequential/state.py:35-44`` for the n observations of a block).  ``rows`` (a ``HostRows`` of at least
+    ``n`` rows): every row also lands in host memory (``rows.wait(q)``), with ``status`` - the int32 status word of the run that
+    produced ``ll`` - next to it."""
     L.require_gpu(w0, ll)
     n, b = ll.shape
     assert w0.shape == (b,) and w0.dtype == ll.dtype and w0.is_contiguous() and ll.is_contiguous()
+    assert rows is None or rows.n >= n
     w_path = torch.empty_like(ll)
     stats = torch.empty((n, 2), dtype=ll.dtype, device=ll.device)
+    rp, seq = (None, 0) if rows is None else (rows.ptr, rows.seq + 1)
     L.check(L.load().pf_theta_path(w0.data_ptr(), ll.data_ptr(), n, b, L.dtype_code(ll.dtype), w_path.data_ptr(), stats.data_ptr(),
-                                   L.stream_ptr()), "pf_theta_path")
+                                   rp, seq, L.ptr(status) if rows is not None else None, L.stream_ptr()), "pf_theta_path")
+    if rows is not None:
+        rows.seq = seq
     return w_path, stats
 
 
@@ -473,6 +479,41 @@ class HostSlot:
                 raise L.PfAmdError("pf_theta_step: the device's write to the host slot never became visible")
         self.status = int(self._status.value)
         return self._vals[0], self._vals[1]
+
+
+class HostRows:
+    """``n`` 32-byte slots of host memory the device writes (``pf_theta_path``'s ``host_rows``): row q of a block's statistics -
+    (ESS, all finite), the launch's sequence number, the status word of the run behind the block - written by row q's own workgroup.
+    ``wait(q)`` spins on row q's sequence number: the host has a block's rows in order, each as soon as it is done, without a
+    device -> host copy command or an event behind the block."""
+
+    SPINS = HostSlot.SPINS
+
+    def __init__(self, n: int):
+        import weakref
+
+        p = C.c_void_p()
+        L.check(L.load().pf_host_alloc(32 * n, C.byref(p)), "pf_host_alloc")
+        self.ptr, self.n, self.seq = p.value, n, 0
+        self._d = (C.c_double * (4 * n)).from_address(self.ptr)
+        self._u = (C.c_uint64 * (4 * n)).from_address(self.ptr)
+        fin = weakref.finalize(self, _free_host, self.ptr)
+        fin.atexit = False
+
+    def __deepcopy__(self, memo):
+        return HostRows(self.n)
+
+    def wait(self, q: int):
+        """(ESS, all-finite flag, status word) of row ``q`` of the latest ``theta_path`` issued with these rows."""
+        want, u, at = self.seq, self._u, 4 * q + 2
+        for _ in range(self.SPINS):
+            if u[at] == want:
+                break
+        else:
+            torch.cuda.current_stream().synchronize()
+            if u[at] != want:
+                raise L.PfAmdError("pf_theta_path: the device's write to the host rows never became visible")
+        return self._d[4 * q], self._d[4 * q + 1], int(u[4 * q + 3])
 
 
 def theta_step(w: torch.Tensor, ll: torch.Tensor, slot: Optional[HostSlot] = None, acc: Optional[torch.Tensor] = None,

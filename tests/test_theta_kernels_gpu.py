@@ -280,6 +280,37 @@ def test_theta_step_updates_in_place_and_reports_to_the_host_slot(dtype, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_theta_path_reports_every_row_into_host_memory(dtype):
+    """``pf_theta_path`` with host rows: row q's (ESS, all finite) pair in host memory equals the device row, for every launch of a
+    sequence on the same rows (the sequence number tells them apart); a non-zero status word of the run behind the block shows in
+    every row and nothing is computed."""
+    b, n = 700, 16
+    g = torch.Generator().manual_seed(3)
+    rows = ops.HostRows(n)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(12):
+        k = n if t % 3 else 5  # (a shorter block on the same rows in between)
+        w0 = torch.randn(b, generator=g, dtype=torch.float64).to(dtype).cuda()
+        ll = torch.randn(k, b, generator=g, dtype=torch.float64).to(dtype).cuda()
+        if t == 7:
+            ll[3, 11] = float("nan")
+        w_path, stats = ops.theta_path(w0, ll, rows, status)
+        torch.testing.assert_close(w_path, ops.theta_path(w0, ll)[0], rtol=0, atol=0, equal_nan=True)
+        host = [rows.wait(q) for q in range(k)]
+        assert [[e, f] for e, f, _ in host] == stats.double().tolist() or t == 7
+        if t == 7:  # (NaN != NaN: compare the flags and the rows before the NaN)
+            assert [f for _, f, _ in host] == [1.0] * 3 + [0.0] * (k - 3) and [e for e, _, _ in host][:3] == stats[:3, 0].double().tolist()
+        assert all(st == 0 for _, _, st in host) and rows._u[2] == rows.seq
+    status.fill_(2)
+    _, stats = ops.theta_path(w0, ll, rows, status)
+    host = [rows.wait(q) for q in range(ll.shape[0])]
+    assert all(st == 2 and f == 0.0 and math.isnan(e) for e, f, st in host) and bool(stats[:, 0].isnan().all())
+    import copy
+
+    assert copy.deepcopy(rows).ptr != rows.ptr
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 @pytest.mark.parametrize("b", [1000, 37, 5000])
 def test_theta_resample_is_normalize_then_systematic(dtype, b):
     from pyfilter_amd.inference.utils import theta_systematic
