@@ -119,12 +119,12 @@ int pf_normalize(void* logw, void* W, void* lse, void* ess, int64_t N, int64_t B
 int pf_systematic(const void* W, const void* u, int u_per_element, const uint8_t* colmask, void* cdf, int32_t* idx,
                   int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes, void* stream);
 
-/* *yes <- 1 when pf_systematic(N, B, dtype, u_per_element) takes cdf == NULL (columns of more than one tile, N % 4 == 0, one u per
+/* *yes <- 1 when pf_systematic / pf_systematic_logw (N, B, dtype, u_per_element) take cdf == NULL (columns of more than one tile, N % 4 == 0, one u per
  * column, float: N <= 2^22), else 0. */
 int pf_systematic_cdf_free(int64_t N, int64_t B, int dtype, int u_per_element, int* yes);
 
 /* systematic with normalized=False (resampling.py:8-21 then :24-52): logw is sanitised in place, the softmax is
- * never materialised (cdf is built from exp(logw - tile max) with an fp64 carry). */
+ * never materialised (cdf is built from exp(logw - tile max) with an fp64 carry).  cdf == NULL: as pf_systematic. */
 int pf_systematic_logw(void* logw, const void* u, int u_per_element, const uint8_t* colmask, void* cdf, int32_t* idx,
                        int64_t N, int64_t B, int dtype, void* ws, size_t ws_bytes, void* stream);
 

@@ -795,25 +795,55 @@ __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, 
 #define PF_CHUNK (PF_WAVE * 4)
 #define PF_CHUNK_WINDOW 5  // chunks staged per window: 256 (alignment slack) + 1 024 positions + 1 <= 1 280 entries
 
-template <typename T>
-__global__ __launch_bounds__(PF_BLOCK) void k_chunk_scan(const T* __restrict__ W, const uint8_t* colmask, double* __restrict__ part,
+// what an element adds to the running sum: the weight itself, or exp(logw - tile maximum) (k_scan's addend: 0 for -inf)
+template <typename T, bool FROM_W> __device__ __forceinline__ double chunk_addend(T v, T mk, bool on) {
+    if constexpr (FROM_W) return (double)v;
+    return (on && v != -Lim<T>::inf()) ? (double)pf_exp_w(v - mk) : 0.0;
+}
+
+// FROM_W: normalised weights, e_j = W_j.  Otherwise log-weights (pf_systematic_logw): sanitised IN PLACE (utils.py:57), then
+// e_j = exp(logw_j - m_k) against the tile's own maximum m_k - the tile record is (m_k, sum e), as k_reduce_logw leaves it.
+template <typename T, bool FROM_W>
+__global__ __launch_bounds__(PF_BLOCK) void k_chunk_scan(T* __restrict__ W, const uint8_t* colmask, double* __restrict__ part,
                                                          double* __restrict__ cb, Geom g, int nchunks) {
     __shared__ double red[PF_NWAVES];
+    __shared__ T redm[PF_NWAVES];
     const int b = blockIdx.y, k = blockIdx.x;
     if (colmask && !colmask[b]) return;
-    const T* col = W + (int64_t)b * g.N;
+    T* col = W + (int64_t)b * g.N;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    double carry = 0.0;
     const int64_t base = (int64_t)k * g.tile_elems;
+    T mk = T(0);
+    if constexpr (!FROM_W) {
+        T m = -Lim<T>::inf();
+        for (int r = 0; r < g.rounds_per_tile; ++r) {
+            const int64_t i0 = base + (int64_t)r * g.round_elems + threadIdx.x * 4;
+            if (i0 >= g.N) break;
+            T v[4];
+            load_vec<T, 4>(col + i0, v);
+            bool changed = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const T sv = sanitize_logw(v[j]);
+                changed |= !(sv == v[j]);
+                v[j] = sv;
+                m = sv > m ? sv : m;
+            }
+            if (changed) store_vec<T, 4>(col + i0, v);  // (read back below by the thread that wrote it)
+        }
+        mk = block_max<T>(m, redm);
+    }
+    double carry = 0.0;
     for (int r = 0; r < g.rounds_per_tile; ++r) {
         const int64_t r0 = base + (int64_t)r * g.round_elems;
         if (r0 >= g.N) break;
         const int64_t i0 = r0 + threadIdx.x * 4;
+        const bool on = i0 < g.N;
         T v[4] = {T(0), T(0), T(0), T(0)};
-        if (i0 < g.N) load_vec<T, 4>(col + i0, v);
+        if (on) load_vec<T, 4>(col + i0, v);
         double run = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) run += (double)v[j];
+        for (int j = 0; j < 4; ++j) run += chunk_addend<T, FROM_W>(v[j], mk, on);
         double total;
         const double excl = block_scan_excl(run, red, total);
         const int64_t c = r0 / PF_CHUNK + wid;
@@ -822,7 +852,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_chunk_scan(const T* __restrict__ W
     }
     if (threadIdx.x == 0) {
         const int64_t stride = (int64_t)g.B * g.tiles;
-        part[PQ_M1 * stride + (int64_t)b * g.tiles + k] = 0.0;
+        part[PQ_M1 * stride + (int64_t)b * g.tiles + k] = FROM_W ? 0.0 : (double)mk;
         part[PQ_S1 * stride + (int64_t)b * g.tiles + k] = carry;
     }
 }
@@ -848,19 +878,22 @@ __device__ __forceinline__ ChunkLoad<T> chunk_load(const T* __restrict__ col, co
     q.basec = q.live ? cbcol[c] : 0.0;
     return q;
 }
-template <typename T>
-__device__ __forceinline__ void chunk_cdf4(const ChunkLoad<T>& q, double P, int N, int lane, T (&out)[4]) {
+// (P, f, Pn, m): the chunk's tile - prefix, factor (1 for weights), the next tile's prefix (the clamp k_scan applies to log-weight
+// tiles: the exps of a tile never carry it past the next one's start), maximum
+template <typename T, bool FROM_W>
+__device__ __forceinline__ void chunk_cdf4(const ChunkLoad<T>& q, double P, double f, double Pn, T m, int N, int lane, T (&out)[4]) {
     double e[4];
     double run = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        run += (double)q.v[j];
+        run += chunk_addend<T, FROM_W>(q.v[j], m, q.in);
         e[j] = run;
     }
     const double wex = wave_scan_incl(run, lane) - run;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const double cv = P + (q.basec + (wex + e[j]));
+        double cv = FROM_W ? P + (q.basec + (wex + e[j])) : P + f * (q.basec + (wex + e[j]));
+        if (!FROM_W && cv > Pn) cv = Pn;
         out[j] = q.in ? ((q.j0 + j == N - 1) ? T(1) : (T)cv) : Lim<T>::inf();
     }
 }
@@ -875,11 +908,14 @@ __device__ __forceinline__ void chunk_cdf4(const ChunkLoad<T>& q, double P, int 
 #define PF_CSTAMP_ARG
 #define PF_CSTAMP(slot) do { } while (0)
 #endif
-template <typename T>
+template <typename T, bool FROM_W>
 __global__ __launch_bounds__(PF_BLOCK) void k_chunk_search(const T* __restrict__ W, const T* __restrict__ u, const uint8_t* colmask,
                                                            const double* __restrict__ part, const double* __restrict__ cb,
                                                            int32_t* __restrict__ idx, Geom g, int nchunks PF_CSTAMP_ARG) {
-    __shared__ double ptab[PF_MAX_TILES];
+    __shared__ double ptab[PF_MAX_TILES + 4];
+    __shared__ double ftab[FROM_W ? 1 : PF_MAX_TILES];  // log-weights: the tiles' factors exp(m_t - M) / S and maxima
+    __shared__ T mtab[FROM_W ? 1 : PF_MAX_TILES];
+    __shared__ T redm[PF_NWAVES];
     __shared__ double red[PF_NWAVES];
     __shared__ int hd[PF_BLOCK * 4 + PF_WAVE];
     __shared__ __attribute__((aligned(32))) T c1buf[PF_CHUNK];
@@ -895,17 +931,42 @@ __global__ __launch_bounds__(PF_BLOCK) void k_chunk_search(const T* __restrict__
     int32_t* out = idx + (int64_t)b * g.N;
     const int64_t base = (int64_t)k * g.tile_elems;
     // ---- the column's tile-prefix table: P_t = sum of the tile sums before t (the same bits in every workgroup) ----
+    // (log-weights: of the tile sums rescaled to the column's maximum, over their total - the normalised prefix k_scan uses)
     {
-        const double* ps = part + PQ_S1 * ((int64_t)g.B * tiles) + (int64_t)b * tiles;
-        double s[4];
+        const int64_t stride = (int64_t)g.B * tiles;
+        const double* ps = part + PQ_S1 * stride + (int64_t)b * tiles;
+        double s[4], f[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[j] = (tid * 4 + j < tiles) ? ps[tid * 4 + j] : 0.0;
+        if constexpr (!FROM_W) {
+            const double* pm = part + PQ_M1 * stride + (int64_t)b * tiles;
+            double m[4];
+            T mx = -Lim<T>::inf();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m[j] = (tid * 4 + j < tiles) ? pm[tid * 4 + j] : -__builtin_huge_val();
+                mx = (T)m[j] > mx ? (T)m[j] : mx;
+            }
+            const double M = (double)block_max<T>(mx, redm);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[j] = exp_diff_t<T>(m[j], M);
+                s[j] *= f[j];
+                mtab[tid * 4 + j] = (T)m[j];
+            }
+        }
         double total;
         const double excl = block_scan_excl((s[0] + s[1]) + (s[2] + s[3]), red, total);
-        ptab[tid * 4 + 0] = excl;
-        ptab[tid * 4 + 1] = excl + s[0];
-        ptab[tid * 4 + 2] = excl + (s[0] + s[1]);
-        ptab[tid * 4 + 3] = excl + ((s[0] + s[1]) + s[2]);
+        const double inv = FROM_W ? 1.0 : 1.0 / total;
+        ptab[tid * 4 + 0] = excl * inv;
+        ptab[tid * 4 + 1] = (excl + s[0]) * inv;
+        ptab[tid * 4 + 2] = (excl + (s[0] + s[1])) * inv;
+        ptab[tid * 4 + 3] = (excl + ((s[0] + s[1]) + s[2])) * inv;
+        if (tid == PF_BLOCK - 1) ptab[PF_MAX_TILES] = FROM_W ? total : 1.0;  // (the end of a column of PF_MAX_TILES tiles)
+        if constexpr (!FROM_W) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ftab[tid * 4 + j] = f[j] * inv;
+        }
     }
     __syncthreads();
     PF_CSTAMP(1);
@@ -930,7 +991,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_chunk_search(const T* __restrict__
         const int c = t * cpt + tid;
         const bool in = tid < cpt && c < nchunks;
         const double v = in ? cbcol[c] : 0.0;
-        int cc = block_count(in && (T)(ptab[t] + v) < p, false, false, false) - 1;
+        int cc = block_count(in && (T)(ptab[t] + (FROM_W ? v : ftab[FROM_W ? 0 : t] * v)) < p, false, false, false) - 1;
         cc = cc < 0 ? 0 : cc;
         return t * cpt + cc;
     };
@@ -955,9 +1016,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_chunk_search(const T* __restrict__
             const ChunkLoad<T> la = chunk_load<T>(col, cbcol, chunk + wid, nchunks, N, lane);
             ChunkLoad<T> lb;
             if (wid == 0) lb = chunk_load<T>(col, cbcol, chunk + 4, nchunks, N, lane);
-            chunk_cdf4<T>(la, la.live ? ptab[t0 + (off + wid >= cpt ? 1 : 0)] : 0.0, N, lane, c0);
+            // (entries past the last tile are beyond the column: +inf whatever the tables hold - the index is only kept in range)
+            const int ta = t0 + (off + wid >= cpt ? 1 : 0) < tiles ? t0 + (off + wid >= cpt ? 1 : 0) : tiles - 1;
+            const int tb = t0 + (off + 4 >= cpt ? 1 : 0) < tiles ? t0 + (off + 4 >= cpt ? 1 : 0) : tiles - 1;
+            chunk_cdf4<T, FROM_W>(la, ptab[ta], FROM_W ? 1.0 : ftab[FROM_W ? 0 : ta], ptab[ta + 1], FROM_W ? T(0) : mtab[FROM_W ? 0 : ta], N, lane, c0);
             if (wid == 0) {
-                chunk_cdf4<T>(lb, lb.live ? ptab[t0 + (off + 4 >= cpt ? 1 : 0)] : 0.0, N, lane, c1);
+                chunk_cdf4<T, FROM_W>(lb, ptab[tb], FROM_W ? 1.0 : ftab[FROM_W ? 0 : tb], ptab[tb + 1], FROM_W ? T(0) : mtab[FROM_W ? 0 : tb], N, lane, c1);
                 store_vec<T, 4>(c1buf + lane * 4, c1);
             }
             __syncthreads();  // c1buf is written (and, first window: hd is zeroed)
@@ -1615,7 +1679,7 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(g.tiles, g.B);
     if (!cdf) {  // no cdf wanted: the two-launch form where it applies (pf_systematic_cdf_free), nothing else
-        if (!from_w || multinomial || !cdf_free_applies(g, dtype, u_per_elem)) return PF_EINVAL;
+        if (multinomial || !cdf_free_applies(g, dtype, u_per_elem)) return PF_EINVAL;
         double* cb = (double*)((char*)ws + wl.off_ctab);
         const int nchunks = (int)((N + PF_CHUNK - 1) / PF_CHUNK);
 #ifdef PF_DEVTOOLS  // (the instrumented build: cycle stamps of the middle workgroup of column 0, tools/chunk_search_stages.py)
@@ -1623,15 +1687,16 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
 #else
 #define PF_CHUNK_DBG
 #endif
+#define PF_CHUNK_CALL(T, FW)                                                                                                 \
+    hipLaunchKernelGGL((k_chunk_scan<T, FW>), grid, dim3(PF_BLOCK), 0, st, (T*)src, colmask, part, cb, g, nchunks);           \
+    hipLaunchKernelGGL((k_chunk_search<T, FW>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (const T*)u, colmask,             \
+                       (const double*)part, (const double*)cb, idx, g, nchunks PF_CHUNK_DBG);
         if (dtype == PF_F32) {
-            hipLaunchKernelGGL((k_chunk_scan<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)src, colmask, part, cb, g, nchunks);
-            hipLaunchKernelGGL((k_chunk_search<float>), grid, dim3(PF_BLOCK), 0, st, (const float*)src, (const float*)u, colmask,
-                               (const double*)part, (const double*)cb, idx, g, nchunks PF_CHUNK_DBG);
+            if (from_w) { PF_CHUNK_CALL(float, true) } else { PF_CHUNK_CALL(float, false) }
         } else {
-            hipLaunchKernelGGL((k_chunk_scan<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)src, colmask, part, cb, g, nchunks);
-            hipLaunchKernelGGL((k_chunk_search<double>), grid, dim3(PF_BLOCK), 0, st, (const double*)src, (const double*)u, colmask,
-                               (const double*)part, (const double*)cb, idx, g, nchunks PF_CHUNK_DBG);
+            if (from_w) { PF_CHUNK_CALL(double, true) } else { PF_CHUNK_CALL(double, false) }
         }
+#undef PF_CHUNK_CALL
 #undef PF_CHUNK_DBG
         PF_CHECK_LAUNCH();
         return PF_OK;

@@ -192,8 +192,8 @@ def systematic_cols(w: torch.Tensor, u: torch.Tensor, normalized: bool, colmask:
         idx = torch.empty((b, n), dtype=torch.int32, device=w.device)
         if colmask is not None:
             idx.copy_(torch.arange(n, device=w.device, dtype=torch.int32).unsqueeze(0).expand(b, n))
-    # normalised weights, several tiles per column: no cdf is materialised (two launches; include/pf_amd.h: pf_systematic, cdf == NULL)
-    cdf = None if (normalized and SYSTEMATIC_CDF_FREE and _cdf_free(n, b, w.dtype, per_elem)) else torch.empty_like(w)
+    # several tiles per column: no cdf is materialised (two launches; include/pf_amd.h: pf_systematic, cdf == NULL)
+    cdf = None if (SYSTEMATIC_CDF_FREE and _cdf_free(n, b, w.dtype, per_elem)) else torch.empty_like(w)
     ws = L.workspace(n, b, w.device)
     fn = L.load().pf_systematic if normalized else L.load().pf_systematic_logw
     L.check(

@@ -166,6 +166,38 @@ def test_systematic_sparse_and_masked_columns(pf, dt, n, b, sys_route):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("n,b", [(1 << 20, 1), (65536, 64), (40960, 3), (4100, 70)])
+def test_systematic_from_log_weights_on_several_tiles(pf, dt, n, b, sys_route):
+    """``systematic(logw, normalized=False)`` on columns of several tiles, both forms: the in-place sanitisation is the reference's,
+    the ancestors are the float64 oracle's up to grid positions within rounding of a cdf boundary (float32: the bar of the
+    degenerate-weights test), and a column with a few finite log-weights among -inf / NaN ones resamples exactly those."""
+    dtype = DT[dt]
+    gen = torch.Generator().manual_seed(3 * n + b)
+    lw = 2.5 * torch.randn(n, b, generator=gen, dtype=dtype)
+    lw[7, 0], lw[n // 2, 0], lw[n - 3, 0] = float("nan"), float("inf"), -float("inf")
+    sparse = b - 1  # the last column: 50 finite entries, equal, far apart
+    lw[:, sparse] = -float("inf")
+    at = torch.randperm(n, generator=gen)[:50].sort().values
+    lw[at, sparse] = 1.5
+    lw[::97, sparse] = float("nan")
+    lw[at, sparse] = 1.5
+    u = torch.rand(b, 1, generator=gen, dtype=dtype)
+    lw_ref = lw.clone()
+    cpu_ref.systematic(lw_ref, normalized=False, u=u)  # (the in-place sanitisation)
+    expect = cpu_ref.systematic(lw.clone().double(), normalized=False, u=u.double())
+    lw_gpu = lw.clone().cuda()
+    got = pf.resampling.systematic(lw_gpu, normalized=False, u=u.cuda()).cpu()
+    assert torch.equal(lw_gpu.cpu(), lw_ref)
+    frac = (got != expect).double().mean().item()
+    assert frac < (5e-3 if dt == "f32" else 1e-9), frac
+    if dt == "f64":
+        assert int((got - expect).abs().max()) <= 1
+    # the sparse column: only its finite entries are ancestors (-inf sanitises to the lowest finite value: weight exp(-huge) = 0)
+    assert set(got[:, sparse].tolist()) <= set(at.tolist()) and len(set(got[:, sparse].tolist())) == 50
+    assert (got[1:] >= got[:-1]).all() and got.min() >= 0 and got.max() <= n - 1
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_systematic_with_nan_weights_terminates(pf, dt, sys_route):
     """Garbage in: NaN weights give no meaningful ancestors (searchsorted on an unsorted cdf) - but every launch ends and every
     index is in range."""

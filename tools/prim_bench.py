@@ -52,6 +52,16 @@ def main():
                 ops.SYSTEMATIC_CDF_FREE = True
 
         rows.insert(2, ("systematic(W) with the cdf (tile sums, scan, search)", three_launches, 4 + 4 + 4 + 4))
+
+        def logw_three():
+            ops.SYSTEMATIC_CDF_FREE = False
+            try:
+                return ops.systematic_cols(lw, u, False)
+            finally:
+                ops.SYSTEMATIC_CDF_FREE = True
+
+        rows.insert(3, ("systematic(logw) -> idx (no cdf where it applies)", lambda: ops.systematic_cols(lw, u, False), 4 + 4 + 4 + 4))
+        rows.insert(4, ("systematic(logw) with the cdf (reduce, scan, search)", logw_three, 4 + 4 + 4 + 4))
         if n * b <= (1 << 24):  # the three-launch path (one offset per grid position always takes it): the A/B of the one-launch resampler
             u_exp = u.unsqueeze(1).expand(b, n).contiguous()
             rows.insert(2, ("systematic(W), three launches (u per position)", lambda: ops.systematic_cols(W, u_exp, True), 4 + 4 + 4 + 4))
