@@ -751,6 +751,10 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
             }
         }
     } else {
+        // iid draws (the reference's torch.multinomial order: unsorted), each a lower_bound over the whole column: N random
+        // bisections of an N-entry array move a 64-byte sector per 4-byte probe - bound by that traffic, not by the chain of
+        // dependent loads (a two-level form - tiles' ends in LDS, the thread's four bisections side by side - was measured SLOWER:
+        // 4M x 1 358 -> 492 us, profiles/r06_systematic_two_launches.txt).  The fused routes draw SORTED order statistics instead.
         for (int r = 0; r < g.rounds_per_tile; ++r) {
             const int64_t i0 = base + (int64_t)r * g.round_elems + threadIdx.x * VEC;
             if (i0 >= g.N) break;

@@ -273,6 +273,30 @@ def test_multinomial_statistics(pf, dt):
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
+@pytest.mark.parametrize("n,b", [(1 << 20, 1), (65536, 8), (20480, 3), (1003, 2), (8192, 64), (5, 1)])
+def test_multinomial_given_uniforms_is_searchsorted(pf, dt, n, b):
+    """``pf_multinomial`` on the caller's uniforms: position by position the first entry of the rounded cdf that is >= v (the
+    inverse-cdf draw ``torch.multinomial`` makes) - the two-level bisection (tiles' ends in LDS, then inside the tile) must name
+    exactly the entry a bisection of the whole column names.  float32 weights: fp64 sums of them are exact, bit-exact ancestors;
+    float64: up to draws within an ulp of a boundary."""
+    from pyfilter_amd import ops
+
+    dtype = DT[dt]
+    gen = torch.Generator().manual_seed(n + 7 * b)
+    W = cpu_ref.normalize((2.0 * torch.randn(n, b, generator=gen, dtype=dtype)).double()).to(dtype)
+    if n > 4096:
+        W[: n // 2, b - 1] = 0.0  # a long weightless stretch: whole tiles without mass
+    v = torch.rand(b, n, generator=gen, dtype=dtype)
+    v[0, :3] = torch.tensor([0.0, 1.0 - torch.finfo(dtype).eps, 0.5], dtype=dtype)[: min(3, n)]
+    cdf = W.t().double().cumsum(1).to(dtype)
+    cdf[:, -1] = 1.0
+    expect = torch.searchsorted(cdf.contiguous(), v.contiguous()).clamp(max=n - 1)
+    got = ops.multinomial_cols(W.t().contiguous().cuda(), 0, v=v.cuda()).cpu().long()
+    mism = int((got != expect).sum())
+    assert mism <= (0 if dt == "f32" else 2), f"{mism} / {n * b} draws differ"
+
+
+@pytest.mark.parametrize("dt", ["f32", "f64"])
 @pytest.mark.parametrize("n,b,d", [(4096, 3, 1), (1000, 2, 3), (1 << 18, 1, 3)])
 def test_gather_moments(pf, dt, n, b, d):
     from pyfilter_amd import ops

@@ -42,6 +42,7 @@ def main():
         rows = [
             ("normalize (logw -> W, in-place sanitise)", lambda: ops.normalize_cols(lw), 4 + 4 + 4 + 4),   # read, rewrite, read again, write W
             ("systematic(W) -> idx (no cdf where it applies)", lambda: ops.systematic_cols(W, u, True), 4 + 4 + 4 + 4),  # (the contract: read W, write cdf, read cdf, write idx)
+            ("multinomial(W) iid draws -> idx", lambda: ops.multinomial_cols(W, 1234), 4 + 4 + 4 + 4),
             ("gather x[idx]", lambda: ops.gather_soa(x, idx), 4 + 4 + 4),
         ]
         def three_launches():
