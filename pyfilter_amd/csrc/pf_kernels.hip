@@ -89,8 +89,31 @@ struct WsLayout {
     size_t off_clu;    // cluster route (pf_cluster.hpp; columns of PF_CLUSTER_MIN_N < N <= PF_CLUSTER_MAX_N particles): int32 error
                        // word (256 B) | granule records [2][B][PF_CLUSTER_NG][64] x 16 B; absent (clu_bytes = 0) otherwise
     size_t clu_bytes;
+    size_t off_tree;   // T [B][CdfTree::total]: the cdf sampled at every 16th, 256th, ... entry (the stand-alone multinomial's search tables)
     size_t total;
 };
+
+// pf_multinomial's search tables: level l holds the LAST cdf entry of every block of 16^(l+1) entries (the column's last entry, 1, closes
+// every level); levels are padded to 16 entries, the top one has at most 16.  N <= 2^30: at most 7 levels, N / 15 entries in all.
+struct CdfTree {
+    int levels, total;
+    int size[8], off[8];
+};
+__host__ __device__ static inline CdfTree cdf_tree(int64_t N) {
+    CdfTree t;
+    int64_t n = N;
+    int cur = 0;
+    t.levels = 0;
+    do {
+        n = (n + 15) / 16;
+        t.size[t.levels] = (int)n;
+        t.off[t.levels] = cur;
+        cur += (int)((n + 15) & ~(int64_t)15);
+        ++t.levels;
+    } while (n > 16 && t.levels < 8);
+    t.total = cur;
+    return t;
+}
 
 // the cluster route's column sizes: above what one workgroup holds (pf_column.hpp), at most 64 chunks of 256 particles
 #define PF_CLUSTER_MIN_N 2048
@@ -125,6 +148,8 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.clu_bytes = (g.N > PF_CLUSTER_MIN_N && g.N <= PF_CLUSTER_MAX_N && g.N % 4 == 0 && ((g.N + 1023) / 1024) * (int64_t)g.B <= 8192)
                       ? 256 + (size_t)2 * g.B * PF_CLUSTER_NG * 64 * 16 : 0;
     o = align256(o + w.clu_bytes);
+    w.off_tree = o;  // pf_multinomial: 16-ary search tables over the cdf (CdfTree), sized for double
+    o = align256(o + sizeof(double) * (size_t)g.B * cdf_tree(g.N).total);
     w.total = o;
     return w;
 }
@@ -557,7 +582,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_tile_sum(const T* __restrict__ W, 
 //   otherwise: e_j = exp(logw_j - m_k),   f_k = exp(m_k - M) / S,      P_k = normalised prefix
 template <typename T, int VEC, bool FROM_W>
 __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __restrict__ cdf_col, const Geom& g, int k,
-                                          T tile_max, double Pk, double fk, double Pnext, double* red, const T (&v_first)[VEC]) {
+                                          T tile_max, double Pk, double fk, double Pnext, double* red, const T (&v_first)[VEC],
+                                          T* __restrict__ tree_col = nullptr) {
+    CdfTree tr;
+    if (tree_col) tr = cdf_tree(g.N);
     double carry = 0.0;
     const int64_t base = (int64_t)k * g.tile_elems;
     for (int r = 0; r < g.rounds_per_tile; ++r) {
@@ -593,6 +621,22 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
                 outv[j] = (i0 + j == g.N - 1) ? T(1) : (T)c;  // cumsum[..., -1] = 1.0  (resampling.py:49)
             }
             if (VEC == 1) cdf_col[i0] = outv[0]; else store_vec<T, VEC>(cdf_col + i0, outv);
+            if (tree_col) {  // (pf_multinomial) the entries that close a block of 16, 256, ... - and the column's last one every level
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int64_t i = i0 + j;
+                    if (i == g.N - 1) {
+                        for (int l = 0; l < tr.levels; ++l) tree_col[tr.off[l] + tr.size[l] - 1] = outv[j];
+                    } else if (((i + 1) & 15) == 0) {
+                        int64_t m = (i + 1) >> 4;
+                        tree_col[tr.off[0] + m - 1] = outv[j];
+                        for (int l = 1; l < tr.levels && (m & 15) == 0; ++l) {
+                            m >>= 4;
+                            tree_col[tr.off[l] + m - 1] = outv[j];
+                        }
+                    }
+                }
+            }
         }
         carry += total;
     }
@@ -600,7 +644,7 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
 
 template <typename T, int VEC, bool FROM_W>
 __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restrict__ cdf, const uint8_t* colmask,
-                                          const double* __restrict__ part, const Geom& g, int b, int k) {
+                                          const double* __restrict__ part, const Geom& g, int b, int k, T* __restrict__ tree = nullptr) {
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
     if (colmask && !colmask[b]) return;
@@ -649,12 +693,13 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
         Pk = c.prefix / c.S;
         Pnext = Pk + sk * fk;
     }
-    scan_tile<T, VEC, FROM_W>(src + (int64_t)b * g.N, cdf + (int64_t)b * g.N, g, k, (T)mk, Pk, fk, Pnext, red, v_first);
+    scan_tile<T, VEC, FROM_W>(src + (int64_t)b * g.N, cdf + (int64_t)b * g.N, g, k, (T)mk, Pk, fk, Pnext, red, v_first,
+                              tree ? tree + (int64_t)b * cdf_tree(g.N).total : nullptr);
 }
 template <typename T, int VEC, bool FROM_W>
 __global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T* __restrict__ cdf,
-                                                   const uint8_t* colmask, const double* __restrict__ part, Geom g) {
-    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, blockIdx.y, blockIdx.x);
+                                                   const uint8_t* colmask, const double* __restrict__ part, Geom g, T* tree) {
+    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, blockIdx.y, blockIdx.x, tree);
 }
 
 // ancestors from the cdf: systematic grid (u per column) or iid uniforms (multinomial)
@@ -662,7 +707,7 @@ template <typename T, int VEC>
 __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* __restrict__ u, int u_per_elem,
                                             const T* __restrict__ v, int multinomial, uint64_t seed, uint32_t step,
                                             const uint8_t* colmask, int32_t* __restrict__ idx, const Geom& g, int force_search,
-                                            int b, int k) {
+                                            int b, int k, const T* __restrict__ tree = nullptr) {
     __shared__ __attribute__((aligned(32))) T win[SearchWin<T, VEC>::WIN];
     __shared__ int sh_j0;
     if (colmask && !colmask[b]) return;
@@ -751,19 +796,59 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
             }
         }
     } else {
-        // iid draws (the reference's torch.multinomial order: unsorted), each a lower_bound over the whole column: N random
-        // bisections of an N-entry array move a 64-byte sector per 4-byte probe - bound by that traffic, not by the chain of
-        // dependent loads (a two-level form - tiles' ends in LDS, the thread's four bisections side by side - was measured SLOWER:
-        // 4M x 1 358 -> 492 us, profiles/r06_systematic_two_launches.txt).  The fused routes draw SORTED order statistics instead.
+        // iid draws (the reference's torch.multinomial order: unsorted), each a lower_bound over the whole column.  A bisection of
+        // N entries moves a 64-byte sector per 4-byte probe, ~10 of them per draw beyond what the caches hold, and that traffic -
+        // not the chain of dependent loads - is what bounds it (4M x 1: 358 us; a two-level bisection with the thread's four
+        // draws side by side was SLOWER, profiles/r06_systematic_two_launches.txt).  So the search is 16-ary over tables the scan
+        // kernel leaves (CdfTree: the cdf at every 16th, 256th, ... entry): a level is ONE aligned 64-byte group of 16 entries per
+        // draw, counted in registers; the top levels (<= 4 096 entries) live in the caches, the 256-stride one in L2, and a draw
+        // touches one or two lines beyond them instead of ten.
+        const CdfTree tr = cdf_tree(g.N);
+        const T* tcol = tree + (int64_t)b * tr.total;
+        // entries of the 16-group at `row` that are < p; `nv` of them exist (a level's padding / the column's end: never counted)
+        auto count16 = [&](const T* __restrict__ row, int nv, T p, bool vector_ok) -> int {
+            int cnt = 0;
+            if (vector_ok) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    T e[4];
+                    load_vec<T, 4>(row + 4 * q4, e);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cnt += (4 * q4 + i < nv && e[i] < p) ? 1 : 0;
+                }
+            } else {
+                for (int i = 0; i < nv; ++i) cnt += (row[i] < p) ? 1 : 0;
+            }
+            return cnt;
+        };
         for (int r = 0; r < g.rounds_per_tile; ++r) {
             const int64_t i0 = base + (int64_t)r * g.round_elems + threadIdx.x * VEC;
             if (i0 >= g.N) break;
-            int res[VEC];
+            T p[VEC];
+            int grp[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int64_t e = (int64_t)b * g.N + i0 + j;
-                const T p = v ? v[e] : uniform_draw<T>(seed, PF_STREAM_MULTINOMIAL, step, (uint64_t)e);
-                int a = thread_lower_bound<T>(col, 0, N, p);
+                p[j] = v ? v[e] : uniform_draw<T>(seed, PF_STREAM_MULTINOMIAL, step, (uint64_t)e);
+                grp[j] = 0;
+            }
+            for (int l = tr.levels - 1; l >= 0; --l) {  // (the thread's VEC draws level by level: independent loads side by side)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int at = grp[j] * 16;  // (< size[l]: the clamp below)
+                    const int nv = tr.size[l] - at > 16 ? 16 : tr.size[l] - at;
+                    const int nxt = at + count16(tcol + tr.off[l] + at, nv, p[j], true);
+                    // (a group's last entry is >= p by the level above, so nxt names an entry of this level - unless NaNs broke the
+                    // order: the clamp keeps every address inside its table)
+                    grp[j] = nxt < tr.size[l] ? nxt : tr.size[l] - 1;
+                }
+            }
+            int res[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int at = grp[j] * 16;  // (< N)
+                const int nv = N - at > 16 ? 16 : N - at;
+                const int a = at + count16(col + at, nv, p[j], VEC == 4 && nv == 16);
                 res[j] = a > N - 1 ? N - 1 : a;
             }
             if (VEC == 1) out[i0] = res[0]; else store_vec<int, VEC>(out + i0, res);
@@ -774,8 +859,8 @@ template <typename T, int VEC>
 __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, const T* __restrict__ u,
                                                      int u_per_elem, const T* __restrict__ v, int multinomial, uint64_t seed,
                                                      uint32_t step, const uint8_t* colmask, int32_t* __restrict__ idx,
-                                                     Geom g, int force_search) {
-    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, force_search, blockIdx.y, blockIdx.x);
+                                                     Geom g, int force_search, const T* tree) {
+    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, force_search, blockIdx.y, blockIdx.x, tree);
 }
 // ---------------------------------------------------------------------------------------------------------------
 // systematic(W) WITHOUT a materialised cdf (pf_systematic with cdf == NULL): two launches instead of three, 12 bytes per particle
@@ -1100,16 +1185,16 @@ template <typename T, int VEC, bool FROM_W>
 __global__ __launch_bounds__(PF_BLOCK) void k_resample_one_tile(T* __restrict__ src, const T* __restrict__ u, int u_per_elem,
                                                                 const T* __restrict__ v, int multinomial, uint64_t seed,
                                                                 uint32_t step, const uint8_t* colmask, T* __restrict__ cdf,
-                                                                int32_t* __restrict__ idx, double* __restrict__ part, Geom g) {
+                                                                int32_t* __restrict__ idx, double* __restrict__ part, Geom g, T* tree) {
     const int b = blockIdx.y;
     if (FROM_W) tile_sum_body<T, VEC>(src, colmask, part, g, b, 0);
     else reduce_logw_body<T, VEC>(src, 1, colmask, part, g, b, 0);
     __threadfence_block();
     __syncthreads();
-    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, b, 0);
+    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, b, 0, multinomial ? tree : nullptr);
     __threadfence_block();
     __syncthreads();
-    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, 0, b, 0);
+    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, 0, b, 0, tree);
 }
 
 template <typename T>
@@ -1705,26 +1790,29 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
         PF_CHECK_LAUNCH();
         return PF_OK;
     }
+    void* tree = multinomial ? (void*)((char*)ws + wl.off_tree) : nullptr;  // (the iid draws' 16-ary search tables, written by the scan)
 #define CALL(T, V)                                                                                                   \
     if (g.tiles == 1) { /* one tile per column: record -> scan -> ancestors in one launch */                          \
         if (from_w)                                                                                                  \
             hipLaunchKernelGGL((k_resample_one_tile<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (T*)src, (const T*)u, \
-                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g);    \
+                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g,     \
+                               (T*)tree);                                                                            \
         else                                                                                                         \
             hipLaunchKernelGGL((k_resample_one_tile<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (T*)src, (const T*)u,\
-                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g);    \
+                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g,     \
+                               (T*)tree);                                                                            \
     } else if (from_w) {                                                                                             \
         hipLaunchKernelGGL((k_tile_sum<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, colmask, part, g);        \
         hipLaunchKernelGGL((k_scan<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,       \
-                           (const double*)part, g);                                                                  \
+                           (const double*)part, g, (T*)tree);                                                        \
     } else {                                                                                                         \
         hipLaunchKernelGGL((k_reduce_logw<T, V>), grid, dim3(PF_BLOCK), 0, st, (T*)src, 1, colmask, part, g);        \
         hipLaunchKernelGGL((k_scan<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,      \
-                           (const double*)part, g);                                                                  \
+                           (const double*)part, g, (T*)tree);                                                        \
     }                                                                                                                \
     if (g.tiles != 1)                                                                                                \
         hipLaunchKernelGGL((k_search<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u, u_per_elem,    \
-                           (const T*)v, multinomial, seed, step, colmask, idx, g, /*force_search*/ 0);
+                           (const T*)v, multinomial, seed, step, colmask, idx, g, /*force_search*/ 0, (const T*)tree);
     PF_DISPATCH_T_VEC(dtype, g.vec, CALL)
 #undef CALL
     PF_CHECK_LAUNCH();
