@@ -509,7 +509,8 @@ __device__ __forceinline__ void normalize_write_body(const T* __restrict__ logw,
                                                      T* __restrict__ ess, const double* __restrict__ part, const Geom& g, int b, int k) {
     __shared__ double red[4 * PF_NWAVES];
     __shared__ double redm[PF_NWAVES];
-    const ColLse c = combine_partials<T>(part, PQ_M1, PQ_S1, PQ_Q1, b, k, g.B, g.tiles, red, redm);
+    // (the sums of squares serve the ESS, which tile 0's workgroup alone reports: the others skip a third of the records)
+    const ColLse c = combine_partials<T>(part, PQ_M1, PQ_S1, (k == 0 && ess) ? PQ_Q1 : -1, b, k, g.B, g.tiles, red, redm);
     if (k == 0 && threadIdx.x == 0) {
         if (lse) lse[b] = (T)(c.M + log(c.S));
         if (ess) ess[b] = (T)(c.S * c.S / c.Q);
