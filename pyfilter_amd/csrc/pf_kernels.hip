@@ -89,30 +89,37 @@ struct WsLayout {
     size_t off_clu;    // cluster route (pf_cluster.hpp; columns of PF_CLUSTER_MIN_N < N <= PF_CLUSTER_MAX_N particles): int32 error
                        // word (256 B) | granule records [2][B][PF_CLUSTER_NG][64] x 16 B; absent (clu_bytes = 0) otherwise
     size_t clu_bytes;
-    size_t off_tree;   // T [B][CdfTree::total]: the cdf sampled at every 16th, 256th, ... entry (the stand-alone multinomial's search tables)
+    size_t off_tree;   // T [B][cdf_tree_total(N)]: the cdf sampled at every 16th, 256th, ... entry (the stand-alone multinomial's search tables)
     size_t total;
 };
 
-// pf_multinomial's search tables: level l holds the LAST cdf entry of every block of 16^(l+1) entries (the column's last entry, 1, closes
-// every level); levels are padded to 16 entries, the top one has at most 16.  N <= 2^30: at most 7 levels, N / 15 entries in all.
-struct CdfTree {
-    int levels, total;
-    int size[8], off[8];
-};
-__host__ __device__ static inline CdfTree cdf_tree(int64_t N) {
-    CdfTree t;
+// pf_multinomial's search tables (the "cdf tree"): level l holds the LAST cdf entry of every block of 16^(l+1) entries (the column's last
+// entry, 1, closes every level); levels are padded to 16 entries, the top one has at most 16.  N <= 2^30: at most 7 levels, N / 15
+// entries in all.  Sizes and offsets are recomputed where they are used (a handful of scalar shifts): kept in per-thread arrays indexed
+// by a run-time level they were promoted to LDS / scratch - 18 KB of LDS in k_scan.
+__host__ __device__ static inline int cdf_tree_levels(int64_t N) {
+    int levels = 0;
     int64_t n = N;
-    int cur = 0;
-    t.levels = 0;
     do {
-        n = (n + 15) / 16;
-        t.size[t.levels] = (int)n;
-        t.off[t.levels] = cur;
-        cur += (int)((n + 15) & ~(int64_t)15);
-        ++t.levels;
-    } while (n > 16 && t.levels < 8);
-    t.total = cur;
-    return t;
+        n = (n + 15) >> 4;
+        ++levels;
+    } while (n > 16 && levels < 8);
+    return levels;
+}
+__host__ __device__ static inline void cdf_tree_level(int64_t N, int l, int& size, int& off) {
+    int64_t n = (N + 15) >> 4;
+    int o = 0;
+    for (int i = 0; i < l; ++i) {
+        o += (int)((n + 15) & ~(int64_t)15);
+        n = (n + 15) >> 4;
+    }
+    size = (int)n;
+    off = o;
+}
+__host__ __device__ static inline int cdf_tree_total(int64_t N) {  // entries per column
+    int size, off;
+    cdf_tree_level(N, cdf_tree_levels(N) - 1, size, off);
+    return off + ((size + 15) & ~15);
 }
 
 // the cluster route's column sizes: above what one workgroup holds (pf_column.hpp), at most 64 chunks of 256 particles
@@ -148,8 +155,8 @@ static inline WsLayout make_ws(const Geom& g, int D) {
     w.clu_bytes = (g.N > PF_CLUSTER_MIN_N && g.N <= PF_CLUSTER_MAX_N && g.N % 4 == 0 && ((g.N + 1023) / 1024) * (int64_t)g.B <= 8192)
                       ? 256 + (size_t)2 * g.B * PF_CLUSTER_NG * 64 * 16 : 0;
     o = align256(o + w.clu_bytes);
-    w.off_tree = o;  // pf_multinomial: 16-ary search tables over the cdf (CdfTree), sized for double
-    o = align256(o + sizeof(double) * (size_t)g.B * cdf_tree(g.N).total);
+    w.off_tree = o;  // pf_multinomial: 16-ary search tables over the cdf (cdf_tree_*), sized for double
+    o = align256(o + sizeof(double) * (size_t)g.B * cdf_tree_total(g.N));
     w.total = o;
     return w;
 }
@@ -585,8 +592,7 @@ template <typename T, int VEC, bool FROM_W>
 __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __restrict__ cdf_col, const Geom& g, int k,
                                           T tile_max, double Pk, double fk, double Pnext, double* red, const T (&v_first)[VEC],
                                           T* __restrict__ tree_col = nullptr) {
-    CdfTree tr;
-    if (tree_col) tr = cdf_tree(g.N);
+    const int tree_levels = tree_col ? cdf_tree_levels(g.N) : 0;
     double carry = 0.0;
     const int64_t base = (int64_t)k * g.tile_elems;
     for (int r = 0; r < g.rounds_per_tile; ++r) {
@@ -626,14 +632,22 @@ __device__ __forceinline__ void scan_tile(const T* __restrict__ src_col, T* __re
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     const int64_t i = i0 + j;
+                    int64_t n = (g.N + 15) >> 4;  // level 0's size; `o` its offset
+                    int o = 0;
                     if (i == g.N - 1) {
-                        for (int l = 0; l < tr.levels; ++l) tree_col[tr.off[l] + tr.size[l] - 1] = outv[j];
+                        for (int l = 0; l < tree_levels; ++l) {
+                            tree_col[o + n - 1] = outv[j];
+                            o += (int)((n + 15) & ~(int64_t)15);
+                            n = (n + 15) >> 4;
+                        }
                     } else if (((i + 1) & 15) == 0) {
                         int64_t m = (i + 1) >> 4;
-                        tree_col[tr.off[0] + m - 1] = outv[j];
-                        for (int l = 1; l < tr.levels && (m & 15) == 0; ++l) {
+                        tree_col[m - 1] = outv[j];
+                        for (int l = 1; l < tree_levels && (m & 15) == 0; ++l) {
+                            o += (int)((n + 15) & ~(int64_t)15);
+                            n = (n + 15) >> 4;
                             m >>= 4;
-                            tree_col[tr.off[l] + m - 1] = outv[j];
+                            tree_col[o + m - 1] = outv[j];
                         }
                     }
                 }
@@ -695,7 +709,7 @@ __device__ __forceinline__ void scan_body(const T* __restrict__ src, T* __restri
         Pnext = Pk + sk * fk;
     }
     scan_tile<T, VEC, FROM_W>(src + (int64_t)b * g.N, cdf + (int64_t)b * g.N, g, k, (T)mk, Pk, fk, Pnext, red, v_first,
-                              tree ? tree + (int64_t)b * cdf_tree(g.N).total : nullptr);
+                              tree ? tree + (int64_t)b * cdf_tree_total(g.N) : nullptr);
 }
 template <typename T, int VEC, bool FROM_W>
 __global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T* __restrict__ cdf,
@@ -704,9 +718,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scan(const T* __restrict__ src, T*
 }
 
 // ancestors from the cdf: systematic grid (u per column) or iid uniforms (multinomial)
-template <typename T, int VEC>
+// MN: iid multinomial draws (pf_multinomial) instead of the systematic grid - a template parameter so that the systematic
+// instantiations do not carry the draws' registers (four 16-entry groups in flight per thread)
+template <typename T, int VEC, bool MN>
 __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* __restrict__ u, int u_per_elem,
-                                            const T* __restrict__ v, int multinomial, uint64_t seed, uint32_t step,
+                                            const T* __restrict__ v, uint64_t seed, uint32_t step,
                                             const uint8_t* colmask, int32_t* __restrict__ idx, const Geom& g, int force_search,
                                             int b, int k, const T* __restrict__ tree = nullptr) {
     __shared__ __attribute__((aligned(32))) T win[SearchWin<T, VEC>::WIN];
@@ -718,7 +734,7 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
     const int64_t base = (int64_t)k * g.tile_elems;
     const int lane = threadIdx.x & 63;
 
-    if (!multinomial) {
+    if constexpr (!MN) {
         const T* u_elem = u_per_elem ? u + (int64_t)b * g.N : nullptr;
         const T ub = u_per_elem ? u_elem[base < g.N ? base : 0] : u[b];
         // (the whole workgroup bracketing the answer with 256 or 1 024 counted probes per round - two or three dependent round
@@ -801,11 +817,11 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
         // N entries moves a 64-byte sector per 4-byte probe, ~10 of them per draw beyond what the caches hold, and that traffic -
         // not the chain of dependent loads - is what bounds it (4M x 1: 358 us; a two-level bisection with the thread's four
         // draws side by side was SLOWER, profiles/r06_systematic_two_launches.txt).  So the search is 16-ary over tables the scan
-        // kernel leaves (CdfTree: the cdf at every 16th, 256th, ... entry): a level is ONE aligned 64-byte group of 16 entries per
+        // kernel leaves (cdf_tree_*: the cdf at every 16th, 256th, ... entry): a level is ONE aligned 64-byte group of 16 entries per
         // draw, counted in registers; the top levels (<= 4 096 entries) live in the caches, the 256-stride one in L2, and a draw
         // touches one or two lines beyond them instead of ten.
-        const CdfTree tr = cdf_tree(g.N);
-        const T* tcol = tree + (int64_t)b * tr.total;
+        const int levels = cdf_tree_levels(g.N);
+        const T* tcol = tree + (int64_t)b * cdf_tree_total(g.N);
         // entries of the 16-group at `row` that are < p; `nv` of them exist (a level's padding / the column's end: never counted)
         auto count16 = [&](const T* __restrict__ row, int nv, T p, bool vector_ok) -> int {
             int cnt = 0;
@@ -822,6 +838,24 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
             }
             return cnt;
         };
+        // The top levels - as many as the window array holds (2 048 / 512 entries) - are copied into LDS once per workgroup: every
+        // lane of a global load names its own line, and at 2^20 x 1 those per-lane requests (20 of them per draw through five levels,
+        // ~1 per clock and CU) were what bounded the kernel; LDS serves the same 16-entry groups without them.
+        constexpr int WIN = SearchWin<T, VEC>::WIN;
+        int lds_from = levels;  // levels [lds_from, levels) sit in `win`, the top one first, each padded to 16 entries
+        {
+            int cum = 0;
+            for (int l = levels - 1; l >= 0; --l) {
+                int size, off;
+                cdf_tree_level(g.N, l, size, off);
+                const int pad = (size + 15) & ~15;
+                if (cum + pad > WIN) break;
+                for (int i = threadIdx.x; i < pad; i += PF_BLOCK) win[cum + i] = tcol[off + i];
+                cum += pad;
+                lds_from = l;
+            }
+        }
+        __syncthreads();
         for (int r = 0; r < g.rounds_per_tile; ++r) {
             const int64_t i0 = base + (int64_t)r * g.round_elems + threadIdx.x * VEC;
             if (i0 >= g.N) break;
@@ -833,15 +867,32 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
                 p[j] = v ? v[e] : uniform_draw<T>(seed, PF_STREAM_MULTINOMIAL, step, (uint64_t)e);
                 grp[j] = 0;
             }
-            for (int l = tr.levels - 1; l >= 0; --l) {  // (the thread's VEC draws level by level: independent loads side by side)
+            for (int l = levels - 1, cum = 0; l >= lds_from; --l) {
+                int size, off;
+                cdf_tree_level(g.N, l, size, off);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const int at = grp[j] * 16;  // (< size[l]: the clamp below)
-                    const int nv = tr.size[l] - at > 16 ? 16 : tr.size[l] - at;
-                    const int nxt = at + count16(tcol + tr.off[l] + at, nv, p[j], true);
+                    const int at = grp[j] * 16;
+                    const int nv = size - at > 16 ? 16 : size - at;
+                    const T* row = win + cum + at;
+                    int cnt = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) cnt += (i < nv && row[i] < p[j]) ? 1 : 0;
+                    grp[j] = at + cnt < size ? at + cnt : size - 1;
+                }
+                cum += (size + 15) & ~15;
+            }
+            for (int l = lds_from - 1; l >= 0; --l) {  // (the thread's VEC draws level by level: independent loads side by side)
+                int size, off;
+                cdf_tree_level(g.N, l, size, off);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int at = grp[j] * 16;  // (< size: the clamp below)
+                    const int nv = size - at > 16 ? 16 : size - at;
+                    const int nxt = at + count16(tcol + off + at, nv, p[j], true);
                     // (a group's last entry is >= p by the level above, so nxt names an entry of this level - unless NaNs broke the
                     // order: the clamp keeps every address inside its table)
-                    grp[j] = nxt < tr.size[l] ? nxt : tr.size[l] - 1;
+                    grp[j] = nxt < size ? nxt : size - 1;
                 }
             }
             int res[VEC];
@@ -856,12 +907,12 @@ __device__ __forceinline__ void search_body(const T* __restrict__ cdf, const T* 
         }
     }
 }
-template <typename T, int VEC>
+template <typename T, int VEC, bool MN>
 __global__ __launch_bounds__(PF_BLOCK) void k_search(const T* __restrict__ cdf, const T* __restrict__ u,
-                                                     int u_per_elem, const T* __restrict__ v, int multinomial, uint64_t seed,
+                                                     int u_per_elem, const T* __restrict__ v, uint64_t seed,
                                                      uint32_t step, const uint8_t* colmask, int32_t* __restrict__ idx,
                                                      Geom g, int force_search, const T* tree) {
-    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, force_search, blockIdx.y, blockIdx.x, tree);
+    search_body<T, VEC, MN>(cdf, u, u_per_elem, v, seed, step, colmask, idx, g, force_search, blockIdx.y, blockIdx.x, tree);
 }
 // ---------------------------------------------------------------------------------------------------------------
 // systematic(W) WITHOUT a materialised cdf (pf_systematic with cdf == NULL): two launches instead of three, 12 bytes per particle
@@ -1182,9 +1233,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_chunk_search(const T* __restrict__
 // 1 024 x 8 192 is one 8-round tile per column) in ONE launch: tile record -> scan -> ancestors, the three kernels' bodies back
 // to back in the column's workgroup (same arithmetic: identical cdf and ancestors; the cdf goes through memory between
 // the stages exactly as between the launches, it is just never re-read from another CU)
-template <typename T, int VEC, bool FROM_W>
+template <typename T, int VEC, bool FROM_W, bool MN>
 __global__ __launch_bounds__(PF_BLOCK) void k_resample_one_tile(T* __restrict__ src, const T* __restrict__ u, int u_per_elem,
-                                                                const T* __restrict__ v, int multinomial, uint64_t seed,
+                                                                const T* __restrict__ v, uint64_t seed,
                                                                 uint32_t step, const uint8_t* colmask, T* __restrict__ cdf,
                                                                 int32_t* __restrict__ idx, double* __restrict__ part, Geom g, T* tree) {
     const int b = blockIdx.y;
@@ -1192,10 +1243,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_resample_one_tile(T* __restrict__ 
     else reduce_logw_body<T, VEC>(src, 1, colmask, part, g, b, 0);
     __threadfence_block();
     __syncthreads();
-    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, b, 0, multinomial ? tree : nullptr);
+    scan_body<T, VEC, FROM_W>(src, cdf, colmask, part, g, b, 0, MN ? tree : nullptr);
     __threadfence_block();
     __syncthreads();
-    search_body<T, VEC>(cdf, u, u_per_elem, v, multinomial, seed, step, colmask, idx, g, 0, b, 0, tree);
+    search_body<T, VEC, MN>(cdf, u, u_per_elem, v, seed, step, colmask, idx, g, 0, b, 0, tree);
 }
 
 template <typename T>
@@ -1792,30 +1843,33 @@ static int systematic_impl(void* src, bool from_w, const void* u, int u_per_elem
         return PF_OK;
     }
     void* tree = multinomial ? (void*)((char*)ws + wl.off_tree) : nullptr;  // (the iid draws' 16-ary search tables, written by the scan)
-#define CALL(T, V)                                                                                                   \
+#define CALL_MN(T, V, MN)                                                                                            \
     if (g.tiles == 1) { /* one tile per column: record -> scan -> ancestors in one launch */                          \
         if (from_w)                                                                                                  \
-            hipLaunchKernelGGL((k_resample_one_tile<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (T*)src, (const T*)u, \
-                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g,     \
+            hipLaunchKernelGGL((k_resample_one_tile<T, V, true, MN>), grid, dim3(PF_BLOCK), 0, st, (T*)src,          \
+                               (const T*)u, u_per_elem, (const T*)v, seed, step, colmask, (T*)cdf, idx, part, g,     \
                                (T*)tree);                                                                            \
         else                                                                                                         \
-            hipLaunchKernelGGL((k_resample_one_tile<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (T*)src, (const T*)u,\
-                               u_per_elem, (const T*)v, multinomial, seed, step, colmask, (T*)cdf, idx, part, g,     \
+            hipLaunchKernelGGL((k_resample_one_tile<T, V, false, MN>), grid, dim3(PF_BLOCK), 0, st, (T*)src,         \
+                               (const T*)u, u_per_elem, (const T*)v, seed, step, colmask, (T*)cdf, idx, part, g,     \
                                (T*)tree);                                                                            \
-    } else if (from_w) {                                                                                             \
-        hipLaunchKernelGGL((k_tile_sum<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, colmask, part, g);        \
-        hipLaunchKernelGGL((k_scan<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,       \
-                           (const double*)part, g, (T*)tree);                                                        \
     } else {                                                                                                         \
-        hipLaunchKernelGGL((k_reduce_logw<T, V>), grid, dim3(PF_BLOCK), 0, st, (T*)src, 1, colmask, part, g);        \
-        hipLaunchKernelGGL((k_scan<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,      \
-                           (const double*)part, g, (T*)tree);                                                        \
-    }                                                                                                                \
-    if (g.tiles != 1)                                                                                                \
-        hipLaunchKernelGGL((k_search<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u, u_per_elem,    \
-                           (const T*)v, multinomial, seed, step, colmask, idx, g, /*force_search*/ 0, (const T*)tree);
+        if (from_w) {                                                                                                \
+            hipLaunchKernelGGL((k_tile_sum<T, V>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, colmask, part, g);    \
+            hipLaunchKernelGGL((k_scan<T, V, true>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,   \
+                               (const double*)part, g, (T*)tree);                                                    \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL((k_reduce_logw<T, V>), grid, dim3(PF_BLOCK), 0, st, (T*)src, 1, colmask, part, g);    \
+            hipLaunchKernelGGL((k_scan<T, V, false>), grid, dim3(PF_BLOCK), 0, st, (const T*)src, (T*)cdf, colmask,  \
+                               (const double*)part, g, (T*)tree);                                                    \
+        }                                                                                                            \
+        hipLaunchKernelGGL((k_search<T, V, MN>), grid, dim3(PF_BLOCK), 0, st, (const T*)cdf, (const T*)u,            \
+                           u_per_elem, (const T*)v, seed, step, colmask, idx, g, /*force_search*/ 0, (const T*)tree);\
+    }
+#define CALL(T, V) if (multinomial) { CALL_MN(T, V, true) } else { CALL_MN(T, V, false) }
     PF_DISPATCH_T_VEC(dtype, g.vec, CALL)
 #undef CALL
+#undef CALL_MN
     PF_CHECK_LAUNCH();
     return PF_OK;
 }
