@@ -197,6 +197,56 @@ def test_systematic_from_log_weights_on_several_tiles(pf, dt, n, b, sys_route):
     assert (got[1:] >= got[:-1]).all() and got.min() >= 0 and got.max() <= n - 1
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_systematic_fuzz_shapes_and_weight_patterns(pf, seed):
+    """A sweep over column sizes (every tile geometry between 2 and ~300 tiles, ragged last tiles and chunks), batch sizes, weight
+    patterns (flat, peaked, a handful of heavy particles, whole weightless tiles, weight only in the last entry) and offsets
+    (0, just below 1, random), normalised weights and log-weights, on whatever form the library picks: float32 ancestors equal the
+    oracle's exactly (exact sums), float64 up to two positions per case within an ulp of a boundary."""
+    import random
+
+    rnd = random.Random(1000 + seed)
+    gen = torch.Generator().manual_seed(2000 + seed)
+    for case in range(10):
+        n = 4 * rnd.randint(513, 75_000) if rnd.random() < 0.8 else rnd.randint(2049, 50_000)
+        b = rnd.choice([1, 1, 2, 3, 7, 16, 40])
+        while n * b > 3_000_000:
+            b = max(1, b // 2)
+        dt = rnd.choice(["f32", "f64"])
+        dtype = DT[dt]
+        pattern = rnd.choice(["flat", "peaked", "heavy", "gaps", "last"])
+        lw = torch.randn(n, b, generator=gen, dtype=torch.float64) * {"flat": 0.3, "peaked": 6.0}.get(pattern, 1.0)
+        if pattern == "heavy":
+            lw[:] = -1e4
+            for col in range(b):
+                lw[torch.randint(0, n, (rnd.randint(1, 30),), generator=gen), col] = 0.0
+        elif pattern == "gaps":
+            for _ in range(3):
+                a = rnd.randint(0, n - 1)
+                lw[a:a + rnd.randint(1, n // 2)] = -1e4
+            lw[rnd.randint(0, n - 1)] = 0.0  # (never everything weightless)
+        elif pattern == "last":
+            lw[:] = -1e4
+            lw[n - 1] = 0.0
+        W = cpu_ref.normalize(lw).to(dtype)
+        u = torch.rand(b, 1, generator=gen, dtype=dtype)
+        if b > 1:
+            u[0, 0] = 0.0
+            u[1, 0] = 1.0 - torch.finfo(dtype).eps
+        expect = cpu_ref.systematic(W, normalized=True, u=u)
+        got = pf.resampling.systematic(W.cuda(), normalized=True, u=u.cuda()).cpu()
+        mism = int((got != expect).sum())
+        assert mism <= (0 if dt == "f32" else 2), (case, n, b, dt, pattern, mism)
+        # the log-weight form on the same weights (float64 log-weights of the float weights: the same categorical distribution)
+        lw_in = W.double().log().to(dtype)
+        got2 = pf.resampling.systematic(lw_in.clone().cuda(), normalized=False, u=u.cuda()).cpu()
+        expect2 = cpu_ref.systematic(lw_in.clone().double(), normalized=False, u=u.double())
+        # (float64: exp() on both sides - a position within an ulp of a boundary may move; with a handful of equal weights and the
+        # offset 0 the boundaries m / k ARE grid positions i / n: exact ties, one per heavy particle, broken by the last bit)
+        mism2 = int((got2 != expect2).sum())
+        assert mism2 <= (5e-3 * n * b if dt == "f32" else (3 + (32 if pattern in ("heavy", "last") else 0))), (case, n, b, dt, pattern, mism2)
+
+
 @pytest.mark.parametrize("dt", ["f32", "f64"])
 def test_systematic_with_nan_weights_terminates(pf, dt, sys_route):
     """Garbage in: NaN weights give no meaningful ancestors (searchsorted on an unsorted cdf) - but every launch ends and every
