@@ -235,16 +235,20 @@ def test_systematic_fuzz_shapes_and_weight_patterns(pf, seed):
             u[1, 0] = 1.0 - torch.finfo(dtype).eps
         expect = cpu_ref.systematic(W, normalized=True, u=u)
         got = pf.resampling.systematic(W.cuda(), normalized=True, u=u.cuda()).cpu()
+        # (float64 with a handful of EQUAL weights and the offset 0: the boundaries m / k are grid positions i / n - exact ties, one per
+        # heavy particle, broken by the last bit of a sum; everything else: two positions within an ulp of a boundary at most)
+        ties = 32 if (dt == "f64" and pattern in ("heavy", "last")) else 0
         mism = int((got != expect).sum())
-        assert mism <= (0 if dt == "f32" else 2), (case, n, b, dt, pattern, mism)
+        assert mism <= (0 if dt == "f32" else 2 + ties), ("W", case, n, b, dt, pattern, mism)
         # the log-weight form on the same weights (float64 log-weights of the float weights: the same categorical distribution)
         lw_in = W.double().log().to(dtype)
         got2 = pf.resampling.systematic(lw_in.clone().cuda(), normalized=False, u=u.cuda()).cpu()
         expect2 = cpu_ref.systematic(lw_in.clone().double(), normalized=False, u=u.double())
-        # (float64: exp() on both sides - a position within an ulp of a boundary may move; with a handful of equal weights and the
-        # offset 0 the boundaries m / k ARE grid positions i / n: exact ties, one per heavy particle, broken by the last bit)
+        # (float32 against the float64 oracle: the cdf itself is rounded to float32 - an ulp of it is n * 6e-8 grid spacings, so that
+        # share of the positions sits within an ulp of a boundary; float64: exp() on both sides, and the ties above)
         mism2 = int((got2 != expect2).sum())
-        assert mism2 <= (5e-3 * n * b if dt == "f32" else (3 + (32 if pattern in ("heavy", "last") else 0))), (case, n, b, dt, pattern, mism2)
+        bar2 = max(5e-3, 2.0 * n * torch.finfo(torch.float32).eps) * n * b if dt == "f32" else 3 + ties
+        assert mism2 <= bar2, ("logw", case, n, b, dt, pattern, mism2, bar2)
 
 
 @pytest.mark.parametrize("dt", ["f32", "f64"])
