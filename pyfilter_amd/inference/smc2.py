@@ -512,6 +512,8 @@ class SMC2:
 
         bufs = self.__dict__.setdefault("_host_row_bufs", {})
         rows = bufs.get(slot)
+        if rows is False:  # (asked once: no coherent host memory)
+            return None
         if rows is None or rows.n < n:
             try:
                 rows = ops.HostRows(max(n, self._block))

@@ -279,6 +279,49 @@ def test_theta_step_updates_in_place_and_reports_to_the_host_slot(dtype, b):
     assert other.ptr != slot.ptr and other.seq == 0
 
 
+@pytest.mark.parametrize("n_state", [300, 4096])
+def test_fit_with_host_rows_is_fit_with_the_copy_and_the_event(n_state, monkeypatch):
+    """``SMC2.fit``: a block's statistics rows polled in host memory (``ops.HostRows``, the default) against the copy command +
+    event per block it falls back to where no coherent host memory is to be had - same seeds, same decisions, the same theta-weights
+    and posterior bit for bit (column route at 300 particles, column-cluster route - status word through the rows - at 4 096)."""
+    from pyfilter_amd import timeseries as ts
+    from pyfilter_amd.filters.particle import APF, proposals
+    from pyfilter_amd.inference import SMC2
+    from pyfilter_amd.timeseries import models
+
+    dtype = torch.float32
+    t = lambda v: torch.tensor(v, dtype=dtype, device="cuda")  # noqa: E731
+    obs = (t(1.0), t(0.05))
+
+    def build(theta):
+        return ts.LinearStateSpaceModel(models.OrnsteinUhlenbeck(theta["kappa"], theta["gamma"], theta["sigma"], dt=1.0), obs)
+
+    g = torch.Generator().manual_seed(5)
+    x, ys = 0.0, []
+    for _ in range(90):
+        x = x * math.exp(-0.05) + 0.15 * math.sqrt((1 - math.exp(-0.1)) / 0.1) * float(torch.randn((), generator=g))
+        ys.append(x + 0.05 * float(torch.randn((), generator=g)))
+    y = torch.tensor(ys, dtype=dtype, device="cuda")
+    pri = {"kappa": Exponential(10.0), "gamma": Normal(0.0, 1.0), "sigma": LogNormal(-2.0, 1.0)}
+    outs = {}
+    for how in ("rows", "copy"):
+        if how == "copy":
+            def no_rows(n):
+                raise ops.L.PfAmdError("no coherent host memory")
+            monkeypatch.setattr(ops, "HostRows", no_rows)
+        alg = SMC2(APF(build, n_state, proposal=proposals.LinearGaussianObservations(), seed=11), 64, pri, threshold=0.5, device="cuda",
+                   dtype=dtype, seed=3)
+        state = alg.fit(y, block=8)
+        bufs = alg.__dict__.get("_host_row_bufs", {})
+        assert (len(bufs) > 0 and all(isinstance(r, ops.HostRows) and r.seq > 0 for r in bufs.values())) if how == "rows" else \
+            all(r is False for r in bufs.values())
+        outs[how] = (state.w.cpu(), alg.posterior_mean(state).cpu(), len(alg._kernel.acceptance_history), torch.stack(state.ess).cpu())
+    assert outs["rows"][2] == outs["copy"][2] >= 1
+    for a, b in zip(outs["rows"], outs["copy"]):
+        if isinstance(a, torch.Tensor):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
 def test_theta_path_reports_every_row_into_host_memory(dtype):
     """``pf_theta_path`` with host rows: row q's (ESS, all finite) pair in host memory equals the device row, for every launch of a
